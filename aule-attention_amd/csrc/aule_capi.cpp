@@ -1,0 +1,686 @@
+// aule_capi.cpp -- extern "C" implementation of include/aule.h on the HIP runtime.
+//
+// Re-exports the C-ABI of the reference's src/lib.zig (global context, 1024-slot
+// tensor table, 512-byte error buffer, negative return codes) over the gfx950
+// kernels in this directory.  The reference's host language for this layer is
+// Zig; no Zig toolchain exists in the build image, so the layer is C++ with
+// identical symbol names and signatures (see INTEGRATION.md for the Zig `extern`
+// block a maintainer would add to bind it).
+//
+// There is deliberately NO CPU fallback here: if no HIP device is present
+// aule_init() fails with -1 and every compute entry point returns -1.
+#include "../../include/aule.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "fa_kernels.h"
+
+namespace {
+
+using aule_hip::BwdArgs;
+using aule_hip::FwdArgs;
+
+struct DevTensor {
+    void* ptr = nullptr;      // device memory, rows padded to `pitch` floats
+    uint32_t shape[4] = {0, 0, 0, 0};
+    uint64_t count = 0;       // logical element count (B*H*S*D)
+    uint32_t pitch = 0;       // padded head_dim (32 / 64 / 128, or D itself if D > 128)
+    bool used = false;
+};
+
+std::mutex g_mu;
+bool g_init = false;
+int g_device = 0;
+uint64_t g_configured_mask = 0;  // devices on which kernel attributes were set
+char g_err[512];
+size_t g_err_len = 0;
+DevTensor g_tensors[AULE_MAX_TENSORS];
+int g_variant = 0;
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    int n = vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    if (n < 0) n = 0;
+    if ((size_t)n >= sizeof(g_err)) n = sizeof(g_err) - 1;
+    g_err_len = (size_t)n;
+}
+
+uint32_t pad_dim(uint32_t d) {
+    if (d <= 32) return 32;
+    if (d <= 64) return 64;
+    if (d <= 128) return 128;
+    return d;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (dev < 0) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+            switched = hipSetDevice(dev) == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+int ensure_configured() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev < 64 && (g_configured_mask >> dev) & 1) return 0;
+    int rc = aule_hip::configure_kernels();
+    if (rc != 0) {
+        set_error("Kernel configuration failed on device %d: %s", dev, hipGetErrorString((hipError_t)rc));
+        return -4;
+    }
+    if (dev < 64) g_configured_mask |= (1ull << dev);
+    return 0;
+}
+
+DevTensor* lookup(uint64_t h) {
+    if (h == 0 || h > AULE_MAX_TENSORS) return nullptr;
+    DevTensor* t = &g_tensors[h - 1];
+    return t->used ? t : nullptr;
+}
+
+void free_tensor(DevTensor* t) {
+    if (t->used && t->ptr) (void)hipFree(t->ptr);
+    *t = DevTensor();
+}
+
+// Padded temporary for the host-pointer entry points.
+struct Temp {
+    float* ptr = nullptr;
+    ~Temp() {
+        if (ptr) (void)hipFree(ptr);
+    }
+    bool alloc(size_t rows, uint32_t pitch) {
+        if (hipMalloc((void**)&ptr, rows * pitch * sizeof(float)) != hipSuccess) return false;
+        return hipMemset(ptr, 0, rows * pitch * sizeof(float)) == hipSuccess;
+    }
+};
+
+bool upload_rows(float* dst, uint32_t pitch, const float* src, size_t rows, uint32_t d) {
+    return hipMemcpy2D(dst, pitch * sizeof(float), src, d * sizeof(float), d * sizeof(float), rows,
+                       hipMemcpyHostToDevice) == hipSuccess;
+}
+
+bool download_rows(float* dst, const float* src, uint32_t pitch, size_t rows, uint32_t d) {
+    return hipMemcpy2D(dst, d * sizeof(float), src, pitch * sizeof(float), d * sizeof(float), rows,
+                       hipMemcpyDeviceToHost) == hipSuccess;
+}
+
+int run_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse, uint32_t B, uint32_t Hq,
+                uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t Dlogical, uint32_t Dp, int causal) {
+    FwdArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse;
+    a.B = (int)B; a.Hq = (int)Hq; a.Hkv = (int)Hkv; a.Sq = (int)Sq; a.Sk = (int)Sk; a.D = (int)Dp;
+    a.scale = 1.0f / std::sqrt((float)Dlogical);  // attention_pipeline.zig:329
+    a.causal = causal != 0;
+    a.dtype = aule_hip::kF32;
+    int rc = aule_hip::launch_fwd(a, nullptr);
+    if (rc != 0) return rc;
+    return (int)hipDeviceSynchronize();
+}
+
+}  // namespace
+
+namespace aule_hip {
+int configure_fwd();
+int configure_bwd();
+int configure_kernels() {
+    int rc = configure_fwd();
+    if (rc) return rc;
+    return configure_bwd();
+}
+}  // namespace aule_hip
+
+extern "C" {
+
+int32_t aule_init(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_init) return 0;  // idempotent (src/lib.zig:60-63)
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("Failed to initialize backend: no HIP device (%s)",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return -1;
+    }
+    int dev = 0;
+    if (const char* s = getenv("AULE_HIP_DEVICE")) {
+        dev = atoi(s);
+        if (dev < 0 || dev >= n) {
+            set_error("Failed to initialize backend: AULE_HIP_DEVICE=%d out of range (0..%d)", dev, n - 1);
+            return -1;
+        }
+    } else if (hipGetDevice(&dev) != hipSuccess) {
+        dev = 0;
+    }
+    g_device = dev;
+    {
+        DeviceGuard g(g_device);
+        int rc = ensure_configured();
+        if (rc != 0) return -1;
+    }
+    g_init = true;
+    g_err_len = 0;
+    return 0;
+}
+
+void aule_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_init) {
+        DeviceGuard g(g_device);
+        for (auto& t : g_tensors) free_tensor(&t);
+    }
+    g_init = false;
+}
+
+const char* aule_get_error(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_err_len == 0) return "No error";
+    g_err[g_err_len] = 0;
+    return g_err;
+}
+
+const char* aule_get_backend_name(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_init ? "HIP/ROCm" : "Not initialized";  // backend.zig:496-502
+}
+
+int32_t aule_get_vendor(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_init ? 1 : -1;
+}
+int32_t aule_get_gpu_vendor(void) { return aule_get_vendor(); }
+
+int32_t aule_is_amd_optimized(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_init ? 1 : -1;
+}
+
+int32_t aule_has_fp16(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_init ? 1 : -1;
+}
+
+int32_t aule_get_subgroup_size(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_init ? 64 : -1;
+}
+
+int32_t aule_get_device_name(uint8_t* buffer, uint32_t buffer_len) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) return -1;
+    if (buffer == nullptr || buffer_len == 0) return 0;
+    hipDeviceProp_t prop;
+    const char* name = "HIP Device";
+    if (hipGetDeviceProperties(&prop, g_device) == hipSuccess) name = prop.name;
+    size_t n = strlen(name);
+    if (n > buffer_len - 1) n = buffer_len - 1;
+    memcpy(buffer, name, n);
+    buffer[n] = 0;
+    return (int32_t)n;
+}
+
+int32_t aule_set_shader_variant(uint8_t variant) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) return -1;
+    if (variant != 0) {
+        set_error("Shader variant %u not available (the HIP build has one kernel family)", (unsigned)variant);
+        return -2;
+    }
+    g_variant = 0;
+    return 0;
+}
+
+int32_t aule_get_shader_variant(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_init ? g_variant : -1;
+}
+
+int32_t aule_has_shader_variant(uint8_t variant) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) return -1;
+    return variant == 0 ? 1 : 0;
+}
+
+int32_t aule_supports_backward(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_init ? 1 : 0;
+}
+
+/* ---------------------------------------------------------------- tensors */
+aule_tensor_handle aule_tensor_create(uint32_t b, uint32_t h, uint32_t s, uint32_t d) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) {
+        set_error("Not initialized");
+        return 0;
+    }
+    int slot = -1;
+    for (int i = 0; i < (int)AULE_MAX_TENSORS; ++i)
+        if (!g_tensors[i].used) {
+            slot = i;
+            break;
+        }
+    if (slot < 0) {
+        set_error("Max tensors reached");
+        return 0;
+    }
+    const uint64_t rows = (uint64_t)b * h * s;
+    const uint32_t pitch = pad_dim(d);
+    DevTensor t;
+    t.shape[0] = b; t.shape[1] = h; t.shape[2] = s; t.shape[3] = d;
+    t.count = rows * d;
+    t.pitch = pitch;
+    const size_t bytes = (size_t)rows * pitch * sizeof(float);
+    DeviceGuard g(g_device);
+    if (bytes > 0) {
+        hipError_t e = hipMalloc(&t.ptr, bytes);
+        if (e != hipSuccess) {
+            set_error("Create tensor failed: %s", hipGetErrorString(e));
+            return 0;
+        }
+        (void)hipMemset(t.ptr, 0, bytes);
+    }
+    t.used = true;
+    g_tensors[slot] = t;
+    return (aule_tensor_handle)(slot + 1);
+}
+
+aule_tensor_handle aule_tensor_create_u32(uint32_t b, uint32_t h, uint32_t s, uint32_t d) {
+    return aule_tensor_create(b, h, s, d);  // src/lib.zig:432-442: u32 aliases fp32 storage
+}
+
+void aule_tensor_destroy(aule_tensor_handle handle) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    DevTensor* t = lookup(handle);
+    if (!t) return;
+    DeviceGuard g(g_device);
+    free_tensor(t);
+}
+
+int32_t aule_tensor_upload(aule_tensor_handle handle, const float* data, uint32_t count) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) return -1;
+    DevTensor* t = lookup(handle);
+    if (!t) return -1;
+    if ((uint64_t)count != t->count) {  // backend.zig:277
+        set_error("Upload failed: size mismatch (tensor has %llu elements, got %u)",
+                  (unsigned long long)t->count, count);
+        return -3;
+    }
+    if (count == 0) return 0;
+    DeviceGuard g(g_device);
+    const size_t rows = (size_t)t->shape[0] * t->shape[1] * t->shape[2];
+    if (!upload_rows((float*)t->ptr, t->pitch, data, rows, t->shape[3])) {
+        set_error("Upload failed: %s", hipGetErrorString(hipGetLastError()));
+        return -3;
+    }
+    return 0;
+}
+
+int32_t aule_tensor_download(aule_tensor_handle handle, float* output, uint32_t count) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) return -1;
+    DevTensor* t = lookup(handle);
+    if (!t) return -1;
+    if ((uint64_t)count != t->count) {  // backend.zig:298
+        set_error("Download failed: size mismatch (tensor has %llu elements, got %u)",
+                  (unsigned long long)t->count, count);
+        return -3;
+    }
+    if (count == 0) return 0;
+    DeviceGuard g(g_device);
+    const size_t rows = (size_t)t->shape[0] * t->shape[1] * t->shape[2];
+    if (!download_rows(output, (const float*)t->ptr, t->pitch, rows, t->shape[3])) {
+        set_error("Download failed: %s", hipGetErrorString(hipGetLastError()));
+        return -3;
+    }
+    return 0;
+}
+
+int32_t aule_tensor_download_u32(aule_tensor_handle handle, uint32_t* output, uint32_t count) {
+    return aule_tensor_download(handle, reinterpret_cast<float*>(output), count);
+}
+
+uint32_t aule_tensor_size(aule_tensor_handle handle) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    DevTensor* t = lookup(handle);
+    return t ? (uint32_t)t->count : 0;
+}
+
+uint32_t aule_tensor_count(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    uint32_t n = 0;
+    for (auto& t : g_tensors) n += t.used ? 1 : 0;
+    return n;
+}
+
+uint32_t aule_tensor_max(void) { return AULE_MAX_TENSORS; }
+
+void aule_tensor_clear_all(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) return;
+    DeviceGuard g(g_device);
+    for (auto& t : g_tensors) free_tensor(&t);
+}
+
+/* ------------------------------------------------------- handle-based fwd */
+int32_t aule_attention_forward_gpu(aule_tensor_handle qh, aule_tensor_handle kh, aule_tensor_handle vh,
+                                   aule_tensor_handle oh, aule_tensor_handle rot_cos,
+                                   aule_tensor_handle rot_sin, int32_t causal, int32_t window_size) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) return -1;
+    DevTensor* q = lookup(qh);
+    DevTensor* k = lookup(kh);
+    DevTensor* v = lookup(vh);
+    DevTensor* o = lookup(oh);
+    if (!q || !k || !v || !o) return -1;
+    if (rot_cos != 0 || rot_sin != 0) {
+        set_error("Attention failed: fused RoPE is not supported by the HIP backend");
+        return -3;
+    }
+    if (window_size > 0) {
+        set_error("Attention failed: sliding window is not supported by the HIP backend");
+        return -3;
+    }
+    // shape rules of attention_gpu.zig:383-404
+    const uint32_t B = q->shape[0], Hq = q->shape[1], Sq = q->shape[2], D = q->shape[3];
+    const uint32_t Hkv = k->shape[1], Sk = k->shape[2];
+    bool ok = k->shape[0] == B && Hkv != 0 && Hq % Hkv == 0 && k->shape[3] == D;
+    ok = ok && v->shape[0] == B && v->shape[1] == Hkv && v->shape[2] == Sk && v->shape[3] == D;
+    ok = ok && o->shape[0] == B && o->shape[1] == Hq && o->shape[2] == Sq && o->shape[3] == D;
+    if (!ok) {
+        set_error("Attention failed: error.ShapeMismatch");
+        return -3;
+    }
+    if (D > 128) {
+        set_error("Attention failed: error.HeadDimTooLarge (head_dim %u > 128)", D);
+        return -3;
+    }
+    if (q->count == 0) return 0;
+    if (Sk == 0) {
+        set_error("Attention failed: error.ShapeMismatch (empty key sequence)");
+        return -3;
+    }
+    DeviceGuard g(g_device);
+    int rc = run_fwd_f32((const float*)q->ptr, (const float*)k->ptr, (const float*)v->ptr, (float*)o->ptr, nullptr,
+                         B, Hq, Hkv, Sq, Sk, D, q->pitch, causal);
+    if (rc != 0) {
+        set_error("Attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported shape");
+        return -3;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------ host-pointer paths */
+static int32_t forward_host(const float* query, const float* key, const float* value, float* output, float* lse,
+                            uint32_t B, uint32_t H, uint32_t S, uint32_t D, int32_t causal) {
+    if (!g_init) {
+        set_error("Library not initialized. Call aule_init() first.");
+        return -1;
+    }
+    if (D > 128) {
+        set_error("Attention failed: error.HeadDimTooLarge (head_dim %u > 128)", D);
+        return -4;
+    }
+    const size_t rows = (size_t)B * H * S;
+    if (rows == 0 || D == 0) return 0;
+    const uint32_t Dp = pad_dim(D);
+    DeviceGuard g(g_device);
+    Temp q, k, v, o, l;
+    if (!q.alloc(rows, Dp) || !k.alloc(rows, Dp) || !v.alloc(rows, Dp) || !o.alloc(rows, Dp) ||
+        (lse && !l.alloc(rows, 1))) {
+        set_error("Create tensor failed: %s", hipGetErrorString(hipGetLastError()));
+        return -2;
+    }
+    if (!upload_rows(q.ptr, Dp, query, rows, D) || !upload_rows(k.ptr, Dp, key, rows, D) ||
+        !upload_rows(v.ptr, Dp, value, rows, D)) {
+        set_error("Upload failed: %s", hipGetErrorString(hipGetLastError()));
+        return -3;
+    }
+    int rc = run_fwd_f32(q.ptr, k.ptr, v.ptr, o.ptr, lse ? l.ptr : nullptr, B, H, H, S, S, D, Dp, causal);
+    if (rc != 0) {
+        set_error("Attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported shape");
+        return -4;
+    }
+    if (!download_rows(output, o.ptr, Dp, rows, D) ||
+        (lse && hipMemcpy(lse, l.ptr, rows * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)) {
+        set_error("Download failed: %s", hipGetErrorString(hipGetLastError()));
+        return -5;
+    }
+    return 0;
+}
+
+int32_t aule_attention_forward(const float* query, const float* key, const float* value, float* output,
+                               uint32_t B, uint32_t H, uint32_t S, uint32_t D, int32_t causal) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return forward_host(query, key, value, output, nullptr, B, H, S, D, causal);
+}
+
+int32_t aule_attention_forward_with_lse(const float* query, const float* key, const float* value, float* output,
+                                        float* lse, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
+                                        int32_t causal) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return forward_host(query, key, value, output, lse, B, H, S, D, causal);
+}
+
+int32_t aule_attention_backward(const float* query, const float* key, const float* value, const float* output,
+                                const float* grad_output, const float* lse, float* grad_query, float* grad_key,
+                                float* grad_value, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
+                                int32_t causal) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) {
+        set_error("Library not initialized. Call aule_init() first.");
+        return -1;
+    }
+    if (D > 128) {
+        set_error("Backward failed: error.HeadDimTooLarge (head_dim %u > 128)", D);
+        return -4;
+    }
+    const size_t rows = (size_t)B * H * S;
+    if (rows == 0 || D == 0) return 0;
+    const uint32_t Dp = pad_dim(D);
+    DeviceGuard g(g_device);
+    Temp q, k, v, o, go, l, dq, dk, dv, ws;
+    const uint64_t wsb = aule_hip::bwd_workspace_bytes((int)B, (int)H, (int)S);
+    if (!q.alloc(rows, Dp) || !k.alloc(rows, Dp) || !v.alloc(rows, Dp) || !o.alloc(rows, Dp) ||
+        !go.alloc(rows, Dp) || !l.alloc(rows, 1) || !dq.alloc(rows, Dp) || !dk.alloc(rows, Dp) ||
+        !dv.alloc(rows, Dp) || !ws.alloc((wsb + 3) / 4, 1)) {
+        set_error("Create tensor failed: %s", hipGetErrorString(hipGetLastError()));
+        return -2;
+    }
+    if (!upload_rows(q.ptr, Dp, query, rows, D) || !upload_rows(k.ptr, Dp, key, rows, D) ||
+        !upload_rows(v.ptr, Dp, value, rows, D) || !upload_rows(o.ptr, Dp, output, rows, D) ||
+        !upload_rows(go.ptr, Dp, grad_output, rows, D) ||
+        hipMemcpy(l.ptr, lse, rows * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("Upload failed: %s", hipGetErrorString(hipGetLastError()));
+        return -3;
+    }
+    BwdArgs a;
+    a.q = q.ptr; a.k = k.ptr; a.v = v.ptr; a.o = o.ptr; a.dout = go.ptr; a.lse = l.ptr;
+    a.dq = dq.ptr; a.dk = dk.ptr; a.dv = dv.ptr; a.delta = ws.ptr;
+    a.B = (int)B; a.Hq = (int)H; a.Hkv = (int)H; a.Sq = (int)S; a.Sk = (int)S; a.D = (int)Dp;
+    a.scale = 1.0f / std::sqrt((float)D);
+    a.causal = causal != 0;
+    a.dtype = aule_hip::kF32;
+    int rc = aule_hip::launch_bwd(a, nullptr);
+    if (rc == 0) rc = (int)hipDeviceSynchronize();
+    if (rc != 0) {
+        set_error("Backward failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported shape");
+        return -4;
+    }
+    if (!download_rows(grad_query, dq.ptr, Dp, rows, D) || !download_rows(grad_key, dk.ptr, Dp, rows, D) ||
+        !download_rows(grad_value, dv.ptr, Dp, rows, D)) {
+        set_error("Download failed: %s", hipGetErrorString(hipGetLastError()));
+        return -5;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------ out-of-scope stubs */
+int32_t aule_attention_forward_paged(aule_tensor_handle, aule_tensor_handle, aule_tensor_handle,
+                                     aule_tensor_handle, aule_tensor_handle, aule_tensor_handle, int32_t,
+                                     int32_t) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) return -1;
+    set_error("PagedAttention failed: not supported by the HIP backend");
+    return -3;
+}
+
+int32_t aule_spatial_sort(aule_tensor_handle, aule_tensor_handle, aule_tensor_handle, uint32_t) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) return -1;
+    set_error("Spatial sort failed: not supported by the HIP backend");
+    return -3;
+}
+
+int32_t aule_attention_forward_gravity(aule_tensor_handle, aule_tensor_handle, aule_tensor_handle,
+                                       aule_tensor_handle, aule_tensor_handle, aule_tensor_handle,
+                                       aule_tensor_handle, int32_t, uint32_t, int32_t) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) return -1;
+    set_error("Gravity Attention failed: not supported by the HIP backend");
+    return -3;
+}
+
+/* ------------------------------------------------------------ _ex entries */
+static int check_common(int32_t dtype, uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk,
+                        uint32_t D, int32_t window) {
+    if (dtype < 0 || dtype > 2) {
+        set_error("Attention failed: unknown dtype %d", dtype);
+        return -3;
+    }
+    if (D != 32 && D != 64 && D != 128) {
+        set_error("Attention failed: head_dim %u unsupported (32, 64 or 128; pad to the next size)", D);
+        return -3;
+    }
+    if (Hkv == 0 || Hq % Hkv != 0) {
+        set_error("Attention failed: heads_q (%u) must be divisible by heads_kv (%u)", Hq, Hkv);
+        return -3;
+    }
+    if (window > 0) {
+        set_error("Attention failed: sliding window is not supported by the HIP backend");
+        return -3;
+    }
+    if ((uint64_t)B * Hq * Sq * D >= (1ull << 40) || Sq >= (1u << 30) || Sk >= (1u << 30)) {
+        set_error("Attention failed: problem too large");
+        return -3;
+    }
+    return 0;
+}
+
+static float resolve_scale(float scale, uint32_t D) {
+    if (scale == 0.0f || std::isnan(scale)) return 1.0f / std::sqrt((float)D);
+    return scale;
+}
+
+int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) {
+        set_error("Library not initialized. Call aule_init() first.");
+        return -1;
+    }
+    if (d == nullptr || d->struct_size != sizeof(aule_attn_desc)) {
+        set_error("Attention failed: bad descriptor (struct_size mismatch)");
+        return -3;
+    }
+    int rc = check_common(d->dtype, d->batch, d->heads_q, d->heads_kv, d->seq_q, d->seq_k, d->head_dim,
+                          d->window_size);
+    if (rc) return rc;
+    if ((uint64_t)d->batch * d->heads_q * d->seq_q == 0) return 0;  // empty output
+    if (d->seq_k == 0) {
+        set_error("Attention failed: empty key sequence");
+        return -3;
+    }
+    if (!d->q || !d->k || !d->v || !d->out) {
+        set_error("Attention failed: null tensor pointer");
+        return -3;
+    }
+    DeviceGuard g(d->device);
+    rc = ensure_configured();
+    if (rc) return rc;
+    FwdArgs a;
+    a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->out; a.lse = d->lse;
+    a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv;
+    a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
+    a.scale = resolve_scale(d->scale, d->head_dim);
+    a.causal = d->causal != 0;
+    a.dtype = d->dtype;
+    rc = aule_hip::launch_fwd(a, (hipStream_t)d->stream);
+    if (rc != 0) {
+        set_error("Attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");
+        return -4;
+    }
+    return 0;
+}
+
+uint64_t aule_attention_backward_workspace_size(const aule_attn_bwd_desc* d) {
+    if (d == nullptr) return 0;
+    return aule_hip::bwd_workspace_bytes((int)d->batch, (int)d->heads_q, (int)d->seq_q);
+}
+
+int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) {
+        set_error("Library not initialized. Call aule_init() first.");
+        return -1;
+    }
+    if (d == nullptr || d->struct_size != sizeof(aule_attn_bwd_desc)) {
+        set_error("Backward failed: bad descriptor (struct_size mismatch)");
+        return -3;
+    }
+    int rc = check_common(d->dtype, d->batch, d->heads_q, d->heads_kv, d->seq_q, d->seq_k, d->head_dim,
+                          d->window_size);
+    if (rc) return rc;
+    if ((uint64_t)d->batch * d->heads_q * d->seq_q == 0 && (uint64_t)d->batch * d->heads_kv * d->seq_k == 0)
+        return 0;
+    if (d->seq_k == 0 || d->seq_q == 0) {
+        set_error("Backward failed: empty sequence");
+        return -3;
+    }
+    if (!d->q || !d->k || !d->v || !d->out || !d->dout || !d->lse || !d->dq || !d->dk || !d->dv) {
+        set_error("Backward failed: null tensor pointer");
+        return -3;
+    }
+    const uint64_t need = aule_hip::bwd_workspace_bytes((int)d->batch, (int)d->heads_q, (int)d->seq_q);
+    if (!d->workspace || d->workspace_bytes < need) {
+        set_error("Backward failed: workspace too small (%llu < %llu bytes)",
+                  (unsigned long long)d->workspace_bytes, (unsigned long long)need);
+        return -3;
+    }
+    DeviceGuard g(d->device);
+    rc = ensure_configured();
+    if (rc) return rc;
+    BwdArgs a;
+    a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->out; a.dout = d->dout; a.lse = d->lse;
+    a.dq = d->dq; a.dk = d->dk; a.dv = d->dv; a.delta = (float*)d->workspace;
+    a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv;
+    a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
+    a.scale = resolve_scale(d->scale, d->head_dim);
+    a.causal = d->causal != 0;
+    a.dtype = d->dtype;
+    rc = aule_hip::launch_bwd(a, (hipStream_t)d->stream);
+    if (rc != 0) {
+        set_error("Backward failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");
+        return -4;
+    }
+    return 0;
+}
+
+const char* aule_hip_build_info(void) { return "aule-hip gfx950 abi1"; }
+
+}  // extern "C"

@@ -1,0 +1,328 @@
+// fa_bwd_f32.hip -- fp32 FlashAttention backward for gfx950 (exact-f32 MFMA).
+//
+// Arithmetic behind the legacy aule_attention_backward (src/lib.zig:639-762 ->
+// src/attention_backward_pipeline.zig:472-537 -> shaders/attention_backward_f32.comp)
+// and behind autograd for fp32 tensors.  Same three-launch structure as the 16-bit
+// backward (fa_bwd_gfx950.hip): delta, dQ (lane owns a query row), dK/dV (lane owns a
+// key row, GQA group reduced by looping the group's query heads).  All tile products use
+// v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate).
+//
+// MFMA 32x32x2 operand map: A[i = lane&31][k = lane>>5], B[k = lane>>5][n = lane&31];
+// step r of a P/dS product contracts the row pair {crow(r,0), crow(r,1)} = {x, x+4},
+// which is exactly what accumulator register r of the two lane halves holds.
+#include "fa_device.h"
+#include "fa_kernels.h"
+
+namespace aule_hip {
+
+int launch_delta_f32(const BwdArgs& a, hipStream_t stream);  // fa_bwd_gfx950.hip
+
+namespace {
+
+struct BwdF32Params {
+    const float* q;
+    const float* k;
+    const float* v;
+    const float* dout;
+    const float* lse;
+    const float* delta;
+    float* dq;
+    float* dk;
+    float* dv;
+    int B, Hq, Hkv, Sq, Sk;
+    float c;      // scale * log2(e)
+    float scale;
+    int nblk;
+};
+
+constexpr int kRows = 128;  // rows per workgroup (4 waves x 32)
+constexpr int kTile = 32;
+
+// Stage a [32 x D] fp32 tile whose rows start at `row0` (clamped to nrows-1) into
+//   tr  : [D][32]  (element (r, d) at tr[d*32 + r])      -- A operand of X . Y^T products
+//   rm  : [32][D]  row-major                              -- A operand of X^T . P products
+// Either destination may be null.
+template <int D>
+__device__ __forceinline__ void stage_tile(const float* __restrict__ g, int row0, int nrows, float* tr, float* rm,
+                                           int tid) {
+    constexpr int C4 = D / 4, NCH = kTile * C4 / 256;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int cidx = tid + 256 * i;
+        if (tr != nullptr) {
+            const int rr = cidx & 31, dc = cidx >> 5;
+            int r = row0 + rr;
+            r = r < nrows ? r : nrows - 1;
+            const f32x4_t x = *reinterpret_cast<const f32x4_t*>(g + (size_t)r * D + 4 * dc);
+            tr[(4 * dc + 0) * 32 + rr] = x[0];
+            tr[(4 * dc + 1) * 32 + rr] = x[1];
+            tr[(4 * dc + 2) * 32 + rr] = x[2];
+            tr[(4 * dc + 3) * 32 + rr] = x[3];
+        }
+        if (rm != nullptr) {
+            const int rr = cidx / C4, cc = cidx % C4;
+            int r = row0 + rr;
+            r = r < nrows ? r : nrows - 1;
+            *reinterpret_cast<f32x4_t*>(&rm[rr * D + 4 * cc]) =
+                *reinterpret_cast<const f32x4_t*>(g + (size_t)r * D + 4 * cc);
+        }
+    }
+}
+
+// lane (row, hi) loads row[2s + hi] for s = 0..D/2-1 (B operand of the 32x32x2 MFMA)
+template <int D>
+__device__ __forceinline__ void load_b_operand(const float* rowp, int hi, float (&f)[D / 2]) {
+#pragma unroll
+    for (int s4 = 0; s4 < D / 4; ++s4) {
+        const f32x4_t x = *reinterpret_cast<const f32x4_t*>(rowp + 4 * s4);
+        f[2 * s4] = hi ? x[1] : x[0];
+        f[2 * s4 + 1] = hi ? x[3] : x[2];
+    }
+}
+
+template <int D, bool CAUSAL>
+__global__ void __launch_bounds__(256) fa_bwd_dq_f32_kernel(const BwdF32Params p) {
+    constexpr int DB = D / 32;
+    __shared__ __attribute__((aligned(16))) float Kt[D * 32];
+    __shared__ __attribute__((aligned(16))) float Krm[kTile * D];
+    __shared__ __attribute__((aligned(16))) float Vt[D * 32];
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WorkItem w = decode_work(blockIdx.x, p.B, p.Hq, p.Hkv, p.nblk, CAUSAL);
+    const int Sq = p.Sq, Sk = p.Sk;
+    const int q0w = w.blk * kRows + wave * 32;
+    const int qrow = q0w + l31;
+    const int qr = qrow < Sq ? qrow : Sq - 1;
+    const size_t qbase = (size_t)(w.b * p.Hq + w.h) * Sq;
+    const float* __restrict__ kg = p.k + (size_t)(w.b * p.Hkv + w.hk) * Sk * D;
+    const float* __restrict__ vg = p.v + (size_t)(w.b * p.Hkv + w.hk) * Sk * D;
+
+    float qf[D / 2], dof[D / 2];
+    load_b_operand<D>(p.q + (qbase + qr) * D, hi, qf);
+    load_b_operand<D>(p.dout + (qbase + qr) * D, hi, dof);
+    const float lse2 = p.lse[qbase + qr] * kLog2e;
+    const float delta = p.delta[qbase + qr];
+    const float c = p.c;
+
+    f32x16_t acc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+    const int kv_hi = CAUSAL ? min(Sk, w.blk * kRows + kRows) : Sk;
+    const int nt = (kv_hi + kTile - 1) / kTile;
+    const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32) : Sk;
+
+    for (int t = 0; t < nt; ++t) {
+        const int kv0 = t * kTile;
+        stage_tile<D>(kg, kv0, Sk, Kt, Krm, tid);
+        stage_tile<D>(vg, kv0, Sk, Vt, nullptr, tid);
+        __syncthreads();
+        if (kv0 < wave_kv_hi) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < D / 2; ++st) {
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[(2 * st + hi) * 32 + l31], qf[st], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[(2 * st + hi) * 32 + l31], dof[st], dp, 0, 0, 0);
+            }
+            const bool need_mask = (CAUSAL && (kv0 + kTile - 1 > q0w)) || (kv0 + kTile > Sk);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = fast_exp2(__builtin_fmaf(s[r], c, -lse2));
+                if (need_mask) {
+                    const int kv = kv0 + crow(r, hi);
+                    const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow);
+                    pv = vis ? pv : 0.f;
+                }
+                s[r] = pv * (dp[r] - delta);  // dS^T (scale applied in the epilogue)
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kvr = crow(r, hi);
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(Krm[kvr * D + 32 * d + l31], s[r], acc[d], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    if (qrow < Sq) {
+        float* orow = p.dq + (qbase + qrow) * D;
+        const float sc = p.scale;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4_t x = {acc[d][4 * g4] * sc, acc[d][4 * g4 + 1] * sc, acc[d][4 * g4 + 2] * sc,
+                             acc[d][4 * g4 + 3] * sc};
+                *reinterpret_cast<f32x4_t*>(orow + 32 * d + 8 * g4 + 4 * hi) = x;
+            }
+    }
+}
+
+template <int D>
+struct DkvF32Cfg {
+    static constexpr int IMG = kTile * D;              // floats per image
+    static constexpr int LDS = (4 * IMG + 64) * 4;     // Qt, Qrm, dOt, dOrm, scal[64]
+};
+
+template <int D, bool CAUSAL>
+__global__ void __launch_bounds__(256) fa_bwd_dkdv_f32_kernel(const BwdF32Params p) {
+    constexpr int DB = D / 32, IMG = DkvF32Cfg<D>::IMG;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* const Qt = reinterpret_cast<float*>(smem_raw);
+    float* const Qrm = Qt + IMG;
+    float* const Gt = Qrm + IMG;
+    float* const Grm = Gt + IMG;
+    float* const scal = Grm + IMG;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = p.Hq / p.Hkv;
+    const WorkItem w = decode_work(blockIdx.x, p.B, p.Hkv, p.Hkv, p.nblk, false);
+    const int Sq = p.Sq, Sk = p.Sk;
+    const int n0w = w.blk * kRows + wave * 32;
+    const int kvrow = n0w + l31;
+    const int kvr = kvrow < Sk ? kvrow : Sk - 1;
+    const size_t kvbase = (size_t)(w.b * p.Hkv + w.hk) * Sk;
+
+    float kf[D / 2], vf[D / 2];
+    load_b_operand<D>(p.k + (kvbase + kvr) * D, hi, kf);
+    load_b_operand<D>(p.v + (kvbase + kvr) * D, hi, vf);
+    const float c = p.c;
+
+    f32x16_t dk[DB], dv[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+
+    const int ntq_all = (Sq + kTile - 1) / kTile;
+    const int first_qt = CAUSAL ? (w.blk * kRows) / kTile : 0;
+
+    for (int hh = 0; hh < g; ++hh) {
+        const size_t qb = (size_t)(w.b * p.Hq + w.hk * g + hh) * Sq;
+        for (int qt = first_qt; qt < ntq_all; ++qt) {
+            const int q0 = qt * kTile;
+            stage_tile<D>(p.q + qb * D, q0, Sq, Qt, Qrm, tid);
+            stage_tile<D>(p.dout + qb * D, q0, Sq, Gt, Grm, tid);
+            if (tid < 64) {
+                int r = q0 + (tid & 31);
+                r = r < Sq ? r : Sq - 1;
+                scal[tid] = tid < 32 ? p.lse[qb + r] * kLog2e : p.delta[qb + r];
+            }
+            __syncthreads();
+            if (!CAUSAL || q0 + kTile - 1 >= n0w) {
+                f32x16_t s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int st = 0; st < D / 2; ++st) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(Qt[(2 * st + hi) * 32 + l31], kf[st], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Gt[(2 * st + hi) * 32 + l31], vf[st], dp, 0, 0, 0);
+                }
+                const bool need_mask = (CAUSAL && (q0 < n0w + 31)) || (q0 + kTile > Sq) || (n0w + 32 > Sk);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = crow(r, hi);
+                    float pv = fast_exp2(__builtin_fmaf(s[r], c, -scal[ql]));
+                    if (need_mask) {
+                        const int q = q0 + ql;
+                        const bool vis = (q < Sq) && (kvrow < Sk) && (!CAUSAL || kvrow <= q);
+                        pv = vis ? pv : 0.f;
+                    }
+                    s[r] = pv;                              // P
+                    dp[r] = pv * (dp[r] - scal[32 + ql]);   // dS (unscaled)
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = crow(r, hi);
+#pragma unroll
+                    for (int d = 0; d < DB; ++d) {
+                        dv[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(Grm[ql * D + 32 * d + l31], s[r], dv[d], 0, 0, 0);
+                        dk[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qrm[ql * D + 32 * d + l31], dp[r], dk[d], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    if (kvrow < Sk) {
+        float* krow = p.dk + (kvbase + kvrow) * D;
+        float* vrow = p.dv + (kvbase + kvrow) * D;
+        const float sc = p.scale;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int de = 32 * d + 8 * g4 + 4 * hi;
+                f32x4_t x = {dk[d][4 * g4] * sc, dk[d][4 * g4 + 1] * sc, dk[d][4 * g4 + 2] * sc,
+                             dk[d][4 * g4 + 3] * sc};
+                f32x4_t y = {dv[d][4 * g4], dv[d][4 * g4 + 1], dv[d][4 * g4 + 2], dv[d][4 * g4 + 3]};
+                *reinterpret_cast<f32x4_t*>(krow + de) = x;
+                *reinterpret_cast<f32x4_t*>(vrow + de) = y;
+            }
+    }
+}
+
+template <int D>
+int launch_bwd_f32_d(const BwdArgs& a, hipStream_t stream) {
+    int rc = launch_delta_f32(a, stream);
+    if (rc) return rc;
+    BwdF32Params p;
+    p.q = (const float*)a.q; p.k = (const float*)a.k; p.v = (const float*)a.v;
+    p.dout = (const float*)a.dout; p.lse = a.lse; p.delta = a.delta;
+    p.dq = (float*)a.dq; p.dk = (float*)a.dk; p.dv = (float*)a.dv;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
+    p.c = a.scale * kLog2e;
+    p.scale = a.scale;
+    const dim3 block(256);
+    {
+        p.nblk = (a.Sq + kRows - 1) / kRows;
+        const dim3 grid((unsigned)(p.nblk * a.B * a.Hq));
+        if (a.causal)
+            hipLaunchKernelGGL((fa_bwd_dq_f32_kernel<D, true>), grid, block, 0, stream, p);
+        else
+            hipLaunchKernelGGL((fa_bwd_dq_f32_kernel<D, false>), grid, block, 0, stream, p);
+        rc = (int)hipGetLastError();
+        if (rc) return rc;
+    }
+    {
+        p.nblk = (a.Sk + kRows - 1) / kRows;
+        const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv));
+        const size_t lds = DkvF32Cfg<D>::LDS;
+        if (a.causal)
+            hipLaunchKernelGGL((fa_bwd_dkdv_f32_kernel<D, true>), grid, block, lds, stream, p);
+        else
+            hipLaunchKernelGGL((fa_bwd_dkdv_f32_kernel<D, false>), grid, block, lds, stream, p);
+        return (int)hipGetLastError();
+    }
+}
+
+template <int D>
+int set_attr_f32() {
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkdv_f32_kernel<D, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, DkvF32Cfg<D>::LDS);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkdv_f32_kernel<D, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, DkvF32Cfg<D>::LDS);
+    return rc;
+}
+
+}  // namespace
+
+int launch_bwd_f32(const BwdArgs& a, hipStream_t stream) {
+    if (a.D == 128) return launch_bwd_f32_d<128>(a, stream);
+    if (a.D == 64) return launch_bwd_f32_d<64>(a, stream);
+    if (a.D == 32) return launch_bwd_f32_d<32>(a, stream);
+    return -1;
+}
+
+int configure_bwd_f32() { return set_attr_f32<128>() | set_attr_f32<64>() | set_attr_f32<32>(); }
+
+}  // namespace aule_hip

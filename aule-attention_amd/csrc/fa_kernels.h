@@ -1,0 +1,59 @@
+// fa_kernels.h -- host-visible launch interface of the gfx950 attention kernels.
+//
+// Plain C++ (no torch, no HIP types beyond hipStream_t) so that aule_capi.cpp
+// can call the launchers.  Every launcher is asynchronous on `stream` and
+// returns a hipError_t-compatible int (0 = success).
+//
+// Tensor layout (row-major contiguous, as the reference's Triton path makes
+// them: python/aule/triton_flash_amd.py:404-407):
+//   Q, O, dO, dQ : [B, Hq,  Sq, D]      K, V, dK, dV : [B, Hkv, Sk, D]
+//   LSE, delta   : [B, Hq, Sq] fp32
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace aule_hip {
+
+enum DType : int { kF32 = 0, kF16 = 1, kBF16 = 2 };
+
+struct FwdArgs {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* o;
+    float* lse;  // may be null
+    int B, Hq, Hkv, Sq, Sk, D;
+    float scale;  // softmax scale (already defaulted by the caller)
+    int causal;
+    int dtype;
+};
+
+struct BwdArgs {
+    const void* q;
+    const void* k;
+    const void* v;
+    const void* o;
+    const void* dout;
+    const float* lse;
+    void* dq;
+    void* dk;
+    void* dv;
+    float* delta;  // workspace [B,Hq,Sq] fp32
+    int B, Hq, Hkv, Sq, Sk, D;
+    float scale;
+    int causal;
+    int dtype;
+};
+
+// Returns 0 on success, a hipError_t value on launch failure, -1 for an
+// unsupported (dtype, D) combination.
+int launch_fwd(const FwdArgs& a, hipStream_t stream);
+int launch_bwd(const BwdArgs& a, hipStream_t stream);
+
+// Bytes of device workspace launch_bwd needs (delta).
+uint64_t bwd_workspace_bytes(int B, int Hq, int Sq);
+
+// Set the max-dynamic-LDS attribute on every kernel (call once per device).
+int configure_kernels();
+
+}  // namespace aule_hip

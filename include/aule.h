@@ -1,0 +1,169 @@
+/*
+ * include/aule.h -- C-ABI of libaule.so (MI355X / gfx950 HIP build).
+ *
+ * Drop-in boundary for the FlashAttention forward/backward hot path of
+ * AuleTechnologies/Aule-Attention.  Every legacy symbol below has the exact
+ * name, argument order, scalar widths and return-code convention of the
+ * reference export it replaces (reference file:line cited per symbol; the
+ * authoritative consumer-side declarations are the ctypes signatures in
+ * python/aule/vulkan.py:224-406).  The "_ex" entry points at the bottom are
+ * ADDITIVE: they carry what the legacy ABI cannot express (bf16/fp16 storage,
+ * GQA/MQA, Sq != Sk, user scale, device pointers, streams).
+ *
+ * Calling convention: C.  No torch / C++ types cross this boundary.
+ * Errors: negative int32 return + text from aule_get_error().
+ * Threading: all entry points are serialised by one internal mutex (superset of
+ * the reference contract, which has no locking: src/lib.zig:12-22).
+ * Legacy compute calls are synchronous (device idle on return), like the
+ * reference (src/attention_pipeline.zig:389-390, src/attention_gpu.zig:467-468).
+ * "_ex" calls are asynchronous on the caller's HIP stream.
+ */
+#ifndef AULE_H
+#define AULE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AULE_MAX_TENSORS 1024u /* src/lib.zig:17 MAX_TENSORS */
+
+/* ---- lifecycle / info ---------------------------------------------------- */
+int32_t aule_init(void);                     /* src/lib.zig:59   0 ok (idempotent), -1 + error text */
+void aule_shutdown(void);                    /* src/lib.zig:105  destroys all tensors + context */
+const char* aule_get_error(void);            /* src/lib.zig:124  static 512-B buffer, "No error" if none */
+const char* aule_get_backend_name(void);     /* src/lib.zig:133  "HIP/ROCm" | "Not initialized" (backend.zig:496-502) */
+int32_t aule_get_vendor(void);               /* src/lib.zig:144  1 = amd; -1 uninitialised */
+int32_t aule_get_gpu_vendor(void);           /* src/lib.zig:274  same table */
+int32_t aule_is_amd_optimized(void);         /* src/lib.zig:168  1 / -1 */
+int32_t aule_has_fp16(void);                 /* src/lib.zig:184  1 / -1 */
+int32_t aule_get_subgroup_size(void);        /* src/lib.zig:296  64 (wavefront) / -1 */
+int32_t aule_get_device_name(uint8_t* buffer, uint32_t buffer_len); /* src/lib.zig:242 bytes copied (NUL-terminated, truncated) / -1 */
+int32_t aule_set_shader_variant(uint8_t variant); /* src/lib.zig:202  0, -1 uninit, -2 unavailable (only variant 0 exists here) */
+int32_t aule_get_shader_variant(void);            /* src/lib.zig:215 */
+int32_t aule_has_shader_variant(uint8_t variant); /* src/lib.zig:226  1/0/-1 */
+int32_t aule_supports_backward(void);        /* src/lib.zig:96   1 */
+
+/* ---- host-pointer forward (MHA, Sq == Sk, fp32, scale = 1/sqrt(D)) -------- */
+/* src/lib.zig:312-367.  0; -1 uninit; -2 alloc; -3 upload; -4 compute; -5 download */
+int32_t aule_attention_forward(const float* query, const float* key, const float* value, float* output,
+                               uint32_t batch_size, uint32_t num_heads, uint32_t seq_len,
+                               uint32_t head_dim, int32_t causal);
+
+/* ---- persistent device tensors (1-based slot handles, 0 = failure) -------- */
+typedef uint64_t aule_tensor_handle;
+aule_tensor_handle aule_tensor_create(uint32_t batch_size, uint32_t num_heads, uint32_t seq_len,
+                                      uint32_t head_dim);      /* src/lib.zig:409 */
+aule_tensor_handle aule_tensor_create_u32(uint32_t batch_size, uint32_t num_heads, uint32_t seq_len,
+                                          uint32_t head_dim);  /* src/lib.zig:432 (aliases fp32 storage) */
+void aule_tensor_destroy(aule_tensor_handle handle);           /* src/lib.zig:444 ignores 0 / out of range */
+int32_t aule_tensor_upload(aule_tensor_handle handle, const float* data, uint32_t count);     /* :457  0; -1 bad handle; -3 size mismatch */
+int32_t aule_tensor_download(aule_tensor_handle handle, float* output, uint32_t count);       /* :469 */
+int32_t aule_tensor_download_u32(aule_tensor_handle handle, uint32_t* output, uint32_t count);/* :481 */
+uint32_t aule_tensor_size(aule_tensor_handle handle);          /* src/lib.zig:626 element count, 0 if invalid */
+uint32_t aule_tensor_count(void);                              /* src/lib.zig:383 */
+uint32_t aule_tensor_max(void);                                /* src/lib.zig:392 */
+void aule_tensor_clear_all(void);                              /* src/lib.zig:397 */
+
+/* ---- handle-based forward: GQA (Hkv from K's shape), cross-attn, causal ---- */
+/* src/lib.zig:496-529 -> backend.zig:318-370 -> attention_gpu.zig:360-453.     */
+/* rot_cos/rot_sin handles must be 0 and window_size must be <= 0 (RoPE /      */
+/* sliding window are "next" rows): otherwise -3 + error text.   */
+int32_t aule_attention_forward_gpu(aule_tensor_handle q, aule_tensor_handle k, aule_tensor_handle v,
+                                   aule_tensor_handle output, aule_tensor_handle rot_cos,
+                                   aule_tensor_handle rot_sin, int32_t causal, int32_t window_size);
+
+/* ---- training path (host pointers, MHA, Sq == Sk, fp32) -------------------- */
+/* src/lib.zig:765-852: O and LSE[B,H,S] = m + ln(l) of the scaled scores.      */
+int32_t aule_attention_forward_with_lse(const float* query, const float* key, const float* value,
+                                        float* output, float* lse, uint32_t batch_size,
+                                        uint32_t num_heads, uint32_t seq_len, uint32_t head_dim,
+                                        int32_t causal);
+/* src/lib.zig:639-762: dQ,dK,dV from Q,K,V,O,dO,LSE.                           */
+int32_t aule_attention_backward(const float* query, const float* key, const float* value,
+                                const float* output, const float* grad_output, const float* lse,
+                                float* grad_query, float* grad_key, float* grad_value,
+                                uint32_t batch_size, uint32_t num_heads, uint32_t seq_len,
+                                uint32_t head_dim, int32_t causal);
+
+/* ---- out-of-scope features: exported so that ctypes attribute lookup in the  */
+/* reference binding (vulkan.py:300-316) keeps working; they return -3.        */
+int32_t aule_attention_forward_paged(aule_tensor_handle q, aule_tensor_handle k, aule_tensor_handle v,
+                                     aule_tensor_handle output, aule_tensor_handle rot_cos,
+                                     aule_tensor_handle rot_sin, int32_t causal,
+                                     int32_t window_size);                    /* src/lib.zig:533 */
+int32_t aule_spatial_sort(aule_tensor_handle keys, aule_tensor_handle values,
+                          aule_tensor_handle indices, uint32_t sort_dim);     /* src/lib.zig:568 */
+int32_t aule_attention_forward_gravity(aule_tensor_handle q, aule_tensor_handle k, aule_tensor_handle v,
+                                       aule_tensor_handle output, aule_tensor_handle rot_cos,
+                                       aule_tensor_handle rot_sin, aule_tensor_handle indices,
+                                       int32_t causal, uint32_t max_attend,
+                                       int32_t window_size);                  /* src/lib.zig:587 */
+
+/* ========================================================================== */
+/* Additive entry points (no reference counterpart; they are what the Python   */
+/* surface aule.flash_attention binds for torch/ROCm tensors, replacing the    */
+/* Triton launch at python/aule/triton_flash_amd.py:393-500).                 */
+/* ========================================================================== */
+typedef enum aule_dtype {
+    AULE_DTYPE_F32 = 0,  /* fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32) */
+    AULE_DTYPE_F16 = 1,  /* fp16 storage, fp16 MFMA, fp32 accumulate/softmax */
+    AULE_DTYPE_BF16 = 2  /* bf16 storage, bf16 MFMA, fp32 accumulate/softmax */
+} aule_dtype;
+
+/* All tensors row-major contiguous: Q,O,dO,dQ [B,Hq,Sq,D]; K,V,dK,dV [B,Hkv,Sk,D];
+ * LSE [B,Hq,Sq] fp32.  Pointers are DEVICE pointers on `device`.
+ * head_dim in {32, 64, 128}; heads_q % heads_kv == 0; causal mask is top-left
+ * aligned (query i sees keys j <= i), as in every reference implementation. */
+typedef struct aule_attn_desc {
+    uint32_t struct_size;  /* = sizeof(aule_attn_desc) */
+    int32_t dtype;         /* aule_dtype */
+    uint32_t batch, heads_q, heads_kv, seq_q, seq_k, head_dim;
+    float scale;           /* softmax scale; 0 or NaN => 1/sqrt(head_dim) */
+    int32_t causal;
+    int32_t window_size;   /* must be <= 0 (full attention) */
+    int32_t device;        /* HIP device ordinal; -1 = current device */
+    void* stream;          /* hipStream_t; NULL = default stream */
+    const void* q;
+    const void* k;
+    const void* v;
+    void* out;
+    float* lse;            /* optional (NULL to skip) */
+} aule_attn_desc;
+
+typedef struct aule_attn_bwd_desc {
+    uint32_t struct_size;  /* = sizeof(aule_attn_bwd_desc) */
+    int32_t dtype;
+    uint32_t batch, heads_q, heads_kv, seq_q, seq_k, head_dim;
+    float scale;
+    int32_t causal;
+    int32_t window_size;
+    int32_t device;
+    void* stream;
+    const void* q;
+    const void* k;
+    const void* v;
+    const void* out;
+    const void* dout;
+    const float* lse;
+    void* dq;
+    void* dk;
+    void* dv;
+    void* workspace;       /* >= aule_attention_backward_workspace_size() bytes, device memory */
+    uint64_t workspace_bytes;
+} aule_attn_bwd_desc;
+
+/* 0 ok; -1 uninitialised; -3 invalid/unsupported arguments; -4 launch failure. Asynchronous. */
+int32_t aule_attention_forward_ex(const aule_attn_desc* desc);
+int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* desc);
+uint64_t aule_attention_backward_workspace_size(const aule_attn_bwd_desc* desc);
+
+/* Build/ABI identification: "aule-hip gfx950 <abi>" */
+const char* aule_hip_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AULE_H */

@@ -1,0 +1,300 @@
+/*
+ * oracle/attention_oracle.c -- CPU restatement of the reference attention path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under aule-attention_amd/ may link, import
+ * or call this file.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and there only as the checker (never as the thing
+ * measured as the product, never shipped).
+ *
+ * What is restated (paths relative to the reference tree):
+ *   - src/attention_ref.zig:18-93    AttentionRef.forward        -> oracle_ref_forward
+ *   - src/attention_ref.zig:97-171   AttentionRef.forwardCausal  -> oracle_ref_forward_causal
+ *   - src/backends/backend.zig:506-569 cpuAttention (2-pass, non-causal, MHA)
+ *                                                                 -> oracle_backend_cpu_attention
+ *   - SURVEY.md Appendix B numerics contract (distilled from
+ *     python/aule/triton_flash_amd.py:97-240 fwd, :247-351 bwd,
+ *     shaders/attention_forward_f32.comp:184-187 LSE,
+ *     shaders/attention_backward_f32.comp:143-233 bwd)           -> oracle_fwd_f64 / oracle_bwd_f64
+ *
+ * The reference's Zig sources cannot be compiled in this image (no zig
+ * toolchain), so this is a restatement, pinned by the reference's own
+ * known-answer tests (attention_ref.zig:250-298, tests/test_attention.zig:158-384)
+ * in tests/test_oracle.py, and by golden vectors generated from the reference's
+ * Python (NumPy fallback + Triton kernels under TRITON_INTERPRET=1) in
+ * tests/golden/ (generator: tests/golden/gen_golden.py).
+ *
+ * Conventions: Q [B,Hq,Sq,D], K/V [B,Hkv,Sk,D], O [B,Hq,Sq,D], LSE [B,Hq,Sq],
+ * all row-major contiguous float32 storage.  Causal masking is TOP-LEFT aligned
+ * (query i sees keys j <= i), GQA map kv_head = q_head / (Hq/Hkv).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* attention_ref.zig:18-93 -- 3-pass fp32, sequential sums in index order.    */
+static int ref_forward_impl(const float* Q, const float* K, const float* V, float* out,
+                            size_t B, size_t H, size_t S, size_t D, int causal) {
+    const float scale = 1.0f / sqrtf((float)D);            /* attention_ref.zig:29 */
+    float* scores = (float*)malloc(sizeof(float) * S * S); /* :32 */
+    if (!scores) return -1;
+    for (size_t b = 0; b < B; ++b) {
+        for (size_t h = 0; h < H; ++h) {
+            const size_t base = (b * H + h) * S * D;       /* :38 */
+            for (size_t i = 0; i < S; ++i) {               /* :42-53 / :114-129 */
+                for (size_t j = 0; j < S; ++j) {
+                    if (causal && j > i) {
+                        scores[i * S + j] = -INFINITY;     /* :120-122 */
+                    } else {
+                        float dot = 0.0f;
+                        for (size_t d = 0; d < D; ++d)
+                            dot += Q[base + i * D + d] * K[base + j * D + d];
+                        scores[i * S + j] = dot * scale;
+                    }
+                }
+            }
+            for (size_t i = 0; i < S; ++i) {               /* :56-78 */
+                float* row = scores + i * S;
+                float row_max = -INFINITY;
+                for (size_t j = 0; j < S; ++j) row_max = row[j] > row_max ? row[j] : row_max;
+                float row_sum = 0.0f;
+                for (size_t j = 0; j < S; ++j) {
+                    const float e = expf(row[j] - row_max);
+                    row[j] = e;
+                    row_sum += e;
+                }
+                const float inv = 1.0f / row_sum;
+                for (size_t j = 0; j < S; ++j) row[j] *= inv;
+            }
+            for (size_t i = 0; i < S; ++i) {               /* :81-90 */
+                for (size_t d = 0; d < D; ++d) {
+                    float acc = 0.0f;
+                    for (size_t j = 0; j < S; ++j) acc += scores[i * S + j] * V[base + j * D + d];
+                    out[base + i * D + d] = acc;
+                }
+            }
+        }
+    }
+    free(scores);
+    return 0;
+}
+
+int oracle_ref_forward(const float* Q, const float* K, const float* V, float* out,
+                       uint32_t B, uint32_t H, uint32_t S, uint32_t D) {
+    return ref_forward_impl(Q, K, V, out, B, H, S, D, 0);
+}
+
+int oracle_ref_forward_causal(const float* Q, const float* K, const float* V, float* out,
+                              uint32_t B, uint32_t H, uint32_t S, uint32_t D) {
+    return ref_forward_impl(Q, K, V, out, B, H, S, D, 1);
+}
+
+/* attention_ref.zig:185-206 */
+float oracle_max_abs_diff(const float* a, const float* b, size_t n) {
+    float m = 0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        const float d = fabsf(a[i] - b[i]);
+        if (d > m) m = d;
+    }
+    return m;
+}
+
+float oracle_mean_abs_diff(const float* a, const float* b, size_t n) {
+    if (n == 0) return INFINITY;
+    float s = 0.0f;
+    for (size_t i = 0; i < n; ++i) s += fabsf(a[i] - b[i]);
+    return s / (float)n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* backend.zig:506-569 cpuAttention -- the C-ABI's own CPU fallback: 2-pass     */
+/* (scores+max, then exp/sum/accumulate), NON-causal, MHA only.                */
+int oracle_backend_cpu_attention(const float* Q, const float* K, const float* V, float* out,
+                                 uint32_t B, uint32_t H, uint32_t S, uint32_t D) {
+    const float scale = 1.0f / sqrtf((float)D);
+    float* scores = (float*)malloc(sizeof(float) * (size_t)S);
+    if (!scores) return -1;
+    for (size_t b = 0; b < B; ++b)
+        for (size_t h = 0; h < H; ++h) {
+            const size_t base = (b * H + h) * (size_t)S * D;
+            for (size_t i = 0; i < S; ++i) {
+                float mx = -INFINITY;
+                for (size_t j = 0; j < S; ++j) {
+                    float dot = 0.0f;
+                    for (size_t d = 0; d < D; ++d) dot += Q[base + i * D + d] * K[base + j * D + d];
+                    scores[j] = dot * scale;
+                    if (scores[j] > mx) mx = scores[j];
+                }
+                float sum = 0.0f;
+                for (size_t j = 0; j < S; ++j) {
+                    scores[j] = expf(scores[j] - mx);
+                    sum += scores[j];
+                }
+                for (size_t d = 0; d < D; ++d) {
+                    float acc = 0.0f;
+                    for (size_t j = 0; j < S; ++j) acc += scores[j] * V[base + j * D + d];
+                    out[base + i * D + d] = acc / sum;
+                }
+            }
+        }
+    free(scores);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* High-precision judge: float32 storage, float64 arithmetic.                 */
+/* Forward per SURVEY Appendix B:                                             */
+/*   s_ij = scale * sum_d q_id k_jd ; vis(i,j) = !causal || j <= i            */
+/*   m_i = max_vis s_ij ; l_i = sum_vis exp(s_ij - m_i)                       */
+/*   O_i = sum_vis exp(s_ij - m_i) v_j / l_i ; LSE_i = m_i + ln l_i           */
+/* (triton_flash_amd.py:169-240, attention_forward_f32.comp:141-187)          */
+int oracle_fwd_f64(const float* Q, const float* K, const float* V, float* O, float* LSE,
+                   uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t D,
+                   double scale, int causal) {
+    if (Hkv == 0 || Hq % Hkv != 0) return -2;
+    const uint32_t g = Hq / Hkv;                             /* triton_flash_amd.py:126-127 */
+    double* p = (double*)malloc(sizeof(double) * (size_t)Sk);
+    double* acc = (double*)malloc(sizeof(double) * (size_t)D);
+    if (!p || !acc) { free(p); free(acc); return -1; }
+    for (size_t b = 0; b < B; ++b)
+        for (size_t h = 0; h < Hq; ++h) {
+            const size_t hk = h / g;
+            const float* q = Q + (b * Hq + h) * (size_t)Sq * D;
+            const float* k = K + (b * Hkv + hk) * (size_t)Sk * D;
+            const float* v = V + (b * Hkv + hk) * (size_t)Sk * D;
+            float* o = O + (b * Hq + h) * (size_t)Sq * D;
+            for (size_t i = 0; i < Sq; ++i) {
+                size_t nvis = causal ? (i + 1 < Sk ? i + 1 : Sk) : Sk;
+                double m = -INFINITY;
+                for (size_t j = 0; j < nvis; ++j) {
+                    double dot = 0.0;
+                    for (size_t d = 0; d < D; ++d) dot += (double)q[i * D + d] * (double)k[j * D + d];
+                    p[j] = dot * scale;
+                    if (p[j] > m) m = p[j];
+                }
+                double l = 0.0;
+                for (size_t d = 0; d < D; ++d) acc[d] = 0.0;
+                for (size_t j = 0; j < nvis; ++j) {
+                    const double e = exp(p[j] - m);
+                    l += e;
+                    for (size_t d = 0; d < D; ++d) acc[d] += e * (double)v[j * D + d];
+                }
+                for (size_t d = 0; d < D; ++d) o[i * D + d] = (float)(acc[d] / l);
+                if (LSE) LSE[(b * Hq + h) * (size_t)Sq + i] = (float)(m + log(l));
+            }
+        }
+    free(p);
+    free(acc);
+    return 0;
+}
+
+/* Backward per SURVEY Appendix B (triton_flash.py:321-350,                    */
+/* attention_backward_f32.comp:143-233): the softmax is recomputed here in     */
+/* float64 from Q,K (not from a saved LSE), delta = rowsum(O*dO) with O also    */
+/* recomputed, so this is an independent judge of the whole fwd+bwd chain.      */
+int oracle_bwd_f64(const float* Q, const float* K, const float* V, const float* dO,
+                   float* dQ, float* dK, float* dV,
+                   uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t D,
+                   double scale, int causal) {
+    if (Hkv == 0 || Hq % Hkv != 0) return -2;
+    const uint32_t g = Hq / Hkv;
+    const size_t nk = (size_t)Sk * D;
+    double* p = (double*)malloc(sizeof(double) * (size_t)Sk);
+    double* dp = (double*)malloc(sizeof(double) * (size_t)Sk);
+    double* dq = (double*)malloc(sizeof(double) * (size_t)D);
+    double* dkacc = (double*)malloc(sizeof(double) * nk);
+    double* dvacc = (double*)malloc(sizeof(double) * nk);
+    if (!p || !dp || !dq || !dkacc || !dvacc) {
+        free(p); free(dp); free(dq); free(dkacc); free(dvacc);
+        return -1;
+    }
+    for (size_t b = 0; b < B; ++b)
+        for (size_t hk = 0; hk < Hkv; ++hk) {
+            const float* k = K + (b * Hkv + hk) * nk;
+            const float* v = V + (b * Hkv + hk) * nk;
+            for (size_t x = 0; x < nk; ++x) { dkacc[x] = 0.0; dvacc[x] = 0.0; }
+            for (size_t hh = 0; hh < g; ++hh) {              /* group reduction, triton_flash.py:345-350 */
+                const size_t h = hk * g + hh;
+                const float* q = Q + (b * Hq + h) * (size_t)Sq * D;
+                const float* go = dO + (b * Hq + h) * (size_t)Sq * D;
+                float* gq = dQ + (b * Hq + h) * (size_t)Sq * D;
+                for (size_t i = 0; i < Sq; ++i) {
+                    size_t nvis = causal ? (i + 1 < Sk ? i + 1 : Sk) : Sk;
+                    double m = -INFINITY;
+                    for (size_t j = 0; j < nvis; ++j) {
+                        double dot = 0.0;
+                        for (size_t d = 0; d < D; ++d) dot += (double)q[i * D + d] * (double)k[j * D + d];
+                        p[j] = dot * scale;
+                        if (p[j] > m) m = p[j];
+                    }
+                    double l = 0.0;
+                    for (size_t j = 0; j < nvis; ++j) { p[j] = exp(p[j] - m); l += p[j]; }
+                    double delta = 0.0;                      /* = sum_j p_ij dp_ij = rowsum(O*dO) */
+                    for (size_t j = 0; j < nvis; ++j) {
+                        p[j] /= l;
+                        double t = 0.0;
+                        for (size_t d = 0; d < D; ++d) t += (double)go[i * D + d] * (double)v[j * D + d];
+                        dp[j] = t;
+                        delta += p[j] * t;
+                    }
+                    for (size_t d = 0; d < D; ++d) dq[d] = 0.0;
+                    for (size_t j = 0; j < nvis; ++j) {
+                        const double ds = p[j] * (dp[j] - delta) * scale; /* triton_flash.py:330 */
+                        for (size_t d = 0; d < D; ++d) {
+                            dq[d] += ds * (double)k[j * D + d];                      /* :336 */
+                            dkacc[j * D + d] += ds * (double)q[i * D + d];           /* :333 */
+                            dvacc[j * D + d] += p[j] * (double)go[i * D + d];        /* :324 */
+                        }
+                    }
+                    for (size_t d = 0; d < D; ++d) gq[i * D + d] = (float)dq[d];
+                }
+            }
+            float* gk = dK + (b * Hkv + hk) * nk;
+            float* gv = dV + (b * Hkv + hk) * nk;
+            for (size_t x = 0; x < nk; ++x) { gk[x] = (float)dkacc[x]; gv[x] = (float)dvacc[x]; }
+        }
+    free(p); free(dp); free(dq); free(dkacc); free(dvacc);
+    return 0;
+}
+
+/* Sampled-row forward judge for full-size configs: computes O and LSE for      */
+/* `nrows` (b,h,i) triples given as flat row ids r = (b*Hq+h)*Sq+i.            */
+int oracle_fwd_rows_f64(const float* Q, const float* K, const float* V,
+                        const int64_t* rows, uint32_t nrows, float* Orows, float* LSErows,
+                        uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t D,
+                        double scale, int causal) {
+    (void)B;
+    if (Hkv == 0 || Hq % Hkv != 0) return -2;
+    const uint32_t g = Hq / Hkv;
+    double* p = (double*)malloc(sizeof(double) * (size_t)Sk);
+    double* acc = (double*)malloc(sizeof(double) * (size_t)D);
+    if (!p || !acc) { free(p); free(acc); return -1; }
+    for (uint32_t r = 0; r < nrows; ++r) {
+        const size_t flat = (size_t)rows[r];
+        const size_t i = flat % Sq, bh = flat / Sq, h = bh % Hq, b = bh / Hq, hk = h / g;
+        const float* q = Q + flat * D;
+        const float* k = K + (b * Hkv + hk) * (size_t)Sk * D;
+        const float* v = V + (b * Hkv + hk) * (size_t)Sk * D;
+        size_t nvis = causal ? (i + 1 < Sk ? i + 1 : Sk) : Sk;
+        double m = -INFINITY;
+        for (size_t j = 0; j < nvis; ++j) {
+            double dot = 0.0;
+            for (size_t d = 0; d < D; ++d) dot += (double)q[d] * (double)k[j * D + d];
+            p[j] = dot * scale;
+            if (p[j] > m) m = p[j];
+        }
+        double l = 0.0;
+        for (size_t d = 0; d < D; ++d) acc[d] = 0.0;
+        for (size_t j = 0; j < nvis; ++j) {
+            const double e = exp(p[j] - m);
+            l += e;
+            for (size_t d = 0; d < D; ++d) acc[d] += e * (double)v[j * D + d];
+        }
+        for (size_t d = 0; d < D; ++d) Orows[(size_t)r * D + d] = (float)(acc[d] / l);
+        if (LSErows) LSErows[r] = (float)(m + log(l));
+    }
+    free(p);
+    free(acc);
+    return 0;
+}
