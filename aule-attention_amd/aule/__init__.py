@@ -1,0 +1,159 @@
+"""aule (MI355X / gfx950 HIP build) -- drop-in for the hot path of aule-attention.
+
+Keeps the public surface of the reference's python/aule/__init__.py for the
+FlashAttention forward/backward path:
+
+    flash_attention(query, key, value, rot_cos=None, rot_sin=None, causal=True,
+                    scale=None, window_size=-1)                    (__init__.py:104)
+
+with the same positional order, defaults, validation (ValueError conditions of
+__init__.py:140-160) and container behaviour (torch in -> torch out on the same
+device/dtype and inside autograd; NumPy in -> NumPy out).  There is ONE backend:
+hand-written HIP kernels for gfx950 behind libaule.so.  No Triton, no Vulkan, no CPU
+fallback -- when the library or a HIP device is missing the call raises AuleError.
+
+Not carried over (out of scope): install()/SDPA shim, ComfyUI
+glue, paged/gravity/sort features, fused RoPE, sliding window.
+"""
+import logging
+import math
+import warnings
+
+from ._capi import AuleError
+
+__version__ = "0.5.0+hip.gfx950"
+logger = logging.getLogger(__name__)
+
+_verbose = False
+
+
+def _validate(query, key, value):
+    """Shape rules of the reference, same messages (__init__.py:140-160)."""
+    if query.ndim != 4:
+        raise ValueError(f"query must be 4D [batch, heads, seq_len, head_dim], got shape {query.shape}")
+    if key.ndim != 4:
+        raise ValueError(f"key must be 4D [batch, heads, seq_len, head_dim], got shape {key.shape}")
+    if value.ndim != 4:
+        raise ValueError(f"value must be 4D [batch, heads, seq_len, head_dim], got shape {value.shape}")
+    batch_q, heads_q, seq_q, head_dim_q = query.shape
+    batch_k, heads_kv, seq_k, head_dim_k = key.shape
+    batch_v, heads_v, seq_v, head_dim_v = value.shape
+    if batch_q != batch_k or batch_q != batch_v:
+        raise ValueError(f"Batch size mismatch: query={batch_q}, key={batch_k}, value={batch_v}")
+    if head_dim_q != head_dim_k or head_dim_q != head_dim_v:
+        raise ValueError(f"head_dim mismatch: query={head_dim_q}, key={head_dim_k}, value={head_dim_v}")
+    if seq_k != seq_v:
+        raise ValueError(f"Key/value seq_len mismatch: key={seq_k}, value={seq_v}")
+    if heads_kv != heads_v:
+        raise ValueError(f"Key/value heads mismatch: key={heads_kv}, value={heads_v}")
+    if heads_q % heads_kv != 0:
+        raise ValueError(f"heads_q ({heads_q}) must be divisible by heads_kv ({heads_kv}) for GQA")
+
+
+def _hip_device():
+    import torch
+    if not torch.cuda.is_available():
+        raise AuleError("aule (HIP build): no ROCm device visible to PyTorch; there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def flash_attention(query, key, value, rot_cos=None, rot_sin=None, causal=True, scale=None, window_size=-1):
+    """FlashAttention-2 on MI355X.
+
+    Args:
+        query: [batch, heads_q, seq_len_q, head_dim] torch.Tensor or numpy.ndarray
+        key, value: [batch, heads_kv, seq_len_k, head_dim]
+        rot_cos, rot_sin: accepted for signature compatibility; ignored with a warning
+            (the reference's ROCm route drops them too: __init__.py:204).
+        causal: top-left aligned causal mask (query i sees keys j <= i)
+        scale: softmax scale, default 1/sqrt(head_dim)
+        window_size: only -1 (full attention) is implemented
+
+    Returns: tensor/array shaped like `query`, same container type and dtype.
+    Raises: ValueError for invalid shapes; AuleError if the HIP backend is unavailable.
+    """
+    import numpy as np
+    try:
+        import torch
+        is_torch = isinstance(query, torch.Tensor)
+    except ImportError as e:  # torch is the device-memory plumbing of this build
+        raise AuleError("aule (HIP build) needs PyTorch-ROCm for device memory") from e
+
+    _validate(query, key, value)
+
+    if rot_cos is not None or rot_sin is not None:
+        warnings.warn("RoPE is not fused in the HIP backend, ignoring rot_cos/rot_sin", stacklevel=2)
+    if window_size is not None and window_size > 0:
+        raise NotImplementedError("sliding window attention is not implemented in the HIP backend "
+                                  "(SURVEY.md 8f row N1); pass window_size=-1")
+
+    from ._torch import flash_attention_hip
+
+    if _verbose:
+        print(f"aule-attention: hip | shape={tuple(query.shape)} | causal={causal}")
+
+    if is_torch:
+        if query.is_cuda:
+            if not (key.is_cuda and value.is_cuda):
+                raise ValueError("query, key and value must be on the same device")
+            return flash_attention_hip(query, key, value, causal=causal, scale=scale)
+        # CPU torch tensor: the reference round-trips through its device backend and
+        # returns a tensor on query.device (__init__.py:210-229); same here.
+        dev = _hip_device()
+        with torch.no_grad():
+            out = flash_attention_hip(query.to(dev), key.to(dev), value.to(dev), causal=causal, scale=scale)
+        return out.to(query.device)
+
+    # NumPy in -> NumPy out (dtype follows the input, like _cpu_attention: __init__.py:247-271)
+    dev = _hip_device()
+    in_dtype = query.dtype
+    comp = np.float16 if in_dtype == np.float16 else np.float32
+    tq = torch.from_numpy(np.ascontiguousarray(query, dtype=comp)).to(dev)
+    tk = torch.from_numpy(np.ascontiguousarray(key, dtype=comp)).to(dev)
+    tv = torch.from_numpy(np.ascontiguousarray(value, dtype=comp)).to(dev)
+    with torch.no_grad():
+        out = flash_attention_hip(tq, tk, tv, causal=causal, scale=scale)
+    out_np = out.cpu().numpy()
+    return out_np if out_np.dtype == in_dtype else out_np.astype(in_dtype)
+
+
+# Alias for compatibility (__init__.py:275)
+attention = flash_attention
+
+
+def get_available_backends():
+    """Reference API (__init__.py:445-457); this build has exactly one backend."""
+    from . import _capi
+    try:
+        _capi.get_lib()
+        return ["hip"]
+    except AuleError:
+        return []
+
+
+def get_backend_errors():
+    from . import _capi
+    try:
+        _capi.get_lib()
+        return {}
+    except AuleError as e:
+        return {"hip": str(e)}
+
+
+def get_backend_info():
+    from . import _capi
+    info = {"backends": get_available_backends(), "version": __version__}
+    if info["backends"]:
+        from .hip import Aule
+        info["hip"] = Aule().get_device_info()
+        info["library"] = _capi.library_path()
+    return info
+
+
+def set_verbose(flag=True):
+    global _verbose
+    _verbose = bool(flag)
+
+
+__all__ = ["flash_attention", "attention", "AuleError", "get_available_backends", "get_backend_errors",
+           "get_backend_info", "set_verbose", "__version__"]

@@ -1,0 +1,182 @@
+"""ctypes binding of libaule.so (include/aule.h) -- the HIP build of the Aule C-ABI.
+
+Counterpart of the reference's python/aule/vulkan.py:31-69 (library lookup) and
+:224-406 (signatures).  The shared object is built in-tree by
+aule-attention_amd/csrc/Makefile into <pkg>/lib/libaule.so, the first location the
+reference binding searches too (vulkan.py:31-69).
+
+There is no fallback: if the library is missing or no HIP device is visible,
+`load()` / `get_lib()` raise AuleError.
+"""
+import ctypes
+import os
+import threading
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_CANDIDATES = [
+    os.path.join(_PKG_DIR, "lib", "libaule.so"),
+]
+
+
+class AuleError(RuntimeError):
+    """Raised for any failure reported by libaule (name kept from vulkan.py)."""
+
+
+class AttnDesc(ctypes.Structure):
+    """struct aule_attn_desc (include/aule.h)."""
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("dtype", ctypes.c_int32),
+        ("batch", ctypes.c_uint32),
+        ("heads_q", ctypes.c_uint32),
+        ("heads_kv", ctypes.c_uint32),
+        ("seq_q", ctypes.c_uint32),
+        ("seq_k", ctypes.c_uint32),
+        ("head_dim", ctypes.c_uint32),
+        ("scale", ctypes.c_float),
+        ("causal", ctypes.c_int32),
+        ("window_size", ctypes.c_int32),
+        ("device", ctypes.c_int32),
+        ("stream", ctypes.c_void_p),
+        ("q", ctypes.c_void_p),
+        ("k", ctypes.c_void_p),
+        ("v", ctypes.c_void_p),
+        ("out", ctypes.c_void_p),
+        ("lse", ctypes.c_void_p),
+    ]
+
+
+class AttnBwdDesc(ctypes.Structure):
+    """struct aule_attn_bwd_desc (include/aule.h)."""
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("dtype", ctypes.c_int32),
+        ("batch", ctypes.c_uint32),
+        ("heads_q", ctypes.c_uint32),
+        ("heads_kv", ctypes.c_uint32),
+        ("seq_q", ctypes.c_uint32),
+        ("seq_k", ctypes.c_uint32),
+        ("head_dim", ctypes.c_uint32),
+        ("scale", ctypes.c_float),
+        ("causal", ctypes.c_int32),
+        ("window_size", ctypes.c_int32),
+        ("device", ctypes.c_int32),
+        ("stream", ctypes.c_void_p),
+        ("q", ctypes.c_void_p),
+        ("k", ctypes.c_void_p),
+        ("v", ctypes.c_void_p),
+        ("out", ctypes.c_void_p),
+        ("dout", ctypes.c_void_p),
+        ("lse", ctypes.c_void_p),
+        ("dq", ctypes.c_void_p),
+        ("dk", ctypes.c_void_p),
+        ("dv", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p),
+        ("workspace_bytes", ctypes.c_uint64),
+    ]
+
+
+DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
+
+# Every symbol include/aule.h declares: (name, restype, argtypes)
+_FP = ctypes.POINTER(ctypes.c_float)
+_U32, _I32, _U64, _U8 = ctypes.c_uint32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint8
+SIGNATURES = [
+    ("aule_init", _I32, []),
+    ("aule_shutdown", None, []),
+    ("aule_get_error", ctypes.c_char_p, []),
+    ("aule_get_backend_name", ctypes.c_char_p, []),
+    ("aule_get_vendor", _I32, []),
+    ("aule_get_gpu_vendor", _I32, []),
+    ("aule_is_amd_optimized", _I32, []),
+    ("aule_has_fp16", _I32, []),
+    ("aule_get_subgroup_size", _I32, []),
+    ("aule_get_device_name", _I32, [ctypes.c_char_p, _U32]),
+    ("aule_set_shader_variant", _I32, [_U8]),
+    ("aule_get_shader_variant", _I32, []),
+    ("aule_has_shader_variant", _I32, [_U8]),
+    ("aule_supports_backward", _I32, []),
+    ("aule_attention_forward", _I32, [_FP, _FP, _FP, _FP, _U32, _U32, _U32, _U32, _I32]),
+    ("aule_tensor_create", _U64, [_U32, _U32, _U32, _U32]),
+    ("aule_tensor_create_u32", _U64, [_U32, _U32, _U32, _U32]),
+    ("aule_tensor_destroy", None, [_U64]),
+    ("aule_tensor_upload", _I32, [_U64, _FP, _U32]),
+    ("aule_tensor_download", _I32, [_U64, _FP, _U32]),
+    ("aule_tensor_download_u32", _I32, [_U64, ctypes.POINTER(_U32), _U32]),
+    ("aule_tensor_size", _U32, [_U64]),
+    ("aule_tensor_count", _U32, []),
+    ("aule_tensor_max", _U32, []),
+    ("aule_tensor_clear_all", None, []),
+    ("aule_attention_forward_gpu", _I32, [_U64, _U64, _U64, _U64, _U64, _U64, _I32, _I32]),
+    ("aule_attention_forward_with_lse", _I32, [_FP, _FP, _FP, _FP, _FP, _U32, _U32, _U32, _U32, _I32]),
+    ("aule_attention_backward", _I32, [_FP] * 9 + [_U32, _U32, _U32, _U32, _I32]),
+    ("aule_attention_forward_paged", _I32, [_U64] * 6 + [_I32, _I32]),
+    ("aule_spatial_sort", _I32, [_U64, _U64, _U64, _U32]),
+    ("aule_attention_forward_gravity", _I32, [_U64] * 7 + [_I32, _U32, _I32]),
+    ("aule_attention_forward_ex", _I32, [ctypes.POINTER(AttnDesc)]),
+    ("aule_attention_backward_ex", _I32, [ctypes.POINTER(AttnBwdDesc)]),
+    ("aule_attention_backward_workspace_size", _U64, [ctypes.POINTER(AttnBwdDesc)]),
+    ("aule_hip_build_info", ctypes.c_char_p, []),
+]
+
+_lib = None
+_lib_path = None
+_initialized = False
+_lock = threading.Lock()
+
+
+def find_library():
+    """Path of libaule.so (AULE_LIBRARY_PATH override, then <pkg>/lib)."""
+    env = os.environ.get("AULE_LIBRARY_PATH")
+    cands = ([env] if env else []) + _LIB_CANDIDATES
+    for p in cands:
+        if p and os.path.exists(p):
+            return p
+    raise AuleError(
+        "libaule.so (HIP build) not found; build it with `make -C aule-attention_amd/csrc` "
+        "or `python -c 'import __graft_entry__ as g; g.build()'`. Searched: " + ", ".join(cands))
+
+
+def load():
+    """dlopen libaule.so and declare every signature. Does NOT need a GPU."""
+    global _lib, _lib_path
+    with _lock:
+        if _lib is None:
+            path = find_library()
+            lib = ctypes.CDLL(path)
+            for name, restype, argtypes in SIGNATURES:
+                fn = getattr(lib, name)  # AttributeError if the export is missing
+                fn.restype = restype
+                fn.argtypes = argtypes
+            _lib, _lib_path = lib, path
+    return _lib
+
+
+def library_path():
+    load()
+    return _lib_path
+
+
+def get_lib():
+    """Loaded AND initialised library (aule_init succeeded => a HIP device exists)."""
+    global _initialized
+    lib = load()
+    if not _initialized:
+        with _lock:
+            if not _initialized:
+                rc = lib.aule_init()
+                if rc != 0:
+                    raise AuleError("aule_init failed (%d): %s" % (rc, last_error(lib)))
+                _initialized = True
+    return lib
+
+
+def last_error(lib=None):
+    lib = lib or load()
+    msg = lib.aule_get_error()
+    return msg.decode("utf-8", "replace") if msg else "unknown error"
+
+
+def check(rc, what):
+    if rc != 0:
+        raise AuleError("%s failed (%d): %s" % (what, rc, last_error()))

@@ -1,0 +1,116 @@
+"""PyTorch-ROCm binding of the gfx950 kernels (zero-copy, current stream, autograd).
+
+Counterpart of the reference's FlashAttentionAMDFunc (python/aule/triton_flash_amd.py:
+392-500) and flash_attention_amd (:503-536): same autograd contract -- forward saves
+(q, k, v, out, lse), backward returns (dq, dk, dv) in the input dtype -- but the launches
+go to libaule.so's aule_attention_forward_ex / aule_attention_backward_ex with
+tensor.data_ptr() and the current HIP stream.  torch is plumbing here (device memory,
+streams, autograd graph); the arithmetic is in aule-attention_amd/csrc/*.hip.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _capi
+
+_DTYPES = {torch.float32: _capi.DTYPE_F32, torch.float16: _capi.DTYPE_F16, torch.bfloat16: _capi.DTYPE_BF16}
+SUPPORTED_HEAD_DIMS = (32, 64, 128)
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def fwd_raw(q, k, v, causal, scale, want_lse=True):
+    """q [B,Hq,Sq,D], k/v [B,Hkv,Sk,D]: contiguous device tensors, D in SUPPORTED_HEAD_DIMS.
+    Returns (out, lse or None).  Asynchronous on the current stream."""
+    lib = _capi.get_lib()
+    B, Hq, Sq, D = q.shape
+    Hkv, Sk = k.shape[1], k.shape[2]
+    out = torch.empty_like(q)
+    lse = torch.empty((B, Hq, Sq), device=q.device, dtype=torch.float32) if want_lse else None
+    if q.numel() == 0:
+        return out, lse
+    d = _capi.AttnDesc()
+    d.struct_size = ctypes.sizeof(_capi.AttnDesc)
+    d.dtype = _DTYPES[q.dtype]
+    d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
+    d.scale = float(scale)
+    d.causal = 1 if causal else 0
+    d.window_size = -1
+    d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
+    d.stream = _stream_ptr(q.device)
+    d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    d.lse = lse.data_ptr() if lse is not None else None
+    _capi.check(lib.aule_attention_forward_ex(ctypes.byref(d)), "aule_attention_forward_ex")
+    return out, lse
+
+
+def bwd_raw(q, k, v, out, dout, lse, causal, scale):
+    lib = _capi.get_lib()
+    B, Hq, Sq, D = q.shape
+    Hkv, Sk = k.shape[1], k.shape[2]
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    if q.numel() == 0 or k.numel() == 0:
+        return dq.zero_(), dk.zero_(), dv.zero_()
+    ws = torch.empty((B * Hq * Sq,), device=q.device, dtype=torch.float32)
+    d = _capi.AttnBwdDesc()
+    d.struct_size = ctypes.sizeof(_capi.AttnBwdDesc)
+    d.dtype = _DTYPES[q.dtype]
+    d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
+    d.scale = float(scale)
+    d.causal = 1 if causal else 0
+    d.window_size = -1
+    d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
+    d.stream = _stream_ptr(q.device)
+    d.q, d.k, d.v, d.out, d.dout, d.lse = (q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                            dout.data_ptr(), lse.data_ptr())
+    d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    _capi.check(lib.aule_attention_backward_ex(ctypes.byref(d)), "aule_attention_backward_ex")
+    return dq, dk, dv
+
+
+class FlashAttentionHipFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, causal, scale):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out, lse = fwd_raw(q, k, v, causal, scale, want_lse=True)
+        ctx.save_for_backward(q, k, v, out, lse)      # triton_flash_amd.py:436
+        ctx.causal, ctx.scale = causal, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dout = dout.contiguous().to(q.dtype)
+        dq, dk, dv = bwd_raw(q, k, v, out, dout, lse, ctx.causal, ctx.scale)
+        return dq, dk, dv, None, None
+
+
+def _pad_head_dim(x, Dp):
+    D = x.shape[-1]
+    return x if D == Dp else torch.nn.functional.pad(x, (0, Dp - D))
+
+
+def flash_attention_hip(q, k, v, causal=True, scale=None):
+    """Device tensors in, device tensor out, autograd-aware.  dtype fp16/bf16/fp32 run
+    natively; anything else is computed in fp32 and cast back."""
+    D = q.shape[-1]
+    if D > 128:
+        raise ValueError(f"head_dim must be <= 128 for the HIP backend, got {D}")
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    orig_dtype = q.dtype
+    if orig_dtype not in _DTYPES:
+        q, k, v = q.float(), k.float(), v.float()
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        k, v = k.to(q.dtype), v.to(q.dtype)
+    Dp = next(x for x in SUPPORTED_HEAD_DIMS if x >= D)
+    if Dp != D:   # zero-padded head dim: dot products and outputs are unchanged
+        q, k, v = _pad_head_dim(q, Dp), _pad_head_dim(k, Dp), _pad_head_dim(v, Dp)
+    out = FlashAttentionHipFunc.apply(q, k, v, bool(causal), float(scale))
+    if Dp != D:
+        out = out[..., :D]
+    return out if out.dtype == orig_dtype else out.to(orig_dtype)

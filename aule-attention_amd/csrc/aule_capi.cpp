@@ -22,6 +22,9 @@
 
 #include "fa_kernels.h"
 
+static_assert(sizeof(aule_attn_desc) == 96, "aule_attn_desc layout is part of the ABI");
+static_assert(sizeof(aule_attn_bwd_desc) == 144, "aule_attn_bwd_desc layout is part of the ABI");
+
 namespace {
 
 using aule_hip::BwdArgs;

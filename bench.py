@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the FlashAttention hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--mode fwd|fwdbwd]
+
+One "step" = one pass of the hot path (aule.flash_attention -> libaule.so -> gfx950
+kernels) over one batch of synthetic [B,H,S,D] tensors already resident in HBM.
+Default workload = BASELINE.json configs[1]:  B=4 H=32 S=4096 D=128 bf16 causal MHA, fwd.
+With N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL) every rank runs
+the same per-GPU batch on its own shard (weak scaling, no data-path collective); the
+optional output all-gather over xGMI is timed separately and reported under "gather".
+
+Rank 0 prints ONE JSON line.  FLOP convention: fwd = 4*B*Hq*D*P with
+P = sum_i min(i+1, Sk) for the top-left causal mask, bwd = 2.5*fwd.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "aule-attention_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+# gfx950 dense peaks (MI355X_MICROARCH.md: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz; "~2.5 PF dense")
+PEAK_TFLOPS = {"bf16": 2516.6, "fp16": 2516.6, "fp32": 157.3}
+
+CONFIGS = {
+    # name: (B per GPU, Hq, Hkv, Sq, Sk, D, dtype, causal, default mode)
+    "c2": (4, 32, 32, 4096, 4096, 128, "bf16", True, "fwd"),      # configs[1] -- the headline
+    "c3": (4, 32, 8, 2048, 2048, 128, "bf16", True, "fwdbwd"),    # configs[2] (B=4 assumed)
+    "c4": (8, 32, 32, 8192, 8192, 128, "bf16", True, "fwd"),      # configs[3]: B=64 over 8 GPUs
+    "c5": (1, 32, 1, 16384, 16384, 64, "fp16", False, "fwd"),     # configs[4]
+}
+
+
+def causal_pairs(Sq, Sk):
+    n = min(Sq, Sk)
+    return n * (n + 1) // 2 + max(0, Sq - Sk) * Sk
+
+
+def fwd_flops(B, Hq, Sq, Sk, D, causal):
+    P = causal_pairs(Sq, Sk) if causal else Sq * Sk
+    return 4.0 * B * Hq * D * P
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle's NumPy restatement of the reference CPU path (python/aule/__init__.py:247-271),
+    timed on this box's host cores on a bounded sample of the C2 workload (one batch element,
+    2 of its 32 heads: B1 H2 S4096 D128 fp32 causal), plus the reference's own C1 case."""
+    import numpy as np
+    import oracle
+    rng = np.random.RandomState(0)
+    H, S, D = 2, 4096, 128
+    q, k, v = (rng.randn(1, H, S, D).astype(np.float32) for _ in range(3))
+    oracle.cpu_attention(q[:, :1, :512], k[:, :1, :512], v[:, :1, :512], True)  # warm-up
+    reps, t_cpu0, t0 = 0, time.process_time(), time.perf_counter()
+    while True:
+        oracle.cpu_attention(q, k, v, True)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s or reps >= 8:
+            break
+    wall = time.perf_counter() - t0
+    cpu = time.process_time() - t_cpu0
+    flops = fwd_flops(1, H, S, S, D, True) * reps
+    # C1 exactly (median of 7)
+    q1, k1, v1 = (rng.randn(1, 8, 256, 64).astype(np.float32) for _ in range(3))
+    ts = []
+    for _ in range(9):
+        a = time.perf_counter()
+        oracle.cpu_attention(q1, k1, v1, True)
+        ts.append(time.perf_counter() - a)
+    c1_ms = sorted(ts)[len(ts) // 2] * 1e3
+    return {
+        "value": flops / wall / 1e12,
+        "unit": "TFLOP/s",
+        "cores": max(1, int(round(cpu / wall))),
+        "host_cores": os.cpu_count(),
+        "kind": "port",
+        "sample": "numpy restatement of _cpu_attention on B1 H%d S%d D%d fp32 causal x%d reps (%.1f s wall); "
+                  "config C1 (B1 H8 S256 D64) median %.1f ms" % (H, S, D, reps, wall, c1_ms),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default=None, choices=["fwd", "fwdbwd"])
+    ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import aule  # raises AuleError at first use if libaule.so / a HIP device is missing
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no ROCm device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    n_gpus = world
+
+    B, Hq, Hkv, Sq, Sk, D, dtype, causal, mode = CONFIGS[args.config]
+    if args.batch:
+        B = args.batch
+    mode = args.mode or mode
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dtype]
+    dev = torch.device("cuda", local_rank)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    q = torch.randn(B, Hq, Sq, D, device=dev, dtype=tdt, generator=gen)
+    k = torch.randn(B, Hkv, Sk, D, device=dev, dtype=tdt, generator=gen)
+    v = torch.randn(B, Hkv, Sk, D, device=dev, dtype=tdt, generator=gen)
+    do = torch.randn(B, Hq, Sq, D, device=dev, dtype=tdt, generator=gen) if mode == "fwdbwd" else None
+    if mode == "fwdbwd":
+        q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+
+    def step():
+        if mode == "fwd":
+            with torch.no_grad():
+                return aule.flash_attention(q, k, v, causal=causal)
+        q.grad = k.grad = v.grad = None
+        out = aule.flash_attention(q, k, v, causal=causal)
+        out.backward(do)
+        return out
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps):
+        sync_all()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+        if dist is not None:
+            t = torch.tensor([wall, dev_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall, dev_ms = float(t[0]), float(t[1])
+            dist.barrier()
+        return wall, dev_ms
+
+    for _ in range(args.warmup):
+        step()
+    wall, dev_ms = timed(step, args.steps)
+
+    f_fwd = fwd_flops(B, Hq, Sq, Sk, D, causal)
+    f_step = f_fwd * (3.5 if mode == "fwdbwd" else 1.0)
+    ms_per_step = wall * 1e3 / args.steps
+    value = f_step * n_gpus * args.steps / wall / 1e12
+    kern_ms = dev_ms / args.steps          # HIP events on the launch stream, per step
+    achieved = f_step / (kern_ms * 1e-3) / 1e12
+
+    result = {
+        "metric": "attention TFLOPS/GPU (fwd, fwd+bwd) + % MFMA roofline at S=4096,D=128",
+        "value": value,
+        "unit": "TFLOP/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": dtype,
+        "data": "synthetic N(0,1) q,k,v resident in HBM, torch.Generator(seed 1234+rank)",
+        "config": {"workload": "%s: B=%d/GPU Hq=%d Hkv=%d Sq=%d Sk=%d D=%d %s %s %s" % (
+            args.config, B, Hq, Hkv, Sq, Sk, D, dtype, "causal" if causal else "non-causal", mode),
+            "global_batch": B * n_gpus, "parallelism": "batch-sharded dp%d, no data-path collective" % n_gpus,
+            "flop_convention": "4*B*Hq*D*sum_i min(i+1,Sk) (causal), bwd=2.5x fwd"},
+        "per_gpu_tflops": value / n_gpus,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_TFLOPS[dtype], "traffic": None,
+                     "kernel_ms": kern_ms,
+                     "note": "achieved = algorithmic FLOPs per step / HIP-event time per step on the launch "
+                             "stream; traffic: see profiles/ (PMC pass) and DESIGN.md"},
+    }
+
+    if n_gpus > 1:
+        # the one collective of the sharded path: all-gather of O over xGMI (RCCL), timed separately
+        out = step() if mode == "fwd" else step().detach()
+        gathered = torch.empty((n_gpus,) + tuple(out.shape), device=dev, dtype=out.dtype)
+
+        def step_gather():
+            o = step() if mode == "fwd" else step().detach()
+            dist.all_gather_into_tensor(gathered, o.contiguous())
+
+        for _ in range(2):
+            step_gather()
+        gsteps = max(1, min(args.steps, 20))
+        gwall, _ = timed(step_gather, gsteps)
+        result["gather"] = {"ms_per_step": gwall * 1e3 / gsteps,
+                            "value": f_step * n_gpus * gsteps / gwall / 1e12,
+                            "bytes_per_rank": out.numel() * out.element_size(),
+                            "collective": "all_gather_into_tensor(O) via RCCL"}
+
+    if rank == 0 and n_gpus == 1 and not args.no_extra and args.config == "c2":
+        # the other half of the metric: fwd+bwd on config #3 (GQA 32q/8kv S=2048), outside the timed region
+        B3, H3, K3, S3, _, D3, _, _, _ = CONFIGS["c3"]
+        g3 = torch.Generator(device=dev).manual_seed(99)
+        q3 = torch.randn(B3, H3, S3, D3, device=dev, dtype=torch.bfloat16, generator=g3).requires_grad_(True)
+        k3 = torch.randn(B3, K3, S3, D3, device=dev, dtype=torch.bfloat16, generator=g3).requires_grad_(True)
+        v3 = torch.randn(B3, K3, S3, D3, device=dev, dtype=torch.bfloat16, generator=g3).requires_grad_(True)
+        d3 = torch.randn(B3, H3, S3, D3, device=dev, dtype=torch.bfloat16, generator=g3)
+
+        def step3():
+            q3.grad = k3.grad = v3.grad = None
+            aule.flash_attention(q3, k3, v3, causal=True).backward(d3)
+
+        for _ in range(3):
+            step3()
+        _, ms3 = timed(step3, 20)
+        f3 = 3.5 * fwd_flops(B3, H3, S3, S3, D3, True)
+        t3 = f3 / (ms3 / 20 * 1e-3) / 1e12
+        result["extra"] = {"c3_fwd_bwd_tflops": t3, "c3_fwd_bwd_frac_of_peak": t3 / PEAK_TFLOPS["bf16"],
+                           "c3_ms_per_step": ms3 / 20,
+                           "c3_workload": "GQA 32q/8kv B=4 S=2048 D=128 bf16 causal fwd+bwd (autograd)"}
+
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

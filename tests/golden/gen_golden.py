@@ -150,7 +150,8 @@ def triton_amd_cases():
         ("mqa_b1h4kv1sq64sk96d32_causal", 60, 1, 4, 1, 64, 96, 32, True, None, "fp32"),
         ("gqa_b1h8kv2s128d64_causal", 61, 1, 8, 2, 128, 128, 64, True, None, "fp32"),
         ("mha_b1h2s96d128_full_scale", 62, 1, 2, 2, 96, 96, 128, False, 0.25, "fp32"),
-        ("gqa_b1h4kv2s128d128_bf16", 63, 1, 4, 2, 128, 128, 128, True, None, "bf16"),
+        # (a bf16 case is not recorded: the Triton CPU interpreter mis-executes this kernel's
+        #  bf16 tl.dot path and returns ~1e8 garbage; bf16 goldens come from the generic kernel)
     ]
     for name, seed, B, Hq, Hkv, Sq, Sk, D, causal, scale, dt in cases:
         q, k, v = make_inputs(seed, B, Hq, Hkv, Sq, Sk, D)

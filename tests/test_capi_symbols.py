@@ -1,0 +1,99 @@
+"""CPU tests of the drop-in boundary: libaule.so loads, exports every symbol that
+include/aule.h declares, and behaves per the reference contract when NOT initialised
+(no compute calls are made here; the GPU tests do that)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+import aule
+from aule import _capi
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "aule.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(aule_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_lists_reference_abi():
+    """The 31 exports of src/lib.zig must all be declared."""
+    ref = """aule_init aule_supports_backward aule_shutdown aule_get_error aule_get_backend_name aule_get_vendor
+    aule_is_amd_optimized aule_has_fp16 aule_set_shader_variant aule_get_shader_variant aule_has_shader_variant
+    aule_get_device_name aule_get_gpu_vendor aule_get_subgroup_size aule_attention_forward aule_tensor_count
+    aule_tensor_max aule_tensor_clear_all aule_tensor_create aule_tensor_create_u32 aule_tensor_destroy
+    aule_tensor_upload aule_tensor_download aule_tensor_download_u32 aule_attention_forward_gpu
+    aule_attention_forward_paged aule_spatial_sort aule_attention_forward_gravity aule_tensor_size
+    aule_attention_backward aule_attention_forward_with_lse""".split()
+    assert len(ref) == 31
+    missing = set(ref) - set(header_symbols())
+    assert not missing, missing
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_capi.find_library())
+    for name in header_symbols():
+        assert hasattr(lib, name), f"libaule.so does not export {name}"
+
+
+def test_binding_covers_header():
+    bound = {s[0] for s in _capi.SIGNATURES}
+    assert bound == set(header_symbols())
+    _capi.load()   # declares argtypes/restypes for all of them
+
+
+def test_descriptor_layout():
+    # x86-64 SysV layout of the structs in include/aule.h
+    assert ctypes.sizeof(_capi.AttnDesc) == 96
+    assert _capi.AttnDesc.stream.offset == 48 and _capi.AttnDesc.lse.offset == 88
+    assert ctypes.sizeof(_capi.AttnBwdDesc) == 144
+    assert _capi.AttnBwdDesc.workspace_bytes.offset == 136
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="needs a box WITHOUT a GPU")
+def test_uninitialised_contract_without_gpu():
+    """src/lib.zig: aule_init -> -1 + error text; everything else reports 'not initialised'."""
+    lib = _capi.load()
+    assert lib.aule_init() == -1
+    assert b"Failed to initialize backend" in lib.aule_get_error()
+    assert lib.aule_get_backend_name() == b"Not initialized"        # backend.zig:496-502
+    assert lib.aule_get_vendor() == -1 and lib.aule_has_fp16() == -1 and lib.aule_get_subgroup_size() == -1
+    assert lib.aule_tensor_create(1, 1, 1, 1) == 0
+    assert lib.aule_get_error() == b"Not initialized"               # lib.zig:416
+    assert lib.aule_tensor_max() == 1024 and lib.aule_tensor_count() == 0
+    assert lib.aule_tensor_size(0) == 0 and lib.aule_tensor_size(5000) == 0
+    lib.aule_tensor_destroy(0)
+    lib.aule_tensor_destroy(99999)
+    assert lib.aule_supports_backward() == 0
+    assert lib.aule_attention_forward_paged(1, 1, 1, 1, 0, 0, 0, -1) == -1
+    buf = (ctypes.c_float * 4)()
+    assert lib.aule_attention_forward(buf, buf, buf, buf, 1, 1, 1, 4, 0) == -1
+    assert b"not initialized" in lib.aule_get_error().lower()
+    d = _capi.AttnDesc()
+    assert lib.aule_attention_forward_ex(ctypes.byref(d)) == -1
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="needs a box WITHOUT a GPU")
+def test_product_fails_loudly_without_gpu(small_qkv):
+    """No CPU fallback: the public API must raise, not silently compute elsewhere."""
+    q, k, v = small_qkv
+    with pytest.raises(aule.AuleError):
+        aule.flash_attention(q, k, v)
+    import torch
+    with pytest.raises(aule.AuleError):
+        aule.flash_attention(torch.from_numpy(q), torch.from_numpy(k), torch.from_numpy(v))
+    assert aule.get_available_backends() == []
+    assert "hip" in aule.get_backend_errors()
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure; nothing under aule-attention_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "aule-attention_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "import oracle" not in txt and "liboracle" not in txt and "oracle/" not in txt, (dp, f)

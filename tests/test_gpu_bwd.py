@@ -1,0 +1,152 @@
+"""GPU parity tests of the backward hot path (run with -m gpu on an MI355X).
+
+dQ, dK, dV from aule_attention_backward_ex are compared with the reference's recorded
+gradients (tests/golden/tr_*), with the fp64 oracle on seeded inputs, and with torch
+autograd through a plain fp32 softmax(QK^T)V (config #3: GQA 32q/8kv S=2048 D=128 bf16)."""
+import math
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden
+from util import BWD_TOL, assert_close, quantize, torch_dtype
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def run_fwd_bwd(torch, q, k, v, do, dtype, causal, scale):
+    """Through the public API + autograd."""
+    import aule
+    dt = torch_dtype(dtype)
+    tq, tk, tv = (torch.from_numpy(np.ascontiguousarray(x)).to("cuda", dt).requires_grad_(True) for x in (q, k, v))
+    out = aule.flash_attention(tq, tk, tv, causal=causal, scale=scale)
+    out.backward(torch.from_numpy(np.ascontiguousarray(do)).to("cuda", dt))
+    torch.cuda.synchronize()
+    assert tq.grad.dtype == dt and tk.grad.shape == tk.shape
+    return (out.detach().float().cpu().numpy(), tq.grad.float().cpu().numpy(), tk.grad.float().cpu().numpy(),
+            tv.grad.float().cpu().numpy())
+
+
+def grad_close(got, ref, dtype, what):
+    atol, rtol = BWD_TOL[dtype]
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert_close(got, ref, atol * scale, rtol, what)
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files("tr_") if "dq" in np.load(p).files],
+                         ids=lambda p: p.split("/")[-1][:-4])
+def test_reference_gradients(torch_cuda, path):
+    g = load_golden(path)
+    _, dq, dk, dv = run_fwd_bwd(torch_cuda, g["q"], g["k"], g["v"], g["dout"], g["dtype"], g["causal"], g["scale"])
+    grad_close(dq, g["dq"], g["dtype"], g["name"] + " dq")
+    grad_close(dk, g["dk"], g["dtype"], g["name"] + " dk")
+    grad_close(dv, g["dv"], g["dtype"], g["name"] + " dv")
+
+
+SWEEP = [
+    # dtype, B, Hq, Hkv, Sq, Sk, D, causal, scale
+    ("bf16", 1, 4, 4, 256, 256, 128, True, None),
+    ("bf16", 2, 8, 2, 320, 320, 128, True, None),
+    ("bf16", 1, 8, 1, 200, 333, 128, False, None),
+    ("bf16", 1, 4, 2, 130, 70, 128, True, None),
+    ("bf16", 1, 4, 2, 70, 300, 128, True, None),      # Sk >> Sq causal: late KV blocks get zero grads
+    ("bf16", 1, 2, 2, 1, 1, 128, True, None),
+    ("bf16", 1, 4, 4, 512, 512, 64, True, None),
+    ("bf16", 1, 6, 3, 97, 161, 64, False, 0.5),
+    ("bf16", 1, 4, 4, 192, 192, 32, True, None),
+    ("fp16", 1, 4, 1, 384, 384, 64, False, None),
+    ("fp16", 1, 4, 4, 300, 300, 128, True, None),
+    ("fp32", 1, 8, 8, 256, 256, 64, True, None),
+    ("fp32", 1, 4, 2, 150, 150, 128, True, None),
+    ("fp32", 2, 4, 1, 77, 201, 64, False, 0.7),
+    ("fp32", 1, 2, 2, 129, 129, 32, True, -0.3),
+]
+
+
+@pytest.mark.parametrize("case", SWEEP, ids=lambda c: "-".join(str(x) for x in c))
+def test_backward_vs_oracle(torch_cuda, oracle_mod, case):
+    dtype, B, Hq, Hkv, Sq, Sk, D, causal, scale = case
+    rng = np.random.RandomState(zlib.crc32(repr(case).encode()) & 0xFFFF)
+    q = quantize(rng.randn(B, Hq, Sq, D), dtype)
+    k = quantize(rng.randn(B, Hkv, Sk, D), dtype)
+    v = quantize(rng.randn(B, Hkv, Sk, D), dtype)
+    do = quantize(rng.randn(B, Hq, Sq, D), dtype)
+    _, dq, dk, dv = run_fwd_bwd(torch_cuda, q, k, v, do, dtype, causal, scale)
+    rq, rk, rv = oracle_mod.bwd_f64(q, k, v, do, causal, scale)
+    grad_close(dq, rq, dtype, "dq")
+    grad_close(dk, rk, dtype, "dk")
+    grad_close(dv, rv, dtype, "dv")
+
+
+def _torch_ref(torch, q, k, v, causal, scale):
+    g = q.shape[1] // k.shape[1]
+    kk = k.repeat_interleave(g, dim=1)
+    vv = v.repeat_interleave(g, dim=1)
+    s = torch.einsum("bhqd,bhkd->bhqk", q, kk) * scale
+    if causal:
+        Sq, Sk = s.shape[-2:]
+        mask = torch.ones(Sq, Sk, dtype=torch.bool, device=q.device).tril()
+        s = s.masked_fill(~mask, float("-inf"))
+    return torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, dim=-1), vv)
+
+
+def test_config3_gqa_torch_autograd_parity(torch_cuda):
+    """BASELINE config #3: GQA 32q/8kv S=2048 D=128 bf16 causal fwd+bwd vs torch autograd
+    (plain fp32 math on the same bf16-quantised inputs)."""
+    import aule
+    torch = torch_cuda
+    B, Hq, Hkv, S, D = 1, 32, 8, 2048, 128
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    q, k, v, do = (torch.randn(B, h, S, D, device="cuda", dtype=torch.bfloat16, generator=gen)
+                   for h in (Hq, Hkv, Hkv, Hq))
+    q1, k1, v1 = (x.clone().requires_grad_(True) for x in (q, k, v))
+    out = aule.flash_attention(q1, k1, v1, causal=True)
+    out.backward(do)
+    q2, k2, v2 = (x.float().requires_grad_(True) for x in (q, k, v))
+    ref = _torch_ref(torch, q2, k2, v2, True, 1.0 / math.sqrt(D))
+    ref.backward(do.float())
+    assert_close(out.float().cpu().numpy(), ref.detach().cpu().numpy(), 1e-3, 2.0 ** -7, "C3 out")
+    for name, a, b in (("dq", q1.grad, q2.grad), ("dk", k1.grad, k2.grad), ("dv", v1.grad, v2.grad)):
+        grad_close(a.float().cpu().numpy(), b.cpu().numpy(), "bf16", "C3 " + name)
+
+
+def test_sgd_step_lowers_loss(torch_cuda):
+    """Intent of the reference's (dead) tests/test_torch_autograd.py:63: one SGD step lowers an MSE."""
+    import aule
+    torch = torch_cuda
+    torch.manual_seed(0)
+    q = torch.randn(1, 4, 64, 64, device="cuda", requires_grad=True)
+    k = torch.randn(1, 4, 64, 64, device="cuda", requires_grad=True)
+    v = torch.randn(1, 4, 64, 64, device="cuda", requires_grad=True)
+    target = torch.randn(1, 4, 64, 64, device="cuda")
+    loss0 = ((aule.flash_attention(q, k, v) - target) ** 2).mean()
+    loss0.backward()
+    with torch.no_grad():
+        for t in (q, k, v):
+            t -= 0.5 * t.grad
+    loss1 = ((aule.flash_attention(q, k, v) - target) ** 2).mean()
+    assert loss1.item() < loss0.item()
+
+
+def test_backward_deterministic(torch_cuda):
+    """No atomics anywhere: two runs are bit-identical."""
+    import aule
+    torch = torch_cuda
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    q, k, v, do = (torch.randn(2, h, 384, 128, device="cuda", dtype=torch.bfloat16, generator=gen)
+                   for h in (8, 2, 2, 8))
+    grads = []
+    for _ in range(2):
+        a, b, c = (x.clone().requires_grad_(True) for x in (q, k, v))
+        aule.flash_attention(a, b, c, causal=True).backward(do)
+        grads.append((a.grad, b.grad, c.grad))
+    for x, y in zip(*grads):
+        assert torch.equal(x, y)
