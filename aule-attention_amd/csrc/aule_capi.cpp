@@ -140,6 +140,7 @@ int run_fwd_f32(const float* q, const float* k, const float* v, float* o, float*
 }  // namespace
 
 namespace aule_hip {
+int launch_fwd_pp_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
 int configure_fwd();
 int configure_bwd();
 int configure_kernels() {
@@ -579,7 +580,9 @@ static int check_common(int32_t dtype, uint32_t B, uint32_t Hq, uint32_t Hkv, ui
         set_error("Attention failed: sliding window is not supported by the HIP backend");
         return -3;
     }
-    if ((uint64_t)B * Hq * Sq * D >= (1ull << 40) || Sq >= (1u << 30) || Sk >= (1u << 30)) {
+    // per-head K/V/Q slabs are addressed through 32-bit buffer descriptors (raw SRD, byte offsets)
+    if ((uint64_t)B * Hq * Sq * D >= (1ull << 40) || (uint64_t)Sq * D * 4 >= (1ull << 31) ||
+        (uint64_t)Sk * D * 4 >= (1ull << 31)) {
         set_error("Attention failed: problem too large");
         return -3;
     }
@@ -685,5 +688,20 @@ int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
 }
 
 const char* aule_hip_build_info(void) { return "aule-hip gfx950 abi1"; }
+
+/* Debug hook (not part of the drop-in ABI): bf16 D=128 forward with per-phase s_memtime stamps of
+ * workgroup 0 written to `stamps` (device pointer, 8 * 256 uint64).  Used by tools/timeline.py. */
+int32_t aule_hip_debug_forward_timeline(const aule_attn_desc* d, unsigned long long* stamps) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init || d == nullptr) return -1;
+    FwdArgs a;
+    a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->out; a.lse = d->lse;
+    a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv;
+    a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
+    a.scale = resolve_scale(d->scale, d->head_dim);
+    a.causal = d->causal != 0;
+    a.dtype = d->dtype;
+    return aule_hip::launch_fwd_pp_timeline(a, stamps, (hipStream_t)d->stream);
+}
 
 }  // extern "C"

@@ -20,6 +20,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 
@@ -81,11 +82,35 @@ __device__ __forceinline__ s16x4_t lds_tr16(const char* lds_ptr) {
         (s16x4_t __attribute__((address_space(3)))*)(lds_ptr));
 }
 
+// v_max3_f32 without the NaN-canonicalising v_max that fmaxf() adds in front of MFMA outputs
+__device__ __forceinline__ float max3(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return fmaxf(a, fmaxf(b, c));
+#endif
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 
 // value of the other 32-lane half (lane ^ 32)
 __device__ __forceinline__ float xhalf(float x) { return __shfl_xor(x, 32, 64); }
+// same through v_permlane32_swap (VALU, no LDS round trip): swap(a, b) exchanges lanes 32-63 of a
+// with lanes 0-31 of b; with a = b = x the two results together hold both halves' values.
+__device__ __forceinline__ float xhalf_fast(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    // r[0] = x[lane & 31] (low half's value everywhere), r[1] = x[32 + (lane & 31)] (high half's value)
+    const unsigned other = (threadIdx.x & 32) ? r[0] : r[1];
+    return __builtin_bit_cast(float, other);
+#else
+    return x;
+#endif
+}
 
 // Work decode shared by fwd and bwd kernels: blockIdx.x -> (batch, kv head,
 // q head, block index inside the sequence), heaviest causal blocks first, and

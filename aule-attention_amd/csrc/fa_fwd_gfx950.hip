@@ -24,6 +24,8 @@
 //     sub-tiles, the layout the transpose-read gathers without bank conflicts.
 //   * grid order: heaviest causal Q blocks first; all blocks of one (batch,
 //     kv-head) on one XCD so K/V are fetched from HBM once per XCD L2.
+#include <cstdlib>
+
 #include "fa_device.h"
 #include "fa_kernels.h"
 
@@ -309,9 +311,22 @@ int set_attr_16() {
 
 int launch_fwd_f32(const FwdArgs& a, hipStream_t stream);  // fa_fwd_f32.hip
 int configure_fwd_f32();
+int launch_fwd_pp(const FwdArgs& a, hipStream_t stream);   // fa_fwd_pp_gfx950.hip
+int configure_fwd_pp();
+
+// AULE_HIP_FWD_KERNEL = "pp" (default: ping-pong schedule) | "v1" (one barrier per tile,
+// all waves in the same phase; kept for A/B measurements)
+static bool use_v1() {
+    static const int v = [] {
+        const char* e = getenv("AULE_HIP_FWD_KERNEL");
+        return (e != nullptr && e[0] == 'v' && e[1] == '1') ? 1 : 0;
+    }();
+    return v == 1;
+}
 
 int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (a.dtype == kF32) return launch_fwd_f32(a, stream);
+    if (!use_v1()) return launch_fwd_pp(a, stream);
     if (a.dtype == kBF16) {
         if (a.D == 128) return launch_fwd_16<Bf16Traits, 128>(a, stream);
         if (a.D == 64) return launch_fwd_16<Bf16Traits, 64>(a, stream);
@@ -333,6 +348,7 @@ int configure_fwd() {
     rc |= set_attr_16<F16Traits, 64>();
     rc |= set_attr_16<F16Traits, 32>();
     rc |= configure_fwd_f32();
+    rc |= configure_fwd_pp();
     return rc;
 }
 

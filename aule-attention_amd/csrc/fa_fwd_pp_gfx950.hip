@@ -1,0 +1,488 @@
+// fa_fwd_pp_gfx950.hip -- ping-pong scheduled FlashAttention-2 forward (16-bit I/O).
+//
+// Same arithmetic, layouts and boundary as fa_fwd_gfx950.hip (read its header first);
+// what changes is the SCHEDULE, designed around how a CDNA4 CU issues work:
+//
+//   * A 512-thread workgroup puts two wavefronts on each of the CU's 4 SIMDs (wave w and
+//     wave w+4).  The matrix pipe and the VALU are separate pipes of a SIMD, but a
+//     barrier-per-tile loop keeps both waves in the same phase (both in MFMAs, then both
+//     in softmax VALU), so the pipes are used one after the other (measured: MFMA busy
+//     30 %, SQ_WAIT_ANY 38 % of wave cycles -- profiles/r1a).
+//   * Here the per-tile work is split into two phases,
+//         V-phase(j): softmax of S_j            (VALU only, no LDS, no MFMA)
+//         M-phase(j): O += P_j V_j  and  S_{j+1} = K_{j+1} Q^T   (32 MFMAs + LDS reads)
+//     and the two wave groups (waves 0-3 / waves 4-7) run ONE PHASE APART, re-aligned by
+//     a workgroup barrier at every phase boundary: while one wave of a SIMD is in its
+//     M-phase its partner is in its V-phase.  QK^T of the next tile is software-pipelined
+//     into the PV phase of the current one so that each phase is either all-matrix or
+//     all-vector.
+//   * K is staged two tiles ahead and V one tile ahead (global -> VGPR at the start of the
+//     V-phase, VGPR -> LDS at the end of the following M-phase), both double-buffered; the
+//     hazard analysis is in DESIGN.md ("forward schedule").
+//   * causal load balance: one workgroup processes the Q-block PAIR (i, n-1-i), so every
+//     workgroup of a head does the same number of KV tiles.
+#include <cstdlib>
+#include <type_traits>
+
+#include "fa_device.h"
+#include "fa_kernels.h"
+
+namespace aule_hip {
+namespace {
+
+struct FwdPPParams {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* o;
+    float* lse;
+    int B, Hq, Hkv, Sq, Sk;
+    float c;      // |scale| * log2(e)
+    int negq;     // scale < 0
+    int nqb;      // 256-row Q blocks
+    int nwork;    // work items per head: ceil(nqb/2) when pairing, else nqb
+    int pair;     // process Q blocks (i, nqb-1-i) in one workgroup
+    int dbg_flags;            // timeline build only: bit0 = group 1 computes nothing, bit1 = group 0 computes nothing
+    unsigned long long* dbg;  // timeline build only: [8 waves][kTLMax] s_memtime stamps of workgroup 0
+};
+
+constexpr int kTLMax = 256;
+
+constexpr int kQBlock = 256;
+constexpr int kKVTile = 64;
+constexpr float kRescaleThr = 8.0f;  // lazy rescale: keep the old running max while the new one is < 2^8 larger
+
+template <int D>
+struct Cfg {
+    static constexpr int RB = D * 2;            // bytes per row in global memory
+    static constexpr int RBP = RB + 16;         // padded LDS row of the K tile / Q slab: each row shifts by one
+                                                // 16-B slot, so a ds_read_b128 lane group (16 rows, same column)
+                                                // covers 16 distinct slots, and every offset is an immediate
+    static constexpr int CPR = RB / 16;         // 16-byte chunks per row
+    static constexpr int KTILE = kKVTile * RBP; // bytes per K tile in LDS
+    static constexpr int VTILE = kKVTile * RB;  // bytes per V tile in LDS ([kv/4][d/16][4][16] sub-tiles)
+    static constexpr int NCHUNK = kKVTile * CPR;
+    static constexpr int CH = (NCHUNK + 511) / 512, KS = D / 16, DB = D / 32;
+    static constexpr int QSLAB = 32 * RBP;      // one wave's Q rows
+    static constexpr int LDS = 2 * KTILE + 2 * VTILE + 8 * QSLAB;
+    static constexpr bool kFull = (NCHUNK % 512) == 0;
+};
+
+// timeline build: make the MFMA results "used" here so that the stamp that follows is taken after them
+__device__ __forceinline__ void keep_live(f32x16_t& a, f32x16_t& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 0" : "+v"(a), "+v"(b));
+#endif
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, unsigned bytes) {
+    // raw buffer (stride 0): loads at offsets >= bytes return 0 -> ragged tiles need no clamping
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+template <class T, int D, bool CAUSAL, bool TL = false>
+__global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
+    using C = Cfg<D>;
+    using v8 = typename T::v8;
+    constexpr int RB = C::RB, RBP = C::RBP, CPR = C::CPR, KTILE = C::KTILE, VTILE = C::VTILE;
+    constexpr int CH = C::CH, KS = C::KS, DB = C::DB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Ks = smem;
+    char* const Vs = smem + 2 * KTILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;  // 0: leads, 1: runs one phase behind
+    const int l31 = lane & 31, hi = lane >> 5;
+    char* const Qs = smem + 2 * KTILE + 2 * VTILE + wave * C::QSLAB;
+    int tl_n = 0;
+    auto stamp = [&]() {
+        if constexpr (TL) {
+            if (blockIdx.x == 0 && tl_n < kTLMax) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0) p.dbg[wave * kTLMax + tl_n] = t;
+                ++tl_n;
+            }
+        }
+    };
+
+    const WorkItem w = decode_work(blockIdx.x, p.B, p.Hq, p.Hkv, p.nwork, false);
+    const int Sq = p.Sq, Sk = p.Sk;
+    const float c = p.c;
+
+    const size_t kvhead = (size_t)(w.b * p.Hkv + w.hk) * Sk * RB;
+    const __amdgpu_buffer_rsrc_t krs = make_srd(reinterpret_cast<const char*>(p.k) + kvhead, (unsigned)Sk * RB);
+    const __amdgpu_buffer_rsrc_t vrs = make_srd(reinterpret_cast<const char*>(p.v) + kvhead, (unsigned)Sk * RB);
+
+    // ---- staging maps (byte offsets inside one 64-row tile; the tile start goes in the SGPR offset).
+    //      K: chunk c = tid + 512 i -> (row, 16-B chunk).
+    //      V: 8 consecutive lanes fetch one [4 kv][16 d] sub-tile, so the LDS image is filled linearly
+    //         by thread id (conflict-free ds_write_b128).
+    int k_g[CH], k_lds[CH], v_g[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int cidx = tid + 512 * i;
+        const int row = cidx / CPR, cc = cidx % CPR;
+        k_g[i] = row * RB + cc * 16;
+        k_lds[i] = row * RBP + cc * 16;
+        const int bidx = (tid >> 3) + 64 * i;  // sub-tile index = kv4 * (D/16) + d16
+        v_g[i] = ((bidx / (D / 16)) * 4 + ((tid >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (tid & 1)) * 16;
+    }
+    const int ka_base = l31 * RBP + hi * 16;  // A operand (K) and B operand (Q): row l31, chunk 2ks + hi
+    const int va_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
+
+    u32x4_t kst[CH], vst[CH];
+    auto issue_k = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (C::kFull || tid + 512 * i < C::NCHUNK)
+                kst[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], kv0 * RB, 0);
+    };
+    auto issue_v = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (C::kFull || tid + 512 * i < C::NCHUNK)
+                vst[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], kv0 * RB, 0);
+    };
+    auto write_k = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (C::kFull || tid + 512 * i < C::NCHUNK)
+                *reinterpret_cast<u32x4_t*>(Ks + buf * KTILE + k_lds[i]) = kst[i];
+    };
+    auto write_v = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (C::kFull || tid + 512 * i < C::NCHUNK)
+                *reinterpret_cast<u32x4_t*>(Vs + buf * VTILE + tid * 16 + i * 8192) = vst[i];
+    };
+
+    const int nparts = (p.pair && (p.nqb - 1 - w.blk) != w.blk) ? 2 : 1;
+    for (int part = 0; part < nparts; ++part) {
+        const int qb = p.pair ? (part == 0 ? p.nqb - 1 - w.blk : w.blk) : w.blk;
+        const int q0w = qb * kQBlock + wave * 32;
+        const int qrow = q0w + l31;
+
+        issue_k(0);
+        issue_v(0);
+        // ---- Q slab -> LDS (wave-private; the B operand of S^T = K.Q^T is re-read per tile: holding
+        //      it in 32 VGPRs does not fit the 256-register budget of two waves per SIMD)
+        {
+            const size_t qhead = (size_t)(w.b * p.Hq + w.h) * Sq * RB;
+            const __amdgpu_buffer_rsrc_t qrs = make_srd(reinterpret_cast<const char*>(p.q) + qhead, (unsigned)Sq * RB);
+            const unsigned flip = p.negq ? 0x80008000u : 0u;
+#pragma unroll
+            for (int i = 0; i < (32 * CPR) / 64; ++i) {
+                const int cidx = lane + 64 * i;
+                const int row = cidx / CPR, cc = cidx % CPR;
+                u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(qrs, row * RB + cc * 16, q0w * RB, 0);
+                x[0] ^= flip; x[1] ^= flip; x[2] ^= flip; x[3] ^= flip;
+                *reinterpret_cast<u32x4_t*>(Qs + row * RBP + cc * 16) = x;
+            }
+        }
+
+        const int kv_hi = CAUSAL ? min(Sk, qb * kQBlock + kQBlock) : Sk;
+        const int nt = (kv_hi + kKVTile - 1) / kKVTile;          // tiles staged by the workgroup
+        const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32) : Sk;  // keys visible to this wave
+        int na = (wave_kv_hi + kKVTile - 1) / kKVTile;           // tiles this wave computes (a prefix)
+        if constexpr (TL) {
+            if ((p.dbg_flags >> grp) & 1) na = 0;
+        }
+
+        f32x16_t o[DB];
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+        float m = -INFINITY, l = 0.f;
+        f32x16_t s[2];
+        v8 pb[2][2];
+
+        // Both MFMA loops are software-pipelined by hand: a wave issues in order, so an MFMA whose LDS
+        // operands were requested just before it stalls for the whole LDS latency (measured: 16 MFMAs
+        // took ~950 cycles instead of 512).  Operands are requested kAhead steps early; the
+        // sched_group_barrier sequence pins "1 MFMA, then the reads of a later step" in the final code.
+        auto qk = [&](int buf) {  // S^T = K_tile . Q^T   (all LDS offsets are immediates)
+            const char* kb = Ks + buf * KTILE + ka_base;
+            const char* qb_ = Qs + ka_base;
+            constexpr int kAhead = 2;
+            u32x4_t qf[KS], kf[KS][2];
+            auto rd = [&](int ks) {
+                qf[ks] = *reinterpret_cast<const u32x4_t*>(qb_ + ks * 32);
+                kf[ks][0] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32);
+                kf[ks][1] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32 + 32 * RBP);
+            };
+            f32x16_t z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < kAhead && ks < KS; ++ks) rd(ks);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3 * (kAhead < KS ? kAhead : KS), 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + kAhead < KS) rd(ks + kAhead);
+                s[0] = T::mfma(as_v8<T>(kf[ks][0]), as_v8<T>(qf[ks]), ks == 0 ? z : s[0]);
+                s[1] = T::mfma(as_v8<T>(kf[ks][1]), as_v8<T>(qf[ks]), ks == 0 ? z : s[1]);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (ks + kAhead < KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+        };
+        auto pv = [&](int buf) {  // O^T += V^T . P^T
+            const char* vb = Vs + buf * VTILE + va_off;
+            constexpr int NST = 4 * DB;  // MFMA steps: (sb, kk) outer, d inner
+            constexpr int kAhead = 3;
+            s16x4_t a0[NST], a1[NST];
+            auto rd = [&](int st) {
+                const int sk = st / DB, d = st % DB;  // sk = 2*sb + kk
+                const int off = ((4 * sk) * (D / 16) + 2 * d) * 128;
+                a0[st] = lds_tr16(vb + off);
+                a1[st] = lds_tr16(vb + off + 2 * (D / 16) * 128);
+            };
+#pragma unroll
+            for (int st = 0; st < kAhead && st < NST; ++st) rd(st);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (kAhead < NST ? kAhead : NST), 0);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                if (st + kAhead < NST) rd(st + kAhead);
+                const int sk = st / DB, d = st % DB;
+                o[d] = T::mfma(as_v8<T>(a0[st], a1[st]), pb[sk >> 1][sk & 1], o[d]);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (st + kAhead < NST) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        };
+        auto softmax = [&](int kv0) {  // S_j -> P_j (16-bit, in registers); updates m, l, o
+            const bool need_mask = (CAUSAL && (kv0 + kKVTile - 1 > q0w)) || (kv0 + kKVTile > Sk);
+            if (need_mask) {
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = kv0 + sb * 32 + crow(r, hi);
+                        const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow);
+                        s[sb][r] = vis ? s[sb][r] : -INFINITY;
+                    }
+            }
+            // row max: four independent v_max3_f32 chains (fmaxf() costs an extra canonicalising v_max per
+            // MFMA output, and one 31-deep chain is latency-bound)
+            float mx4[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int sb = q4 >> 1, b0 = 8 * (q4 & 1);
+                mx4[q4] = max3(s[sb][b0], s[sb][b0 + 1], s[sb][b0 + 2]);
+                mx4[q4] = max3(mx4[q4], s[sb][b0 + 3], s[sb][b0 + 4]);
+                mx4[q4] = max3(mx4[q4], s[sb][b0 + 5], s[sb][b0 + 6]);
+            }
+            float mx = max3(mx4[0], mx4[1], s[0][7]);
+            mx = max3(mx, mx4[2], s[0][15]);
+            mx = max3(mx, mx4[3], s[1][7]);
+            mx = fmaxf(mx, s[1][15]);
+            mx = fmaxf(mx, xhalf_fast(mx));
+            const float mxc = mx * c;
+            stamp();
+            // lazy rescale (exact algebra, different rounding): the running max is only raised -- and O, l
+            // rescaled -- when some row's new maximum exceeds the kept one by more than 2^kRescaleThr;
+            // otherwise P is formed against the kept max (P <= 2^8, fine for bf16/fp16 and fp32 sums).
+            if (__builtin_amdgcn_ballot_w64(mxc > m + kRescaleThr) != 0) {
+                const float m_new = fmaxf(m, mxc);
+                const float alpha = fast_exp2(m - m_new);
+                m = m_new;
+                l *= alpha;
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
+            const f32x2_t c2 = {c, c};
+            const f32x2_t nm2 = {-m, -m};
+            f32x2_t ls[2] = {{0.f, 0.f}, {0.f, 0.f}};
+            u32x4_t pu[2][2];
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    f32x2_t t = {s[sb][2 * i], s[sb][2 * i + 1]};
+                    t = __builtin_elementwise_fma(t, c2, nm2);   // v_pk_fma_f32
+                    t[0] = fast_exp2(t[0]);
+                    t[1] = fast_exp2(t[1]);
+                    ls[i & 1] += t;                                // v_pk_add_f32, two chains
+                    pu[sb][i >> 2][i & 3] = T::pack2(t[0], t[1]);
+                }
+            const f32x2_t lt2 = ls[0] + ls[1];
+            l += lt2[0] + lt2[1];
+            // Pin the results of this phase HERE: the softmax is register-only code that LLVM otherwise
+            // sinks past the barrier into the block that consumes P (next to this wave's own MFMAs).
+            asm volatile("" : "+v"(pu[0][0]), "+v"(pu[0][1]), "+v"(pu[1][0]), "+v"(pu[1][1]), "+v"(l), "+v"(m));
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) pb[sb][kk] = as_v8<T>(pu[sb][kk]);
+        };
+
+        // ---- prologue: K0, V0 -> buffers 0 (one exposed memory latency, shared with the Q slab load
+        //      above); K1 is requested now and written after the pre-phase, under QK_0's shadow.
+        write_k(0);
+        write_v(0);
+        if (nt > 1) issue_k(kKVTile);
+        __syncthreads();
+        if (grp == 1) __syncthreads();  // group 1 starts one phase late
+        if (na > 0) qk(0);              // pre-phase: S_0
+        if (nt > 1) write_k(1);         // K buffer 1 is first read in M-phase(0), two barriers from here
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+
+        // One tile step = V-phase + barrier + M-phase + barrier.  MODE is a compile-time constant so that
+        // the steady-state loop body is straight-line code (a per-iteration branch on `na` made hipcc
+        // copy the 64 O accumulators at every merge point): 2 = softmax, PV and next QK^T; 1 = softmax
+        // and PV (this wave's last active tile); 0 = fully masked tile, only staging and barriers.
+        auto tile_step = [&](int j, auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            // ---- V-phase(j): prefetch V_{j+1}, K_{j+2} into registers; softmax(S_j)
+            if (j + 1 < nt) issue_v((j + 1) * kKVTile);
+            if (j + 2 < nt) issue_k((j + 2) * kKVTile);
+            stamp();
+            if constexpr (MODE >= 1) softmax(j * kKVTile);
+            stamp();
+            // phase boundary: nothing may move across (hipcc would interleave this wave's softmax with
+            // its own MFMAs -- measured with tools/timeline.py -- which defeats the group alternation)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            stamp();
+            // ---- M-phase(j): O += P_j V_j ; S_{j+1} = K_{j+1} Q^T ; stage the prefetched tiles
+            __builtin_amdgcn_s_setprio(1);
+            if constexpr (MODE >= 1) pv(j & 1);
+            if constexpr (MODE == 2) {
+                __builtin_amdgcn_sched_barrier(0);  // P dies after PV, S is born in QK: do not overlap them
+                if constexpr (TL) { keep_live(o[0], o[DB - 1]); stamp(); }
+                qk((j + 1) & 1);
+                if constexpr (TL) { keep_live(s[0], s[1]); stamp(); }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (j + 1 < nt) write_v((j + 1) & 1);
+            if (j + 2 < nt) write_k(j & 1);
+            stamp();
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int j = 0;
+        for (; j + 1 < na; ++j) tile_step(j, std::integral_constant<int, 2>{});
+        if (j < na) { tile_step(j, std::integral_constant<int, 1>{}); ++j; }
+        for (; j < nt; ++j) tile_step(j, std::integral_constant<int, 0>{});
+
+        // ---- epilogue: O = O^T / l, transposed through this wave's (now idle) Q slab so that the
+        //      global stores are whole 16-byte chunks of full rows (the direct form is 16 row-strided
+        //      8-byte stores per lane and was ~16k cycles per Q block); LSE = (m + log2 l) * ln2
+        const float lt = l + xhalf(l);
+        const float inv = 1.0f / lt;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2_t u;
+                u[0] = T::pack2(o[d][4 * g4 + 0] * inv, o[d][4 * g4 + 1] * inv);
+                u[1] = T::pack2(o[d][4 * g4 + 2] * inv, o[d][4 * g4 + 3] * inv);
+                *reinterpret_cast<u32x2_t*>(Qs + l31 * RBP + (32 * d + 8 * g4 + 4 * hi) * 2) = u;
+            }
+        // (wave-private LDS: program order + the compiler's lgkmcnt wait are enough, no barrier)
+        {
+            char* obase = reinterpret_cast<char*>(p.o) + ((size_t)(w.b * p.Hq + w.h) * Sq) * RB;
+#pragma unroll
+            for (int i = 0; i < (32 * CPR) / 64; ++i) {
+                const int cidx = lane + 64 * i;
+                const int row = cidx / CPR, cc = cidx % CPR;
+                const u32x4_t x = *reinterpret_cast<const u32x4_t*>(Qs + row * RBP + cc * 16);
+                if (q0w + row < Sq) *reinterpret_cast<u32x4_t*>(obase + (size_t)(q0w + row) * RB + cc * 16) = x;
+            }
+        }
+        if (qrow < Sq && p.lse != nullptr && hi == 0)
+            p.lse[(size_t)(w.b * p.Hq + w.h) * Sq + qrow] = (m + fast_log2(lt)) * kLn2;
+        if (grp == 0) __syncthreads();  // pairs with group 1's last phase barrier
+    }
+}
+
+template <class T, int D>
+int launch_pp(const FwdArgs& a, hipStream_t stream) {
+    FwdPPParams p;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o; p.lse = a.lse;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
+    float c = a.scale * kLog2e;
+    p.negq = c < 0.f;
+    c = c < 0.f ? -c : c;
+    if (c == 0.f) c = 1e-30f;
+    p.c = c;
+    p.nqb = (a.Sq + kQBlock - 1) / kQBlock;
+    p.pair = a.causal ? 1 : 0;
+    p.nwork = p.pair ? (p.nqb + 1) / 2 : p.nqb;
+    p.dbg = nullptr;
+    p.dbg_flags = 0;
+    const dim3 grid((unsigned)(p.nwork * a.B * a.Hq)), block(512);
+    const size_t lds = Cfg<D>::LDS;
+    if (a.causal)
+        hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, true>), grid, block, lds, stream, p);
+    else
+        hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false>), grid, block, lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+template <class T, int D>
+int set_attr_pp() {
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS);
+    return rc;
+}
+
+}  // namespace
+
+// Debug: run the bf16 D=128 kernel with s_memtime stamps (4 per tile per wave, workgroup 0):
+// [V-phase start, V-phase end, M-phase start (after barrier), M-phase end].
+int launch_fwd_pp_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream) {
+    if (a.dtype != kBF16 || a.D != 128) return -1;
+    FwdPPParams p;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o; p.lse = a.lse;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
+    p.c = a.scale * kLog2e; p.negq = 0;
+    p.nqb = (a.Sq + kQBlock - 1) / kQBlock;
+    p.pair = a.causal ? 1 : 0;
+    p.nwork = p.pair ? (p.nqb + 1) / 2 : p.nqb;
+    p.dbg = dbg;
+    p.dbg_flags = getenv("AULE_TL_FLAGS") ? atoi(getenv("AULE_TL_FLAGS")) : 0;
+    const dim3 grid((unsigned)(p.nwork * a.B * a.Hq)), block(512);
+    const size_t lds = Cfg<128>::LDS;
+    if (a.causal) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<Bf16Traits, 128, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((fa_fwd_pp_kernel<Bf16Traits, 128, true, true>), grid, block, lds, stream, p);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<Bf16Traits, 128, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((fa_fwd_pp_kernel<Bf16Traits, 128, false, true>), grid, block, lds, stream, p);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_fwd_pp(const FwdArgs& a, hipStream_t stream) {
+    if (a.dtype == kBF16) {
+        if (a.D == 128) return launch_pp<Bf16Traits, 128>(a, stream);
+        if (a.D == 64) return launch_pp<Bf16Traits, 64>(a, stream);
+        if (a.D == 32) return launch_pp<Bf16Traits, 32>(a, stream);
+    } else if (a.dtype == kF16) {
+        if (a.D == 128) return launch_pp<F16Traits, 128>(a, stream);
+        if (a.D == 64) return launch_pp<F16Traits, 64>(a, stream);
+        if (a.D == 32) return launch_pp<F16Traits, 32>(a, stream);
+    }
+    return -1;
+}
+
+int configure_fwd_pp() {
+    return set_attr_pp<Bf16Traits, 128>() | set_attr_pp<Bf16Traits, 64>() | set_attr_pp<Bf16Traits, 32>() |
+           set_attr_pp<F16Traits, 128>() | set_attr_pp<F16Traits, 64>() | set_attr_pp<F16Traits, 32>();
+}
+
+}  // namespace aule_hip
