@@ -48,6 +48,9 @@ struct FwdPPParams {
 
 constexpr int kTLMax = 256;
 
+#ifndef AULE_MPRIO
+#define AULE_MPRIO 1
+#endif
 constexpr int kQBlock = 256;
 constexpr int kKVTile = 64;
 constexpr float kRescaleThr = 8.0f;  // lazy rescale: keep the old running max while the new one is < 2^8 larger
@@ -321,15 +324,23 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                 for (int kk = 0; kk < 2; ++kk) pb[sb][kk] = as_v8<T>(pu[sb][kk]);
         };
 
-        // ---- prologue: K0, V0 -> buffers 0 (one exposed memory latency, shared with the Q slab load
-        //      above); K1 is requested now and written after the pre-phase, under QK_0's shadow.
+        // ---- prologue.  Staging rule of the main loop: ALL global->LDS staging happens in the V-phases
+        //      (the VALU-bound phase, whose LDS/VMEM issue ports are idle), never in the M-phases:
+        //      in V-phase(t) group d (0 or 1) first writes the tiles it loaded one phase earlier,
+        //      V_{t+d} and K_{t+1+d}, then requests V_{t+1+d} and K_{t+2+d}.  Entry state for t = 0:
+        //      K_0 in LDS; group 0 holds (V_0, K_1) in registers, group 1 has written its share of
+        //      (V_0, K_1) and holds (V_1, K_2).  Hazard analysis: DESIGN.md "forward schedule".
         write_k(0);
-        write_v(0);
         if (nt > 1) issue_k(kKVTile);
+        if (grp == 1) {
+            write_v(0);
+            if (nt > 1) write_k(1);
+            if (nt > 1) issue_v(kKVTile);
+            if (nt > 2) issue_k(2 * kKVTile);
+        }
         __syncthreads();
         if (grp == 1) __syncthreads();  // group 1 starts one phase late
         if (na > 0) qk(0);              // pre-phase: S_0
-        if (nt > 1) write_k(1);         // K buffer 1 is first read in M-phase(0), two barriers from here
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
@@ -340,10 +351,12 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
         // and PV (this wave's last active tile); 0 = fully masked tile, only staging and barriers.
         auto tile_step = [&](int j, auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
-            // ---- V-phase(j): prefetch V_{j+1}, K_{j+2} into registers; softmax(S_j)
-            if (j + 1 < nt) issue_v((j + 1) * kKVTile);
-            if (j + 2 < nt) issue_k((j + 2) * kKVTile);
+            // ---- V-phase(j): stage (see the prologue comment), then softmax(S_j)
             stamp();
+            if (j + grp < nt) write_v((j + grp) & 1);
+            if (j + 1 + grp < nt) write_k((j + 1 + grp) & 1);
+            if (j + 1 + grp < nt) issue_v((j + 1 + grp) * kKVTile);
+            if (j + 2 + grp < nt) issue_k((j + 2 + grp) * kKVTile);
             if constexpr (MODE >= 1) softmax(j * kKVTile);
             stamp();
             // phase boundary: nothing may move across (hipcc would interleave this wave's softmax with
@@ -352,8 +365,8 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
             stamp();
-            // ---- M-phase(j): O += P_j V_j ; S_{j+1} = K_{j+1} Q^T ; stage the prefetched tiles
-            __builtin_amdgcn_s_setprio(1);
+            // ---- M-phase(j): O += P_j V_j ; S_{j+1} = K_{j+1} Q^T   (MFMA + LDS reads only)
+            __builtin_amdgcn_s_setprio(AULE_MPRIO);
             if constexpr (MODE >= 1) pv(j & 1);
             if constexpr (MODE == 2) {
                 __builtin_amdgcn_sched_barrier(0);  // P dies after PV, S is born in QK: do not overlap them
@@ -362,8 +375,6 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                 if constexpr (TL) { keep_live(s[0], s[1]); stamp(); }
             }
             __builtin_amdgcn_s_setprio(0);
-            if (j + 1 < nt) write_v((j + 1) & 1);
-            if (j + 2 < nt) write_k(j & 1);
             stamp();
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
