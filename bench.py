@@ -47,6 +47,16 @@ def fwd_flops(B, Hq, Sq, Sk, D, causal):
     return 4.0 * B * Hq * D * P
 
 
+def hbm_traffic(config, mode):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 note in
+    MI355X_MICROARCH.md, + WRITE_SIZE), recorded by tools/profile.sh into profiles/hbm_traffic.json."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
+            return json.load(fh).get("%s_%s" % (config, mode), {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(budget_s=12.0):
     """The oracle's NumPy restatement of the reference CPU path (python/aule/__init__.py:247-271),
     timed on this box's host cores on a bounded sample of the C2 workload (one batch element,
@@ -192,10 +202,13 @@ def main():
             "flop_convention": "4*B*Hq*D*sum_i min(i+1,Sk) (causal), bwd=2.5x fwd"},
         "per_gpu_tflops": value / n_gpus,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_TFLOPS[dtype], "traffic": None,
+                     "frac": achieved / PEAK_TFLOPS[dtype], "traffic": hbm_traffic(args.config, mode),
                      "kernel_ms": kern_ms,
                      "note": "achieved = algorithmic FLOPs per step / HIP-event time per step on the launch "
-                             "stream; traffic: see profiles/ (PMC pass) and DESIGN.md"},
+                             "stream; traffic = HBM bytes per launch from the rocprofv3 PMC passes in "
+                             "profiles/ (FETCH_SIZE x2 + WRITE_SIZE), algorithmic bytes %d" % int(
+                                 (2 if dtype != "fp32" else 4) * (2 * B * Hq * Sq * D + 2 * B * Hkv * Sk * D)
+                                 + 4 * B * Hq * Sq)},
     }
 
     if n_gpus > 1:

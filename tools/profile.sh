@@ -12,7 +12,7 @@ OUT=$R/gpurun_out/prof_$LABEL
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-extra $*"
+ARGS="--steps 50 --warmup 10 --no-cpu-baseline --no-extra $*"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py $ARGS > $OUT/kt.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_sq -- python $R/bench.py $ARGS > $OUT/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $OUT/pmc_sq2 -- python $R/bench.py $ARGS > $OUT/pmc_sq2.log 2>&1

@@ -37,3 +37,23 @@ for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
             print("  ", k)
             for c in sorted(acc[k]):
                 print("      %-32s %16.1f   (n=%d)" % (c, acc[k][c] / max(1, cnt[k][c]), cnt[k][c]))
+
+# machine-readable HBM traffic for bench.py (KB counters; gfx950: FETCH_SIZE counts 128-B requests as 64 B)
+import json
+traffic = {}
+for sub, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    for f in find(sub, "*counter_collection.csv"):
+        tot, n = 0.0, 0
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if "fa_fwd" in row.get("Kernel_Name", "") and row.get("Counter_Name") == key:
+                    tot += float(row["Counter_Value"]); n += 1
+        if n:
+            traffic[key] = tot / n
+if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic:
+    b = (2.0 * traffic["FETCH_SIZE"] + traffic["WRITE_SIZE"]) * 1024.0
+    print("== HBM traffic per fwd launch: read %.1f MB (2 x FETCH_SIZE) + write %.1f MB = %.1f MB" % (
+        2 * traffic["FETCH_SIZE"] * 1024 / 1e6, traffic["WRITE_SIZE"] * 1024 / 1e6, b / 1e6))
+    with open(os.path.join(root, "hbm_traffic.json"), "w") as fh:
+        json.dump({"c2_fwd": {"bytes_per_launch": b, "fetch_size_kb": traffic["FETCH_SIZE"],
+                              "write_size_kb": traffic["WRITE_SIZE"]}}, fh)
