@@ -54,7 +54,6 @@ def bwd_raw(q, k, v, out, dout, lse, causal, scale):
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     if q.numel() == 0 or k.numel() == 0:
         return dq.zero_(), dk.zero_(), dv.zero_()
-    ws = torch.empty((B * Hq * Sq,), device=q.device, dtype=torch.float32)
     d = _capi.AttnBwdDesc()
     d.struct_size = ctypes.sizeof(_capi.AttnBwdDesc)
     d.dtype = _DTYPES[q.dtype]
@@ -67,7 +66,10 @@ def bwd_raw(q, k, v, out, dout, lse, causal, scale):
     d.q, d.k, d.v, d.out, d.dout, d.lse = (q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                             dout.data_ptr(), lse.data_ptr())
     d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
-    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    # delta [B,Hq,Sq] fp32 (+ fp32 dK/dV partials when the GQA head loop is split over workgroups)
+    nbytes = int(lib.aule_attention_backward_workspace_size(ctypes.byref(d)))
+    ws = torch.empty((nbytes,), device=q.device, dtype=torch.uint8)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
     _capi.check(lib.aule_attention_backward_ex(ctypes.byref(d)), "aule_attention_backward_ex")
     return dq, dk, dv
 

@@ -500,7 +500,7 @@ int32_t aule_attention_backward(const float* query, const float* key, const floa
     const uint32_t Dp = pad_dim(D);
     DeviceGuard g(g_device);
     Temp q, k, v, o, go, l, dq, dk, dv, ws;
-    const uint64_t wsb = aule_hip::bwd_workspace_bytes((int)B, (int)H, (int)S);
+    const uint64_t wsb = aule_hip::bwd_workspace_bytes((int)B, (int)H, (int)H, (int)S, (int)S, (int)Dp, causal != 0, aule_hip::kF32);
     if (!q.alloc(rows, Dp) || !k.alloc(rows, Dp) || !v.alloc(rows, Dp) || !o.alloc(rows, Dp) ||
         !go.alloc(rows, Dp) || !l.alloc(rows, 1) || !dq.alloc(rows, Dp) || !dk.alloc(rows, Dp) ||
         !dv.alloc(rows, Dp) || !ws.alloc((wsb + 3) / 4, 1)) {
@@ -636,7 +636,8 @@ int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
 
 uint64_t aule_attention_backward_workspace_size(const aule_attn_bwd_desc* d) {
     if (d == nullptr) return 0;
-    return aule_hip::bwd_workspace_bytes((int)d->batch, (int)d->heads_q, (int)d->seq_q);
+    return aule_hip::bwd_workspace_bytes((int)d->batch, (int)d->heads_q, (int)d->heads_kv, (int)d->seq_q, (int)d->seq_k,
+                                         (int)d->head_dim, d->causal != 0, d->dtype);
 }
 
 int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
@@ -662,7 +663,8 @@ int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
         set_error("Backward failed: null tensor pointer");
         return -3;
     }
-    const uint64_t need = aule_hip::bwd_workspace_bytes((int)d->batch, (int)d->heads_q, (int)d->seq_q);
+    const uint64_t need = aule_hip::bwd_workspace_bytes((int)d->batch, (int)d->heads_q, (int)d->heads_kv, (int)d->seq_q,
+                                                        (int)d->seq_k, (int)d->head_dim, d->causal != 0, d->dtype);
     if (!d->workspace || d->workspace_bytes < need) {
         set_error("Backward failed: workspace too small (%llu < %llu bytes)",
                   (unsigned long long)d->workspace_bytes, (unsigned long long)need);

@@ -20,6 +20,8 @@
 //                       group reduction is the loop, not an atomic.
 // The softmax is recomputed twice (once per kernel): 7 tile matmuls instead of the
 // 5 of the atomic formulation, in exchange for no fp32 atomics on dQ.
+#include <type_traits>
+
 #include "fa_device.h"
 #include "fa_kernels.h"
 
@@ -73,6 +75,11 @@ __global__ void __launch_bounds__(256) fa_bwd_delta_f32_kernel(const DeltaParams
 }
 
 // ------------------------------------------------------------- shared bits ----
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd_b(const void* base, unsigned bytes) {
+    // raw buffer (stride 0): loads at offsets >= bytes return 0 -> ragged tiles need no clamping
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
 struct BwdParams {
     const void* q;
     const void* k;
@@ -86,7 +93,9 @@ struct BwdParams {
     int B, Hq, Hkv, Sq, Sk;
     float c;      // scale * log2(e)   (sign kept; no max is taken in the backward)
     float scale;  // applied to dQ / dK in the epilogue
-    int nblk;     // Q blocks (dq kernel) or KV blocks (dkdv kernel)
+    int nblk;     // Q blocks (dq kernel) or KV blocks / block pairs (dkdv kernel)
+    int gsplit;   // dkdv: the query heads of a GQA group are split over this many workgroups
+    float* part;  // dkdv, gsplit > 1: fp32 partials [2 (dK,dV)][gsplit][B,Hkv,Sk,D]
 };
 
 // Row-major image swizzle (shared with the forward's K image).
@@ -280,198 +289,291 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
 }
 
 // ------------------------------------------------------------ dK/dV kernel ----
-constexpr int kKvBlock = 128;  // 4 waves x 32 key rows
+// One workgroup per PAIR of 256-row KV blocks (i, n-1-i) under a causal mask (uniform work per
+// workgroup), else per block; 8 waves x 32 key rows = two waves per SIMD, so one wave's LDS latency and
+// VALU work hide under its partner's MFMAs (a 4-wave, one-wave-per-SIMD version with K and V both in
+// registers ran at 27 % of this kernel's MFMA rate: everything it did was exposed).  To fit the
+// 256-register budget of two waves per SIMD next to the 128 accumulator registers (dK^T, dV^T), only the
+// K fragments stay in registers; V lives in a per-wave LDS slab (padded rows) and is re-read per tile as
+// the B operand of dP = dO.V^T.  Query tiles of 32 rows are double-buffered in LDS in two images each
+// (Q and dO): row-major with rows padded by 16 B (A operand of S = Q.K^T and dP, conflict-free
+// ds_read_b128, immediate offsets) and [q/4][d/16][4][16] sub-tiles (transpose-read source for
+// dV^T += dO^T.P and dK^T += Q^T.dS).
+constexpr int kKvBlock = 256;  // 8 waves x 32 key rows
 constexpr int kQT = 32;        // query rows per tile
 
 template <int D>
 struct DkvCfg {
-    static constexpr int RB = D * 2, CPR = RB / 16, TILE = kQT * RB, NCHUNK = TILE / 16;
-    static constexpr int CH = (NCHUNK + 255) / 256, KS = D / 16, DB = D / 32;
-    // per stage: Q row-major, Q sub-tiled, dO row-major, dO sub-tiled, LSE*log2e[32], delta[32]
-    static constexpr int STAGE = 4 * TILE + 256;
-    static constexpr int LDS = 2 * STAGE;
+    static constexpr int RB = D * 2, RBP = RB + 16, CPR = RB / 16;
+    static constexpr int RM = kQT * RBP;                 // row-major padded image
+    static constexpr int ST = kQT * RB;                  // sub-tiled image
+    static constexpr int NCHUNK = kQT * CPR;             // <= 512: at most one chunk per thread and tensor
+    static constexpr int KS = D / 16, DB = D / 32;
+    static constexpr int VSLAB = 32 * RBP;               // one wave's V rows
+    // per stage: Q rm, Q st, dO rm, dO st, LSE*log2e[32], delta[32]
+    static constexpr int STAGE = 2 * RM + 2 * ST + 256;
+    static constexpr int LDS = 8 * VSLAB + 2 * STAGE;
 };
 
 template <class T, int D, bool CAUSAL>
-__global__ void __launch_bounds__(256) fa_bwd_dkdv_kernel(const BwdParams p) {
+__global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
     using Cfg = DkvCfg<D>;
     using v8 = typename T::v8;
-    constexpr int RB = Cfg::RB, CPR = Cfg::CPR, TILE = Cfg::TILE, CH = Cfg::CH, KS = Cfg::KS, DB = Cfg::DB;
-    constexpr int STAGE = Cfg::STAGE;
+    constexpr int RB = Cfg::RB, RBP = Cfg::RBP, CPR = Cfg::CPR, RM = Cfg::RM, ST = Cfg::ST;
+    constexpr int KS = Cfg::KS, DB = Cfg::DB, STAGE = Cfg::STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* const Vslab = smem + wave * Cfg::VSLAB;
+    char* const stage0 = smem + 8 * Cfg::VSLAB;
     const int g = p.Hq / p.Hkv;
-    // one work item per (batch, kv head, kv block): reuse decode_work with Hq := Hkv
-    const WorkItem w = decode_work(blockIdx.x, p.B, p.Hkv, p.Hkv, p.nblk, false);
+    const int nkb = (p.Sk + kKvBlock - 1) / kKvBlock;
+    // one work item per (batch, kv head, kv block or block pair, head-split index): decode_work with
+    // Hq := Hkv * gsplit, so that `h - hk*gsplit` is the split index
+    const WorkItem w = decode_work(blockIdx.x, p.B, p.Hkv * p.gsplit, p.Hkv, p.nblk, false);
+    const int si = w.h - w.hk * p.gsplit;
+    const int gh = g / p.gsplit;  // query heads handled by this workgroup: [si*gh, (si+1)*gh)
     const int Sq = p.Sq, Sk = p.Sk;
-    const int n0w = w.blk * kKvBlock + wave * 32;  // first key row of this wave
-    const int kvrow = n0w + l31;
-    const int kvr = kvrow < Sk ? kvrow : Sk - 1;
-    const size_t kvbase = (size_t)(w.b * p.Hkv + w.hk) * Sk;
-
-    v8 kf[KS], vf[KS];  // B operands: lane (kv, hi) holds d = 16ks + 8hi .. +7
-    {
-        const u32x4_t* kp = reinterpret_cast<const u32x4_t*>(p.k) + (kvbase + kvr) * CPR;
-        const u32x4_t* vp = reinterpret_cast<const u32x4_t*>(p.v) + (kvbase + kvr) * CPR;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = as_v8<T>(kp[2 * ks + hi]);
-            vf[ks] = as_v8<T>(vp[2 * ks + hi]);
-        }
-    }
     const float c = p.c;
+    const size_t kvbase = (size_t)(w.b * p.Hkv + w.hk) * Sk;
+    const bool stager = Cfg::NCHUNK == 512 || tid < Cfg::NCHUNK;  // wave-uniform (NCHUNK is a multiple of 64)
 
-    int st_row[CH], st_cc[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        const int cidx = tid + 256 * i;
-        st_row[i] = cidx / CPR;
-        st_cc[i] = cidx % CPR;
-    }
-    int a_off[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a_off[ks] = rm_off<D>(l31, 2 * ks + hi);
+    // staging map: 8 consecutive lanes fetch one [4 q][16 d] sub-tile, so the sub-tiled image is filled
+    // linearly by thread id; the same registers are also written to the padded row-major image.
+    const int bidx = tid >> 3;  // sub-tile index = q4 * (D/16) + d16
+    const int st_row = (bidx / (D / 16)) * 4 + ((tid >> 1) & 3);
+    const int st_cc = (bidx % (D / 16)) * 2 + (tid & 1);
+    const int st_g = st_row * RB + st_cc * 16;
+    const int st_rm = st_row * RBP + st_cc * 16;
+    const int a_base = l31 * RBP + hi * 16;  // operand rows l31, chunk 2ks + hi (row-major padded images)
     const int tr_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
 
-    // query tiles that can see this KV block (top-left causal: q >= kv)
-    const int ntq_all = (Sq + kQT - 1) / kQT;
-    const int first_qt = CAUSAL ? (w.blk * kKvBlock) / kQT : 0;
-    const int ntq = ntq_all > first_qt ? ntq_all - first_qt : 0;
-    const int nit = ntq * g;  // flattened (group head, q tile) loop
+    const int nparts = (CAUSAL && (nkb - 1 - w.blk) != w.blk) ? 2 : 1;
+    for (int part = 0; part < nparts; ++part) {
+        const int kb = CAUSAL ? (part == 0 ? w.blk : nkb - 1 - w.blk) : w.blk;
+        const int n0w = kb * kKvBlock + wave * 32;  // first key row of this wave
+        const int kvrow = n0w + l31;
 
-    u32x4_t qst[CH], dst[CH];
-    float sc_st = 0.f;  // staged LSE (threads 0..31) or delta (threads 32..63)
-    auto issue_loads = [&](int it) {
-        const int hh = it / ntq, qt = first_qt + it % ntq;
-        const size_t qb = (size_t)(w.b * p.Hq + w.hk * g + hh) * Sq;
-        const int q0 = qt * kQT;
+        v8 kf[KS];  // B operand of S: lane (kv, hi) holds d = 16ks + 8hi .. +7 (rows >= Sk read as 0)
+        {
+            const __amdgpu_buffer_rsrc_t krs = make_srd_b(reinterpret_cast<const char*>(p.k) + kvbase * RB, (unsigned)Sk * RB);
+            const __amdgpu_buffer_rsrc_t vrs = make_srd_b(reinterpret_cast<const char*>(p.v) + kvbase * RB, (unsigned)Sk * RB);
 #pragma unroll
-        for (int i = 0; i < CH; ++i)
-            if (Cfg::NCHUNK % 256 == 0 || tid + 256 * i < Cfg::NCHUNK) {
-                int r = q0 + st_row[i];
+            for (int ks = 0; ks < KS; ++ks)
+                kf[ks] = as_v8<T>(__builtin_amdgcn_raw_buffer_load_b128(krs, kvrow * RB + (2 * ks + hi) * 16, 0, 0));
+            // this wave's 32 V rows -> its LDS slab (wave-private: program order suffices, no barrier)
+#pragma unroll
+            for (int i = 0; i < (32 * CPR) / 64; ++i) {
+                const int cidx = lane + 64 * i;
+                const int row = cidx / CPR, cc = cidx % CPR;
+                const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(vrs, row * RB + cc * 16, n0w * RB, 0);
+                *reinterpret_cast<u32x4_t*>(Vslab + row * RBP + cc * 16) = x;
+            }
+        }
+
+        // query tiles that can see this KV block (top-left causal: q >= kv)
+        const int ntq_all = (Sq + kQT - 1) / kQT;
+        const int first_qt = CAUSAL ? (kb * kKvBlock) / kQT : 0;
+        const int ntq = ntq_all > first_qt ? ntq_all - first_qt : 0;
+        const int nit = ntq * gh;  // flattened (group head, q tile) loop
+
+        u32x4_t qst, dst;
+        float sc_st = 0.f;  // staged LSE*log2e (threads 0..31) or delta (threads 32..63)
+        auto issue_loads = [&](int it) {
+            const int hh = si * gh + it / ntq, qt = first_qt + it % ntq;
+            const size_t qb = (size_t)(w.b * p.Hq + w.hk * g + hh) * Sq;
+            const __amdgpu_buffer_rsrc_t qrs = make_srd_b(reinterpret_cast<const char*>(p.q) + qb * RB, (unsigned)Sq * RB);
+            const __amdgpu_buffer_rsrc_t grs = make_srd_b(reinterpret_cast<const char*>(p.dout) + qb * RB, (unsigned)Sq * RB);
+            const int q0 = qt * kQT;
+            if (stager) {
+                qst = __builtin_amdgcn_raw_buffer_load_b128(qrs, st_g, q0 * RB, 0);
+                dst = __builtin_amdgcn_raw_buffer_load_b128(grs, st_g, q0 * RB, 0);
+            }
+            if (tid < 64) {
+                int r = q0 + (tid & 31);
                 r = r < Sq ? r : Sq - 1;
-                qst[i] = reinterpret_cast<const u32x4_t*>(p.q)[(qb + r) * CPR + st_cc[i]];
-                dst[i] = reinterpret_cast<const u32x4_t*>(p.dout)[(qb + r) * CPR + st_cc[i]];
+                sc_st = tid < 32 ? p.lse[qb + r] * kLog2e : p.delta[qb + r];
             }
-        if (tid < 64) {
-            int r = q0 + (tid & 31);
-            r = r < Sq ? r : Sq - 1;
-            sc_st = tid < 32 ? p.lse[qb + r] * kLog2e : p.delta[qb + r];
-        }
-    };
-    auto write_stage = [&](int buf) {
-        char* base = smem + buf * STAGE;
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-            if (Cfg::NCHUNK % 256 == 0 || tid + 256 * i < Cfg::NCHUNK) {
-                *reinterpret_cast<u32x4_t*>(base + rm_off<D>(st_row[i], st_cc[i])) = qst[i];
-                *reinterpret_cast<u32x4_t*>(base + TILE + st_off<D>(st_row[i], st_cc[i])) = qst[i];
-                *reinterpret_cast<u32x4_t*>(base + 2 * TILE + rm_off<D>(st_row[i], st_cc[i])) = dst[i];
-                *reinterpret_cast<u32x4_t*>(base + 3 * TILE + st_off<D>(st_row[i], st_cc[i])) = dst[i];
+        };
+        auto write_stage = [&](int buf) {
+            char* base = stage0 + buf * STAGE;
+            if (stager) {
+                *reinterpret_cast<u32x4_t*>(base + st_rm) = qst;
+                *reinterpret_cast<u32x4_t*>(base + RM + tid * 16) = qst;
+                *reinterpret_cast<u32x4_t*>(base + RM + ST + st_rm) = dst;
+                *reinterpret_cast<u32x4_t*>(base + 2 * RM + ST + tid * 16) = dst;
             }
-        if (tid < 64) reinterpret_cast<float*>(base + 4 * TILE)[tid] = sc_st;
-    };
+            if (tid < 64) reinterpret_cast<float*>(base + 2 * RM + 2 * ST)[tid] = sc_st;
+        };
 
-    f32x16_t dk[DB], dv[DB];
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
-
-    if (nit > 0) {
-        issue_loads(0);
-        write_stage(0);
-    }
-    __syncthreads();
-
-    for (int it = 0; it < nit; ++it) {
-        const int cur = it & 1;
-        const int q0 = (first_qt + it % ntq) * kQT;
-        if (it + 1 < nit) issue_loads(it + 1);
-        // the tile contributes to this wave's keys iff some query row q >= key row exists
-        if (!CAUSAL || q0 + kQT - 1 >= n0w) {
-            const char* base = smem + cur * STAGE;
-            const char* qrm = base;
-            const char* qst_img = base + TILE + tr_off;
-            const char* drm = base + 2 * TILE;
-            const char* dst_img = base + 3 * TILE + tr_off;
-            const float* scal = reinterpret_cast<const float*>(base + 4 * TILE);
-
-            f32x16_t s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const u32x4_t qa = *reinterpret_cast<const u32x4_t*>(qrm + a_off[ks]);
-                const u32x4_t da = *reinterpret_cast<const u32x4_t*>(drm + a_off[ks]);
-                s = T::mfma(as_v8<T>(qa), kf[ks], s);    // S  = Q  . K^T   (rows q, cols kv)
-                dp = T::mfma(as_v8<T>(da), vf[ks], dp);  // dP = dO . V^T
-            }
-            const bool need_mask = (CAUSAL && (q0 < n0w + 31)) || (q0 + kQT > Sq) || (n0w + 32 > Sk);
-            float pr[16], ds[16];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(scal + 8 * g4 + 4 * hi);
-                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(scal + 32 + 8 * g4 + 4 * hi);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * g4 + j;
-                    float pv = fast_exp2(__builtin_fmaf(s[r], c, -l4[j]));
-                    if (need_mask) {
-                        const int q = q0 + crow(r, hi);
-                        const bool vis = (q < Sq) && (kvrow < Sk) && (!CAUSAL || kvrow <= q);
-                        pv = vis ? pv : 0.f;
-                    }
-                    pr[r] = pv;
-                    ds[r] = pv * (dp[r] - d4[j]);
-                }
-            }
-            v8 pb[2], dsb[2];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                u32x4_t u, u2;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    u[j] = T::pack2(pr[8 * kk + 2 * j], pr[8 * kk + 2 * j + 1]);
-                    u2[j] = T::pack2(ds[8 * kk + 2 * j], ds[8 * kk + 2 * j + 1]);
-                }
-                pb[kk] = as_v8<T>(u);
-                dsb[kk] = as_v8<T>(u2);
-            }
-            // dV^T += dO^T . P ; dK^T += Q^T . dS   (A by transpose read, k-slot = query row)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int d = 0; d < DB; ++d) {
-                    const int off = ((4 * kk) * (D / 16) + 2 * d) * 128;
-                    const s16x4_t x0 = lds_tr16(dst_img + off);
-                    const s16x4_t x1 = lds_tr16(dst_img + off + 2 * (D / 16) * 128);
-                    dv[d] = T::mfma(as_v8<T>(x0, x1), pb[kk], dv[d]);
-                    const s16x4_t y0 = lds_tr16(qst_img + off);
-                    const s16x4_t y1 = lds_tr16(qst_img + off + 2 * (D / 16) * 128);
-                    dk[d] = T::mfma(as_v8<T>(y0, y1), dsb[kk], dk[d]);
-                }
-        }
-        if (it + 1 < nit) write_stage(cur ^ 1);
-        __syncthreads();
-    }
-
-    if (kvrow < Sk) {
-        char* krow = reinterpret_cast<char*>(p.dk) + (kvbase + kvrow) * RB;
-        char* vrow = reinterpret_cast<char*>(p.dv) + (kvbase + kvrow) * RB;
-        const float sc = p.scale;
+        f32x16_t dk[DB], dv[DB];
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int de = 32 * d + 8 * g4 + 4 * hi;
-                store4<T>(krow, de, dk[d][4 * g4] * sc, dk[d][4 * g4 + 1] * sc, dk[d][4 * g4 + 2] * sc,
-                          dk[d][4 * g4 + 3] * sc);
-                store4<T>(vrow, de, dv[d][4 * g4], dv[d][4 * g4 + 1], dv[d][4 * g4 + 2], dv[d][4 * g4 + 3]);
+            for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+
+        if (nit > 0) {
+            issue_loads(0);
+            write_stage(0);
+        }
+        __syncthreads();
+
+        for (int it = 0; it < nit; ++it) {
+            const int cur = it & 1;
+            const int q0 = (first_qt + it % ntq) * kQT;
+            if (it + 1 < nit) issue_loads(it + 1);
+            // the tile contributes to this wave's keys iff some query row q >= key row exists
+            if (!CAUSAL || q0 + kQT - 1 >= n0w) {
+                const char* base = stage0 + cur * STAGE;
+                const char* qrm = base + a_base;
+                const char* qtr = base + RM + tr_off;
+                const char* grm = base + RM + ST + a_base;
+                const char* gtr = base + 2 * RM + ST + tr_off;
+                const char* vsl = Vslab + a_base;
+                const float* scal = reinterpret_cast<const float*>(base + 2 * RM + 2 * ST);
+
+                f32x16_t s, dp, z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const u32x4_t qa = *reinterpret_cast<const u32x4_t*>(qrm + ks * 32);
+                    const u32x4_t da = *reinterpret_cast<const u32x4_t*>(grm + ks * 32);
+                    const u32x4_t vb = *reinterpret_cast<const u32x4_t*>(vsl + ks * 32);
+                    s = T::mfma(as_v8<T>(qa), kf[ks], ks == 0 ? z : s);              // S  = Q  . K^T
+                    dp = T::mfma(as_v8<T>(da), as_v8<T>(vb), ks == 0 ? z : dp);      // dP = dO . V^T
+                }
+                const bool need_mask = (CAUSAL && (q0 < n0w + 31)) || (q0 + kQT > Sq) || (n0w + 32 > Sk);
+                const f32x2_t c2 = {c, c};
+                v8 pb[2], dsb[2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    u32x4_t pu, du;
+#pragma unroll
+                    for (int g4 = 0; g4 < 2; ++g4) {
+                        const int r0 = 8 * kk + 4 * g4;  // registers r0..r0+3 = 4 consecutive query rows
+                        const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(scal + 2 * r0 + 4 * hi);
+                        const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(scal + 32 + 2 * r0 + 4 * hi);
+#pragma unroll
+                        for (int j2 = 0; j2 < 2; ++j2) {
+                            const int r = r0 + 2 * j2;
+                            f32x2_t t = {s[r], s[r + 1]};
+                            const f32x2_t nl = {-l4[2 * j2], -l4[2 * j2 + 1]};
+                            t = __builtin_elementwise_fma(t, c2, nl);
+                            t[0] = fast_exp2(t[0]);
+                            t[1] = fast_exp2(t[1]);
+                            if (need_mask) {
+                                const int q = q0 + crow(r, hi);
+                                const bool okc = kvrow < Sk;
+                                t[0] = (okc && q < Sq && (!CAUSAL || kvrow <= q)) ? t[0] : 0.f;
+                                t[1] = (okc && q + 1 < Sq && (!CAUSAL || kvrow <= q + 1)) ? t[1] : 0.f;
+                            }
+                            const f32x2_t dpv = {dp[r] - d4[2 * j2], dp[r + 1] - d4[2 * j2 + 1]};
+                            const f32x2_t dsv = t * dpv;
+                            pu[2 * g4 + j2] = T::pack2(t[0], t[1]);
+                            du[2 * g4 + j2] = T::pack2(dsv[0], dsv[1]);
+                        }
+                    }
+                    pb[kk] = as_v8<T>(pu);
+                    dsb[kk] = as_v8<T>(du);
+                }
+                // dV^T += dO^T . P ; dK^T += Q^T . dS   (A by transpose read, k-slot = query row)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int d = 0; d < DB; ++d) {
+                        const int off = ((4 * kk) * (D / 16) + 2 * d) * 128;
+                        const s16x4_t x0 = lds_tr16(gtr + off);
+                        const s16x4_t x1 = lds_tr16(gtr + off + 2 * (D / 16) * 128);
+                        dv[d] = T::mfma(as_v8<T>(x0, x1), pb[kk], dv[d]);
+                        const s16x4_t y0 = lds_tr16(qtr + off);
+                        const s16x4_t y1 = lds_tr16(qtr + off + 2 * (D / 16) * 128);
+                        dk[d] = T::mfma(as_v8<T>(y0, y1), dsb[kk], dk[d]);
+                    }
             }
+            if (it + 1 < nit) write_stage(cur ^ 1);
+            __syncthreads();
+        }
+
+        if (kvrow < Sk) {
+            const float sc = p.scale;
+            if (p.gsplit == 1) {
+                char* krow = reinterpret_cast<char*>(p.dk) + (kvbase + kvrow) * RB;
+                char* vrow = reinterpret_cast<char*>(p.dv) + (kvbase + kvrow) * RB;
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int de = 32 * d + 8 * g4 + 4 * hi;
+                        store4<T>(krow, de, dk[d][4 * g4] * sc, dk[d][4 * g4 + 1] * sc, dk[d][4 * g4 + 2] * sc,
+                                  dk[d][4 * g4 + 3] * sc);
+                        store4<T>(vrow, de, dv[d][4 * g4], dv[d][4 * g4 + 1], dv[d][4 * g4 + 2], dv[d][4 * g4 + 3]);
+                    }
+            } else {  // fp32 partials, summed in a fixed order by fa_bwd_reduce_kernel (deterministic)
+                const size_t tensor = (size_t)p.B * p.Hkv * Sk * D;
+                float* kp = p.part + (size_t)si * tensor + (kvbase + kvrow) * D;
+                float* vp = p.part + ((size_t)p.gsplit + si) * tensor + (kvbase + kvrow) * D;
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int de = 32 * d + 8 * g4 + 4 * hi;
+                        const f32x4_t a = {dk[d][4 * g4] * sc, dk[d][4 * g4 + 1] * sc, dk[d][4 * g4 + 2] * sc,
+                                           dk[d][4 * g4 + 3] * sc};
+                        const f32x4_t b = {dv[d][4 * g4], dv[d][4 * g4 + 1], dv[d][4 * g4 + 2], dv[d][4 * g4 + 3]};
+                        *reinterpret_cast<f32x4_t*>(kp + de) = a;
+                        *reinterpret_cast<f32x4_t*>(vp + de) = b;
+                    }
+            }
+        }
     }
+}
+
+// dK/dV = sum over the head-split partials (fixed order), cast to the storage dtype.  HBM-bound.
+struct ReduceParams {
+    const float* part;
+    void* dk;
+    void* dv;
+    long long n4;     // elements / 4 per tensor
+    int gsplit;
+};
+
+template <class T>
+__global__ void __launch_bounds__(256) fa_bwd_reduce_kernel(const ReduceParams p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * p.n4) return;
+    const int which = i >= p.n4;  // 0: dK, 1: dV
+    const long long e = which ? i - p.n4 : i;
+    const f32x4_t* src = reinterpret_cast<const f32x4_t*>(p.part) + (long long)which * p.gsplit * p.n4 + e;
+    f32x4_t acc = src[0];
+    for (int s = 1; s < p.gsplit; ++s) {
+        const f32x4_t x = src[(long long)s * p.n4];
+        acc[0] += x[0]; acc[1] += x[1]; acc[2] += x[2]; acc[3] += x[3];
+    }
+    u32x2_t u;
+    u[0] = T::pack2(acc[0], acc[1]);
+    u[1] = T::pack2(acc[2], acc[3]);
+    reinterpret_cast<u32x2_t*>(which ? p.dv : p.dk)[e] = u;
+}
+
+// Head split of the dK/dV kernel: a GQA/MQA problem has few (batch, kv-head) units, so the query heads
+// of a group are spread over `gsplit` workgroups (a divisor of g) until the grid covers the chip.
+constexpr int kTargetWorkgroups = 256;  // MI355X: 256 CUs, one 512-thread workgroup each
+inline int dkdv_gsplit(int B, int Hq, int Hkv, int Sk, int causal) {
+    const int g = Hq / Hkv;
+    const int nkb = (Sk + kKvBlock - 1) / kKvBlock;
+    const long long base = (long long)B * Hkv * (causal ? (nkb + 1) / 2 : nkb);
+    int sp = 1;
+    while (sp < g && base * sp < kTargetWorkgroups) {
+        int next = sp + 1;
+        while (next < g && g % next != 0) ++next;
+        sp = next;
+    }
+    return sp;
+}
+inline uint64_t delta_bytes(int B, int Hq, int Sq) {
+    return (((uint64_t)B * Hq * Sq * sizeof(float)) + 255) / 256 * 256;
 }
 
 template <class T, int D>
@@ -503,12 +605,21 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
         if (rc) return rc;
     }
     {
-        p.nblk = (a.Sk + kKvBlock - 1) / kKvBlock;
-        const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv)), block(256);
+        const int nkb = (a.Sk + kKvBlock - 1) / kKvBlock;
+        p.nblk = a.causal ? (nkb + 1) / 2 : nkb;  // causal: one workgroup per block pair (i, n-1-i)
+        p.gsplit = dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal);
+        p.part = reinterpret_cast<float*>(reinterpret_cast<char*>(a.delta) + delta_bytes(a.B, a.Hq, a.Sq));
+        const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv * p.gsplit)), block(512);
         if (a.causal)
             hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, true>), grid, block, DkvCfg<D>::LDS, stream, p);
         else
             hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, false>), grid, block, DkvCfg<D>::LDS, stream, p);
+        int rc = (int)hipGetLastError();
+        if (rc || p.gsplit == 1) return rc;
+        ReduceParams r;
+        r.part = p.part; r.dk = a.dk; r.dv = a.dv; r.gsplit = p.gsplit;
+        r.n4 = (long long)a.B * a.Hkv * a.Sk * D / 4;
+        hipLaunchKernelGGL((fa_bwd_reduce_kernel<T>), dim3((unsigned)((2 * r.n4 + 255) / 256)), dim3(256), 0, stream, r);
         return (int)hipGetLastError();
     }
 }
@@ -553,7 +664,14 @@ int launch_delta_f32(const BwdArgs& a, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-uint64_t bwd_workspace_bytes(int B, int Hq, int Sq) { return (uint64_t)B * Hq * Sq * sizeof(float); }
+uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype) {
+    uint64_t bytes = delta_bytes(B, Hq, Sq);
+    if (dtype != kF32) {
+        const int sp = dkdv_gsplit(B, Hq, Hkv, Sk, causal);
+        if (sp > 1) bytes += 2ull * sp * B * Hkv * Sk * D * sizeof(float);
+    }
+    return bytes;
+}
 
 int launch_bwd(const BwdArgs& a, hipStream_t stream) {
     if (a.dtype == kF32) return launch_bwd_f32(a, stream);

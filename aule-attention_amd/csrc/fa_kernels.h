@@ -38,7 +38,7 @@ struct BwdArgs {
     void* dq;
     void* dk;
     void* dv;
-    float* delta;  // workspace [B,Hq,Sq] fp32
+    float* delta;  // workspace of bwd_workspace_bytes(): delta [B,Hq,Sq] fp32 first
     int B, Hq, Hkv, Sq, Sk, D;
     float scale;
     int causal;
@@ -50,8 +50,9 @@ struct BwdArgs {
 int launch_fwd(const FwdArgs& a, hipStream_t stream);
 int launch_bwd(const BwdArgs& a, hipStream_t stream);
 
-// Bytes of device workspace launch_bwd needs (delta).
-uint64_t bwd_workspace_bytes(int B, int Hq, int Sq);
+// Bytes of device workspace launch_bwd needs: delta [B,Hq,Sq] fp32, plus (16-bit GQA/MQA problems that
+// do not fill the chip) fp32 dK/dV partials of the head-split dK/dV kernel.
+uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype);
 
 // Set the max-dynamic-LDS attribute on every kernel (call once per device).
 int configure_kernels();
