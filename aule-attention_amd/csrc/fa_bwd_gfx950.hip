@@ -126,14 +126,20 @@ __device__ __forceinline__ void store4(char* row_ptr, int d_elem, float a, float
 }
 
 // --------------------------------------------------------------- dQ kernel ----
+// One workgroup per 256-row Q block (causal: per block PAIR (i, n-1-i), uniform work), 8 waves x 32 query
+// rows; lane owns one query row (Q, dO fragments in registers; LSE, delta lane-local scalars).  64-row KV
+// tiles are double-buffered in LDS: K row-major padded (A operand of S^T = K.Q^T), K sub-tiled
+// (transpose-read source of dQ^T += K^T.dS^T), V row-major padded (A operand of dP^T = V.dO^T).
 constexpr int kDqQBlock = 256;
 constexpr int kDqKV = 64;
 
 template <int D>
 struct DqCfg {
-    static constexpr int RB = D * 2, CPR = RB / 16, TILE = kDqKV * RB, NCHUNK = TILE / 16;
+    static constexpr int RB = D * 2, RBP = RB + 16, CPR = RB / 16;
+    static constexpr int RM = kDqKV * RBP, ST = kDqKV * RB, NCHUNK = kDqKV * CPR;
     static constexpr int CH = (NCHUNK + 511) / 512, KS = D / 16, DB = D / 32;
-    static constexpr int STAGE = 3 * TILE;  // K row-major, K sub-tiled, V row-major
+    static constexpr bool kFull = (NCHUNK % 512) == 0;
+    static constexpr int STAGE = 2 * RM + ST;  // K row-major, V row-major, K sub-tiled
     static constexpr int LDS = 2 * STAGE;
 };
 
@@ -141,150 +147,161 @@ template <class T, int D, bool CAUSAL>
 __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
     using Cfg = DqCfg<D>;
     using v8 = typename T::v8;
-    constexpr int RB = Cfg::RB, CPR = Cfg::CPR, TILE = Cfg::TILE, CH = Cfg::CH, KS = Cfg::KS, DB = Cfg::DB;
+    constexpr int RB = Cfg::RB, RBP = Cfg::RBP, RM = Cfg::RM, ST = Cfg::ST, CH = Cfg::CH, KS = Cfg::KS, DB = Cfg::DB;
     constexpr int STAGE = Cfg::STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const WorkItem w = decode_work(blockIdx.x, p.B, p.Hq, p.Hkv, p.nblk, CAUSAL);
+    const WorkItem w = decode_work(blockIdx.x, p.B, p.Hq, p.Hkv, p.nblk, false);
     const int Sq = p.Sq, Sk = p.Sk;
-    const int q0w = w.blk * kDqQBlock + wave * 32;
-    const int qrow = q0w + l31;
-    const int qr = qrow < Sq ? qrow : Sq - 1;
-    const size_t qbase = (size_t)(w.b * p.Hq + w.h) * Sq;
-
-    const u32x4_t* __restrict__ kg = reinterpret_cast<const u32x4_t*>(p.k) + (size_t)(w.b * p.Hkv + w.hk) * Sk * CPR;
-    const u32x4_t* __restrict__ vg = reinterpret_cast<const u32x4_t*>(p.v) + (size_t)(w.b * p.Hkv + w.hk) * Sk * CPR;
-
-    v8 qf[KS], dof[KS];
-    {
-        const u32x4_t* qp = reinterpret_cast<const u32x4_t*>(p.q) + (qbase + qr) * CPR;
-        const u32x4_t* gp = reinterpret_cast<const u32x4_t*>(p.dout) + (qbase + qr) * CPR;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = as_v8<T>(qp[2 * ks + hi]);
-            dof[ks] = as_v8<T>(gp[2 * ks + hi]);
-        }
-    }
-    const float lse2 = p.lse[qbase + qr] * kLog2e;
-    const float delta = p.delta[qbase + qr];
     const float c = p.c;
+    const int nqb = (Sq + kDqQBlock - 1) / kDqQBlock;
+    const size_t qbase = (size_t)(w.b * p.Hq + w.h) * Sq;
+    const size_t kvhead = (size_t)(w.b * p.Hkv + w.hk) * Sk * RB;
+    const __amdgpu_buffer_rsrc_t krs = make_srd_b(reinterpret_cast<const char*>(p.k) + kvhead, (unsigned)Sk * RB);
+    const __amdgpu_buffer_rsrc_t vrs = make_srd_b(reinterpret_cast<const char*>(p.v) + kvhead, (unsigned)Sk * RB);
+    const __amdgpu_buffer_rsrc_t qrs = make_srd_b(reinterpret_cast<const char*>(p.q) + qbase * RB, (unsigned)Sq * RB);
+    const __amdgpu_buffer_rsrc_t grs = make_srd_b(reinterpret_cast<const char*>(p.dout) + qbase * RB, (unsigned)Sq * RB);
 
-    int st_row[CH], st_cc[CH];
+    // staging map: 8 consecutive lanes fetch one [4 kv][16 d] sub-tile (sub-tiled image filled linearly by
+    // thread id); the same K registers also go to the padded row-major image; V uses the same map.
+    int st_g[CH], st_rm[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        const int cidx = tid + 512 * i;
-        st_row[i] = cidx / CPR;
-        st_cc[i] = cidx % CPR;
+        const int bidx = (tid >> 3) + 64 * i;
+        const int row = (bidx / (D / 16)) * 4 + ((tid >> 1) & 3);
+        const int cc = (bidx % (D / 16)) * 2 + (tid & 1);
+        st_g[i] = row * RB + cc * 16;
+        st_rm[i] = row * RBP + cc * 16;
     }
-    int a_off[KS];  // row-major A-operand offsets (row l31, chunk 2ks+hi)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a_off[ks] = rm_off<D>(l31, 2 * ks + hi);
+    const int a_base = l31 * RBP + hi * 16;
     const int tr_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
-
-    const int kv_hi = CAUSAL ? min(Sk, w.blk * kDqQBlock + kDqQBlock) : Sk;
-    const int nt = (kv_hi + kDqKV - 1) / kDqKV;
-    const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32) : Sk;
 
     u32x4_t kst[CH], vst[CH];
     auto issue_loads = [&](int kv0) {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
-            if (Cfg::NCHUNK % 512 == 0 || tid + 512 * i < Cfg::NCHUNK) {
-                int r = kv0 + st_row[i];
-                r = r < Sk ? r : Sk - 1;
-                kst[i] = kg[(size_t)r * CPR + st_cc[i]];
-                vst[i] = vg[(size_t)r * CPR + st_cc[i]];
+            if (Cfg::kFull || tid + 512 * i < Cfg::NCHUNK) {
+                kst[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, st_g[i], kv0 * RB, 0);
+                vst[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, st_g[i], kv0 * RB, 0);
             }
     };
     auto write_stage = [&](int buf) {
         char* base = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < CH; ++i)
-            if (Cfg::NCHUNK % 512 == 0 || tid + 512 * i < Cfg::NCHUNK) {
-                *reinterpret_cast<u32x4_t*>(base + rm_off<D>(st_row[i], st_cc[i])) = kst[i];
-                *reinterpret_cast<u32x4_t*>(base + TILE + st_off<D>(st_row[i], st_cc[i])) = kst[i];
-                *reinterpret_cast<u32x4_t*>(base + 2 * TILE + rm_off<D>(st_row[i], st_cc[i])) = vst[i];
+            if (Cfg::kFull || tid + 512 * i < Cfg::NCHUNK) {
+                *reinterpret_cast<u32x4_t*>(base + st_rm[i]) = kst[i];
+                *reinterpret_cast<u32x4_t*>(base + RM + st_rm[i]) = vst[i];
+                *reinterpret_cast<u32x4_t*>(base + 2 * RM + tid * 16 + i * 8192) = kst[i];
             }
     };
 
-    f32x16_t acc[DB];
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+    const int nparts = (CAUSAL && (nqb - 1 - w.blk) != w.blk) ? 2 : 1;
+    for (int part = 0; part < nparts; ++part) {
+        const int qb = CAUSAL ? (part == 0 ? nqb - 1 - w.blk : w.blk) : w.blk;
+        const int q0w = qb * kDqQBlock + wave * 32;
+        const int qrow = q0w + l31;
+        const int qr = qrow < Sq ? qrow : Sq - 1;
 
-    issue_loads(0);
-    write_stage(0);
-    __syncthreads();
-
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        const int kv0 = t * kDqKV;
-        if (t + 1 < nt) issue_loads(kv0 + kDqKV);
-        if (kv0 < wave_kv_hi) {
-            const char* krm = smem + cur * STAGE;
-            const char* kst_img = krm + TILE + tr_off;
-            const char* vrm = krm + 2 * TILE;
+        v8 qf[KS], dof[KS];
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
-                if (sb == 1 && kv0 + 32 >= wave_kv_hi) break;  // second half fully masked (wave-uniform)
-                f32x16_t s, dp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const u32x4_t ka = *reinterpret_cast<const u32x4_t*>(krm + a_off[ks] + sb * 32 * RB);
-                    const u32x4_t va = *reinterpret_cast<const u32x4_t*>(vrm + a_off[ks] + sb * 32 * RB);
-                    s = T::mfma(as_v8<T>(ka), qf[ks], s);      // S^T  = K  . Q^T
-                    dp = T::mfma(as_v8<T>(va), dof[ks], dp);   // dP^T = V  . dO^T
-                }
-                const bool need_mask = (CAUSAL && (kv0 + sb * 32 + 31 > q0w)) || (kv0 + sb * 32 + 32 > Sk);
-                float ds[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float pv = fast_exp2(__builtin_fmaf(s[r], c, -lse2));
-                    if (need_mask) {
-                        const int kv = kv0 + sb * 32 + crow(r, hi);
-                        const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow);
-                        pv = vis ? pv : 0.f;
-                    }
-                    ds[r] = pv * (dp[r] - delta);
-                }
-                v8 dsb[2];
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    u32x4_t u;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) u[j] = T::pack2(ds[8 * kk + 2 * j], ds[8 * kk + 2 * j + 1]);
-                    dsb[kk] = as_v8<T>(u);
-                }
-                // dQ^T += K^T . dS^T  (A = K^T by transpose read, B = dS in registers)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int d = 0; d < DB; ++d) {
-                        const int off = ((8 * sb + 4 * kk) * (D / 16) + 2 * d) * 128;
-                        const s16x4_t a0 = lds_tr16(kst_img + off);
-                        const s16x4_t a1 = lds_tr16(kst_img + off + 2 * (D / 16) * 128);
-                        acc[d] = T::mfma(as_v8<T>(a0, a1), dsb[kk], acc[d]);
-                    }
-            }
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = as_v8<T>(__builtin_amdgcn_raw_buffer_load_b128(qrs, qrow * RB + (2 * ks + hi) * 16, 0, 0));
+            dof[ks] = as_v8<T>(__builtin_amdgcn_raw_buffer_load_b128(grs, qrow * RB + (2 * ks + hi) * 16, 0, 0));
         }
-        if (t + 1 < nt) write_stage(cur ^ 1);
-        __syncthreads();
-    }
+        const float nlse2 = -p.lse[qbase + qr] * kLog2e;
+        const float delta = p.delta[qbase + qr];
 
-    if (qrow < Sq) {
-        char* orow = reinterpret_cast<char*>(p.dq) + (qbase + qrow) * RB;
-        const float sc = p.scale;
+        const int kv_hi = CAUSAL ? min(Sk, qb * kDqQBlock + kDqQBlock) : Sk;
+        const int nt = (kv_hi + kDqKV - 1) / kDqKV;
+        const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32) : Sk;
+
+        f32x16_t acc[DB];
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-                store4<T>(orow, 32 * d + 8 * g4 + 4 * hi, acc[d][4 * g4] * sc, acc[d][4 * g4 + 1] * sc,
-                          acc[d][4 * g4 + 2] * sc, acc[d][4 * g4 + 3] * sc);
+            for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+        issue_loads(0);
+        write_stage(0);
+        __syncthreads();
+
+        for (int t = 0; t < nt; ++t) {
+            const int cur = t & 1;
+            const int kv0 = t * kDqKV;
+            if (t + 1 < nt) issue_loads(kv0 + kDqKV);
+            if (kv0 < wave_kv_hi) {
+                const char* krm = smem + cur * STAGE + a_base;
+                const char* vrm = smem + cur * STAGE + RM + a_base;
+                const char* ktr = smem + cur * STAGE + 2 * RM + tr_off;
+                f32x16_t z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                f32x16_t s[2], dp[2];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb) {
+                        const u32x4_t ka = *reinterpret_cast<const u32x4_t*>(krm + sb * 32 * RBP + ks * 32);
+                        const u32x4_t va = *reinterpret_cast<const u32x4_t*>(vrm + sb * 32 * RBP + ks * 32);
+                        s[sb] = T::mfma(as_v8<T>(ka), qf[ks], ks == 0 ? z : s[sb]);      // S^T  = K . Q^T
+                        dp[sb] = T::mfma(as_v8<T>(va), dof[ks], ks == 0 ? z : dp[sb]);   // dP^T = V . dO^T
+                    }
+                const bool need_mask = (CAUSAL && (kv0 + kDqKV - 1 > q0w)) || (kv0 + kDqKV > Sk);
+                const f32x2_t c2 = {c, c}, nl2 = {nlse2, nlse2}, dl2 = {delta, delta};
+                v8 dsb[2][2];
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        u32x4_t du;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int r = 8 * kk + 2 * j;
+                            f32x2_t t2 = {s[sb][r], s[sb][r + 1]};
+                            t2 = __builtin_elementwise_fma(t2, c2, nl2);
+                            t2[0] = fast_exp2(t2[0]);
+                            t2[1] = fast_exp2(t2[1]);
+                            if (need_mask) {
+                                const int kv = kv0 + sb * 32 + crow(r, hi);
+                                t2[0] = ((kv < Sk) && (!CAUSAL || kv <= qrow)) ? t2[0] : 0.f;
+                                t2[1] = ((kv + 1 < Sk) && (!CAUSAL || kv + 1 <= qrow)) ? t2[1] : 0.f;
+                            }
+                            const f32x2_t dpv = {dp[sb][r], dp[sb][r + 1]};
+                            const f32x2_t dsv = t2 * (dpv - dl2);
+                            du[j] = T::pack2(dsv[0], dsv[1]);
+                        }
+                        dsb[sb][kk] = as_v8<T>(du);
+                    }
+                // dQ^T += K^T . dS^T  (A = K^T by transpose read, B = dS in registers)
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int d = 0; d < DB; ++d) {
+                            const int off = ((8 * sb + 4 * kk) * (D / 16) + 2 * d) * 128;
+                            const s16x4_t a0 = lds_tr16(ktr + off);
+                            const s16x4_t a1 = lds_tr16(ktr + off + 2 * (D / 16) * 128);
+                            acc[d] = T::mfma(as_v8<T>(a0, a1), dsb[sb][kk], acc[d]);
+                        }
+            }
+            if (t + 1 < nt) write_stage(cur ^ 1);
+            __syncthreads();
+        }
+
+        if (qrow < Sq) {
+            char* orow = reinterpret_cast<char*>(p.dq) + (qbase + qrow) * RB;
+            const float sc = p.scale;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    store4<T>(orow, 32 * d + 8 * g4 + 4 * hi, acc[d][4 * g4] * sc, acc[d][4 * g4 + 1] * sc,
+                              acc[d][4 * g4 + 2] * sc, acc[d][4 * g4 + 3] * sc);
+        }
     }
 }
 
@@ -595,7 +612,10 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     p.c = a.scale * kLog2e;
     p.scale = a.scale;
     {
-        p.nblk = (a.Sq + kDqQBlock - 1) / kDqQBlock;
+        const int nqb = (a.Sq + kDqQBlock - 1) / kDqQBlock;
+        p.nblk = a.causal ? (nqb + 1) / 2 : nqb;  // causal: one workgroup per Q-block pair (i, n-1-i)
+        p.gsplit = 1;
+        p.part = nullptr;
         const dim3 grid((unsigned)(p.nblk * a.B * a.Hq)), block(512);
         if (a.causal)
             hipLaunchKernelGGL((fa_bwd_dq_kernel<T, D, true>), grid, block, DqCfg<D>::LDS, stream, p);

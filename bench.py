@@ -117,7 +117,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no ROCm device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also exercised with 1 rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
@@ -211,7 +211,7 @@ def main():
                                  + 4 * B * Hq * Sq)},
     }
 
-    if n_gpus > 1:
+    if dist is not None and (n_gpus > 1 or os.environ.get("AULE_BENCH_FORCE_GATHER")):
         # the one collective of the sharded path: all-gather of O over xGMI (RCCL), timed separately
         out = step() if mode == "fwd" else step().detach()
         gathered = torch.empty((n_gpus,) + tuple(out.shape), device=dev, dtype=out.dtype)

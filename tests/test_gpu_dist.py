@@ -1,0 +1,57 @@
+"""GPU test of the multi-GPU driver code on ONE GPU (the box has one): a 1-rank RCCL process group
+runs aule.dist.flash_attention_sharded and bench.py's torch.distributed path end to end, so that
+init / all_reduce / all_gather_into_tensor / barrier are exercised before the driver's 8-GPU run.
+(The sharding arithmetic itself is covered with world_size 2 on gloo in tests/test_dist_gloo.py.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cmd, extra_env=None):
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    env.update(extra_env or {})
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_under_torchrun_one_rank():
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+              "--master-addr", "127.0.0.1", "--master-port", "29517", "bench.py", "--gpus", "1", "--steps", "3",
+              "--warmup", "1", "--batch", "1", "--no-cpu-baseline", "--no-extra"],
+             {"AULE_BENCH_FORCE_GATHER": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["unit"] == "TFLOP/s"
+    assert "gather" in rec and rec["gather"]["ms_per_step"] > 0
+    assert rec["roofline"]["bound"] == "mfma" and 0 < rec["roofline"]["frac"] < 1
+
+
+def test_sharded_api_one_rank_nccl():
+    code = r"""
+import os, sys
+sys.path.insert(0, os.path.join(%r, "aule-attention_amd"))
+import torch, torch.distributed as dist
+import aule
+from aule import dist as adist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29518")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+q = torch.randn(2, 8, 256, 128, device="cuda", dtype=torch.bfloat16)
+k = torch.randn(2, 2, 256, 128, device="cuda", dtype=torch.bfloat16)
+v = torch.randn(2, 2, 256, 128, device="cuda", dtype=torch.bfloat16)
+full = adist.flash_attention_sharded(q, k, v, causal=True)
+ref = aule.flash_attention(q, k, v, causal=True)
+assert torch.equal(full, ref)
+dist.destroy_process_group()
+print("OK")
+""" % ROOT
+    r = _run([sys.executable, "-c", code])
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
