@@ -127,9 +127,16 @@ __device__ __forceinline__ void store4(char* row_ptr, int d_elem, float a, float
 
 // --------------------------------------------------------------- dQ kernel ----
 // One workgroup per 256-row Q block (causal: per block PAIR (i, n-1-i), uniform work), 8 waves x 32 query
-// rows; lane owns one query row (Q, dO fragments in registers; LSE, delta lane-local scalars).  64-row KV
-// tiles are double-buffered in LDS: K row-major padded (A operand of S^T = K.Q^T), K sub-tiled
-// (transpose-read source of dQ^T += K^T.dS^T), V row-major padded (A operand of dP^T = V.dO^T).
+// rows; lane owns one query row (Q, dO fragments in registers; LSE, delta lane-local scalars).
+// Same two-group "ping-pong" schedule as the forward (fa_fwd_pp_gfx950.hip): per 64-row KV tile a
+// V-phase (P, dS from S^T, dP^T: VALU only) and an M-phase (dQ^T += K_j^T.dS_j^T, then S^T_{j+1} =
+// K_{j+1}.Q^T and dP^T_{j+1} = V_{j+1}.dO^T: 48 MFMAs), wave groups 0-3 / 4-7 one phase apart.
+// LDS images per KV tile t: K row-major padded (Krm[t&1]), V row-major padded (Vrm[t&1]) -- both read in
+// M-phase(t-1) -- and K sub-tiled (Kst[t%3], transpose-read source, read in M-phase(t); three buffers
+// because it lives one tile longer than the row-major images written with it).  Staging rule (all in
+// V-phases): in V-phase(tau) group d writes the tile it loaded one phase earlier, tile tau+1+d, then
+// requests tile tau+2+d.  Write slot of tile T: 2T-2 (group 0) / 2T-3 (group 1); its buffers' previous
+// readers finished in slot 2T-4; its first reader is group 0's M-phase(T-1) in slot 2T-1.
 constexpr int kDqQBlock = 256;
 constexpr int kDqKV = 64;
 
@@ -139,8 +146,7 @@ struct DqCfg {
     static constexpr int RM = kDqKV * RBP, ST = kDqKV * RB, NCHUNK = kDqKV * CPR;
     static constexpr int CH = (NCHUNK + 511) / 512, KS = D / 16, DB = D / 32;
     static constexpr bool kFull = (NCHUNK % 512) == 0;
-    static constexpr int STAGE = 2 * RM + ST;  // K row-major, V row-major, K sub-tiled
-    static constexpr int LDS = 2 * STAGE;
+    static constexpr int LDS = 4 * RM + 3 * ST;  // Krm x2, Vrm x2, Kst x3
 };
 
 template <class T, int D, bool CAUSAL>
@@ -148,11 +154,14 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
     using Cfg = DqCfg<D>;
     using v8 = typename T::v8;
     constexpr int RB = Cfg::RB, RBP = Cfg::RBP, RM = Cfg::RM, ST = Cfg::ST, CH = Cfg::CH, KS = Cfg::KS, DB = Cfg::DB;
-    constexpr int STAGE = Cfg::STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Krm = smem;
+    char* const Vrm = smem + 2 * RM;
+    char* const Kst = smem + 4 * RM;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
     const WorkItem w = decode_work(blockIdx.x, p.B, p.Hq, p.Hkv, p.nblk, false);
     const int Sq = p.Sq, Sk = p.Sk;
     const float c = p.c;
@@ -179,22 +188,24 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
     const int tr_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
 
     u32x4_t kst[CH], vst[CH];
-    auto issue_loads = [&](int kv0) {
+    auto issue_loads = [&](int t) {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if (Cfg::kFull || tid + 512 * i < Cfg::NCHUNK) {
-                kst[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, st_g[i], kv0 * RB, 0);
-                vst[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, st_g[i], kv0 * RB, 0);
+                kst[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, st_g[i], t * kDqKV * RB, 0);
+                vst[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, st_g[i], t * kDqKV * RB, 0);
             }
     };
-    auto write_stage = [&](int buf) {
-        char* base = smem + buf * STAGE;
+    auto write_tile = [&](int t) {
+        char* krm = Krm + (t & 1) * RM;
+        char* vrm = Vrm + (t & 1) * RM;
+        char* kst_img = Kst + (t % 3) * ST;
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if (Cfg::kFull || tid + 512 * i < Cfg::NCHUNK) {
-                *reinterpret_cast<u32x4_t*>(base + st_rm[i]) = kst[i];
-                *reinterpret_cast<u32x4_t*>(base + RM + st_rm[i]) = vst[i];
-                *reinterpret_cast<u32x4_t*>(base + 2 * RM + tid * 16 + i * 8192) = kst[i];
+                *reinterpret_cast<u32x4_t*>(krm + st_rm[i]) = kst[i];
+                *reinterpret_cast<u32x4_t*>(vrm + st_rm[i]) = vst[i];
+                *reinterpret_cast<u32x4_t*>(kst_img + tid * 16 + i * 8192) = kst[i];
             }
     };
 
@@ -205,6 +216,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
         const int qrow = q0w + l31;
         const int qr = qrow < Sq ? qrow : Sq - 1;
 
+        issue_loads(0);
         v8 qf[KS], dof[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -213,84 +225,146 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
         }
         const float nlse2 = -p.lse[qbase + qr] * kLog2e;
         const float delta = p.delta[qbase + qr];
+        const int kv_lim = CAUSAL ? min(Sk - 1, qrow) : Sk - 1;  // last key visible to this lane's query row
 
         const int kv_hi = CAUSAL ? min(Sk, qb * kDqQBlock + kDqQBlock) : Sk;
         const int nt = (kv_hi + kDqKV - 1) / kDqKV;
         const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32) : Sk;
+        const int na = (wave_kv_hi + kDqKV - 1) / kDqKV;
 
         f32x16_t acc[DB];
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+        f32x16_t s[2], dp[2];
+        v8 dsb[2][2];
 
-        issue_loads(0);
-        write_stage(0);
-        __syncthreads();
-
-        for (int t = 0; t < nt; ++t) {
-            const int cur = t & 1;
-            const int kv0 = t * kDqKV;
-            if (t + 1 < nt) issue_loads(kv0 + kDqKV);
-            if (kv0 < wave_kv_hi) {
-                const char* krm = smem + cur * STAGE + a_base;
-                const char* vrm = smem + cur * STAGE + RM + a_base;
-                const char* ktr = smem + cur * STAGE + 2 * RM + tr_off;
-                f32x16_t z;
+        auto sdp = [&](int t) {  // S^T = K_t.Q^T ; dP^T = V_t.dO^T
+            int kro = (t & 1) * RM + a_base;
+            asm volatile("" : "+v"(kro));
+            const char* krm = Krm + kro;
+            const char* vrm = Vrm + kro;
+            f32x16_t z;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                f32x16_t s[2], dp[2];
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            constexpr int kAhead = 0;
+            u32x4_t ka[KS][2], va[KS][2];
+            auto rd = [&](int ks) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                for (int sb = 0; sb < 2; ++sb) {
+                    ka[ks][sb] = *reinterpret_cast<const u32x4_t*>(krm + sb * 32 * RBP + ks * 32);
+                    va[ks][sb] = *reinterpret_cast<const u32x4_t*>(vrm + sb * 32 * RBP + ks * 32);
+                }
+            };
 #pragma unroll
-                    for (int sb = 0; sb < 2; ++sb) {
-                        const u32x4_t ka = *reinterpret_cast<const u32x4_t*>(krm + sb * 32 * RBP + ks * 32);
-                        const u32x4_t va = *reinterpret_cast<const u32x4_t*>(vrm + sb * 32 * RBP + ks * 32);
-                        s[sb] = T::mfma(as_v8<T>(ka), qf[ks], ks == 0 ? z : s[sb]);      // S^T  = K . Q^T
-                        dp[sb] = T::mfma(as_v8<T>(va), dof[ks], ks == 0 ? z : dp[sb]);   // dP^T = V . dO^T
-                    }
-                const bool need_mask = (CAUSAL && (kv0 + kDqKV - 1 > q0w)) || (kv0 + kDqKV > Sk);
-                const f32x2_t c2 = {c, c}, nl2 = {nlse2, nlse2}, dl2 = {delta, delta};
-                v8 dsb[2][2];
+            for (int ks = 0; ks < kAhead && ks < KS; ++ks) rd(ks);
 #pragma unroll
-                for (int sb = 0; sb < 2; ++sb)
+            for (int ks = 0; ks < KS; ++ks) {
+                if (kAhead == 0) rd(ks);
+                else if (ks + kAhead < KS) rd(ks + kAhead);
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        u32x4_t du;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int r = 8 * kk + 2 * j;
-                            f32x2_t t2 = {s[sb][r], s[sb][r + 1]};
-                            t2 = __builtin_elementwise_fma(t2, c2, nl2);
-                            t2[0] = fast_exp2(t2[0]);
-                            t2[1] = fast_exp2(t2[1]);
-                            if (need_mask) {
-                                const int kv = kv0 + sb * 32 + crow(r, hi);
-                                t2[0] = ((kv < Sk) && (!CAUSAL || kv <= qrow)) ? t2[0] : 0.f;
-                                t2[1] = ((kv + 1 < Sk) && (!CAUSAL || kv + 1 <= qrow)) ? t2[1] : 0.f;
-                            }
-                            const f32x2_t dpv = {dp[sb][r], dp[sb][r + 1]};
-                            const f32x2_t dsv = t2 * (dpv - dl2);
-                            du[j] = T::pack2(dsv[0], dsv[1]);
-                        }
-                        dsb[sb][kk] = as_v8<T>(du);
-                    }
-                // dQ^T += K^T . dS^T  (A = K^T by transpose read, B = dS in registers)
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                        for (int d = 0; d < DB; ++d) {
-                            const int off = ((8 * sb + 4 * kk) * (D / 16) + 2 * d) * 128;
-                            const s16x4_t a0 = lds_tr16(ktr + off);
-                            const s16x4_t a1 = lds_tr16(ktr + off + 2 * (D / 16) * 128);
-                            acc[d] = T::mfma(as_v8<T>(a0, a1), dsb[sb][kk], acc[d]);
-                        }
+                for (int sb = 0; sb < 2; ++sb) {
+                    s[sb] = T::mfma(as_v8<T>(ka[ks][sb]), qf[ks], ks == 0 ? z : s[sb]);
+                    dp[sb] = T::mfma(as_v8<T>(va[ks][sb]), dof[ks], ks == 0 ? z : dp[sb]);
+                }
             }
-            if (t + 1 < nt) write_stage(cur ^ 1);
-            __syncthreads();
+        };
+        auto dq_mm = [&](int t) {  // dQ^T += K_t^T . dS_t^T  (A = K^T by transpose read, B = dS in registers)
+            int kofs = 4 * RM + (t % 3) * ST + tr_off;
+            asm volatile("" : "+v"(kofs));  // one base register + 16-bit immediates (else 32 hoisted addresses spill)
+            const char* ktr = smem + kofs;
+            constexpr int NST = 4 * DB, kAhead = 2;
+            s16x4_t a0[NST], a1[NST];
+            auto rd = [&](int st) {
+                const int sk = st / DB, d = st % DB;  // sk = 2*sb + kk
+                const int off = ((4 * sk) * (D / 16) + 2 * d) * 128;
+                a0[st] = lds_tr16(ktr + off);
+                a1[st] = lds_tr16(ktr + off + 2 * (D / 16) * 128);
+            };
+#pragma unroll
+            for (int st = 0; st < kAhead && st < NST; ++st) rd(st);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                if (st + kAhead < NST) rd(st + kAhead);
+                const int sk = st / DB, d = st % DB;
+                acc[d] = T::mfma(as_v8<T>(a0[st], a1[st]), dsb[sk >> 1][sk & 1], acc[d]);
+            }
+        };
+        auto softmax = [&](int kv0) {  // P^T = exp2(S^T c - LSE log2e) (0 where masked) ; dS^T = P^T o (dP^T - delta)
+            const bool need_mask = (CAUSAL && (kv0 + kDqKV - 1 > q0w)) || (kv0 + kDqKV > Sk);
+            const f32x2_t c2 = {c, c}, nl2 = {nlse2, nlse2}, dl2 = {delta, delta};
+            int rel = kv0 - kv_lim;  // key index relative to the last visible key of this lane's row
+            asm volatile("" : "+v"(rel));  // (opaque: otherwise hipcc hoists 32 per-element constants out of the loop and spills them)
+            u32x4_t du[2][2];
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 8 * kk + 2 * j;
+                        f32x2_t t2 = {s[sb][r], s[sb][r + 1]};
+                        t2 = __builtin_elementwise_fma(t2, c2, nl2);
+                        t2[0] = fast_exp2(t2[0]);
+                        t2[1] = fast_exp2(t2[1]);
+                        if (need_mask) {  // visible iff kv <= kv_lim (one compare per element, no branches)
+                            const int kvr = rel + sb * 32 + crow(r, hi);
+                            t2[0] = kvr <= 0 ? t2[0] : 0.f;
+                            t2[1] = kvr < 0 ? t2[1] : 0.f;
+                        }
+                        const f32x2_t dpv = {dp[sb][r], dp[sb][r + 1]};
+                        const f32x2_t dsv = t2 * (dpv - dl2);
+                        du[sb][kk][j] = T::pack2(dsv[0], dsv[1]);
+                    }
+            // pin the phase's results here (see fa_fwd_pp_gfx950.hip: hipcc sinks register-only code past barriers)
+            asm volatile("" : "+v"(du[0][0]), "+v"(du[0][1]), "+v"(du[1][0]), "+v"(du[1][1]));
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) dsb[sb][kk] = as_v8<T>(du[sb][kk]);
+        };
+
+        // ---- prologue: tile 0 -> all images (all waves); group 0 holds tile 1 in registers, group 1 writes
+        //      its share of tile 1 and holds tile 2.
+        write_tile(0);
+        if (nt > 1) issue_loads(1);
+        if (grp == 1) {
+            if (nt > 1) write_tile(1);
+            if (nt > 2) issue_loads(2);
         }
+        __syncthreads();
+        if (grp == 1) __syncthreads();  // group 1 starts one phase late
+        if (na > 0) sdp(0);             // pre-phase
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+
+        auto tile_step = [&](int j, auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            // ---- V-phase(j): staging, then P/dS of tile j
+            if (j + 1 + grp < nt) write_tile(j + 1 + grp);
+            if (j + 2 + grp < nt) issue_loads(j + 2 + grp);
+            if constexpr (MODE >= 1) softmax(j * kDqKV);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- M-phase(j): dQ^T += K_j^T.dS_j^T ; S^T_{j+1}, dP^T_{j+1}
+            __builtin_amdgcn_s_setprio(1);
+            if constexpr (MODE >= 1) dq_mm(j);
+            if constexpr (MODE == 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                sdp(j + 1);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int j = 0;
+        for (; j + 1 < na; ++j) tile_step(j, std::integral_constant<int, 2>{});
+        if (j < na) { tile_step(j, std::integral_constant<int, 1>{}); ++j; }
+        for (; j < nt; ++j) tile_step(j, std::integral_constant<int, 0>{});
 
         if (qrow < Sq) {
             char* orow = reinterpret_cast<char*>(p.dq) + (qbase + qrow) * RB;
@@ -302,6 +376,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
                     store4<T>(orow, 32 * d + 8 * g4 + 4 * hi, acc[d][4 * g4] * sc, acc[d][4 * g4 + 1] * sc,
                               acc[d][4 * g4 + 2] * sc, acc[d][4 * g4 + 3] * sc);
         }
+        if (grp == 0) __syncthreads();  // pairs with group 1's last phase barrier
     }
 }
 

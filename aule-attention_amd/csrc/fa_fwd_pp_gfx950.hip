@@ -51,6 +51,9 @@ constexpr int kTLMax = 256;
 #ifndef AULE_MPRIO
 #define AULE_MPRIO 1
 #endif
+#ifndef AULE_VPRIO
+#define AULE_VPRIO 0
+#endif
 constexpr int kQBlock = 256;
 constexpr int kKVTile = 64;
 constexpr float kRescaleThr = 8.0f;  // lazy rescale: keep the old running max while the new one is < 2^8 larger
@@ -170,19 +173,20 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
 
         issue_k(0);
         issue_v(0);
-        // ---- Q slab -> LDS (wave-private; the B operand of S^T = K.Q^T is re-read per tile: holding
-        //      it in 32 VGPRs does not fit the 256-register budget of two waves per SIMD)
+        // ---- Q fragments (B operand of S^T = K.Q^T) in registers: lane (q, hi) holds d = 16ks+8hi..+7.
+        //      (An earlier version re-read Q from LDS per tile because the kernel did not fit 256 VGPRs; with
+        //      the straight-line loop it uses ~190, so the 32 registers are affordable and save 8 of the 24
+        //      ds_read_b128 of every QK^T phase.)  Rows >= Sq read as 0 (buffer bounds check).
+        v8 qf[KS];
         {
             const size_t qhead = (size_t)(w.b * p.Hq + w.h) * Sq * RB;
             const __amdgpu_buffer_rsrc_t qrs = make_srd(reinterpret_cast<const char*>(p.q) + qhead, (unsigned)Sq * RB);
             const unsigned flip = p.negq ? 0x80008000u : 0u;
 #pragma unroll
-            for (int i = 0; i < (32 * CPR) / 64; ++i) {
-                const int cidx = lane + 64 * i;
-                const int row = cidx / CPR, cc = cidx % CPR;
-                u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(qrs, row * RB + cc * 16, q0w * RB, 0);
+            for (int ks = 0; ks < KS; ++ks) {
+                u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(qrs, qrow * RB + (2 * ks + hi) * 16, 0, 0);
                 x[0] ^= flip; x[1] ^= flip; x[2] ^= flip; x[3] ^= flip;
-                *reinterpret_cast<u32x4_t*>(Qs + row * RBP + cc * 16) = x;
+                qf[ks] = as_v8<T>(x);
             }
         }
 
@@ -209,11 +213,9 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
         // sched_group_barrier sequence pins "1 MFMA, then the reads of a later step" in the final code.
         auto qk = [&](int buf) {  // S^T = K_tile . Q^T   (all LDS offsets are immediates)
             const char* kb = Ks + buf * KTILE + ka_base;
-            const char* qb_ = Qs + ka_base;
             constexpr int kAhead = 2;
-            u32x4_t qf[KS], kf[KS][2];
+            u32x4_t kf[KS][2];
             auto rd = [&](int ks) {
-                qf[ks] = *reinterpret_cast<const u32x4_t*>(qb_ + ks * 32);
                 kf[ks][0] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32);
                 kf[ks][1] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32 + 32 * RBP);
             };
@@ -222,14 +224,14 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < kAhead && ks < KS; ++ks) rd(ks);
-            __builtin_amdgcn_sched_group_barrier(0x100, 3 * (kAhead < KS ? kAhead : KS), 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (kAhead < KS ? kAhead : KS), 0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + kAhead < KS) rd(ks + kAhead);
-                s[0] = T::mfma(as_v8<T>(kf[ks][0]), as_v8<T>(qf[ks]), ks == 0 ? z : s[0]);
-                s[1] = T::mfma(as_v8<T>(kf[ks][1]), as_v8<T>(qf[ks]), ks == 0 ? z : s[1]);
+                s[0] = T::mfma(as_v8<T>(kf[ks][0]), qf[ks], ks == 0 ? z : s[0]);
+                s[1] = T::mfma(as_v8<T>(kf[ks][1]), qf[ks], ks == 0 ? z : s[1]);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (ks + kAhead < KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                if (ks + kAhead < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
         };
@@ -357,7 +359,9 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
             if (j + 1 + grp < nt) write_k((j + 1 + grp) & 1);
             if (j + 1 + grp < nt) issue_v((j + 1 + grp) * kKVTile);
             if (j + 2 + grp < nt) issue_k((j + 2 + grp) * kKVTile);
+            __builtin_amdgcn_s_setprio(AULE_VPRIO);
             if constexpr (MODE >= 1) softmax(j * kKVTile);
+            __builtin_amdgcn_s_setprio(0);
             stamp();
             // phase boundary: nothing may move across (hipcc would interleave this wave's softmax with
             // its own MFMAs -- measured with tools/timeline.py -- which defeats the group alternation)
