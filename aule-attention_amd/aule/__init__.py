@@ -12,7 +12,8 @@ device/dtype and inside autograd; NumPy in -> NumPy out).  There is ONE backend:
 hand-written HIP kernels for gfx950 behind libaule.so.  No Triton, no Vulkan, no CPU
 fallback -- when the library or a HIP device is missing the call raises AuleError.
 
-Not carried over (out of scope): install()/SDPA shim, ComfyUI
+Also carried: the SDPA shim install() / uninstall() / scaled_dot_product_attention
+(__init__.py:288-442).  Not carried over (out of scope): ComfyUI
 glue, paged/gravity/sort features, fused RoPE, sliding window.
 """
 import logging
@@ -121,6 +122,76 @@ def flash_attention(query, key, value, rot_cos=None, rot_sin=None, causal=True, 
 attention = flash_attention
 
 
+# =============================================================================
+# PyTorch SDPA compatibility layer (reference __init__.py:288-442)
+# =============================================================================
+_original_sdpa = None
+_installed = False
+_SDPA_DTYPES = ("torch.float16", "torch.bfloat16", "torch.float32")
+
+
+def scaled_dot_product_attention(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False,
+                                 scale=None, enable_gqa=False):
+    """Drop-in for torch.nn.functional.scaled_dot_product_attention (same signature as the reference's
+    shim, __init__.py:288-297).  Runs the HIP kernels when it can and defers to PyTorch's own SDPA for
+    what the kernels do not cover: attn_mask, dropout, head_dim > 128, non-4-D or non-ROCm tensors,
+    dtypes other than fp16/bf16/fp32, and mismatched head counts without enable_gqa (PyTorch raises).
+    torch's is_causal mask is top-left aligned, like this library's."""
+    import torch
+    import torch.nn.functional as F
+    fallback = (
+        attn_mask is not None or dropout_p > 0.0
+        or not (isinstance(query, torch.Tensor) and query.is_cuda and key.is_cuda and value.is_cuda)
+        or query.dim() != 4 or key.dim() != 4 or value.dim() != 4
+        or query.shape[-1] > 128 or key.shape[-1] != query.shape[-1] or value.shape[-1] != query.shape[-1]
+        or str(query.dtype) not in _SDPA_DTYPES
+        or (query.shape[1] != key.shape[1] and not enable_gqa)
+        or key.shape[1] == 0 or query.shape[1] % max(1, key.shape[1]) != 0
+        or key.shape[2] == 0
+    )
+    if fallback:
+        fn = _original_sdpa if _original_sdpa is not None else F.scaled_dot_product_attention
+        if fn is scaled_dot_product_attention:   # installed without a saved original: cannot recurse
+            raise AuleError("scaled_dot_product_attention fallback requested but the original SDPA is unavailable")
+        return fn(query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal,
+                  scale=scale, enable_gqa=enable_gqa)
+    return flash_attention(query, key, value, causal=is_causal, scale=scale)
+
+
+def install(backend=None, verbose=False):
+    """Route every torch.nn.functional.scaled_dot_product_attention call through this library
+    (reference __init__.py:353-406).  `backend` may be None or 'hip' (the only backend of this build)."""
+    global _original_sdpa, _installed, _verbose
+    import torch
+    import torch.nn.functional as F
+    if backend is not None and backend != "hip":
+        raise ValueError(f"Invalid backend '{backend}'. This build has one backend: 'hip' (or None)")
+    _verbose = bool(verbose)
+    if _installed:
+        print(f"aule-attention: Updated (backend=hip, verbose={verbose})")
+        return
+    _original_sdpa = F.scaled_dot_product_attention
+    F.scaled_dot_product_attention = scaled_dot_product_attention
+    torch.nn.functional.scaled_dot_product_attention = scaled_dot_product_attention
+    _installed = True
+    print("aule-attention: Installed (HIP gfx950%s)" % (", verbose" if verbose else ""))
+
+
+def uninstall():
+    """Restore PyTorch's own SDPA (reference __init__.py:409-430)."""
+    global _installed
+    if not _installed:
+        print("aule-attention: Not installed")
+        return
+    import torch
+    import torch.nn.functional as F
+    if _original_sdpa is not None:
+        F.scaled_dot_product_attention = _original_sdpa
+        torch.nn.functional.scaled_dot_product_attention = _original_sdpa
+    _installed = False
+    print("aule-attention: Uninstalled, restored PyTorch SDPA")
+
+
 def get_available_backends():
     """Reference API (__init__.py:445-457); this build has exactly one backend."""
     from . import _capi
@@ -155,5 +226,5 @@ def set_verbose(flag=True):
     _verbose = bool(flag)
 
 
-__all__ = ["flash_attention", "attention", "AuleError", "get_available_backends", "get_backend_errors",
-           "get_backend_info", "set_verbose", "__version__"]
+__all__ = ["flash_attention", "attention", "AuleError", "scaled_dot_product_attention", "install", "uninstall",
+           "get_available_backends", "get_backend_errors", "get_backend_info", "set_verbose", "__version__"]

@@ -52,3 +52,30 @@ def test_version_and_exports():
     assert aule.__version__.startswith("0.5.0")
     for name in ("flash_attention", "attention", "AuleError", "get_available_backends"):
         assert hasattr(aule, name)
+
+
+def test_sdpa_shim_install_uninstall_and_cpu_fallback(capsys):
+    """Reference __init__.py:288-442: install() swaps F.scaled_dot_product_attention, unsupported
+    calls (here: CPU tensors, attn_mask, dropout) defer to the saved original, uninstall() restores."""
+    import torch
+    import torch.nn.functional as F
+    orig = F.scaled_dot_product_attention
+    sig = inspect.signature(aule.scaled_dot_product_attention)
+    assert list(sig.parameters) == ["query", "key", "value", "attn_mask", "dropout_p", "is_causal", "scale", "enable_gqa"]
+    with pytest.raises(ValueError):
+        aule.install(backend="vulkan")
+    aule.install()
+    try:
+        assert F.scaled_dot_product_attention is aule.scaled_dot_product_attention
+        q = torch.randn(1, 2, 8, 16)
+        out = F.scaled_dot_product_attention(q, q, q, is_causal=True)       # CPU tensor -> original SDPA
+        assert torch.allclose(out, orig(q, q, q, is_causal=True))
+        mask = torch.ones(8, 8, dtype=torch.bool).tril()
+        assert torch.allclose(F.scaled_dot_product_attention(q, q, q, attn_mask=mask), orig(q, q, q, attn_mask=mask))
+        aule.install(verbose=True)   # re-install only updates flags
+    finally:
+        aule.uninstall()
+        aule.set_verbose(False)
+    assert F.scaled_dot_product_attention is orig
+    aule.uninstall()
+    assert "Not installed" in capsys.readouterr().out

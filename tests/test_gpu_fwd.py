@@ -231,3 +231,27 @@ def test_config5_mqa_fp16_long_noncausal_sampled_rows(torch_cuda, oracle_mod):
         r, _ = oracle_mod.fwd_f64(q[:, :, :sq].float().cpu().numpy(), k.float().cpu().numpy(),
                                   v.float().cpu().numpy(), False, None)
         assert_close(o.float().cpu().numpy(), r, *fwd_tol("fp16", v.float().abs().max().item()), f"C5 Sq={sq}")
+
+
+def test_sdpa_shim_matches_torch_math(torch_cuda):
+    """install(): F.scaled_dot_product_attention runs the HIP kernels (causal, GQA, custom scale) and
+    agrees with PyTorch's own SDPA; unsupported arguments fall back."""
+    import aule
+    import torch.nn.functional as F
+    torch = torch_cuda
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    q = torch.randn(2, 8, 200, 64, device="cuda", dtype=torch.float16, generator=gen)
+    k = torch.randn(2, 2, 200, 64, device="cuda", dtype=torch.float16, generator=gen)
+    v = torch.randn(2, 2, 200, 64, device="cuda", dtype=torch.float16, generator=gen)
+    want = F.scaled_dot_product_attention(q.float(), k.float().repeat_interleave(4, 1), v.float().repeat_interleave(4, 1),
+                                          is_causal=True, scale=0.2)
+    aule.install()
+    try:
+        got = F.scaled_dot_product_attention(q, k, v, is_causal=True, scale=0.2, enable_gqa=True)
+        mask = torch.ones(200, 200, dtype=torch.bool, device="cuda").tril()
+        fb = F.scaled_dot_product_attention(q[:, :2], k, v, attn_mask=mask)     # falls back to torch
+    finally:
+        aule.uninstall()
+    assert got.dtype == torch.float16
+    assert_close(got.float().cpu().numpy(), want.cpu().numpy(), *fwd_tol("fp16", v.float().abs().max().item()), "sdpa")
+    assert tuple(fb.shape) == (2, 2, 200, 64)
