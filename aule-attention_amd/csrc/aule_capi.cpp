@@ -141,6 +141,7 @@ int run_fwd_f32(const float* q, const float* k, const float* v, float* o, float*
 
 namespace aule_hip {
 int launch_fwd_pp_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
+int launch_fwd_iw_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
 int configure_fwd();
 int configure_bwd();
 int configure_kernels() {
@@ -703,6 +704,9 @@ int32_t aule_hip_debug_forward_timeline(const aule_attn_desc* d, unsigned long l
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
     a.dtype = d->dtype;
+    if (const char* e = getenv("AULE_HIP_FWD_KERNEL"))
+        if (e[0] == 'i' && e[1] == 'w')  // 4 waves x 512 stamps
+            return aule_hip::launch_fwd_iw_timeline(a, stamps, (hipStream_t)d->stream);
     return aule_hip::launch_fwd_pp_timeline(a, stamps, (hipStream_t)d->stream);
 }
 

@@ -313,19 +313,29 @@ int launch_fwd_f32(const FwdArgs& a, hipStream_t stream);  // fa_fwd_f32.hip
 int configure_fwd_f32();
 int launch_fwd_pp(const FwdArgs& a, hipStream_t stream);   // fa_fwd_pp_gfx950.hip
 int configure_fwd_pp();
+int launch_fwd_iw(const FwdArgs& a, hipStream_t stream);   // fa_fwd_iw_gfx950.hip (-1: shape not covered)
+int configure_fwd_iw();
 
-// AULE_HIP_FWD_KERNEL = "pp" (default: ping-pong schedule) | "v1" (one barrier per tile,
-// all waves in the same phase; kept for A/B measurements)
-static bool use_v1() {
+// AULE_HIP_FWD_KERNEL = "pp" (8-wave ping-pong schedule) | "iw" (4-wave in-wave ping-pong, D = 128) |
+// "v1" (one barrier per tile, all waves in the same phase); the non-default ones are kept for A/B measurements
+static int fwd_kernel_choice() {
     static const int v = [] {
         const char* e = getenv("AULE_HIP_FWD_KERNEL");
-        return (e != nullptr && e[0] == 'v' && e[1] == '1') ? 1 : 0;
+        if (e != nullptr && e[0] == 'v' && e[1] == '1') return 1;
+        if (e != nullptr && e[0] == 'i' && e[1] == 'w') return 2;
+        if (e != nullptr && e[0] == 'p' && e[1] == 'p') return 0;
+        return 0;
     }();
-    return v == 1;
+    return v;
 }
+static bool use_v1() { return fwd_kernel_choice() == 1; }
 
 int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (a.dtype == kF32) return launch_fwd_f32(a, stream);
+    if (fwd_kernel_choice() == 2) {
+        const int rc = launch_fwd_iw(a, stream);
+        if (rc != -1) return rc;
+    }
     if (!use_v1()) return launch_fwd_pp(a, stream);
     if (a.dtype == kBF16) {
         if (a.D == 128) return launch_fwd_16<Bf16Traits, 128>(a, stream);
@@ -349,6 +359,7 @@ int configure_fwd() {
     rc |= set_attr_16<F16Traits, 32>();
     rc |= configure_fwd_f32();
     rc |= configure_fwd_pp();
+    rc |= configure_fwd_iw();
     return rc;
 }
 
