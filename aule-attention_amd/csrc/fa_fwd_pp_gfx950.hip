@@ -81,12 +81,24 @@ __device__ __forceinline__ void keep_live(f32x16_t& a, f32x16_t& b) {
 #endif
 }
 
+__device__ __forceinline__ void add_pinned(float& acc, float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x));
+#else
+    acc += x;
+#endif
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, unsigned bytes) {
     // raw buffer (stride 0): loads at offsets >= bytes return 0 -> ragged tiles need no clamping
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <class T, int D, bool CAUSAL, bool TL = false>
+// RAWOK: try the "raw" softmax first -- P = exp2(S) against the fixed reference 0, S = K.(Q*scale*log2e)^T with
+// the factor folded into the 16-bit Q fragments: no row maximum, no subtraction, no O rescale in the tile loop
+// (valid while every row sum stays in [2^-100, 2^110], i.e. |logit*log2e| < ~100; bf16 only, P needs the
+// fp32 exponent range).  A Q block whose row sums leave that range is recomputed with the classic online softmax.
+template <class T, int D, bool CAUSAL, bool TL = false, bool RAWOK = false>
 __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
     using C = Cfg<D>;
     using v8 = typename T::v8;
@@ -103,8 +115,10 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
     const int grp = wave >> 2;  // 0: leads, 1: runs one phase behind
     const int l31 = lane & 31, hi = lane >> 5;
     char* const Qs = smem + 2 * KTILE + 2 * VTILE + wave * C::QSLAB;
+    int* const redo_flag = reinterpret_cast<int*>(smem + C::LDS);
+    if (RAWOK && tid == 0) *redo_flag = 0;
     int tl_n = 0;
-    auto stamp = [&]() {
+    auto stamp = [&]() __attribute__((always_inline)) {
         if constexpr (TL) {
             if (blockIdx.x == 0 && tl_n < kTLMax) {
                 const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -140,25 +154,25 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
     const int va_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
 
     u32x4_t kst[CH], vst[CH];
-    auto issue_k = [&](int kv0) {
+    auto issue_k = [&](int kv0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if (C::kFull || tid + 512 * i < C::NCHUNK)
                 kst[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], kv0 * RB, 0);
     };
-    auto issue_v = [&](int kv0) {
+    auto issue_v = [&](int kv0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if (C::kFull || tid + 512 * i < C::NCHUNK)
                 vst[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], kv0 * RB, 0);
     };
-    auto write_k = [&](int buf) {
+    auto write_k = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if (C::kFull || tid + 512 * i < C::NCHUNK)
                 *reinterpret_cast<u32x4_t*>(Ks + buf * KTILE + k_lds[i]) = kst[i];
     };
-    auto write_v = [&](int buf) {
+    auto write_v = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if (C::kFull || tid + 512 * i < C::NCHUNK)
@@ -171,25 +185,6 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
         const int q0w = qb * kQBlock + wave * 32;
         const int qrow = q0w + l31;
 
-        issue_k(0);
-        issue_v(0);
-        // ---- Q fragments (B operand of S^T = K.Q^T) in registers: lane (q, hi) holds d = 16ks+8hi..+7.
-        //      (An earlier version re-read Q from LDS per tile because the kernel did not fit 256 VGPRs; with
-        //      the straight-line loop it uses ~190, so the 32 registers are affordable and save 8 of the 24
-        //      ds_read_b128 of every QK^T phase.)  Rows >= Sq read as 0 (buffer bounds check).
-        v8 qf[KS];
-        {
-            const size_t qhead = (size_t)(w.b * p.Hq + w.h) * Sq * RB;
-            const __amdgpu_buffer_rsrc_t qrs = make_srd(reinterpret_cast<const char*>(p.q) + qhead, (unsigned)Sq * RB);
-            const unsigned flip = p.negq ? 0x80008000u : 0u;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(qrs, qrow * RB + (2 * ks + hi) * 16, 0, 0);
-                x[0] ^= flip; x[1] ^= flip; x[2] ^= flip; x[3] ^= flip;
-                qf[ks] = as_v8<T>(x);
-            }
-        }
-
         const int kv_hi = CAUSAL ? min(Sk, qb * kQBlock + kQBlock) : Sk;
         const int nt = (kv_hi + kKVTile - 1) / kKVTile;          // tiles staged by the workgroup
         const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32) : Sk;  // keys visible to this wave
@@ -197,197 +192,269 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
         if constexpr (TL) {
             if ((p.dbg_flags >> grp) & 1) na = 0;
         }
-
         f32x16_t o[DB];
-#pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-        float m = -INFINITY, l = 0.f;
-        f32x16_t s[2];
-        v8 pb[2][2];
+        float m, l;
 
-        // Both MFMA loops are software-pipelined by hand: a wave issues in order, so an MFMA whose LDS
-        // operands were requested just before it stalls for the whole LDS latency (measured: 16 MFMAs
-        // took ~950 cycles instead of 512).  Operands are requested kAhead steps early; the
-        // sched_group_barrier sequence pins "1 MFMA, then the reads of a later step" in the final code.
-        auto qk = [&](int buf) {  // S^T = K_tile . Q^T   (all LDS offsets are immediates)
-            const char* kb = Ks + buf * KTILE + ka_base;
-            constexpr int kAhead = 2;
-            u32x4_t kf[KS][2];
-            auto rd = [&](int ks) {
-                kf[ks][0] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32);
-                kf[ks][1] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32 + 32 * RBP);
-            };
-            f32x16_t z;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < kAhead && ks < KS; ++ks) rd(ks);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (kAhead < KS ? kAhead : KS), 0);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (ks + kAhead < KS) rd(ks + kAhead);
-                s[0] = T::mfma(as_v8<T>(kf[ks][0]), qf[ks], ks == 0 ? z : s[0]);
-                s[1] = T::mfma(as_v8<T>(kf[ks][1]), qf[ks], ks == 0 ? z : s[1]);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (ks + kAhead < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
-        };
-        auto pv = [&](int buf) {  // O^T += V^T . P^T
-            const char* vb = Vs + buf * VTILE + va_off;
-            constexpr int NST = 4 * DB;  // MFMA steps: (sb, kk) outer, d inner
-            constexpr int kAhead = 3;
-            s16x4_t a0[NST], a1[NST];
-            auto rd = [&](int st) {
-                const int sk = st / DB, d = st % DB;  // sk = 2*sb + kk
-                const int off = ((4 * sk) * (D / 16) + 2 * d) * 128;
-                a0[st] = lds_tr16(vb + off);
-                a1[st] = lds_tr16(vb + off + 2 * (D / 16) * 128);
-            };
-#pragma unroll
-            for (int st = 0; st < kAhead && st < NST; ++st) rd(st);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (kAhead < NST ? kAhead : NST), 0);
-#pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                if (st + kAhead < NST) rd(st + kAhead);
-                const int sk = st / DB, d = st % DB;
-                o[d] = T::mfma(as_v8<T>(a0[st], a1[st]), pb[sk >> 1][sk & 1], o[d]);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (st + kAhead < NST) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            }
-        };
-        auto softmax = [&](int kv0) {  // S_j -> P_j (16-bit, in registers); updates m, l, o
-            const bool need_mask = (CAUSAL && (kv0 + kKVTile - 1 > q0w)) || (kv0 + kKVTile > Sk);
-            if (need_mask) {
-#pragma unroll
-                for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int kv = kv0 + sb * 32 + crow(r, hi);
-                        const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow);
-                        s[sb][r] = vis ? s[sb][r] : -INFINITY;
+        auto run_part = [&](auto raw_tag) __attribute__((always_inline)) {
+            constexpr bool RAW = decltype(raw_tag)::value != 0;
+            issue_k(0);
+            issue_v(0);
+            // ---- Q fragments (B operand of S^T = K.Q^T) in registers: lane (q, hi) holds d = 16ks+8hi..+7.
+            //      (An earlier version re-read Q from LDS per tile because the kernel did not fit 256 VGPRs; with
+            //      the straight-line loop it uses ~190, so the 32 registers are affordable and save 8 of the 24
+            //      ds_read_b128 of every QK^T phase.)  Rows >= Sq read as 0 (buffer bounds check).
+            v8 qf[KS];
+            {
+                const size_t qhead = (size_t)(w.b * p.Hq + w.h) * Sq * RB;
+                const __amdgpu_buffer_rsrc_t qrs = make_srd(reinterpret_cast<const char*>(p.q) + qhead, (unsigned)Sq * RB);
+                const unsigned flip = p.negq ? 0x80008000u : 0u;
+                const float cs = p.negq ? -c : c;
+                u32x4_t qx[KS];
+    #pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    qx[ks] = __builtin_amdgcn_raw_buffer_load_b128(qrs, qrow * RB + (2 * ks + hi) * 16, 0, 0);
+    #pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    u32x4_t x = qx[ks];
+                    if constexpr (RAW) {
+    #pragma unroll
+                        for (int i = 0; i < 4; ++i) x[i] = T::pack2(T::lo(x[i]) * cs, T::hi(x[i]) * cs);
+                    } else {
+                        x[0] ^= flip; x[1] ^= flip; x[2] ^= flip; x[3] ^= flip;
                     }
-            }
-            // row max: four independent v_max3_f32 chains (fmaxf() costs an extra canonicalising v_max per
-            // MFMA output, and one 31-deep chain is latency-bound)
-            float mx4[4];
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int sb = q4 >> 1, b0 = 8 * (q4 & 1);
-                mx4[q4] = max3(s[sb][b0], s[sb][b0 + 1], s[sb][b0 + 2]);
-                mx4[q4] = max3(mx4[q4], s[sb][b0 + 3], s[sb][b0 + 4]);
-                mx4[q4] = max3(mx4[q4], s[sb][b0 + 5], s[sb][b0 + 6]);
-            }
-            float mx = max3(mx4[0], mx4[1], s[0][7]);
-            mx = max3(mx, mx4[2], s[0][15]);
-            mx = max3(mx, mx4[3], s[1][7]);
-            mx = fmaxf(mx, s[1][15]);
-            mx = fmaxf(mx, xhalf_fast(mx));
-            const float mxc = mx * c;
-            stamp();
-            // lazy rescale (exact algebra, different rounding): the running max is only raised -- and O, l
-            // rescaled -- when some row's new maximum exceeds the kept one by more than 2^kRescaleThr;
-            // otherwise P is formed against the kept max (P <= 2^8, fine for bf16/fp16 and fp32 sums).
-            if (__builtin_amdgcn_ballot_w64(mxc > m + kRescaleThr) != 0) {
-                const float m_new = fmaxf(m, mxc);
-                const float alpha = fast_exp2(m - m_new);
-                m = m_new;
-                l *= alpha;
-#pragma unroll
-                for (int d = 0; d < DB; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            }
-            const f32x2_t c2 = {c, c};
-            const f32x2_t nm2 = {-m, -m};
-            f32x2_t ls[2] = {{0.f, 0.f}, {0.f, 0.f}};
-            u32x4_t pu[2][2];
-#pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    f32x2_t t = {s[sb][2 * i], s[sb][2 * i + 1]};
-                    t = __builtin_elementwise_fma(t, c2, nm2);   // v_pk_fma_f32
-                    t[0] = fast_exp2(t[0]);
-                    t[1] = fast_exp2(t[1]);
-                    ls[i & 1] += t;                                // v_pk_add_f32, two chains
-                    pu[sb][i >> 2][i & 3] = T::pack2(t[0], t[1]);
+                    qf[ks] = as_v8<T>(x);
                 }
-            const f32x2_t lt2 = ls[0] + ls[1];
-            l += lt2[0] + lt2[1];
-            // Pin the results of this phase HERE: the softmax is register-only code that LLVM otherwise
-            // sinks past the barrier into the block that consumes P (next to this wave's own MFMAs).
-            asm volatile("" : "+v"(pu[0][0]), "+v"(pu[0][1]), "+v"(pu[1][0]), "+v"(pu[1][1]), "+v"(l), "+v"(m));
-#pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) pb[sb][kk] = as_v8<T>(pu[sb][kk]);
-        };
-
-        // ---- prologue.  Staging rule of the main loop: ALL global->LDS staging happens in the V-phases
-        //      (the VALU-bound phase, whose LDS/VMEM issue ports are idle), never in the M-phases:
-        //      in V-phase(t) group d (0 or 1) first writes the tiles it loaded one phase earlier,
-        //      V_{t+d} and K_{t+1+d}, then requests V_{t+1+d} and K_{t+2+d}.  Entry state for t = 0:
-        //      K_0 in LDS; group 0 holds (V_0, K_1) in registers, group 1 has written its share of
-        //      (V_0, K_1) and holds (V_1, K_2).  Hazard analysis: DESIGN.md "forward schedule".
-        write_k(0);
-        if (nt > 1) issue_k(kKVTile);
-        if (grp == 1) {
-            write_v(0);
-            if (nt > 1) write_k(1);
-            if (nt > 1) issue_v(kKVTile);
-            if (nt > 2) issue_k(2 * kKVTile);
-        }
-        __syncthreads();
-        if (grp == 1) __syncthreads();  // group 1 starts one phase late
-        if (na > 0) qk(0);              // pre-phase: S_0
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-
-        // One tile step = V-phase + barrier + M-phase + barrier.  MODE is a compile-time constant so that
-        // the steady-state loop body is straight-line code (a per-iteration branch on `na` made hipcc
-        // copy the 64 O accumulators at every merge point): 2 = softmax, PV and next QK^T; 1 = softmax
-        // and PV (this wave's last active tile); 0 = fully masked tile, only staging and barriers.
-        auto tile_step = [&](int j, auto mode_tag) {
-            constexpr int MODE = decltype(mode_tag)::value;
-            // ---- V-phase(j): stage (see the prologue comment), then softmax(S_j)
-            stamp();
-            if (j + grp < nt) write_v((j + grp) & 1);
-            if (j + 1 + grp < nt) write_k((j + 1 + grp) & 1);
-            if (j + 1 + grp < nt) issue_v((j + 1 + grp) * kKVTile);
-            if (j + 2 + grp < nt) issue_k((j + 2 + grp) * kKVTile);
-            __builtin_amdgcn_s_setprio(AULE_VPRIO);
-            if constexpr (MODE >= 1) softmax(j * kKVTile);
-            __builtin_amdgcn_s_setprio(0);
-            stamp();
-            // phase boundary: nothing may move across (hipcc would interleave this wave's softmax with
-            // its own MFMAs -- measured with tools/timeline.py -- which defeats the group alternation)
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            stamp();
-            // ---- M-phase(j): O += P_j V_j ; S_{j+1} = K_{j+1} Q^T   (MFMA + LDS reads only)
-            __builtin_amdgcn_s_setprio(AULE_MPRIO);
-            if constexpr (MODE >= 1) pv(j & 1);
-            if constexpr (MODE == 2) {
-                __builtin_amdgcn_sched_barrier(0);  // P dies after PV, S is born in QK: do not overlap them
-                if constexpr (TL) { keep_live(o[0], o[DB - 1]); stamp(); }
-                qk((j + 1) & 1);
-                if constexpr (TL) { keep_live(s[0], s[1]); stamp(); }
             }
-            __builtin_amdgcn_s_setprio(0);
-            stamp();
+
+    #pragma unroll
+            for (int d = 0; d < DB; ++d)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+            m = RAW ? 0.f : -INFINITY;
+            l = 0.f;
+            f32x16_t s[2];
+            v8 pb[2][2];
+
+            // Both MFMA loops are software-pipelined by hand: a wave issues in order, so an MFMA whose LDS
+            // operands were requested just before it stalls for the whole LDS latency (measured: 16 MFMAs
+            // took ~950 cycles instead of 512).  Operands are requested kAhead steps early; the
+            // sched_group_barrier sequence pins "1 MFMA, then the reads of a later step" in the final code.
+            auto qk = [&](int buf) __attribute__((always_inline)) {  // S^T = K_tile . Q^T   (all LDS offsets are immediates)
+                const char* kb = Ks + buf * KTILE + ka_base;
+                constexpr int kAhead = 2;
+                u32x4_t kf[KS][2];
+                auto rd = [&](int ks) __attribute__((always_inline)) {
+                    kf[ks][0] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32);
+                    kf[ks][1] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32 + 32 * RBP);
+                };
+                f32x16_t z;
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    #pragma unroll
+                for (int ks = 0; ks < kAhead && ks < KS; ++ks) rd(ks);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (kAhead < KS ? kAhead : KS), 0);
+    #pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks + kAhead < KS) rd(ks + kAhead);
+                    s[0] = T::mfma(as_v8<T>(kf[ks][0]), qf[ks], ks == 0 ? z : s[0]);
+                    s[1] = T::mfma(as_v8<T>(kf[ks][1]), qf[ks], ks == 0 ? z : s[1]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (ks + kAhead < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+            };
+            auto pv = [&](int buf) __attribute__((always_inline)) {  // O^T += V^T . P^T
+                const char* vb = Vs + buf * VTILE + va_off;
+                constexpr int NST = 4 * DB;  // MFMA steps: (sb, kk) outer, d inner
+                constexpr int kAhead = 3;
+                s16x4_t a0[NST], a1[NST];
+                auto rd = [&](int st) __attribute__((always_inline)) {
+                    const int sk = st / DB, d = st % DB;  // sk = 2*sb + kk
+                    const int off = ((4 * sk) * (D / 16) + 2 * d) * 128;
+                    a0[st] = lds_tr16(vb + off);
+                    a1[st] = lds_tr16(vb + off + 2 * (D / 16) * 128);
+                };
+    #pragma unroll
+                for (int st = 0; st < kAhead && st < NST; ++st) rd(st);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (kAhead < NST ? kAhead : NST), 0);
+    #pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    if (st + kAhead < NST) rd(st + kAhead);
+                    const int sk = st / DB, d = st % DB;
+                    o[d] = T::mfma(as_v8<T>(a0[st], a1[st]), pb[sk >> 1][sk & 1], o[d]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (st + kAhead < NST) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+            };
+            auto softmax = [&](int kv0) __attribute__((always_inline)) {  // S_j -> P_j (16-bit, in registers); updates m, l, o
+                const bool need_mask = (CAUSAL && (kv0 + kKVTile - 1 > q0w)) || (kv0 + kKVTile > Sk);
+                if (need_mask) {
+    #pragma unroll
+                    for (int sb = 0; sb < 2; ++sb)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int kv = kv0 + sb * 32 + crow(r, hi);
+                            const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow);
+                            s[sb][r] = vis ? s[sb][r] : -INFINITY;
+                        }
+                }
+                if constexpr (RAW) {
+                    // two pinned add chains (plain IR adds get SLP-packed into v_pk_add_f32, the slower form)
+                    float a0 = 0.f, a1 = 0.f;
+                    u32x4_t pr[2][2];
+    #pragma unroll
+                    for (int sb = 0; sb < 2; ++sb)
+    #pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float p0 = fast_exp2(s[sb][2 * i]), p1 = fast_exp2(s[sb][2 * i + 1]);
+                            add_pinned(a0, p0);
+                            add_pinned(a1, p1);
+                            pr[sb][i >> 2][i & 3] = T::pack2(p0, p1);
+                        }
+                    l += a0 + a1;
+                    asm volatile("" : "+v"(pr[0][0]), "+v"(pr[0][1]), "+v"(pr[1][0]), "+v"(pr[1][1]), "+v"(l));
+    #pragma unroll
+                    for (int sb = 0; sb < 2; ++sb)
+    #pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) pb[sb][kk] = as_v8<T>(pr[sb][kk]);
+                    return;
+                }
+                // row max: four independent v_max3_f32 chains (fmaxf() costs an extra canonicalising v_max per
+                // MFMA output, and one 31-deep chain is latency-bound)
+                float mx4[4];
+    #pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int sb = q4 >> 1, b0 = 8 * (q4 & 1);
+                    mx4[q4] = max3(s[sb][b0], s[sb][b0 + 1], s[sb][b0 + 2]);
+                    mx4[q4] = max3(mx4[q4], s[sb][b0 + 3], s[sb][b0 + 4]);
+                    mx4[q4] = max3(mx4[q4], s[sb][b0 + 5], s[sb][b0 + 6]);
+                }
+                float mx = max3(mx4[0], mx4[1], s[0][7]);
+                mx = max3(mx, mx4[2], s[0][15]);
+                mx = max3(mx, mx4[3], s[1][7]);
+                mx = fmaxf(mx, s[1][15]);
+                mx = fmaxf(mx, xhalf_fast(mx));
+                const float mxc = mx * c;
+                stamp();
+                // lazy rescale (exact algebra, different rounding): the running max is only raised -- and O, l
+                // rescaled -- when some row's new maximum exceeds the kept one by more than 2^kRescaleThr;
+                // otherwise P is formed against the kept max (P <= 2^8, fine for bf16/fp16 and fp32 sums).
+                if (__builtin_amdgcn_ballot_w64(mxc > m + kRescaleThr) != 0) {
+                    const float m_new = fmaxf(m, mxc);
+                    const float alpha = fast_exp2(m - m_new);
+                    m = m_new;
+                    l *= alpha;
+    #pragma unroll
+                    for (int d = 0; d < DB; ++d)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                }
+                const f32x2_t c2 = {c, c};
+                const f32x2_t nm2 = {-m, -m};
+                f32x2_t ls[2] = {{0.f, 0.f}, {0.f, 0.f}};
+                u32x4_t pu[2][2];
+    #pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+    #pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        f32x2_t t = {s[sb][2 * i], s[sb][2 * i + 1]};
+                        t = __builtin_elementwise_fma(t, c2, nm2);   // v_pk_fma_f32
+                        t[0] = fast_exp2(t[0]);
+                        t[1] = fast_exp2(t[1]);
+                        ls[i & 1] += t;                                // v_pk_add_f32, two chains
+                        pu[sb][i >> 2][i & 3] = T::pack2(t[0], t[1]);
+                    }
+                const f32x2_t lt2 = ls[0] + ls[1];
+                l += lt2[0] + lt2[1];
+                // Pin the results of this phase HERE: the softmax is register-only code that LLVM otherwise
+                // sinks past the barrier into the block that consumes P (next to this wave's own MFMAs).
+                asm volatile("" : "+v"(pu[0][0]), "+v"(pu[0][1]), "+v"(pu[1][0]), "+v"(pu[1][1]), "+v"(l), "+v"(m));
+    #pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+    #pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) pb[sb][kk] = as_v8<T>(pu[sb][kk]);
+            };
+
+            // ---- prologue.  Staging rule of the main loop: ALL global->LDS staging happens in the V-phases
+            //      (the VALU-bound phase, whose LDS/VMEM issue ports are idle), never in the M-phases:
+            //      in V-phase(t) group d (0 or 1) first writes the tiles it loaded one phase earlier,
+            //      V_{t+d} and K_{t+1+d}, then requests V_{t+1+d} and K_{t+2+d}.  Entry state for t = 0:
+            //      K_0 in LDS; group 0 holds (V_0, K_1) in registers, group 1 has written its share of
+            //      (V_0, K_1) and holds (V_1, K_2).  Hazard analysis: DESIGN.md "forward schedule".
+            write_k(0);
+            if (nt > 1) issue_k(kKVTile);
+            if (grp == 1) {
+                write_v(0);
+                if (nt > 1) write_k(1);
+                if (nt > 1) issue_v(kKVTile);
+                if (nt > 2) issue_k(2 * kKVTile);
+            }
+            __syncthreads();
+            if (grp == 1) __syncthreads();  // group 1 starts one phase late
+            if (na > 0) qk(0);              // pre-phase: S_0
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
+
+            // One tile step = V-phase + barrier + M-phase + barrier.  MODE is a compile-time constant so that
+            // the steady-state loop body is straight-line code (a per-iteration branch on `na` made hipcc
+            // copy the 64 O accumulators at every merge point): 2 = softmax, PV and next QK^T; 1 = softmax
+            // and PV (this wave's last active tile); 0 = fully masked tile, only staging and barriers.
+            auto tile_step = [&](int j, auto mode_tag) __attribute__((always_inline)) {
+                constexpr int MODE = decltype(mode_tag)::value;
+                // ---- V-phase(j): stage (see the prologue comment), then softmax(S_j)
+                stamp();
+                if (j + grp < nt) write_v((j + grp) & 1);
+                if (j + 1 + grp < nt) write_k((j + 1 + grp) & 1);
+                if (j + 1 + grp < nt) issue_v((j + 1 + grp) * kKVTile);
+                if (j + 2 + grp < nt) issue_k((j + 2 + grp) * kKVTile);
+                __builtin_amdgcn_s_setprio(AULE_VPRIO);
+                if constexpr (MODE >= 1) softmax(j * kKVTile);
+                __builtin_amdgcn_s_setprio(0);
+                stamp();
+                // phase boundary: nothing may move across (hipcc would interleave this wave's softmax with
+                // its own MFMAs -- measured with tools/timeline.py -- which defeats the group alternation)
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                stamp();
+                // ---- M-phase(j): O += P_j V_j ; S_{j+1} = K_{j+1} Q^T   (MFMA + LDS reads only)
+                __builtin_amdgcn_s_setprio(AULE_MPRIO);
+                if constexpr (MODE >= 1) pv(j & 1);
+                if constexpr (MODE == 2) {
+                    __builtin_amdgcn_sched_barrier(0);  // P dies after PV, S is born in QK: do not overlap them
+                    if constexpr (TL) { keep_live(o[0], o[DB - 1]); stamp(); }
+                    qk((j + 1) & 1);
+                    if constexpr (TL) { keep_live(s[0], s[1]); stamp(); }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                stamp();
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            int j = 0;
+            for (; j + 1 < na; ++j) tile_step(j, std::integral_constant<int, 2>{});
+            if (j < na) { tile_step(j, std::integral_constant<int, 1>{}); ++j; }
+            for (; j < nt; ++j) tile_step(j, std::integral_constant<int, 0>{});
+
+            if (grp == 0) __syncthreads();  // pairs with group 1's last phase barrier: all waves aligned again
         };
-        int j = 0;
-        for (; j + 1 < na; ++j) tile_step(j, std::integral_constant<int, 2>{});
-        if (j < na) { tile_step(j, std::integral_constant<int, 1>{}); ++j; }
-        for (; j < nt; ++j) tile_step(j, std::integral_constant<int, 0>{});
+        if constexpr (RAWOK) {
+            run_part(std::integral_constant<int, 1>{});
+            const float lsum = l + xhalf(l);
+            const bool ok = (na == 0) || ((lsum > 0x1p-100f) && (lsum < 0x1p110f));  // NaN fails too
+            if (__builtin_amdgcn_ballot_w64(!ok) != 0 && lane == 0) *redo_flag = 1;
+            __syncthreads();
+            const int redo = *redo_flag;
+            __syncthreads();
+            if (redo) {
+                if (tid == 0) *redo_flag = 0;
+                run_part(std::integral_constant<int, 0>{});
+            }
+        } else {
+            run_part(std::integral_constant<int, 0>{});
+        }
 
         // ---- epilogue: O = O^T / l, transposed through this wave's (now idle) Q slab so that the
         //      global stores are whole 16-byte chunks of full rows (the direct form is 16 row-strided
@@ -416,8 +483,16 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
         }
         if (qrow < Sq && p.lse != nullptr && hi == 0)
             p.lse[(size_t)(w.b * p.Hq + w.h) * Sq + qrow] = (m + fast_log2(lt)) * kLn2;
-        if (grp == 0) __syncthreads();  // pairs with group 1's last phase barrier
     }
+}
+
+// AULE_HIP_FWD_SOFTMAX = "raw" (default for bf16) | "classic" (always the online softmax; A/B measurements)
+static bool raw_softmax_enabled() {
+    static const int v = [] {
+        const char* e = getenv("AULE_HIP_FWD_SOFTMAX");
+        return (e != nullptr && e[0] == 'c') ? 0 : 1;
+    }();
+    return v == 1;
 }
 
 template <class T, int D>
@@ -436,7 +511,16 @@ int launch_pp(const FwdArgs& a, hipStream_t stream) {
     p.dbg = nullptr;
     p.dbg_flags = 0;
     const dim3 grid((unsigned)(p.nwork * a.B * a.Hq)), block(512);
-    const size_t lds = Cfg<D>::LDS;
+    const size_t lds = Cfg<D>::LDS + 16;
+    if constexpr (std::is_same<T, Bf16Traits>::value) {
+        if (raw_softmax_enabled()) {
+            if (a.causal)
+                hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, true, false, true>), grid, block, lds, stream, p);
+            else
+                hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false, false, true>), grid, block, lds, stream, p);
+            return (int)hipGetLastError();
+        }
+    }
     if (a.causal)
         hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, true>), grid, block, lds, stream, p);
     else
@@ -447,9 +531,15 @@ int launch_pp(const FwdArgs& a, hipStream_t stream) {
 template <class T, int D>
 int set_attr_pp() {
     int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS);
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
+    if constexpr (std::is_same<T, Bf16Traits>::value) {
+        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, true, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
+        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, false, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
+    }
     return rc;
 }
 
@@ -469,15 +559,17 @@ int launch_fwd_pp_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_
     p.dbg = dbg;
     p.dbg_flags = getenv("AULE_TL_FLAGS") ? atoi(getenv("AULE_TL_FLAGS")) : 0;
     const dim3 grid((unsigned)(p.nwork * a.B * a.Hq)), block(512);
-    const size_t lds = Cfg<128>::LDS;
-    if (a.causal) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<Bf16Traits, 128, true, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((fa_fwd_pp_kernel<Bf16Traits, 128, true, true>), grid, block, lds, stream, p);
+    const size_t lds = Cfg<128>::LDS + 16;
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    };
+    if (raw_softmax_enabled()) {
+        if (a.causal) go(&fa_fwd_pp_kernel<Bf16Traits, 128, true, true, true>);
+        else go(&fa_fwd_pp_kernel<Bf16Traits, 128, false, true, true>);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<Bf16Traits, 128, false, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((fa_fwd_pp_kernel<Bf16Traits, 128, false, true>), grid, block, lds, stream, p);
+        if (a.causal) go(&fa_fwd_pp_kernel<Bf16Traits, 128, true, true, false>);
+        else go(&fa_fwd_pp_kernel<Bf16Traits, 128, false, true, false>);
     }
     return (int)hipGetLastError();
 }

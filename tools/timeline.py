@@ -47,9 +47,14 @@ for w in range(8):
     row = t[w]
     print(f"wave {w}: start+{int(row[0]) - t0}")
     segs = []
-    NS = 7  # stamps per tile: V0, after-rowmax, V-end, M0, after-PV, after-QK, M-end
+    # stamps per tile: V0, after-rowmax (classic softmax only), V-end, M0, after-PV, after-QK, M-end
+    NS = 7 if os.environ.get("AULE_HIP_FWD_SOFTMAX", "raw")[0] == "c" else 6
     for j in range(0, NT):
-        v0, v1, v2, m0, m1, m2, m3 = (int(row[NS * j + i]) for i in range(NS))
+        if NS == 7:
+            v0, v1, v2, m0, m1, m2, m3 = (int(row[NS * j + i]) for i in range(NS))
+        else:
+            v0, v2, m0, m1, m2, m3 = (int(row[NS * j + i]) for i in range(NS))
+            v1 = v0
         nxt = int(row[NS * j + NS])
         segs.append(f"max{v1 - v0:5d} exp{v2 - v1:5d} bar{m0 - v2:5d} PV{m1 - m0:5d} QK{m2 - m1:5d} wr{m3 - m2:5d} bar{nxt - m3:5d}")
     for k in range(0, len(segs), 4):
