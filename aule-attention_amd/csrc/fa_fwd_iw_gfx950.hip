@@ -114,6 +114,30 @@ __device__ __forceinline__ unsigned pack_bf16_pinned(float a, float b) {
     return 0;
 #endif
 }
+// fused per-slot softmax work of the fast path (see `slice`)
+__device__ __forceinline__ float slot_first(const float& s_e) {
+    float r = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_accvgpr_read_b32 %0, %1\n\ts_nop 0\n\tv_exp_f32 %0, %0" : "=v"(r) : "a"(s_e));
+#endif
+    return r;
+}
+__device__ __forceinline__ float slot_odd(const float& s_e, float& acc, float p_prev) {
+    float r = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_add_f32 %1, %1, %3\n\tv_exp_f32 %0, %0"
+                 : "=&v"(r), "+v"(acc) : "a"(s_e), "v"(p_prev));
+#endif
+    return r;
+}
+__device__ __forceinline__ float slot_even(const float& s_e, float& acc, float p_prev2, float p_prev, unsigned& packed) {
+    float r = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_accvgpr_read_b32 %0, %3\n\tv_add_f32 %1, %1, %5\n\tv_exp_f32 %0, %0\n\tv_cvt_pk_bf16_f32 %2, %4, %5"
+                 : "=&v"(r), "+v"(acc), "=&v"(packed) : "a"(s_e), "v"(p_prev2), "v"(p_prev));
+#endif
+    return r;
+}
 __device__ __forceinline__ void scale_acc(f32x16_t& t, float alpha) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -313,6 +337,28 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
                 float pe[33];
                 u32x4_t pu[2][2];
                 auto slice = [&](int e) __attribute__((always_inline)) {
+                    if constexpr (SM == 1) {
+                        // unmasked tile: ONE asm statement per element -- S_e -> VGPR, row-sum add of e-1 (also
+                        // the independent instruction between the read and the exp), exp_e, pack of (e-2, e-1)
+                        if (e == 0) {
+                            { const float s0 = s[BS][0][0]; pe[0] = slot_first(s0); }
+                        } else if (e < 32) {
+                            const int h = e >> 4, r = e & 15;
+                            if (e & 1) {
+                                { const float se = s[BS][h][r]; pe[e] = slot_odd(se, acc, pe[e - 1]); }
+                            } else {
+                                const int h2 = (e - 1) >> 4, i = ((e - 1) & 15) >> 1;
+                                unsigned pk;
+                                const float se = s[BS][h][r];
+                                pe[e] = slot_even(se, acc, pe[e - 2], pe[e - 1], pk);
+                                pu[h2][i >> 2][i & 3] = pk;
+                            }
+                        } else {
+                            add_pinned(acc, pe[31]);
+                            pu[1][1][3] = pack_bf16_pinned(pe[30], pe[31]);
+                        }
+                        return;
+                    }
                     if (e < 32) pe[e] = exp2_pinned(xval(e));
                     if (e >= 1) {
                         add_pinned(acc, pe[e - 1]);

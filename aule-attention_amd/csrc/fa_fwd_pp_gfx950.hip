@@ -89,15 +89,62 @@ __device__ __forceinline__ void add_pinned(float& acc, float x) {
 #endif
 }
 
+__device__ __forceinline__ float exp2_pinned(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return x;
+#endif
+}
+__device__ __forceinline__ unsigned pack_bf16_pinned(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return 0;
+#endif
+}
+__device__ __forceinline__ unsigned softmax_pair_bf16(float s0, float s1, float c, float nm, float& a0, float& a1) {
+    unsigned packed = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    float x0, x1;
+    asm volatile(
+        "v_fma_f32 %1, %5, %7, %8\n\t"
+        "v_fma_f32 %2, %6, %7, %8\n\t"
+        "v_exp_f32 %1, %1\n\t"
+        "v_exp_f32 %2, %2\n\t"
+        "v_add_f32 %3, %3, %1\n\t"
+        "v_add_f32 %4, %4, %2\n\t"
+        "v_cvt_pk_bf16_f32 %0, %1, %2"
+        : "=v"(packed), "=&v"(x0), "=&v"(x1), "+v"(a0), "+v"(a1)
+        : "v"(s0), "v"(s1), "v"(c), "v"(nm));
+#endif
+    return packed;
+}
+__device__ __forceinline__ float fma_pinned(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return a * b + c;
+#endif
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, unsigned bytes) {
     // raw buffer (stride 0): loads at offsets >= bytes return 0 -> ragged tiles need no clamping
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-// RAWOK: try the "raw" softmax first -- P = exp2(S) against the fixed reference 0, S = K.(Q*scale*log2e)^T with
-// the factor folded into the 16-bit Q fragments: no row maximum, no subtraction, no O rescale in the tile loop
-// (valid while every row sum stays in [2^-100, 2^110], i.e. |logit*log2e| < ~100; bf16 only, P needs the
-// fp32 exponent range).  A Q block whose row sums leave that range is recomputed with the classic online softmax.
+// RAWOK: try the "fixed-reference" softmax first -- the row maximum of the FIRST tile stays the reference for
+// the whole row, P = exp2(S*c - m_ref) (one v_fma + v_exp per element, the same arithmetic as the online
+// form): no per-tile row maximum, no cross-half exchange, no O rescale test in the tile loop.  Exact algebra;
+// valid while every row sum stays in [2^-100, 2^110], i.e. while no later logit exceeds the first tile's
+// maximum by more than ~100 in log2 units (bf16 only: P needs the fp32 exponent range).  A Q block whose row
+// sums leave that range is recomputed with the classic online softmax (workgroup-uniform decision).
 template <class T, int D, bool CAUSAL, bool TL = false, bool RAWOK = false>
 __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
     using C = Cfg<D>;
@@ -208,29 +255,23 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                 const size_t qhead = (size_t)(w.b * p.Hq + w.h) * Sq * RB;
                 const __amdgpu_buffer_rsrc_t qrs = make_srd(reinterpret_cast<const char*>(p.q) + qhead, (unsigned)Sq * RB);
                 const unsigned flip = p.negq ? 0x80008000u : 0u;
-                const float cs = p.negq ? -c : c;
                 u32x4_t qx[KS];
-    #pragma unroll
+#pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
                     qx[ks] = __builtin_amdgcn_raw_buffer_load_b128(qrs, qrow * RB + (2 * ks + hi) * 16, 0, 0);
-    #pragma unroll
+#pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     u32x4_t x = qx[ks];
-                    if constexpr (RAW) {
-    #pragma unroll
-                        for (int i = 0; i < 4; ++i) x[i] = T::pack2(T::lo(x[i]) * cs, T::hi(x[i]) * cs);
-                    } else {
-                        x[0] ^= flip; x[1] ^= flip; x[2] ^= flip; x[3] ^= flip;
-                    }
+                    x[0] ^= flip; x[1] ^= flip; x[2] ^= flip; x[3] ^= flip;
                     qf[ks] = as_v8<T>(x);
                 }
             }
 
-    #pragma unroll
+#pragma unroll
             for (int d = 0; d < DB; ++d)
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-            m = RAW ? 0.f : -INFINITY;
+            m = -INFINITY;
             l = 0.f;
             f32x16_t s[2];
             v8 pb[2][2];
@@ -248,12 +289,12 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                     kf[ks][1] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32 + 32 * RBP);
                 };
                 f32x16_t z;
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = 0.f;
-    #pragma unroll
+#pragma unroll
                 for (int ks = 0; ks < kAhead && ks < KS; ++ks) rd(ks);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2 * (kAhead < KS ? kAhead : KS), 0);
-    #pragma unroll
+#pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     if (ks + kAhead < KS) rd(ks + kAhead);
                     s[0] = T::mfma(as_v8<T>(kf[ks][0]), qf[ks], ks == 0 ? z : s[0]);
@@ -274,10 +315,10 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                     a0[st] = lds_tr16(vb + off);
                     a1[st] = lds_tr16(vb + off + 2 * (D / 16) * 128);
                 };
-    #pragma unroll
+#pragma unroll
                 for (int st = 0; st < kAhead && st < NST; ++st) rd(st);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2 * (kAhead < NST ? kAhead : NST), 0);
-    #pragma unroll
+#pragma unroll
                 for (int st = 0; st < NST; ++st) {
                     if (st + kAhead < NST) rd(st + kAhead);
                     const int sk = st / DB, d = st % DB;
@@ -286,43 +327,47 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                     if (st + kAhead < NST) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
             };
-            auto softmax = [&](int kv0) __attribute__((always_inline)) {  // S_j -> P_j (16-bit, in registers); updates m, l, o
+            auto softmax = [&](int kv0, auto fixed_tag) __attribute__((always_inline)) {
+                constexpr bool FIXED = decltype(fixed_tag)::value != 0;  // S_j -> P_j (16-bit, in registers); updates m, l, o
                 const bool need_mask = (CAUSAL && (kv0 + kKVTile - 1 > q0w)) || (kv0 + kKVTile > Sk);
                 if (need_mask) {
-    #pragma unroll
+#pragma unroll
                     for (int sb = 0; sb < 2; ++sb)
-    #pragma unroll
+#pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int kv = kv0 + sb * 32 + crow(r, hi);
                             const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow);
                             s[sb][r] = vis ? s[sb][r] : -INFINITY;
                         }
                 }
-                if constexpr (RAW) {
-                    // two pinned add chains (plain IR adds get SLP-packed into v_pk_add_f32, the slower form)
+                if constexpr (FIXED) {
+                    // pinned single-issue forms: as plain IR hipcc packs the pairs into v_pk_fma_f32 /
+                    // v_pk_add_f32, which cost more than two scalar instructions next to the partner's MFMAs
+                    const float nm = -m;
                     float a0 = 0.f, a1 = 0.f;
                     u32x4_t pr[2][2];
-    #pragma unroll
+#pragma unroll
                     for (int sb = 0; sb < 2; ++sb)
-    #pragma unroll
+#pragma unroll
                         for (int i = 0; i < 8; ++i) {
-                            const float p0 = fast_exp2(s[sb][2 * i]), p1 = fast_exp2(s[sb][2 * i + 1]);
-                            add_pinned(a0, p0);
-                            add_pinned(a1, p1);
-                            pr[sb][i >> 2][i & 3] = T::pack2(p0, p1);
+                            // ONE asm statement per element pair (hipcc pads separate asm statements with s_nop):
+                            // x = S*c - m_ref, P = exp2(x), row-sum adds (two chains), pack.  The order keeps one
+                            // independent instruction between each v_exp and the first use of its result -- inline
+                            // asm is invisible to the hazard recogniser.
+                            pr[sb][i >> 2][i & 3] = softmax_pair_bf16(s[sb][2 * i], s[sb][2 * i + 1], c, nm, a0, a1);
                         }
-                    l += a0 + a1;
+                    l += a0 + a1;  // (two asm adds behind the last v_exp)
                     asm volatile("" : "+v"(pr[0][0]), "+v"(pr[0][1]), "+v"(pr[1][0]), "+v"(pr[1][1]), "+v"(l));
-    #pragma unroll
+#pragma unroll
                     for (int sb = 0; sb < 2; ++sb)
-    #pragma unroll
+#pragma unroll
                         for (int kk = 0; kk < 2; ++kk) pb[sb][kk] = as_v8<T>(pr[sb][kk]);
                     return;
                 }
                 // row max: four independent v_max3_f32 chains (fmaxf() costs an extra canonicalising v_max per
                 // MFMA output, and one 31-deep chain is latency-bound)
                 float mx4[4];
-    #pragma unroll
+#pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const int sb = q4 >> 1, b0 = 8 * (q4 & 1);
                     mx4[q4] = max3(s[sb][b0], s[sb][b0 + 1], s[sb][b0 + 2]);
@@ -344,18 +389,18 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                     const float alpha = fast_exp2(m - m_new);
                     m = m_new;
                     l *= alpha;
-    #pragma unroll
+#pragma unroll
                     for (int d = 0; d < DB; ++d)
-    #pragma unroll
+#pragma unroll
                         for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
                 }
                 const f32x2_t c2 = {c, c};
                 const f32x2_t nm2 = {-m, -m};
                 f32x2_t ls[2] = {{0.f, 0.f}, {0.f, 0.f}};
                 u32x4_t pu[2][2];
-    #pragma unroll
+#pragma unroll
                 for (int sb = 0; sb < 2; ++sb)
-    #pragma unroll
+#pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         f32x2_t t = {s[sb][2 * i], s[sb][2 * i + 1]};
                         t = __builtin_elementwise_fma(t, c2, nm2);   // v_pk_fma_f32
@@ -369,9 +414,9 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                 // Pin the results of this phase HERE: the softmax is register-only code that LLVM otherwise
                 // sinks past the barrier into the block that consumes P (next to this wave's own MFMAs).
                 asm volatile("" : "+v"(pu[0][0]), "+v"(pu[0][1]), "+v"(pu[1][0]), "+v"(pu[1][1]), "+v"(l), "+v"(m));
-    #pragma unroll
+#pragma unroll
                 for (int sb = 0; sb < 2; ++sb)
-    #pragma unroll
+#pragma unroll
                     for (int kk = 0; kk < 2; ++kk) pb[sb][kk] = as_v8<T>(pu[sb][kk]);
             };
 
@@ -400,7 +445,7 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
             // the steady-state loop body is straight-line code (a per-iteration branch on `na` made hipcc
             // copy the 64 O accumulators at every merge point): 2 = softmax, PV and next QK^T; 1 = softmax
             // and PV (this wave's last active tile); 0 = fully masked tile, only staging and barriers.
-            auto tile_step = [&](int j, auto mode_tag) __attribute__((always_inline)) {
+            auto tile_step = [&](int j, auto mode_tag, auto fixed_tag) __attribute__((always_inline)) {
                 constexpr int MODE = decltype(mode_tag)::value;
                 // ---- V-phase(j): stage (see the prologue comment), then softmax(S_j)
                 stamp();
@@ -409,7 +454,7 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                 if (j + 1 + grp < nt) issue_v((j + 1 + grp) * kKVTile);
                 if (j + 2 + grp < nt) issue_k((j + 2 + grp) * kKVTile);
                 __builtin_amdgcn_s_setprio(AULE_VPRIO);
-                if constexpr (MODE >= 1) softmax(j * kKVTile);
+                if constexpr (MODE >= 1) softmax(j * kKVTile, fixed_tag);
                 __builtin_amdgcn_s_setprio(0);
                 stamp();
                 // phase boundary: nothing may move across (hipcc would interleave this wave's softmax with
@@ -433,10 +478,18 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
             };
+            using std::integral_constant;
             int j = 0;
-            for (; j + 1 < na; ++j) tile_step(j, std::integral_constant<int, 2>{});
-            if (j < na) { tile_step(j, std::integral_constant<int, 1>{}); ++j; }
-            for (; j < nt; ++j) tile_step(j, std::integral_constant<int, 0>{});
+            if constexpr (RAW) {  // tile 0 sets the reference with the online form; every later tile keeps it
+                if (na > 1) { tile_step(0, integral_constant<int, 2>{}, integral_constant<int, 0>{}); j = 1; }
+            }
+            for (; j + 1 < na; ++j) tile_step(j, integral_constant<int, 2>{}, integral_constant<int, RAW ? 1 : 0>{});
+            if (j < na) {
+                if (RAW && j > 0) tile_step(j, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+                else tile_step(j, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+                ++j;
+            }
+            for (; j < nt; ++j) tile_step(j, integral_constant<int, 0>{}, integral_constant<int, 0>{});
 
             if (grp == 0) __syncthreads();  // pairs with group 1's last phase barrier: all waves aligned again
         };
