@@ -43,7 +43,8 @@ struct FwdIWParams {
     void* o;
     float* lse;
     int B, Hq, Hkv, Sq, Sk;
-    float c;    // scale * log2(e), signed
+    float c;    // |scale| * log2(e)
+    int negq;   // scale < 0: the sign goes into the Q fragments
     int nqb;    // 256-row Q blocks
     int nwork;  // work items per head: ceil(nqb/2) when pairing, else nqb
     int pair;   // process Q blocks (i, nqb-1-i) in one workgroup
@@ -65,7 +66,7 @@ struct IWCfg {
     static constexpr int CH = NCHUNK / 256;      // 16-byte chunks per thread per tile (D=32: 1, 64: 2, 128: 4)
     static constexpr int KS = D / 16, DB = D / 32;
     static constexpr int OSLAB = 64 * RBP;       // one wave's output rows (epilogue transpose)
-    static constexpr int RING = 3 * KTILE + 3 * VTILE;
+    static constexpr int RING = 2 * KTILE + 2 * VTILE;
     static constexpr int LDS = RING > 4 * OSLAB ? RING : 4 * OSLAB;
 };
 
@@ -114,30 +115,6 @@ __device__ __forceinline__ unsigned pack_bf16_pinned(float a, float b) {
     return 0;
 #endif
 }
-// fused per-slot softmax work of the fast path (see `slice`)
-__device__ __forceinline__ float slot_first(const float& s_e) {
-    float r = 0.f;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("v_accvgpr_read_b32 %0, %1\n\ts_nop 0\n\tv_exp_f32 %0, %0" : "=v"(r) : "a"(s_e));
-#endif
-    return r;
-}
-__device__ __forceinline__ float slot_odd(const float& s_e, float& acc, float p_prev) {
-    float r = 0.f;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_add_f32 %1, %1, %3\n\tv_exp_f32 %0, %0"
-                 : "=&v"(r), "+v"(acc) : "a"(s_e), "v"(p_prev));
-#endif
-    return r;
-}
-__device__ __forceinline__ float slot_even(const float& s_e, float& acc, float p_prev2, float p_prev, unsigned& packed) {
-    float r = 0.f;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("v_accvgpr_read_b32 %0, %3\n\tv_add_f32 %1, %1, %5\n\tv_exp_f32 %0, %0\n\tv_cvt_pk_bf16_f32 %2, %4, %5"
-                 : "=&v"(r), "+v"(acc), "=&v"(packed) : "a"(s_e), "v"(p_prev2), "v"(p_prev));
-#endif
-    return r;
-}
 __device__ __forceinline__ void scale_acc(f32x16_t& t, float alpha) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -151,22 +128,55 @@ __device__ __forceinline__ void scale_acc(f32x16_t& t, float alpha) {
 #endif
 }
 
-// SAFE = false: the hot path.  P = exp2(x) against the FIXED reference 0 (x = q~.k already carries
-//   scale*log2(e) through the prescaled Q): no row maximum, no subtraction, no rescale of O -- valid while
-//   every partial row sum stays inside [2^-100, 2^110], which holds for |logit * log2 e| < ~100.
-// SAFE = true: classic online softmax (running maximum, O rescaled when it grows), not software-pipelined
-//   into the MFMA slots.  A workgroup re-runs a Q block in this mode when the fast pass left the range.
+// Fused per-slot softmax work of the fast pass, software-pipelined over four elements so that no instruction
+// reads the result of the one or two before it (one wave per SIMD: nobody else fills a dependency bubble):
+//     step k:  t_k = S_k (AGPR -> VGPR) ; x_{k-1} = t_{k-1}*c - m_ref ; p_{k-2} = exp2(x_{k-2}) ; l += p_{k-3}
+//              and, when k-3 is odd, the bf16 pack of (p_{k-4}, p_{k-3}).
+// One asm statement per step: hipcc pads separate asm statements with s_nop, and inline asm is invisible to
+// its hazard recogniser (a transcendental's result must not be read by the next instruction: here it is
+// first read one whole step later).
+__device__ __forceinline__ void sp_step(const float& s_k, float& t_k, float t_km1, float& x_km1, float x_km2, float& p_km2,
+                                        float p_km3, float& acc, float c, float nm) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_fma_f32 %1, %5, %8, %9\n\tv_exp_f32 %2, %6\n\tv_add_f32 %3, %3, %7"
+                 : "=&v"(t_k), "=&v"(x_km1), "=&v"(p_km2), "+v"(acc)
+                 : "a"(s_k), "v"(t_km1), "v"(x_km2), "v"(p_km3), "v"(c), "v"(nm));
+#endif
+}
+__device__ __forceinline__ void sp_step_pk(const float& s_k, float& t_k, float t_km1, float& x_km1, float x_km2, float& p_km2,
+                                           float p_km3, float p_km4, float& acc, float c, float nm, unsigned& packed) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_accvgpr_read_b32 %0, %5\n\tv_fma_f32 %1, %6, %10, %11\n\tv_exp_f32 %2, %7\n\tv_add_f32 %3, %3, %8\n\t"
+                 "v_cvt_pk_bf16_f32 %4, %9, %8"
+                 : "=&v"(t_k), "=&v"(x_km1), "=&v"(p_km2), "+v"(acc), "=&v"(packed)
+                 : "a"(s_k), "v"(t_km1), "v"(x_km2), "v"(p_km3), "v"(p_km4), "v"(c), "v"(nm));
+#endif
+}
+__device__ __forceinline__ float fma_pinned(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return a * b + c;
+#endif
+}
+
+// FAST pass: the row maximum of the first tile stays the softmax reference of the row (exact algebra, see
+// fa_fwd_pp_gfx950.hip "fixed-reference softmax"); valid while every row sum stays in [2^-100, 2^110].
+// SAFE pass: classic online softmax, tile by tile, not software-pipelined; a workgroup re-runs a Q block in
+// this mode when the fast pass left the range.
 template <class T, int D, bool CAUSAL, bool TL = false>
 __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
     using C = IWCfg<D>;
     using v8 = typename T::v8;
-    static_assert(std::is_same<T, Bf16Traits>::value, "the fast path relies on bf16's fp32 exponent range for P");
+    static_assert(std::is_same<T, Bf16Traits>::value, "the fast pass relies on bf16's fp32 exponent range for P");
     constexpr int RB = C::RB, RBP = C::RBP, CPR = C::CPR, KTILE = C::KTILE, VTILE = C::VTILE;
     constexpr int CH = C::CH, KS = C::KS, DB = C::DB;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Ks = smem;
-    char* const Vs = smem + 3 * KTILE;
+    char* const Vs = smem + 2 * KTILE;
     int* const flag = reinterpret_cast<int*>(smem + C::LDS);  // one word behind the ring / slabs
 
     const int tid = threadIdx.x;
@@ -186,7 +196,7 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
 
     const WorkItem w = decode_work(blockIdx.x, p.B, p.Hq, p.Hkv, p.nwork, false);
     const int Sq = p.Sq, Sk = p.Sk;
-    const float c = p.c;
+    const float c = p.c;  // |scale| * log2(e); the sign goes into Q
 
     const size_t kvhead = (size_t)(w.b * p.Hkv + w.hk) * Sk * RB;
     const __amdgpu_buffer_rsrc_t krs = iw_srd(reinterpret_cast<const char*>(p.k) + kvhead, (unsigned)Sk * RB);
@@ -239,39 +249,187 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
         const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 64) : Sk;  // keys visible to this wave
         const int na = (wave_kv_hi + kIWTile - 1) / kIWTile;     // tiles this wave computes (a prefix, >= 1)
 
-        // Q fragments (B operand of S^T = K.Q^T), prescaled by scale*log2(e) and rounded back to 16 bits
+        // Q fragments (B operand of S^T = K.Q^T): lane (q, hi) of block b holds d = 16ks+8hi..+7
         v8 qf[2][KS];
         {
             const size_t qhead = (size_t)(w.b * p.Hq + w.h) * Sq * RB;
             const __amdgpu_buffer_rsrc_t qrs = iw_srd(reinterpret_cast<const char*>(p.q) + qhead, (unsigned)Sq * RB);
+            const unsigned flip = p.negq ? 0x80008000u : 0u;
+            u32x4_t qx[2][KS];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    qx[b][ks] = __builtin_amdgcn_raw_buffer_load_b128(qrs, (q0w + 32 * b + l31) * RB + (2 * ks + hi) * 16, 0, 0);
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(qrs, (q0w + 32 * b + l31) * RB + (2 * ks + hi) * 16, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) x[i] = T::pack2(T::lo(x[i]) * c, T::hi(x[i]) * c);
+                    u32x4_t x = qx[b][ks];
+                    x[0] ^= flip; x[1] ^= flip; x[2] ^= flip; x[3] ^= flip;
                     qf[b][ks] = as_v8<T>(x);
                 }
         }
 
         f32x16_t o[2][DB];
         float m[2], l[2];
-        f32x16_t s[2][2];
-        v8 pb[2][2][2];
+        f32x16_t s[2][2][2];   // [tile parity][block][kv half]
+        v8 pb[2][2][2][2];     // [tile parity][block][kv half][k-step inside the half]
 
-        auto run_part = [&](auto safe_tag) __attribute__((always_inline)) {
-            constexpr bool SAFE = decltype(safe_tag)::value != 0;
+        auto zero_state = [&](float m0) __attribute__((always_inline)) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
 #pragma unroll
                 for (int d = 0; d < DB; ++d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[b][d][r] = 0.f;
-                m[b] = SAFE ? -INFINITY : 0.f;
+                m[b] = m0;
                 l[b] = 0.f;
             }
-            // ---- prologue: K_0, V_0, K_1 -> LDS
+        };
+        f32x16_t z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+
+        // masked / unmasked x of one S element of tile `kv0` (log2 units, relative to nm = -m_ref)
+        auto xmask = [&](float x, int kv0, int blk, int h, int r, auto sm_tag) __attribute__((always_inline)) -> float {
+            if constexpr (decltype(sm_tag)::value == 2) {
+                const int kv = kv0 + 32 * h + crow(r, hi);
+                const bool vis = (kv < Sk) && (!CAUSAL || kv <= q0w + 32 * blk + l31);
+                x = vis ? x : -INFINITY;
+            }
+            return x;
+        };
+
+        // ---- softmax of one half (kv half H of both blocks, 32 elements) of the tile with parity PAR, element e
+        //      handled in MFMA slot e of the caller (or back to back when there is no MFMA stream).
+        //      Element order = consumption order of the PV phase: (block 0, r 0..7), (block 1, r 0..7),
+        //      (block 0, r 8..15), (block 1, r 8..15).
+        auto elem_blk = [](int e) { return (e >> 3) & 1; };
+        auto elem_r = [](int e) { return (e & 7) + 8 * (e >> 4); };
+
+        // ---- phase A of tile j (parity PAR): S_{j+1} = K_{j+1} Q^T for both blocks (HAS_QK), with the second
+        //      half of softmax(S_j) in its slots (SM: 0 none, 1 plain, 2 masked).
+        // ---- phase B of tile j: O += V_j^T P_j for both blocks, with the first half of softmax(S_{j+1}).
+        // One pipeline step k (0 .. 34) of a half: see sp_step.  Boundary steps and masked tiles go through the
+        // single pinned instructions.
+        struct Pipe { float t[36], x[36], p[36]; };
+        auto half_softmax_step = [&](auto par_tag, auto h_tag, auto sm_tag, int kv0, int k, Pipe& q, const float (&nm)[2]) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_tag)::value, H = decltype(h_tag)::value, SM = decltype(sm_tag)::value;
+            auto put_pack = [&](int e_hi, unsigned pk) __attribute__((always_inline)) {  // pack of elements (e_hi - 1, e_hi)
+                const int b2 = elem_blk(e_hi), i2 = elem_r(e_hi) >> 1;
+                u32x4_t t = __builtin_bit_cast(u32x4_t, pb[PAR][b2][H][i2 >> 2]);
+                t[i2 & 3] = pk;
+                pb[PAR][b2][H][i2 >> 2] = as_v8<T>(t);
+            };
+            if constexpr (SM == 1) {
+                if (k >= 4 && k <= 31) {
+                    const float sk_ = s[PAR][elem_blk(k)][H][elem_r(k)];
+                    if ((k - 3) & 1) {
+                        unsigned pk;
+                        sp_step_pk(sk_, q.t[k], q.t[k - 1], q.x[k - 1], q.x[k - 2], q.p[k - 2], q.p[k - 3], q.p[k - 4],
+                                   l[elem_blk(k - 3)], c, nm[elem_blk(k - 1)], pk);
+                        put_pack(k - 3, pk);
+                    } else {
+                        sp_step(sk_, q.t[k], q.t[k - 1], q.x[k - 1], q.x[k - 2], q.p[k - 2], q.p[k - 3],
+                                l[elem_blk(k - 3)], c, nm[elem_blk(k - 1)]);
+                    }
+                    return;
+                }
+            }
+            if (k <= 31) {
+                const float sk_ = s[PAR][elem_blk(k)][H][elem_r(k)];
+                q.t[k] = acc_read(sk_);
+            }
+            if (k >= 1 && k - 1 <= 31) {
+                const int e = k - 1;
+                float x = fma_pinned(q.t[e], c, nm[elem_blk(e)]);
+                x = xmask(x, kv0, elem_blk(e), H, elem_r(e), sm_tag);
+                q.x[e] = x;
+            }
+            if (k >= 2 && k - 2 <= 31) q.p[k - 2] = exp2_pinned(q.x[k - 2]);
+            if (k >= 3 && k - 3 <= 31) {
+                const int e = k - 3;
+                add_pinned(l[elem_blk(e)], q.p[e]);
+                if (e & 1) put_pack(e, pack_bf16_pinned(q.p[e - 1], q.p[e]));
+            }
+        };
+        constexpr int kSteps = 35;
+
+        auto phaseA = [&](auto par_tag, auto qk_tag, auto sm_tag, int kv0, const float (&nm)[2]) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_tag)::value, NXT = PAR ^ 1;
+            constexpr bool HAS_QK = decltype(qk_tag)::value != 0;
+            constexpr int SM = decltype(sm_tag)::value;
+            constexpr int NOP = 2 * KS;            // K operands: t = 2 ks + h, each feeds both blocks
+            constexpr int kAhead = 2;
+            Pipe pq;
+            if constexpr (HAS_QK) {
+                const char* kb = Ks + NXT * KTILE + ka_base;
+                u32x4_t kf[NOP];
+                auto rd = [&](int t) __attribute__((always_inline)) {
+                    kf[t] = *reinterpret_cast<const u32x4_t*>(kb + (t >> 1) * 32 + (t & 1) * 32 * RBP);
+                };
+#pragma unroll
+                for (int t = 0; t < kAhead && t < NOP; ++t) rd(t);
+#pragma unroll
+                for (int sl = 0; sl < 2 * NOP; ++sl) {
+                    const int t = sl >> 1, b = sl & 1, ks = t >> 1, h = t & 1;
+                    if (b == 0 && t + kAhead < NOP) rd(t + kAhead);
+                    s[NXT][b][h] = T::mfma(as_v8<T>(kf[t]), qf[b][ks], ks == 0 ? z : s[NXT][b][h]);
+                    if constexpr (SM != 0) {
+#pragma unroll
+                        for (int k = (kSteps * sl) / (2 * NOP); k < (kSteps * (sl + 1)) / (2 * NOP); ++k)
+                            half_softmax_step(par_tag, ic<1>{}, sm_tag, kv0, k, pq, nm);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (SM != 0) {
+#pragma unroll
+                for (int k = 0; k < kSteps; ++k) half_softmax_step(par_tag, ic<1>{}, sm_tag, kv0, k, pq, nm);
+            }
+        };
+        auto phaseB = [&](auto par_tag, auto pv_tag, auto sm_tag, int kv0_next, const float (&nm)[2]) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_tag)::value, NXT = PAR ^ 1;
+            constexpr bool HAS_PV = decltype(pv_tag)::value != 0;
+            constexpr int SM = decltype(sm_tag)::value;
+            constexpr int NOP = 4 * DB;            // V operands: t = sk * DB + d, each feeds both blocks
+            constexpr int kAhead = 2;
+            constexpr int kLead = 3;               // S_{j+1} was written by the last MFMAs of phase A
+            Pipe pq;
+            if constexpr (HAS_PV) {
+                const char* vb = Vs + PAR * VTILE + va_off;
+                s16x4_t a0[NOP], a1[NOP];
+                auto rd = [&](int t) __attribute__((always_inline)) {
+                    const int sk = t / DB, d = t % DB;
+                    const int off = ((4 * sk) * (D / 16) + 2 * d) * 128;
+                    a0[t] = lds_tr16(vb + off);
+                    a1[t] = lds_tr16(vb + off + 2 * (D / 16) * 128);
+                };
+                constexpr int NSL = 2 * NOP;
+                auto first_step = [&](int sl) __attribute__((always_inline)) { return sl <= kLead ? 0 : (kSteps * (sl - kLead)) / (NSL - kLead); };
+#pragma unroll
+                for (int t = 0; t < kAhead && t < NOP; ++t) rd(t);
+#pragma unroll
+                for (int sl = 0; sl < NSL; ++sl) {
+                    const int t = sl >> 1, b = sl & 1, sk = t / DB, d = t % DB;
+                    if (b == 0 && t + kAhead < NOP) rd(t + kAhead);
+                    o[b][d] = T::mfma(as_v8<T>(a0[t], a1[t]), pb[PAR][b][sk >> 1][sk & 1], o[b][d]);
+                    if constexpr (SM != 0) {
+#pragma unroll
+                        for (int k = first_step(sl); k < first_step(sl + 1); ++k)
+                            half_softmax_step(ic<NXT>{}, ic<0>{}, sm_tag, kv0_next, k, pq, nm);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (SM != 0) {
+#pragma unroll
+                for (int k = 0; k < kSteps; ++k) half_softmax_step(ic<NXT>{}, ic<0>{}, sm_tag, kv0_next, k, pq, nm);
+            }
+        };
+
+        // =========================== FAST pass ===========================
+        auto run_fast = [&]() __attribute__((always_inline)) {
+            zero_state(0.f);
             issue_k(0);
             issue_v(0);
             write_k(0);
@@ -279,223 +437,138 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
             issue_k(kIWTile);
             write_k(1);
             __syncthreads();
-
-            // One segment: the MFMA stream of block BM (PV of the tile in V buffer vbuf, then QK^T of the tile
-            // in K buffer kbuf) with the softmax of block 1-BM (tile starting at key kv0) sliced into its slots.
-            auto seg = [&](auto bm_tag, auto pv_tag, auto qk_tag, auto sm_tag, int vbuf, int kbuf, int kv0) __attribute__((always_inline)) {
-                constexpr int BM = decltype(bm_tag)::value, BS = 1 - BM;
-                constexpr bool HAS_PV = decltype(pv_tag)::value != 0, HAS_QK = decltype(qk_tag)::value != 0;
-                constexpr int SM = decltype(sm_tag)::value;  // 0: no softmax, 1: plain, 2: masked (causal diagonal / ragged Sk)
-                constexpr int NPV = HAS_PV ? 4 * DB : 0, NQK = HAS_QK ? 2 * KS : 0, NS = NPV + NQK;
-                constexpr int kAhead = 3;
-                static_assert(NS > 0, "empty segment");
-                const char* vb = Vs + vbuf * VTILE + va_off;
-                const char* kb = Ks + kbuf * KTILE + ka_base;
-                const int qrow_s = q0w + 32 * BS + l31;  // query row of the softmaxed block
-
-                s16x4_t a0[NS], a1[NS];
-                u32x4_t kf[NS];
-                auto rd = [&](int sl) __attribute__((always_inline)) {
-                    if (sl < NPV) {
-                        const int sk = sl / DB, d = sl % DB;
-                        const int off = ((4 * sk) * (D / 16) + 2 * d) * 128;
-                        a0[sl] = lds_tr16(vb + off);
-                        a1[sl] = lds_tr16(vb + off + 2 * (D / 16) * 128);
-                    } else {
-                        const int qi = sl - NPV, ks = qi >> 1, h = qi & 1;
-                        kf[sl] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32 + h * 32 * RBP);
-                    }
-                };
-                f32x16_t z;
+            float nm[2] = {0.f, 0.f};
+            // pre-phase: S_0 (parity 0), its row maximum = the reference, first half of softmax(S_0)
+            phaseA(ic<1>{}, ic<1>{}, ic<0>{}, 0, nm);  // "tile -1" has parity 1: writes s[0] from K buffer 0
+            {
+                const bool last0 = (na == 1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                auto mf = [&](int sl) __attribute__((always_inline)) {
-                    if (sl < NPV) {
-                        const int sk = sl / DB, d = sl % DB;
-                        o[BM][d] = T::mfma(as_v8<T>(a0[sl], a1[sl]), pb[BM][sk >> 1][sk & 1], o[BM][d]);
-                    } else {
-                        const int qi = sl - NPV, ks = qi >> 1, h = qi & 1;
-                        s[BM][h] = T::mfma(as_v8<T>(kf[sl]), qf[BM][ks], ks == 0 ? z : s[BM][h]);
-                    }
-                };
-                // x of element e = 16 h + r of block BS's two S tuples (log2 units), masked where needed
-                auto xval = [&](int e) __attribute__((always_inline)) -> float {
-                    const int h = e >> 4, r = e & 15;
-                    float x = acc_read(s[BS][h][r]);
-                    if constexpr (SM == 2) {
-                        const int kv = kv0 + 32 * h + crow(r, hi);
-                        const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow_s);
-                        x = vis ? x : -INFINITY;
-                    }
-                    return x;
-                };
-                // Fast-path slot work, written as asm volatile so that it STAYS in its slot (as plain IR hipcc moves
-                // every exp/add/cvt behind the last MFMA of the segment): exp of element e, row-sum add of element
-                // e-1, pack of (e-2, e-1).  A transcendental's result needs one independent instruction before
-                // its first use, hence the one-slot lag; inline asm is invisible to the hazard recogniser.
-                float acc = 0.f;
-                float pe[33];
-                u32x4_t pu[2][2];
-                auto slice = [&](int e) __attribute__((always_inline)) {
-                    if constexpr (SM == 1) {
-                        // unmasked tile: ONE asm statement per element -- S_e -> VGPR, row-sum add of e-1 (also
-                        // the independent instruction between the read and the exp), exp_e, pack of (e-2, e-1)
-                        if (e == 0) {
-                            { const float s0 = s[BS][0][0]; pe[0] = slot_first(s0); }
-                        } else if (e < 32) {
-                            const int h = e >> 4, r = e & 15;
-                            if (e & 1) {
-                                { const float se = s[BS][h][r]; pe[e] = slot_odd(se, acc, pe[e - 1]); }
-                            } else {
-                                const int h2 = (e - 1) >> 4, i = ((e - 1) & 15) >> 1;
-                                unsigned pk;
-                                const float se = s[BS][h][r];
-                                pe[e] = slot_even(se, acc, pe[e - 2], pe[e - 1], pk);
-                                pu[h2][i >> 2][i & 3] = pk;
-                            }
-                        } else {
-                            add_pinned(acc, pe[31]);
-                            pu[1][1][3] = pack_bf16_pinned(pe[30], pe[31]);
-                        }
-                        return;
-                    }
-                    if (e < 32) pe[e] = exp2_pinned(xval(e));
-                    if (e >= 1) {
-                        add_pinned(acc, pe[e - 1]);
-                        if ((e - 1) & 1) {
-                            const int h = (e - 1) >> 4, i = ((e - 1) & 15) >> 1;
-                            pu[h][i >> 2][i & 3] = pack_bf16_pinned(pe[e - 2], pe[e - 1]);
-                        }
-                    }
-                };
-                // S of this block was written by the last MFMAs of the previous segment: leave kLead slots
-                // (>= 2 MFMA issues) before the first v_accvgpr_read of it
-                constexpr int kLead = NS >= 8 ? 2 : 0;
-                auto first_elem = [&](int sl) __attribute__((always_inline)) { return sl <= kLead ? 0 : (32 * (sl - kLead)) / (NS - kLead); };
-
-#pragma unroll
-                for (int sl = 0; sl < kAhead && sl < NS; ++sl) rd(sl);
-#pragma unroll
-                for (int sl = 0; sl < NS; ++sl) {
-                    if (sl + kAhead < NS) rd(sl + kAhead);
-                    mf(sl);
-                    if constexpr (SM != 0 && !SAFE) {
-#pragma unroll
-                        for (int e = first_elem(sl); e < first_elem(sl + 1); ++e) slice(e);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (SM != 0 && !SAFE) {
-                    slice(32);
-                    l[BS] += acc;
-                    asm volatile("" : "+v"(pu[0][0]), "+v"(pu[0][1]), "+v"(pu[1][0]), "+v"(pu[1][1]), "+v"(l[BS]));
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) pb[BS][h][kk] = as_v8<T>(pu[h][kk]);
-                }
-                if constexpr (SM != 0 && SAFE) {
-                    float x[32];
+                for (int b = 0; b < 2; ++b) {
                     float mx = -INFINITY;
 #pragma unroll
-                    for (int e = 0; e < 32; ++e) {
-                        x[e] = xval(e);
-                        mx = fmaxf(mx, x[e]);
-                    }
-                    mx = fmaxf(mx, xhalf(mx));
-                    const float m_new = fmaxf(m[BS], mx);
-                    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                    const float alpha = fast_exp2(m[BS] - m_use);  // exp2(-inf) = 0 on the first tile (O = l = 0)
-                    m[BS] = m_new;
-                    l[BS] *= alpha;
-                    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-                        for (int d = 0; d < DB; ++d) scale_acc(o[BS][d], alpha);
-                    }
-                    float a2 = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 32; e += 2) {
-                        const float p0 = fast_exp2(x[e] - m_use), p1 = fast_exp2(x[e + 1] - m_use);
-                        a2 += p0 + p1;
-                        const int h = e >> 4, i = (e & 15) >> 1;
-                        pu[h][i >> 2][i & 3] = T::pack2(p0, p1);
-                    }
-                    l[BS] += a2;
-#pragma unroll
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) pb[BS][h][kk] = as_v8<T>(pu[h][kk]);
+                        for (int r = 0; r < 16; ++r) {
+                            float x = acc_read(s[0][b][h][r]);
+                            if (last0) x = xmask(x, 0, b, h, r, ic<2>{});
+                            mx = fmaxf(mx, x);
+                        }
+                    mx = fmaxf(mx, xhalf(mx));
+                    m[b] = (mx == -INFINITY) ? 0.f : mx * c;
+                    nm[b] = -m[b];
                 }
-            };
+                if (last0) phaseB(ic<1>{}, ic<0>{}, ic<2>{}, 0, nm);
+                else phaseB(ic<1>{}, ic<0>{}, ic<1>{}, 0, nm);
+            }
+            __syncthreads();  // nobody may still read K_0 when K_2 is staged into its buffer
 
-            // pre-phase: S0_0 = K_0 Q0^T
-            seg(ic<0>{}, ic<0>{}, ic<1>{}, ic<0>{}, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-
-            // rolling ring indices: V_{j-1}, V_j, V_{j+1} and K_j, K_{j+1}, K_{j+2}
-            int vp = 2, vc = 0, vn = 1, k0 = 0, k1 = 1, k2 = 2;
-            // One tile step.  KIND (compile time): 0 first tile (of several), 1 steady state, 2 last active
-            // tile, 3 the only tile, 4 post (PV of block 1's last tile), 5 idle (staging and barrier only).
-            auto tile_step = [&](int j, auto kind_tag) __attribute__((always_inline)) {
-                constexpr int KIND = decltype(kind_tag)::value;
+            // One tile step (parity PAR = j & 1).  KIND: 0 steady (tile j+1 is not the last), 1 tile j+1 is the
+            // last one (its softmax is masked), 2 tile j is the last, 3 idle (staging and barrier only).
+            auto tile_step = [&](int j, auto par_tag, auto kind_tag) __attribute__((always_inline)) {
+                constexpr int PAR = decltype(par_tag)::value, NXT = PAR ^ 1, KIND = decltype(kind_tag)::value;
                 stamp();
                 issue_v((j + 1) * kIWTile);
                 issue_k((j + 2) * kIWTile);
                 const int kv0 = j * kIWTile;
                 if constexpr (KIND == 0) {
-                    seg(ic<1>{}, ic<0>{}, ic<1>{}, ic<1>{}, vp, k0, kv0);
+                    phaseA(par_tag, ic<1>{}, ic<1>{}, kv0, nm);
                     stamp();
-                    seg(ic<0>{}, ic<1>{}, ic<1>{}, ic<1>{}, vc, k1, kv0);
+                    phaseB(par_tag, ic<1>{}, ic<1>{}, kv0 + kIWTile, nm);
                 } else if constexpr (KIND == 1) {
-                    seg(ic<1>{}, ic<1>{}, ic<1>{}, ic<1>{}, vp, k0, kv0);
+                    phaseA(par_tag, ic<1>{}, ic<1>{}, kv0, nm);
                     stamp();
-                    seg(ic<0>{}, ic<1>{}, ic<1>{}, ic<1>{}, vc, k1, kv0);
+                    phaseB(par_tag, ic<1>{}, ic<2>{}, kv0 + kIWTile, nm);
                 } else if constexpr (KIND == 2) {
-                    seg(ic<1>{}, ic<1>{}, ic<1>{}, ic<2>{}, vp, k0, kv0);
+                    phaseA(par_tag, ic<0>{}, ic<2>{}, kv0, nm);
                     stamp();
-                    seg(ic<0>{}, ic<1>{}, ic<0>{}, ic<2>{}, vc, k1, kv0);
-                } else if constexpr (KIND == 3) {
-                    seg(ic<1>{}, ic<0>{}, ic<1>{}, ic<2>{}, vp, k0, kv0);
-                    stamp();
-                    seg(ic<0>{}, ic<1>{}, ic<0>{}, ic<2>{}, vc, k1, kv0);
-                } else if constexpr (KIND == 4) {
-                    seg(ic<1>{}, ic<1>{}, ic<0>{}, ic<0>{}, vp, k0, kv0);
-                    stamp();
+                    phaseB(par_tag, ic<1>{}, ic<0>{}, kv0 + kIWTile, nm);
                 } else {
                     stamp();
                 }
                 stamp();
                 __builtin_amdgcn_sched_barrier(0);
-                write_v(vn);
-                write_k(k2);
-                {
-                    int t = vp; vp = vc; vc = vn; vn = t;
-                    t = k0; k0 = k1; k1 = k2; k2 = t;
-                }
+                write_v(NXT);
+                write_k(PAR);
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
                 stamp();
             };
             int j = 0;
-            if (na == 1) {
-                tile_step(0, ic<3>{});
-                j = 1;
-            } else {
-                tile_step(0, ic<0>{});
-                for (j = 1; j + 1 < na; ++j) tile_step(j, ic<1>{});
-                tile_step(j, ic<2>{});
-                ++j;
+            for (; j + 3 < na; j += 2) {
+                tile_step(j, ic<0>{}, ic<0>{});
+                tile_step(j + 1, ic<1>{}, ic<0>{});
             }
-            if (j < nt) {
-                tile_step(j, ic<4>{});
-                for (++j; j < nt; ++j) tile_step(j, ic<5>{});
+            const int rem = na - j;  // 1, 2 or 3; j is even
+            if (rem == 3) {
+                tile_step(j, ic<0>{}, ic<0>{});
+                tile_step(j + 1, ic<1>{}, ic<1>{});
+                tile_step(j + 2, ic<0>{}, ic<2>{});
+            } else if (rem == 2) {
+                tile_step(j, ic<0>{}, ic<1>{});
+                tile_step(j + 1, ic<1>{}, ic<2>{});
             } else {
-                seg(ic<1>{}, ic<1>{}, ic<0>{}, ic<0>{}, vp, k0, 0);
+                tile_step(j, ic<0>{}, ic<2>{});
             }
-            __syncthreads();  // every wave is done with the ring
+            for (j = na; j < nt; ++j) {
+                if (j & 1) tile_step(j, ic<1>{}, ic<3>{});
+                else tile_step(j, ic<0>{}, ic<3>{});
+            }
         };
 
-        run_part(ic<0>{});
+        // =========================== SAFE pass ===========================
+        auto run_safe = [&]() __attribute__((always_inline)) {
+            zero_state(-INFINITY);
+            const float nm0[2] = {0.f, 0.f};
+            for (int j = 0; j < nt; ++j) {
+                __syncthreads();  // previous tile's readers are done with buffer 1 / 0
+                issue_k(j * kIWTile);
+                issue_v(j * kIWTile);
+                write_k(1);
+                write_v(0);
+                __syncthreads();
+                if (j < na) {
+                    phaseA(ic<0>{}, ic<1>{}, ic<0>{}, 0, nm0);  // s[1] = K(buffer 1) Q^T
+                    const bool need_mask = (CAUSAL && (j * kIWTile + kIWTile - 1 > q0w)) || (j * kIWTile + kIWTile > Sk);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        float x[32];
+                        float mx = -INFINITY;
+#pragma unroll
+                        for (int e = 0; e < 32; ++e) {
+                            const int h = e >> 4, r = e & 15;
+                            x[e] = acc_read(s[1][b][h][r]) * c;
+                            if (need_mask) x[e] = xmask(x[e], j * kIWTile, b, h, r, ic<2>{});
+                            mx = fmaxf(mx, x[e]);
+                        }
+                        mx = fmaxf(mx, xhalf(mx));
+                        const float m_new = fmaxf(m[b], mx);
+                        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                        const float alpha = fast_exp2(m[b] - m_use);  // exp2(-inf) = 0 on the first tile (O = l = 0)
+                        m[b] = m_new;
+                        l[b] *= alpha;
+                        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+                            for (int d = 0; d < DB; ++d) scale_acc(o[b][d], alpha);
+                        }
+                        float a2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 32; e += 2) {
+                            const float p0 = fast_exp2(x[e] - m_use), p1 = fast_exp2(x[e + 1] - m_use);
+                            a2 += p0 + p1;
+                            const int h = e >> 4, i = (e & 15) >> 1;
+                            u32x4_t t = __builtin_bit_cast(u32x4_t, pb[0][b][h][i >> 2]);
+                            t[i & 3] = T::pack2(p0, p1);
+                            pb[0][b][h][i >> 2] = as_v8<T>(t);
+                        }
+                        l[b] += a2;
+                    }
+                    phaseB(ic<0>{}, ic<1>{}, ic<0>{}, 0, nm0);  // O += V(buffer 0)^T P (pb[0])
+                }
+            }
+            __syncthreads();
+        };
+
+        run_fast();
         // range check of the fast pass (NaN fails it too); one verdict per workgroup
         {
             bool ok = true;
@@ -510,7 +583,7 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
             __syncthreads();
             if (redo) {
                 if (tid == 0) *flag = 0;
-                run_part(ic<1>{});
+                run_safe();
             }
         }
 
@@ -554,6 +627,9 @@ int launch_iw_t(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg) {
     p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o; p.lse = a.lse;
     p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
     p.c = a.scale * kLog2e;
+    p.negq = p.c < 0.f;
+    p.c = p.negq ? -p.c : p.c;
+    if (p.c == 0.f) p.c = 1e-30f;
     p.nqb = (a.Sq + kIWQBlock - 1) / kIWQBlock;
     p.pair = a.causal ? 1 : 0;
     p.nwork = p.pair ? (p.nqb + 1) / 2 : p.nqb;
