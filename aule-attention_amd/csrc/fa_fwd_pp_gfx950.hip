@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
     const int l31 = lane & 31, hi = lane >> 5;
     char* const Qs = smem + 2 * KTILE + 2 * VTILE + wave * C::QSLAB;
     int* const redo_flag = reinterpret_cast<int*>(smem + C::LDS);
-    if (RAWOK && tid == 0) *redo_flag = 0;
+    if (RAWOK && tid < 2) redo_flag[tid] = 0;  // one verdict word per part (a workgroup has at most two)
     int tl_n = 0;
     auto stamp = [&]() __attribute__((always_inline)) {
         if constexpr (TL) {
@@ -244,8 +244,20 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
 
         auto run_part = [&](auto raw_tag) __attribute__((always_inline)) {
             constexpr bool RAW = decltype(raw_tag)::value != 0;
+            // Every tile the prologue needs is requested up front (one HBM round trip, not two): K_0, V_0, K_1 by
+            // all waves, V_1 and K_2 by group 1 (see the entry state below); loads past the end of K/V read 0.
             issue_k(0);
             issue_v(0);
+            u32x4_t kpre1[CH], vpre1[CH], kpre2[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if (C::kFull || tid + 512 * i < C::NCHUNK) {
+                    kpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], kKVTile * RB, 0);
+                    if (grp == 1) {
+                        vpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], kKVTile * RB, 0);
+                        kpre2[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], 2 * kKVTile * RB, 0);
+                    }
+                }
             // ---- Q fragments (B operand of S^T = K.Q^T) in registers: lane (q, hi) holds d = 16ks+8hi..+7.
             //      (An earlier version re-read Q from LDS per tile because the kernel did not fit 256 VGPRs; with
             //      the straight-line loop it uses ~190, so the 32 registers are affordable and save 8 of the 24
@@ -426,17 +438,25 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
             //      V_{t+d} and K_{t+1+d}, then requests V_{t+1+d} and K_{t+2+d}.  Entry state for t = 0:
             //      K_0 in LDS; group 0 holds (V_0, K_1) in registers, group 1 has written its share of
             //      (V_0, K_1) and holds (V_1, K_2).  Hazard analysis: DESIGN.md "forward schedule".
+            stamp();  // TL: part start (loads issued)
             write_k(0);
-            if (nt > 1) issue_k(kKVTile);
+            stamp();  // TL: K_0/V_0/Q arrived
+#pragma unroll
+            for (int i = 0; i < CH; ++i) kst[i] = kpre1[i];  // K_1
             if (grp == 1) {
                 write_v(0);
                 if (nt > 1) write_k(1);
-                if (nt > 1) issue_v(kKVTile);
-                if (nt > 2) issue_k(2 * kKVTile);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    vst[i] = vpre1[i];  // V_1
+                    kst[i] = kpre2[i];  // K_2
+                }
             }
             __syncthreads();
+            stamp();  // TL: prologue barrier passed
             if (grp == 1) __syncthreads();  // group 1 starts one phase late
             if (na > 0) qk(0);              // pre-phase: S_0
+            stamp();  // TL: pre-phase done
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
@@ -445,6 +465,13 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
             // the steady-state loop body is straight-line code (a per-iteration branch on `na` made hipcc
             // copy the 64 O accumulators at every merge point): 2 = softmax, PV and next QK^T; 1 = softmax
             // and PV (this wave's last active tile); 0 = fully masked tile, only staging and barriers.
+            // fixed-reference pass: every wave posts its range verdict (NaN fails it too) BEFORE the barrier that
+            // re-aligns the two groups, so the workgroup-uniform decision costs no barrier of its own
+            auto flag_range = [&]() __attribute__((always_inline)) {
+                const float lsum = l + xhalf(l);
+                const bool ok = (na == 0) || ((lsum > 0x1p-100f) && (lsum < 0x1p110f));
+                if (__builtin_amdgcn_ballot_w64(!ok) != 0 && lane == 0) redo_flag[part] = 1;
+            };
             auto tile_step = [&](int j, auto mode_tag, auto fixed_tag) __attribute__((always_inline)) {
                 constexpr int MODE = decltype(mode_tag)::value;
                 // ---- V-phase(j): stage (see the prologue comment), then softmax(S_j)
@@ -474,6 +501,9 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                 }
                 __builtin_amdgcn_s_setprio(0);
                 stamp();
+                if constexpr (RAW && MODE <= 1) {
+                    if (grp == 1 && j == nt - 1) flag_range();  // group 1: last barrier of the part follows
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
@@ -491,18 +521,18 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
             }
             for (; j < nt; ++j) tile_step(j, integral_constant<int, 0>{}, integral_constant<int, 0>{});
 
+            stamp();  // TL: end of tile loop
+            if constexpr (RAW) {
+                if (grp == 0) flag_range();
+            }
             if (grp == 0) __syncthreads();  // pairs with group 1's last phase barrier: all waves aligned again
+            stamp();  // TL: aligned
         };
         if constexpr (RAWOK) {
             run_part(std::integral_constant<int, 1>{});
-            const float lsum = l + xhalf(l);
-            const bool ok = (na == 0) || ((lsum > 0x1p-100f) && (lsum < 0x1p110f));  // NaN fails too
-            if (__builtin_amdgcn_ballot_w64(!ok) != 0 && lane == 0) *redo_flag = 1;
-            __syncthreads();
-            const int redo = *redo_flag;
-            __syncthreads();
+            const int redo = redo_flag[part];
+            stamp();  // TL: range check done
             if (redo) {
-                if (tid == 0) *redo_flag = 0;
                 run_part(std::integral_constant<int, 0>{});
             }
         } else {
@@ -536,6 +566,7 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
         }
         if (qrow < Sq && p.lse != nullptr && hi == 0)
             p.lse[(size_t)(w.b * p.Hq + w.h) * Sq + qrow] = (m + fast_log2(lt)) * kLn2;
+        stamp();  // TL: epilogue issued
     }
 }
 
