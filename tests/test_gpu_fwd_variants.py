@@ -1,0 +1,62 @@
+"""Parity of the NON-default forward kernels / softmax forms (selected by environment variables that the
+library reads once per process, hence one subprocess per variant):
+
+  AULE_HIP_FWD_KERNEL=iw        4-wave in-wave ping-pong kernel (bf16, D=128), fixed-reference fast pass + SAFE pass
+  AULE_HIP_FWD_KERNEL=v1        first lock-step kernel
+  AULE_HIP_FWD_SOFTMAX=classic  ping-pong kernel with the online softmax only (no fixed-reference pass)
+
+Each variant runs the same seeded cases against the fp64 oracle, including a large-logit case that the
+fixed-reference pass must hand over to the online form (its row sums leave the safe range).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import json, math, os, sys
+sys.path.insert(0, os.path.join(%(root)r, "aule-attention_amd")); sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch
+import oracle
+from aule import _torch as at
+from util import fwd_tol, LSE_TOL
+res = []
+cases = [  # B, Hq, Hkv, Sq, Sk, causal, magnitude
+    (1, 2, 2, 64, 64, True, 1.0), (1, 2, 2, 300, 300, True, 1.0), (2, 4, 1, 1024, 1024, True, 1.0),
+    (1, 2, 2, 200, 333, False, 1.0), (1, 2, 2, 777, 130, False, 1.0), (1, 4, 2, 512, 512, True, 1.0),
+    (1, 2, 2, 512, 512, True, 6.0), (1, 2, 2, 512, 512, False, 12.0),
+]
+for (B, Hq, Hkv, Sq, Sk, causal, mag) in cases:
+    rng = np.random.RandomState(7)
+    mk = lambda *s: torch.from_numpy((rng.randn(*s) * mag).astype(np.float32)).to(torch.bfloat16)
+    q, k, v = mk(B, Hq, Sq, 128), mk(B, Hkv, Sk, 128), mk(B, Hkv, Sk, 128)
+    out, lse = at.fwd_raw(q.cuda(), k.cuda(), v.cuda(), causal, 1 / math.sqrt(128))
+    torch.cuda.synchronize()
+    ref, rl = oracle.fwd_f64(q.float().numpy(), k.float().numpy(), v.float().numpy(), causal)
+    o = out.float().cpu().numpy()
+    atol, rtol = fwd_tol("bf16", float(v.float().abs().max()))
+    bad = int((np.abs(o - ref) > atol + rtol * np.abs(ref)).sum())
+    lbad = int((np.abs(lse.cpu().numpy() - rl) > LSE_TOL["bf16"] * max(1.0, mag) + 1e-5 * np.abs(rl)).sum())
+    res.append({"case": [B, Hq, Hkv, Sq, Sk, int(causal), mag], "bad": bad, "lse_bad": lbad,
+                "nan": int(np.isnan(o).sum()), "max_err": float(np.abs(o - ref).max())})
+print("RESULT " + json.dumps(res))
+'''
+
+
+@pytest.mark.parametrize("env", [{"AULE_HIP_FWD_KERNEL": "iw"}, {"AULE_HIP_FWD_KERNEL": "v1"},
+                                 {"AULE_HIP_FWD_SOFTMAX": "classic"}],
+                         ids=["kernel-iw", "kernel-v1", "softmax-classic"])
+def test_forward_variant_matches_oracle(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    for c in json.loads(line[7:]):
+        assert c["nan"] == 0 and c["bad"] == 0 and c["lse_bad"] == 0, c
