@@ -55,19 +55,21 @@ constexpr int kIWQBlock = 256;
 constexpr int kIWTile = 64;
 constexpr int kIWTLMax = 512;
 
-template <int D>
+template <int D, int NB>
 struct IWCfg {
+    static constexpr int NT = 512 / NB;          // threads: NB = 2 -> 4 waves x 64 rows, NB = 1 -> 8 waves x 32 rows
+    static constexpr int NWAVES = NT / 64;
     static constexpr int RB = D * 2;
     static constexpr int RBP = RB + 16;          // padded LDS row (K tile, epilogue slab)
     static constexpr int CPR = RB / 16;
     static constexpr int KTILE = kIWTile * RBP;
     static constexpr int VTILE = kIWTile * RB;   // [kv/4][d/16][4][16] sub-tiles
     static constexpr int NCHUNK = kIWTile * CPR;
-    static constexpr int CH = NCHUNK / 256;      // 16-byte chunks per thread per tile (D=32: 1, 64: 2, 128: 4)
+    static constexpr int CH = NCHUNK / NT;       // 16-byte chunks per thread per tile
     static constexpr int KS = D / 16, DB = D / 32;
-    static constexpr int OSLAB = 64 * RBP;       // one wave's output rows (epilogue transpose)
+    static constexpr int OSLAB = 32 * NB * RBP;  // one wave's output rows (epilogue transpose)
     static constexpr int RING = 2 * KTILE + 2 * VTILE;
-    static constexpr int LDS = RING > 4 * OSLAB ? RING : 4 * OSLAB;
+    static constexpr int LDS = RING > NWAVES * OSLAB ? RING : NWAVES * OSLAB;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t iw_srd(const void* base, unsigned bytes) {
@@ -81,11 +83,16 @@ template <int V> using ic = std::integral_constant<int, V>;
 // element with v_accvgpr_read (placed by hand in the MFMA slots), and O -- which only MFMAs touch, except in
 // the SAFE path below -- must never be dragged into the arch VGPRs (hipcc then moves 64 registers per
 // segment back and forth), so it is rescaled in place through v_accvgpr_read/write.
+template <bool AG>
 __device__ __forceinline__ float acc_read(const float& a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    float r;
-    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(a));
-    return r;
+    if constexpr (AG) {
+        float r;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(a));
+        return r;
+    } else {
+        return a;
+    }
 #else
     return a;
 #endif
@@ -115,8 +122,14 @@ __device__ __forceinline__ unsigned pack_bf16_pinned(float a, float b) {
     return 0;
 #endif
 }
+template <bool AG>
 __device__ __forceinline__ void scale_acc(f32x16_t& t, float alpha) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (!AG) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] *= alpha;
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float tmp;
@@ -152,6 +165,22 @@ __device__ __forceinline__ void sp_step_pk(const float& s_k, float& t_k, float t
                  : "a"(s_k), "v"(t_km1), "v"(x_km2), "v"(p_km3), "v"(p_km4), "v"(c), "v"(nm));
 #endif
 }
+// VGPR-form kernels (8 waves x 32 rows, at most 256 registers: the MFMA results are in arch VGPRs): the same step
+// without the AGPR read -- x_{k-1} = S_{k-1}*c - m_ref ; p_{k-2} = exp2(x_{k-2}) ; l += p_{k-3} [; pack (p_{k-4}, p_{k-3})]
+__device__ __forceinline__ void sp_step_v(float s_km1, float& x_km1, float x_km2, float& p_km2, float p_km3, float& acc, float c, float nm) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_fma_f32 %0, %3, %6, %7\n\tv_exp_f32 %1, %4\n\tv_add_f32 %2, %2, %5"
+                 : "=&v"(x_km1), "=&v"(p_km2), "+v"(acc) : "v"(s_km1), "v"(x_km2), "v"(p_km3), "v"(c), "v"(nm));
+#endif
+}
+__device__ __forceinline__ void sp_step_pk_v(float s_km1, float& x_km1, float x_km2, float& p_km2, float p_km3, float p_km4, float& acc,
+                                             float c, float nm, unsigned& packed) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_fma_f32 %0, %4, %8, %9\n\tv_exp_f32 %1, %5\n\tv_add_f32 %2, %2, %6\n\tv_cvt_pk_bf16_f32 %3, %7, %6"
+                 : "=&v"(x_km1), "=&v"(p_km2), "+v"(acc), "=&v"(packed)
+                 : "v"(s_km1), "v"(x_km2), "v"(p_km3), "v"(p_km4), "v"(c), "v"(nm));
+#endif
+}
 __device__ __forceinline__ float fma_pinned(float a, float b, float c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float r;
@@ -166,9 +195,12 @@ __device__ __forceinline__ float fma_pinned(float a, float b, float c) {
 // fa_fwd_pp_gfx950.hip "fixed-reference softmax"); valid while every row sum stays in [2^-100, 2^110].
 // SAFE pass: classic online softmax, tile by tile, not software-pipelined; a workgroup re-runs a Q block in
 // this mode when the fast pass left the range.
-template <class T, int D, bool CAUSAL, bool TL = false>
-__global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
-    using C = IWCfg<D>;
+template <class T, int D, bool CAUSAL, int NB = 2, bool TL = false>
+__global__ void __launch_bounds__(512 / NB) fa_fwd_iw_kernel(const FwdIWParams p) {
+    using C = IWCfg<D, NB>;
+    constexpr int NT = C::NT;
+    constexpr bool AG = (NB == 2);   // 512-register budget: AGPR-form MFMAs (S and O live in AGPRs)
+    constexpr int NE = 16 * NB;      // softmax elements per half (kv half h of all blocks of the wave)
     using v8 = typename T::v8;
     static_assert(std::is_same<T, Bf16Traits>::value, "the fast pass relies on bf16's fp32 exponent range for P");
     constexpr int RB = C::RB, RBP = C::RBP, CPR = C::CPR, KTILE = C::KTILE, VTILE = C::VTILE;
@@ -209,11 +241,11 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
     int k_g[CH], k_lds[CH], v_g[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        const int cidx = tid + 256 * i;
+        const int cidx = tid + NT * i;
         const int row = cidx / CPR, cc = cidx % CPR;
         k_g[i] = row * RB + cc * 16;
         k_lds[i] = row * RBP + cc * 16;
-        const int bidx = (tid >> 3) + 32 * i;  // sub-tile index = kv4 * (D/16) + d16
+        const int bidx = (tid >> 3) + (NT / 8) * i;  // sub-tile index = kv4 * (D/16) + d16
         v_g[i] = ((bidx / (D / 16)) * 4 + ((tid >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (tid & 1)) * 16;
     }
     const int ka_base = l31 * RBP + hi * 16;
@@ -234,7 +266,7 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
     };
     auto write_v = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) *reinterpret_cast<u32x4_t*>(Vs + buf * VTILE + tid * 16 + i * 4096) = vst[i];
+        for (int i = 0; i < CH; ++i) *reinterpret_cast<u32x4_t*>(Vs + buf * VTILE + tid * 16 + i * (NT * 16)) = vst[i];
     };
 
     if (tid == 0) *flag = 0;
@@ -242,27 +274,27 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
     const int nparts = (p.pair && (p.nqb - 1 - w.blk) != w.blk) ? 2 : 1;
     for (int part = 0; part < nparts; ++part) {
         const int qb = p.pair ? (part == 0 ? p.nqb - 1 - w.blk : w.blk) : w.blk;
-        const int q0w = qb * kIWQBlock + wave * 64;
+        const int q0w = qb * kIWQBlock + wave * (32 * NB);
 
         const int kv_hi = CAUSAL ? min(Sk, qb * kIWQBlock + kIWQBlock) : Sk;
         const int nt = (kv_hi + kIWTile - 1) / kIWTile;          // tiles staged by the workgroup (>= 1)
-        const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 64) : Sk;  // keys visible to this wave
+        const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32 * NB) : Sk;  // keys visible to this wave
         const int na = (wave_kv_hi + kIWTile - 1) / kIWTile;     // tiles this wave computes (a prefix, >= 1)
 
         // Q fragments (B operand of S^T = K.Q^T): lane (q, hi) of block b holds d = 16ks+8hi..+7
-        v8 qf[2][KS];
+        v8 qf[NB][KS];
         {
             const size_t qhead = (size_t)(w.b * p.Hq + w.h) * Sq * RB;
             const __amdgpu_buffer_rsrc_t qrs = iw_srd(reinterpret_cast<const char*>(p.q) + qhead, (unsigned)Sq * RB);
             const unsigned flip = p.negq ? 0x80008000u : 0u;
-            u32x4_t qx[2][KS];
+            u32x4_t qx[NB][KS];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
                     qx[b][ks] = __builtin_amdgcn_raw_buffer_load_b128(qrs, (q0w + 32 * b + l31) * RB + (2 * ks + hi) * 16, 0, 0);
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     u32x4_t x = qx[b][ks];
@@ -271,14 +303,14 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
                 }
         }
 
-        f32x16_t o[2][DB];
-        float m[2], l[2];
-        f32x16_t s[2][2][2];   // [tile parity][block][kv half]
-        v8 pb[2][2][2][2];     // [tile parity][block][kv half][k-step inside the half]
+        f32x16_t o[NB][DB];
+        float m[NB], l[NB];
+        f32x16_t s[2][NB][2];   // [tile parity][block][kv half]
+        v8 pb[2][NB][2][2];     // [tile parity][block][kv half][k-step inside the half]
 
         auto zero_state = [&](float m0) __attribute__((always_inline)) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
+            for (int b = 0; b < NB; ++b) {
 #pragma unroll
                 for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -305,16 +337,16 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
         //      handled in MFMA slot e of the caller (or back to back when there is no MFMA stream).
         //      Element order = consumption order of the PV phase: (block 0, r 0..7), (block 1, r 0..7),
         //      (block 0, r 8..15), (block 1, r 8..15).
-        auto elem_blk = [](int e) { return (e >> 3) & 1; };
-        auto elem_r = [](int e) { return (e & 7) + 8 * (e >> 4); };
+        auto elem_blk = [](int e) { return NB == 2 ? ((e >> 3) & 1) : 0; };
+        auto elem_r = [](int e) { return NB == 2 ? ((e & 7) + 8 * (e >> 4)) : e; };
 
         // ---- phase A of tile j (parity PAR): S_{j+1} = K_{j+1} Q^T for both blocks (HAS_QK), with the second
         //      half of softmax(S_j) in its slots (SM: 0 none, 1 plain, 2 masked).
         // ---- phase B of tile j: O += V_j^T P_j for both blocks, with the first half of softmax(S_{j+1}).
         // One pipeline step k (0 .. 34) of a half: see sp_step.  Boundary steps and masked tiles go through the
         // single pinned instructions.
-        struct Pipe { float t[36], x[36], p[36]; };
-        auto half_softmax_step = [&](auto par_tag, auto h_tag, auto sm_tag, int kv0, int k, Pipe& q, const float (&nm)[2]) __attribute__((always_inline)) {
+        struct Pipe { float t[NE + 4], x[NE + 4], p[NE + 4]; };
+        auto half_softmax_step = [&](auto par_tag, auto h_tag, auto sm_tag, int kv0, int k, Pipe& q, const float (&nm)[NB]) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_tag)::value, H = decltype(h_tag)::value, SM = decltype(sm_tag)::value;
             auto put_pack = [&](int e_hi, unsigned pk) __attribute__((always_inline)) {  // pack of elements (e_hi - 1, e_hi)
                 const int b2 = elem_blk(e_hi), i2 = elem_r(e_hi) >> 1;
@@ -323,40 +355,53 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
                 pb[PAR][b2][H][i2 >> 2] = as_v8<T>(t);
             };
             if constexpr (SM == 1) {
-                if (k >= 4 && k <= 31) {
+                if (k >= 4 && k <= NE - 1) {
                     const float sk_ = s[PAR][elem_blk(k)][H][elem_r(k)];
-                    if ((k - 3) & 1) {
-                        unsigned pk;
-                        sp_step_pk(sk_, q.t[k], q.t[k - 1], q.x[k - 1], q.x[k - 2], q.p[k - 2], q.p[k - 3], q.p[k - 4],
-                                   l[elem_blk(k - 3)], c, nm[elem_blk(k - 1)], pk);
-                        put_pack(k - 3, pk);
+                    if constexpr (AG) {
+                        if ((k - 3) & 1) {
+                            unsigned pk;
+                            sp_step_pk(sk_, q.t[k], q.t[k - 1], q.x[k - 1], q.x[k - 2], q.p[k - 2], q.p[k - 3], q.p[k - 4],
+                                       l[elem_blk(k - 3)], c, nm[elem_blk(k - 1)], pk);
+                            put_pack(k - 3, pk);
+                        } else {
+                            sp_step(sk_, q.t[k], q.t[k - 1], q.x[k - 1], q.x[k - 2], q.p[k - 2], q.p[k - 3],
+                                    l[elem_blk(k - 3)], c, nm[elem_blk(k - 1)]);
+                        }
                     } else {
-                        sp_step(sk_, q.t[k], q.t[k - 1], q.x[k - 1], q.x[k - 2], q.p[k - 2], q.p[k - 3],
-                                l[elem_blk(k - 3)], c, nm[elem_blk(k - 1)]);
+                        q.t[k] = sk_;  // already in an arch VGPR
+                        if ((k - 3) & 1) {
+                            unsigned pk;
+                            sp_step_pk_v(q.t[k - 1], q.x[k - 1], q.x[k - 2], q.p[k - 2], q.p[k - 3], q.p[k - 4],
+                                         l[elem_blk(k - 3)], c, nm[elem_blk(k - 1)], pk);
+                            put_pack(k - 3, pk);
+                        } else {
+                            sp_step_v(q.t[k - 1], q.x[k - 1], q.x[k - 2], q.p[k - 2], q.p[k - 3],
+                                      l[elem_blk(k - 3)], c, nm[elem_blk(k - 1)]);
+                        }
                     }
                     return;
                 }
             }
-            if (k <= 31) {
+            if (k <= NE - 1) {
                 const float sk_ = s[PAR][elem_blk(k)][H][elem_r(k)];
-                q.t[k] = acc_read(sk_);
+                q.t[k] = acc_read<AG>(sk_);
             }
-            if (k >= 1 && k - 1 <= 31) {
+            if (k >= 1 && k - 1 <= NE - 1) {
                 const int e = k - 1;
                 float x = fma_pinned(q.t[e], c, nm[elem_blk(e)]);
                 x = xmask(x, kv0, elem_blk(e), H, elem_r(e), sm_tag);
                 q.x[e] = x;
             }
-            if (k >= 2 && k - 2 <= 31) q.p[k - 2] = exp2_pinned(q.x[k - 2]);
-            if (k >= 3 && k - 3 <= 31) {
+            if (k >= 2 && k - 2 <= NE - 1) q.p[k - 2] = exp2_pinned(q.x[k - 2]);
+            if (k >= 3 && k - 3 <= NE - 1) {
                 const int e = k - 3;
                 add_pinned(l[elem_blk(e)], q.p[e]);
                 if (e & 1) put_pack(e, pack_bf16_pinned(q.p[e - 1], q.p[e]));
             }
         };
-        constexpr int kSteps = 35;
+        constexpr int kSteps = NE + 3;
 
-        auto phaseA = [&](auto par_tag, auto qk_tag, auto sm_tag, int kv0, const float (&nm)[2]) __attribute__((always_inline)) {
+        auto phaseA = [&](auto par_tag, auto qk_tag, auto sm_tag, int kv0, const float (&nm)[NB]) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_tag)::value, NXT = PAR ^ 1;
             constexpr bool HAS_QK = decltype(qk_tag)::value != 0;
             constexpr int SM = decltype(sm_tag)::value;
@@ -372,13 +417,13 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
 #pragma unroll
                 for (int t = 0; t < kAhead && t < NOP; ++t) rd(t);
 #pragma unroll
-                for (int sl = 0; sl < 2 * NOP; ++sl) {
-                    const int t = sl >> 1, b = sl & 1, ks = t >> 1, h = t & 1;
+                for (int sl = 0; sl < NB * NOP; ++sl) {
+                    const int t = sl / NB, b = sl % NB, ks = t >> 1, h = t & 1;
                     if (b == 0 && t + kAhead < NOP) rd(t + kAhead);
                     s[NXT][b][h] = T::mfma(as_v8<T>(kf[t]), qf[b][ks], ks == 0 ? z : s[NXT][b][h]);
                     if constexpr (SM != 0) {
 #pragma unroll
-                        for (int k = (kSteps * sl) / (2 * NOP); k < (kSteps * (sl + 1)) / (2 * NOP); ++k)
+                        for (int k = (kSteps * sl) / (NB * NOP); k < (kSteps * (sl + 1)) / (NB * NOP); ++k)
                             half_softmax_step(par_tag, ic<1>{}, sm_tag, kv0, k, pq, nm);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -388,7 +433,7 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
                 for (int k = 0; k < kSteps; ++k) half_softmax_step(par_tag, ic<1>{}, sm_tag, kv0, k, pq, nm);
             }
         };
-        auto phaseB = [&](auto par_tag, auto pv_tag, auto sm_tag, int kv0_next, const float (&nm)[2]) __attribute__((always_inline)) {
+        auto phaseB = [&](auto par_tag, auto pv_tag, auto sm_tag, int kv0_next, const float (&nm)[NB]) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_tag)::value, NXT = PAR ^ 1;
             constexpr bool HAS_PV = decltype(pv_tag)::value != 0;
             constexpr int SM = decltype(sm_tag)::value;
@@ -405,13 +450,13 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
                     a0[t] = lds_tr16(vb + off);
                     a1[t] = lds_tr16(vb + off + 2 * (D / 16) * 128);
                 };
-                constexpr int NSL = 2 * NOP;
+                constexpr int NSL = NB * NOP;
                 auto first_step = [&](int sl) __attribute__((always_inline)) { return sl <= kLead ? 0 : (kSteps * (sl - kLead)) / (NSL - kLead); };
 #pragma unroll
                 for (int t = 0; t < kAhead && t < NOP; ++t) rd(t);
 #pragma unroll
                 for (int sl = 0; sl < NSL; ++sl) {
-                    const int t = sl >> 1, b = sl & 1, sk = t / DB, d = t % DB;
+                    const int t = sl / NB, b = sl % NB, sk = t / DB, d = t % DB;
                     if (b == 0 && t + kAhead < NOP) rd(t + kAhead);
                     o[b][d] = T::mfma(as_v8<T>(a0[t], a1[t]), pb[PAR][b][sk >> 1][sk & 1], o[b][d]);
                     if constexpr (SM != 0) {
@@ -437,19 +482,21 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
             issue_k(kIWTile);
             write_k(1);
             __syncthreads();
-            float nm[2] = {0.f, 0.f};
+            float nm[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) nm[b] = 0.f;
             // pre-phase: S_0 (parity 0), its row maximum = the reference, first half of softmax(S_0)
             phaseA(ic<1>{}, ic<1>{}, ic<0>{}, 0, nm);  // "tile -1" has parity 1: writes s[0] from K buffer 0
             {
                 const bool last0 = (na == 1);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     float mx = -INFINITY;
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            float x = acc_read(s[0][b][h][r]);
+                            float x = acc_read<AG>(s[0][b][h][r]);
                             if (last0) x = xmask(x, 0, b, h, r, ic<2>{});
                             mx = fmaxf(mx, x);
                         }
@@ -518,7 +565,9 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
         // =========================== SAFE pass ===========================
         auto run_safe = [&]() __attribute__((always_inline)) {
             zero_state(-INFINITY);
-            const float nm0[2] = {0.f, 0.f};
+            float nm0[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) nm0[b] = 0.f;
             for (int j = 0; j < nt; ++j) {
                 __syncthreads();  // previous tile's readers are done with buffer 1 / 0
                 issue_k(j * kIWTile);
@@ -530,13 +579,13 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
                     phaseA(ic<0>{}, ic<1>{}, ic<0>{}, 0, nm0);  // s[1] = K(buffer 1) Q^T
                     const bool need_mask = (CAUSAL && (j * kIWTile + kIWTile - 1 > q0w)) || (j * kIWTile + kIWTile > Sk);
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
+                    for (int b = 0; b < NB; ++b) {
                         float x[32];
                         float mx = -INFINITY;
 #pragma unroll
                         for (int e = 0; e < 32; ++e) {
                             const int h = e >> 4, r = e & 15;
-                            x[e] = acc_read(s[1][b][h][r]) * c;
+                            x[e] = acc_read<AG>(s[1][b][h][r]) * c;
                             if (need_mask) x[e] = xmask(x[e], j * kIWTile, b, h, r, ic<2>{});
                             mx = fmaxf(mx, x[e]);
                         }
@@ -548,7 +597,7 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
                         l[b] *= alpha;
                         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-                            for (int d = 0; d < DB; ++d) scale_acc(o[b][d], alpha);
+                            for (int d = 0; d < DB; ++d) scale_acc<AG>(o[b][d], alpha);
                         }
                         float a2 = 0.f;
 #pragma unroll
@@ -573,7 +622,7 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
         {
             bool ok = true;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 const float lt = l[b] + xhalf(l[b]);
                 ok = ok && (lt > 0x1p-100f) && (lt < 0x1p110f);
             }
@@ -591,7 +640,7 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
         //      LSE = (m + log2 l) * ln2
         char* const Os = smem + wave * C::OSLAB;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const float lt = l[b] + xhalf(l[b]);
             const float inv = 1.0f / lt;
 #pragma unroll
@@ -610,7 +659,7 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
         {
             char* obase = reinterpret_cast<char*>(p.o) + ((size_t)(w.b * p.Hq + w.h) * Sq) * RB;
 #pragma unroll
-            for (int i = 0; i < CPR; ++i) {
+            for (int i = 0; i < (32 * NB * CPR) / 64; ++i) {
                 const int cidx = lane + 64 * i;
                 const int row = cidx / CPR, cc = cidx % CPR;
                 const u32x4_t x = *reinterpret_cast<const u32x4_t*>(Os + row * RBP + cc * 16);
@@ -621,7 +670,7 @@ __global__ void __launch_bounds__(256) fa_fwd_iw_kernel(const FwdIWParams p) {
     }
 }
 
-template <class T, int D>
+template <class T, int D, int NB>
 int launch_iw_t(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg) {
     FwdIWParams p;
     p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o; p.lse = a.lse;
@@ -634,55 +683,44 @@ int launch_iw_t(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg) {
     p.pair = a.causal ? 1 : 0;
     p.nwork = p.pair ? (p.nqb + 1) / 2 : p.nqb;
     p.dbg = dbg;
-    const dim3 grid((unsigned)(p.nwork * a.B * a.Hq)), block(256);
-    const size_t lds = IWCfg<D>::LDS + 16;
+    const dim3 grid((unsigned)(p.nwork * a.B * a.Hq)), block(IWCfg<D, NB>::NT);
+    const size_t lds = IWCfg<D, NB>::LDS + 16;
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    };
     if (dbg != nullptr) {
-        if constexpr (D == 128 && std::is_same<T, Bf16Traits>::value) {
-            if (a.causal) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_iw_kernel<T, D, true, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipLaunchKernelGGL((fa_fwd_iw_kernel<T, D, true, true>), grid, block, lds, stream, p);
-            } else {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_iw_kernel<T, D, false, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipLaunchKernelGGL((fa_fwd_iw_kernel<T, D, false, true>), grid, block, lds, stream, p);
-            }
-            return (int)hipGetLastError();
-        }
-        return -1;
+        if (a.causal) go(&fa_fwd_iw_kernel<T, D, true, NB, true>);
+        else go(&fa_fwd_iw_kernel<T, D, false, NB, true>);
+    } else {
+        if (a.causal) go(&fa_fwd_iw_kernel<T, D, true, NB, false>);
+        else go(&fa_fwd_iw_kernel<T, D, false, NB, false>);
     }
-    if (a.causal)
-        hipLaunchKernelGGL((fa_fwd_iw_kernel<T, D, true>), grid, block, lds, stream, p);
-    else
-        hipLaunchKernelGGL((fa_fwd_iw_kernel<T, D, false>), grid, block, lds, stream, p);
     return (int)hipGetLastError();
 }
 
-template <class T, int D>
-int set_attr_iw() {
-    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_iw_kernel<T, D, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, IWCfg<D>::LDS + 16);
-    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_iw_kernel<T, D, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, IWCfg<D>::LDS + 16);
-    return rc;
+// AULE_HIP_FWD_KERNEL = "iw" (4 waves x 64 rows, AGPR form) | "iw1" (8 waves x 32 rows, VGPR form)
+static int iw_blocks() {
+    static const int v = [] {
+        const char* e = getenv("AULE_HIP_FWD_KERNEL");
+        return (e != nullptr && e[0] == 'i' && e[1] == 'w' && e[2] == '1') ? 1 : 2;
+    }();
+    return v;
 }
 
 }  // namespace
 
 int launch_fwd_iw(const FwdArgs& a, hipStream_t stream) {
-    if (a.dtype == kBF16) {
-        if (a.D == 128) return launch_iw_t<Bf16Traits, 128>(a, stream, nullptr);
-    }
+    if (a.dtype == kBF16 && a.D == 128)
+        return iw_blocks() == 1 ? launch_iw_t<Bf16Traits, 128, 1>(a, stream, nullptr) : launch_iw_t<Bf16Traits, 128, 2>(a, stream, nullptr);
     return -1;  // fp16 (P would leave the fp16 range without a running maximum) and D < 128: ping-pong kernel
 }
 
 int launch_fwd_iw_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream) {
     if (a.dtype != kBF16 || a.D != 128) return -1;
-    return launch_iw_t<Bf16Traits, 128>(a, stream, dbg);
+    return iw_blocks() == 1 ? launch_iw_t<Bf16Traits, 128, 1>(a, stream, dbg) : launch_iw_t<Bf16Traits, 128, 2>(a, stream, dbg);
 }
 
-int configure_fwd_iw() {
-    return set_attr_iw<Bf16Traits, 128>();
-}
+int configure_fwd_iw() { return 0; }  // the launcher sets the LDS attribute itself
 
 }  // namespace aule_hip

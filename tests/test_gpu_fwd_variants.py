@@ -1,7 +1,8 @@
 """Parity of the NON-default forward kernels / softmax forms (selected by environment variables that the
 library reads once per process, hence one subprocess per variant):
 
-  AULE_HIP_FWD_KERNEL=iw        4-wave in-wave ping-pong kernel (bf16, D=128), fixed-reference fast pass + SAFE pass
+  AULE_HIP_FWD_KERNEL=iw        4-wave x 64-row in-wave pipelined kernel (bf16, D=128), fixed-reference fast pass + SAFE pass
+  AULE_HIP_FWD_KERNEL=iw1       the same schedule with 8 waves x 32 rows (VGPR-form MFMAs)
   AULE_HIP_FWD_KERNEL=v1        first lock-step kernel
   AULE_HIP_FWD_SOFTMAX=classic  ping-pong kernel with the online softmax only (no fixed-reference pass)
 
@@ -49,9 +50,9 @@ print("RESULT " + json.dumps(res))
 '''
 
 
-@pytest.mark.parametrize("env", [{"AULE_HIP_FWD_KERNEL": "iw"}, {"AULE_HIP_FWD_KERNEL": "v1"},
+@pytest.mark.parametrize("env", [{"AULE_HIP_FWD_KERNEL": "iw"}, {"AULE_HIP_FWD_KERNEL": "iw1"}, {"AULE_HIP_FWD_KERNEL": "v1"},
                                  {"AULE_HIP_FWD_SOFTMAX": "classic"}],
-                         ids=["kernel-iw", "kernel-v1", "softmax-classic"])
+                         ids=["kernel-iw", "kernel-iw1", "kernel-v1", "softmax-classic"])
 def test_forward_variant_matches_oracle(env):
     e = dict(os.environ)
     e.update(env)

@@ -5,7 +5,7 @@ Y segment, staging writes and barrier wait in shader cycles."""
 import ctypes, math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "aule-attention_amd"))
-os.environ["AULE_HIP_FWD_KERNEL"] = "iw"
+os.environ.setdefault("AULE_HIP_FWD_KERNEL", "iw")
 import torch
 from aule import _capi
 
@@ -18,7 +18,8 @@ lib.aule_hip_debug_forward_timeline.restype = ctypes.c_int32
 lib.aule_hip_debug_forward_timeline.argtypes = [ctypes.POINTER(_capi.AttnDesc), ctypes.c_void_p]
 q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
 out = torch.empty_like(q)
-st = torch.zeros(4 * 512, device="cuda", dtype=torch.int64)
+NW = 8 if os.environ["AULE_HIP_FWD_KERNEL"] == "iw1" else 4
+st = torch.zeros(8 * 512, device="cuda", dtype=torch.int64)
 d = _capi.AttnDesc()
 d.struct_size = ctypes.sizeof(_capi.AttnDesc)
 d.dtype = 2
@@ -33,9 +34,9 @@ for _ in range(2):
     rc = lib.aule_hip_debug_forward_timeline(ctypes.byref(d), ctypes.c_void_p(st.data_ptr()))
 torch.cuda.synchronize()
 print("rc", rc)
-t = st.cpu().view(4, 512)
+t = st.cpu().view(8, 512)
 t0 = int(t[:, 0].min())
-for w in range(4):
+for w in range(NW):
     row = [int(x) for x in t[w]]
     print(f"wave {w}: start+{row[0] - t0}")
     segs = []
