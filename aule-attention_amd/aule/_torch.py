@@ -22,7 +22,7 @@ def _stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def fwd_raw(q, k, v, causal, scale, want_lse=True):
+def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1):
     """q [B,Hq,Sq,D], k/v [B,Hkv,Sk,D]: contiguous device tensors, D in SUPPORTED_HEAD_DIMS.
     Returns (out, lse or None).  Asynchronous on the current stream."""
     lib = _capi.get_lib()
@@ -38,7 +38,7 @@ def fwd_raw(q, k, v, causal, scale, want_lse=True):
     d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
     d.scale = float(scale)
     d.causal = 1 if causal else 0
-    d.window_size = -1
+    d.window_size = int(window) if window is not None and window > 0 else -1
     d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
     d.stream = _stream_ptr(q.device)
     d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
@@ -47,7 +47,7 @@ def fwd_raw(q, k, v, causal, scale, want_lse=True):
     return out, lse
 
 
-def bwd_raw(q, k, v, out, dout, lse, causal, scale):
+def bwd_raw(q, k, v, out, dout, lse, causal, scale, window=-1):
     lib = _capi.get_lib()
     B, Hq, Sq, D = q.shape
     Hkv, Sk = k.shape[1], k.shape[2]
@@ -60,7 +60,7 @@ def bwd_raw(q, k, v, out, dout, lse, causal, scale):
     d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
     d.scale = float(scale)
     d.causal = 1 if causal else 0
-    d.window_size = -1
+    d.window_size = int(window) if window is not None and window > 0 else -1
     d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
     d.stream = _stream_ptr(q.device)
     d.q, d.k, d.v, d.out, d.dout, d.lse = (q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),

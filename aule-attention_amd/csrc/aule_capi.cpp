@@ -125,8 +125,9 @@ bool download_rows(float* dst, const float* src, uint32_t pitch, size_t rows, ui
 }
 
 int run_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse, uint32_t B, uint32_t Hq,
-                uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t Dlogical, uint32_t Dp, int causal) {
+                uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t Dlogical, uint32_t Dp, int causal, int window = -1) {
     FwdArgs a;
+    a.window = window;
     a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse;
     a.B = (int)B; a.Hq = (int)Hq; a.Hkv = (int)Hkv; a.Sq = (int)Sq; a.Sk = (int)Sk; a.D = (int)Dp;
     a.scale = 1.0f / std::sqrt((float)Dlogical);  // attention_pipeline.zig:329
@@ -398,10 +399,8 @@ int32_t aule_attention_forward_gpu(aule_tensor_handle qh, aule_tensor_handle kh,
         set_error("Attention failed: fused RoPE is not supported by the HIP backend");
         return -3;
     }
-    if (window_size > 0) {
-        set_error("Attention failed: sliding window is not supported by the HIP backend");
-        return -3;
-    }
+    // window_size > 0: sliding window, key j visible to query i only if i - j < window_size (the convention of
+    // the kernel the reference runs on ROCm, triton_flash_amd.py:179-183; the Vulkan shaders use others)
     // shape rules of attention_gpu.zig:383-404
     const uint32_t B = q->shape[0], Hq = q->shape[1], Sq = q->shape[2], D = q->shape[3];
     const uint32_t Hkv = k->shape[1], Sk = k->shape[2];
@@ -423,7 +422,7 @@ int32_t aule_attention_forward_gpu(aule_tensor_handle qh, aule_tensor_handle kh,
     }
     DeviceGuard g(g_device);
     int rc = run_fwd_f32((const float*)q->ptr, (const float*)k->ptr, (const float*)v->ptr, (float*)o->ptr, nullptr,
-                         B, Hq, Hkv, Sq, Sk, D, q->pitch, causal);
+                         B, Hq, Hkv, Sq, Sk, D, q->pitch, causal, window_size);
     if (rc != 0) {
         set_error("Attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported shape");
         return -3;
@@ -577,10 +576,7 @@ static int check_common(int32_t dtype, uint32_t B, uint32_t Hq, uint32_t Hkv, ui
         set_error("Attention failed: heads_q (%u) must be divisible by heads_kv (%u)", Hq, Hkv);
         return -3;
     }
-    if (window > 0) {
-        set_error("Attention failed: sliding window is not supported by the HIP backend");
-        return -3;
-    }
+    (void)window;  // any value is accepted: <= 0 means full attention
     // per-head K/V/Q slabs are addressed through 32-bit buffer descriptors (raw SRD, byte offsets)
     if ((uint64_t)B * Hq * Sq * D >= (1ull << 40) || (uint64_t)Sq * D * 4 >= (1ull << 31) ||
         (uint64_t)Sk * D * 4 >= (1ull << 31)) {
@@ -627,6 +623,7 @@ int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
     a.dtype = d->dtype;
+    a.window = d->window_size;
     rc = aule_hip::launch_fwd(a, (hipStream_t)d->stream);
     if (rc != 0) {
         set_error("Attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");
@@ -682,6 +679,7 @@ int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
     a.dtype = d->dtype;
+    a.window = d->window_size;
     rc = aule_hip::launch_bwd(a, (hipStream_t)d->stream);
     if (rc != 0) {
         set_error("Backward failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");

@@ -29,6 +29,7 @@ struct FwdF32Params {
     int B, Hq, Hkv, Sq, Sk;
     float c;   // scale * log2(e)  (sign kept: the max is taken on c*s)
     int nqb;
+    int window;  // sliding window: key j visible to query i only if i - j < window (0: off)
 };
 
 constexpr int kQB = 128;  // 4 waves x 32 rows
@@ -79,8 +80,11 @@ __global__ void __launch_bounds__(256) fa_fwd_f32_kernel(const FwdF32Params p) {
     const int kv_hi = CAUSAL ? min(Sk, w.blk * kQB + kQB) : Sk;
     const int nt = (kv_hi + kKV - 1) / kKV;
     const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32) : Sk;
+    const int W = p.window;
+    const int t_lo = W > 0 ? max(0, w.blk * kQB - W + 1) / kKV : 0;   // tiles before the block's window: skipped
+    const int wave_kv_lo = W > 0 ? q0w - W + 1 : 0;                  // first key any row of this wave can see
 
-    for (int t = 0; t < nt; ++t) {
+    for (int t = t_lo; t < nt; ++t) {
         const int kv0 = t * kKV;
         // ---- stage K (transposed) and V (row-major)
 #pragma unroll
@@ -106,7 +110,7 @@ __global__ void __launch_bounds__(256) fa_fwd_f32_kernel(const FwdF32Params p) {
         }
         __syncthreads();
 
-        if (kv0 < wave_kv_hi) {
+        if (kv0 < wave_kv_hi && kv0 + kKV > wave_kv_lo) {
             f32x16_t s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -115,14 +119,14 @@ __global__ void __launch_bounds__(256) fa_fwd_f32_kernel(const FwdF32Params p) {
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[(2 * st + hi) * 32 + l31], qf[st], s, 0, 0, 0);
 
             // t = c * s ; mask ; online softmax in the exp2 domain
-            const bool need_mask = (CAUSAL && (kv0 + kKV - 1 > q0w)) || (kv0 + kKV > Sk);
+            const bool need_mask = (CAUSAL && (kv0 + kKV - 1 > q0w)) || (kv0 + kKV > Sk) || (W > 0 && q0w + 31 - kv0 >= W);
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float x = s[r] * c;
                 if (need_mask) {
                     const int kv = kv0 + crow(r, hi);
-                    const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow);
+                    const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow) && (W <= 0 || qrow - kv < W);
                     x = vis ? x : -INFINITY;
                 }
                 s[r] = x;
@@ -130,7 +134,8 @@ __global__ void __launch_bounds__(256) fa_fwd_f32_kernel(const FwdF32Params p) {
             }
             mx = fmaxf(mx, xhalf(mx));
             const float m_new = fmaxf(m, mx);
-            const float alpha = fast_exp2(m - m_new);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // row without a visible key so far (window)
+            const float alpha = (m_new == -INFINITY) ? 1.0f : fast_exp2(m - m_new);
             m = m_new;
             l *= alpha;
 #pragma unroll
@@ -139,7 +144,7 @@ __global__ void __launch_bounds__(256) fa_fwd_f32_kernel(const FwdF32Params p) {
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = fast_exp2(s[r] - m_new);
+                s[r] = fast_exp2(s[r] - m_use);
                 l += s[r];
             }
             // O^T += V^T . P^T : step r contracts kv pair {crow(r,0), crow(r,1)}
@@ -155,7 +160,7 @@ __global__ void __launch_bounds__(256) fa_fwd_f32_kernel(const FwdF32Params p) {
     }
 
     const float lt = l + xhalf(l);
-    const float inv = 1.0f / lt;
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;  // no visible key at all (window beyond Sk): O = 0, LSE = -inf
     if (qrow < Sq) {
         float* orow = p.o + ((size_t)(w.b * p.Hq + w.h) * Sq + qrow) * D;
 #pragma unroll
@@ -179,6 +184,7 @@ int launch_f32(const FwdArgs& a, hipStream_t stream) {
     p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
     p.c = a.scale * kLog2e;
     p.nqb = (a.Sq + kQB - 1) / kQB;
+    p.window = a.window > 0 ? a.window : 0;
     const dim3 grid((unsigned)(p.nqb * a.B * a.Hq)), block(256);
     if (a.causal)
         hipLaunchKernelGGL((fa_fwd_f32_kernel<D, true>), grid, block, 0, stream, p);

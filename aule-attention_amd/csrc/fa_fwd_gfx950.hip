@@ -332,11 +332,11 @@ static bool use_v1() { return fwd_kernel_choice() == 1; }
 
 int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (a.dtype == kF32) return launch_fwd_f32(a, stream);
-    if (fwd_kernel_choice() == 2) {
+    if (fwd_kernel_choice() == 2 && a.window <= 0) {
         const int rc = launch_fwd_iw(a, stream);
         if (rc != -1) return rc;
     }
-    if (!use_v1()) return launch_fwd_pp(a, stream);
+    if (!use_v1() || a.window > 0) return launch_fwd_pp(a, stream);  // the sliding window lives in the ping-pong kernel
     if (a.dtype == kBF16) {
         if (a.D == 128) return launch_fwd_16<Bf16Traits, 128>(a, stream);
         if (a.D == 64) return launch_fwd_16<Bf16Traits, 64>(a, stream);

@@ -42,6 +42,7 @@ struct FwdPPParams {
     int nqb;      // 256-row Q blocks
     int nwork;    // work items per head: ceil(nqb/2) when pairing, else nqb
     int pair;     // process Q blocks (i, nqb-1-i) in one workgroup
+    int window;   // sliding window: key j visible to query i only if i - j < window (<= 0: off)
     int dbg_flags;            // timeline build only: bit0 = group 1 computes nothing, bit1 = group 0 computes nothing
     unsigned long long* dbg;  // timeline build only: [8 waves][kTLMax] s_memtime stamps of workgroup 0
 };
@@ -145,8 +146,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, uns
 // valid while every row sum stays in [2^-100, 2^110], i.e. while no later logit exceeds the first tile's
 // maximum by more than ~100 in log2 units (bf16 only: P needs the fp32 exponent range).  A Q block whose row
 // sums leave that range is recomputed with the classic online softmax (workgroup-uniform decision).
-template <class T, int D, bool CAUSAL, bool TL = false, bool RAWOK = false>
+// WIN: sliding window (the convention of triton_flash_amd.py:179-183: on top of the causal rule,
+// key j is visible to query i only if i - j < window).  KV tiles entirely before the window of the Q block's first
+// row are skipped by the whole workgroup; the online softmax tolerates rows whose keys in a tile are all masked.
+template <class T, int D, bool CAUSAL, bool TL = false, bool RAWOK = false, bool WIN = false>
 __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
+    static_assert(!(RAWOK && WIN), "the fixed-reference pass needs a visible key in the first tile of every row");
     using C = Cfg<D>;
     using v8 = typename T::v8;
     constexpr int RB = C::RB, RBP = C::RBP, CPR = C::CPR, KTILE = C::KTILE, VTILE = C::VTILE;
@@ -201,17 +206,18 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
     const int va_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
 
     u32x4_t kst[CH], vst[CH];
+    int kvb = 0;  // first key of the first staged tile of the current Q block (window skipping)
     auto issue_k = [&](int kv0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if (C::kFull || tid + 512 * i < C::NCHUNK)
-                kst[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], kv0 * RB, 0);
+                kst[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], (kvb + kv0) * RB, 0);
     };
     auto issue_v = [&](int kv0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if (C::kFull || tid + 512 * i < C::NCHUNK)
-                vst[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], kv0 * RB, 0);
+                vst[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], (kvb + kv0) * RB, 0);
     };
     auto write_k = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -233,9 +239,12 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
         const int qrow = q0w + l31;
 
         const int kv_hi = CAUSAL ? min(Sk, qb * kQBlock + kQBlock) : Sk;
-        const int nt = (kv_hi + kKVTile - 1) / kKVTile;          // tiles staged by the workgroup
+        int t_lo = 0;  // first tile any row of this Q block can see
+        if constexpr (WIN) t_lo = min(max(0, qb * kQBlock - p.window + 1) / kKVTile, (kv_hi + kKVTile - 1) / kKVTile - 1);
+        kvb = t_lo * kKVTile;
+        const int nt = (kv_hi + kKVTile - 1) / kKVTile - t_lo;   // tiles staged by the workgroup (>= 1)
         const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32) : Sk;  // keys visible to this wave
-        int na = (wave_kv_hi + kKVTile - 1) / kKVTile;           // tiles this wave computes (a prefix)
+        int na = max(1, (wave_kv_hi + kKVTile - 1) / kKVTile - t_lo);  // tiles this wave computes (a prefix)
         if constexpr (TL) {
             if ((p.dbg_flags >> grp) & 1) na = 0;
         }
@@ -252,10 +261,10 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
 #pragma unroll
             for (int i = 0; i < CH; ++i)
                 if (C::kFull || tid + 512 * i < C::NCHUNK) {
-                    kpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], kKVTile * RB, 0);
+                    kpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], (kvb + kKVTile) * RB, 0);
                     if (grp == 1) {
-                        vpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], kKVTile * RB, 0);
-                        kpre2[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], 2 * kKVTile * RB, 0);
+                        vpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], (kvb + kKVTile) * RB, 0);
+                        kpre2[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], (kvb + 2 * kKVTile) * RB, 0);
                     }
                 }
             // ---- Q fragments (B operand of S^T = K.Q^T) in registers: lane (q, hi) holds d = 16ks+8hi..+7.
@@ -341,14 +350,15 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
             };
             auto softmax = [&](int kv0, auto fixed_tag) __attribute__((always_inline)) {
                 constexpr bool FIXED = decltype(fixed_tag)::value != 0;  // S_j -> P_j (16-bit, in registers); updates m, l, o
-                const bool need_mask = (CAUSAL && (kv0 + kKVTile - 1 > q0w)) || (kv0 + kKVTile > Sk);
+                const bool need_mask = (CAUSAL && (kv0 + kKVTile - 1 > q0w)) || (kv0 + kKVTile > Sk) ||
+                                       (WIN && (q0w + 31 - kv0 >= p.window));
                 if (need_mask) {
 #pragma unroll
                     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int kv = kv0 + sb * 32 + crow(r, hi);
-                            const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow);
+                            const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow) && (!WIN || qrow - kv < p.window);
                             s[sb][r] = vis ? s[sb][r] : -INFINITY;
                         }
                 }
@@ -398,7 +408,8 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                 // otherwise P is formed against the kept max (P <= 2^8, fine for bf16/fp16 and fp32 sums).
                 if (__builtin_amdgcn_ballot_w64(mxc > m + kRescaleThr) != 0) {
                     const float m_new = fmaxf(m, mxc);
-                    const float alpha = fast_exp2(m - m_new);
+                    float alpha = fast_exp2(m - m_new);
+                    if constexpr (WIN) alpha = (m_new == -INFINITY) ? 1.0f : alpha;  // row still without a visible key
                     m = m_new;
                     l *= alpha;
 #pragma unroll
@@ -407,7 +418,8 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                         for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
                 }
                 const f32x2_t c2 = {c, c};
-                const f32x2_t nm2 = {-m, -m};
+                const float m_sub = (WIN && m == -INFINITY) ? 0.f : m;  // (-inf) - (-inf) would be NaN; P = exp2(-inf) = 0
+                const f32x2_t nm2 = {-m_sub, -m_sub};
                 f32x2_t ls[2] = {{0.f, 0.f}, {0.f, 0.f}};
                 u32x4_t pu[2][2];
 #pragma unroll
@@ -481,7 +493,7 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                 if (j + 1 + grp < nt) issue_v((j + 1 + grp) * kKVTile);
                 if (j + 2 + grp < nt) issue_k((j + 2 + grp) * kKVTile);
                 __builtin_amdgcn_s_setprio(AULE_VPRIO);
-                if constexpr (MODE >= 1) softmax(j * kKVTile, fixed_tag);
+                if constexpr (MODE >= 1) softmax(kvb + j * kKVTile, fixed_tag);
                 __builtin_amdgcn_s_setprio(0);
                 stamp();
                 // phase boundary: nothing may move across (hipcc would interleave this wave's softmax with
@@ -543,7 +555,7 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
         //      global stores are whole 16-byte chunks of full rows (the direct form is 16 row-strided
         //      8-byte stores per lane and was ~16k cycles per Q block); LSE = (m + log2 l) * ln2
         const float lt = l + xhalf(l);
-        const float inv = 1.0f / lt;
+        const float inv = (WIN && !(lt > 0.f)) ? 0.f : 1.0f / lt;  // a row with no visible key at all: O = 0, LSE = -inf
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -594,8 +606,16 @@ int launch_pp(const FwdArgs& a, hipStream_t stream) {
     p.nwork = p.pair ? (p.nqb + 1) / 2 : p.nqb;
     p.dbg = nullptr;
     p.dbg_flags = 0;
+    p.window = a.window > 0 ? a.window : 0;
     const dim3 grid((unsigned)(p.nwork * a.B * a.Hq)), block(512);
     const size_t lds = Cfg<D>::LDS + 16;
+    if (p.window > 0) {  // sliding window: online softmax only
+        if (a.causal)
+            hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, true, false, false, true>), grid, block, lds, stream, p);
+        else
+            hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false, false, false, true>), grid, block, lds, stream, p);
+        return (int)hipGetLastError();
+    }
     if constexpr (std::is_same<T, Bf16Traits>::value) {
         if (raw_softmax_enabled()) {
             if (a.causal)
@@ -617,6 +637,10 @@ int set_attr_pp() {
     int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, true, false, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, false, false, false, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
     if constexpr (std::is_same<T, Bf16Traits>::value) {
         rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, true, false, true>),
@@ -640,6 +664,7 @@ int launch_fwd_pp_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_
     p.nqb = (a.Sq + kQBlock - 1) / kQBlock;
     p.pair = a.causal ? 1 : 0;
     p.nwork = p.pair ? (p.nqb + 1) / 2 : p.nqb;
+    p.window = 0;
     p.dbg = dbg;
     p.dbg_flags = getenv("AULE_TL_FLAGS") ? atoi(getenv("AULE_TL_FLAGS")) : 0;
     const dim3 grid((unsigned)(p.nwork * a.B * a.Hq)), block(512);

@@ -26,6 +26,7 @@ struct FwdArgs {
     float scale;  // softmax scale (already defaulted by the caller)
     int causal;
     int dtype;
+    int window = -1;  // sliding window: key j visible to query i only if i - j < window (<= 0: off)
 };
 
 struct BwdArgs {
@@ -43,6 +44,7 @@ struct BwdArgs {
     float scale;
     int causal;
     int dtype;
+    int window = -1;  // as FwdArgs::window (the reference's backward ignores it; this one honours it)
 };
 
 // Returns 0 on success, a hipError_t value on launch failure, -1 for an

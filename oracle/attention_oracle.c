@@ -149,9 +149,16 @@ int oracle_backend_cpu_attention(const float* Q, const float* K, const float* V,
 /*   m_i = max_vis s_ij ; l_i = sum_vis exp(s_ij - m_i)                       */
 /*   O_i = sum_vis exp(s_ij - m_i) v_j / l_i ; LSE_i = m_i + ln l_i           */
 /* (triton_flash_amd.py:169-240, attention_forward_f32.comp:141-187)          */
-int oracle_fwd_f64(const float* Q, const float* K, const float* V, float* O, float* LSE,
-                   uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t D,
-                   double scale, int causal) {
+/* Sliding window, the convention of the kernel the reference runs on ROCm            */
+/* (triton_flash_amd.py:179-183): with window W > 0 key j is visible to query i only if i - j < W, in    */
+/* ADDITION to the causal rule; without causal, keys after i stay visible.  First visible key:           */
+static size_t win_lo(size_t i, int window) {
+    return (window > 0 && i + 1 > (size_t)window) ? i + 1 - (size_t)window : 0;
+}
+
+int oracle_fwd_f64_w(const float* Q, const float* K, const float* V, float* O, float* LSE,
+                     uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t D,
+                     double scale, int causal, int window) {
     if (Hkv == 0 || Hq % Hkv != 0) return -2;
     const uint32_t g = Hq / Hkv;                             /* triton_flash_amd.py:126-127 */
     double* p = (double*)malloc(sizeof(double) * (size_t)Sk);
@@ -166,8 +173,9 @@ int oracle_fwd_f64(const float* Q, const float* K, const float* V, float* O, flo
             float* o = O + (b * Hq + h) * (size_t)Sq * D;
             for (size_t i = 0; i < Sq; ++i) {
                 size_t nvis = causal ? (i + 1 < Sk ? i + 1 : Sk) : Sk;
+                const size_t jlo = win_lo(i, window);
                 double m = -INFINITY;
-                for (size_t j = 0; j < nvis; ++j) {
+                for (size_t j = jlo; j < nvis; ++j) {
                     double dot = 0.0;
                     for (size_t d = 0; d < D; ++d) dot += (double)q[i * D + d] * (double)k[j * D + d];
                     p[j] = dot * scale;
@@ -175,13 +183,14 @@ int oracle_fwd_f64(const float* Q, const float* K, const float* V, float* O, flo
                 }
                 double l = 0.0;
                 for (size_t d = 0; d < D; ++d) acc[d] = 0.0;
-                for (size_t j = 0; j < nvis; ++j) {
+                for (size_t j = jlo; j < nvis; ++j) {
                     const double e = exp(p[j] - m);
                     l += e;
                     for (size_t d = 0; d < D; ++d) acc[d] += e * (double)v[j * D + d];
                 }
-                for (size_t d = 0; d < D; ++d) o[i * D + d] = (float)(acc[d] / l);
-                if (LSE) LSE[(b * Hq + h) * (size_t)Sq + i] = (float)(m + log(l));
+                /* a row without any visible key (window and Sk < i - W + 1): O = 0, LSE = -inf */
+                for (size_t d = 0; d < D; ++d) o[i * D + d] = l > 0.0 ? (float)(acc[d] / l) : 0.0f;
+                if (LSE) LSE[(b * Hq + h) * (size_t)Sq + i] = l > 0.0 ? (float)(m + log(l)) : -INFINITY;
             }
         }
     free(p);
@@ -189,14 +198,20 @@ int oracle_fwd_f64(const float* Q, const float* K, const float* V, float* O, flo
     return 0;
 }
 
+int oracle_fwd_f64(const float* Q, const float* K, const float* V, float* O, float* LSE,
+                   uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t D,
+                   double scale, int causal) {
+    return oracle_fwd_f64_w(Q, K, V, O, LSE, B, Hq, Hkv, Sq, Sk, D, scale, causal, -1);
+}
+
 /* Backward per SURVEY Appendix B (triton_flash.py:321-350,                    */
 /* attention_backward_f32.comp:143-233): the softmax is recomputed here in     */
 /* float64 from Q,K (not from a saved LSE), delta = rowsum(O*dO) with O also    */
 /* recomputed, so this is an independent judge of the whole fwd+bwd chain.      */
-int oracle_bwd_f64(const float* Q, const float* K, const float* V, const float* dO,
-                   float* dQ, float* dK, float* dV,
-                   uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t D,
-                   double scale, int causal) {
+int oracle_bwd_f64_w(const float* Q, const float* K, const float* V, const float* dO,
+                     float* dQ, float* dK, float* dV,
+                     uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t D,
+                     double scale, int causal, int window) {
     if (Hkv == 0 || Hq % Hkv != 0) return -2;
     const uint32_t g = Hq / Hkv;
     const size_t nk = (size_t)Sk * D;
@@ -221,17 +236,18 @@ int oracle_bwd_f64(const float* Q, const float* K, const float* V, const float* 
                 float* gq = dQ + (b * Hq + h) * (size_t)Sq * D;
                 for (size_t i = 0; i < Sq; ++i) {
                     size_t nvis = causal ? (i + 1 < Sk ? i + 1 : Sk) : Sk;
+                    const size_t jlo = win_lo(i, window);
                     double m = -INFINITY;
-                    for (size_t j = 0; j < nvis; ++j) {
+                    for (size_t j = jlo; j < nvis; ++j) {
                         double dot = 0.0;
                         for (size_t d = 0; d < D; ++d) dot += (double)q[i * D + d] * (double)k[j * D + d];
                         p[j] = dot * scale;
                         if (p[j] > m) m = p[j];
                     }
                     double l = 0.0;
-                    for (size_t j = 0; j < nvis; ++j) { p[j] = exp(p[j] - m); l += p[j]; }
+                    for (size_t j = jlo; j < nvis; ++j) { p[j] = exp(p[j] - m); l += p[j]; }
                     double delta = 0.0;                      /* = sum_j p_ij dp_ij = rowsum(O*dO) */
-                    for (size_t j = 0; j < nvis; ++j) {
+                    for (size_t j = jlo; j < nvis; ++j) {
                         p[j] /= l;
                         double t = 0.0;
                         for (size_t d = 0; d < D; ++d) t += (double)go[i * D + d] * (double)v[j * D + d];
@@ -239,7 +255,7 @@ int oracle_bwd_f64(const float* Q, const float* K, const float* V, const float* 
                         delta += p[j] * t;
                     }
                     for (size_t d = 0; d < D; ++d) dq[d] = 0.0;
-                    for (size_t j = 0; j < nvis; ++j) {
+                    for (size_t j = jlo; j < nvis; ++j) {
                         const double ds = p[j] * (dp[j] - delta) * scale; /* triton_flash.py:330 */
                         for (size_t d = 0; d < D; ++d) {
                             dq[d] += ds * (double)k[j * D + d];                      /* :336 */
@@ -258,12 +274,19 @@ int oracle_bwd_f64(const float* Q, const float* K, const float* V, const float* 
     return 0;
 }
 
+int oracle_bwd_f64(const float* Q, const float* K, const float* V, const float* dO,
+                   float* dQ, float* dK, float* dV,
+                   uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t D,
+                   double scale, int causal) {
+    return oracle_bwd_f64_w(Q, K, V, dO, dQ, dK, dV, B, Hq, Hkv, Sq, Sk, D, scale, causal, -1);
+}
+
 /* Sampled-row forward judge for full-size configs: computes O and LSE for      */
 /* `nrows` (b,h,i) triples given as flat row ids r = (b*Hq+h)*Sq+i.            */
-int oracle_fwd_rows_f64(const float* Q, const float* K, const float* V,
-                        const int64_t* rows, uint32_t nrows, float* Orows, float* LSErows,
-                        uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t D,
-                        double scale, int causal) {
+int oracle_fwd_rows_f64_w(const float* Q, const float* K, const float* V,
+                          const int64_t* rows, uint32_t nrows, float* Orows, float* LSErows,
+                          uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t D,
+                          double scale, int causal, int window) {
     (void)B;
     if (Hkv == 0 || Hq % Hkv != 0) return -2;
     const uint32_t g = Hq / Hkv;
@@ -277,8 +300,9 @@ int oracle_fwd_rows_f64(const float* Q, const float* K, const float* V,
         const float* k = K + (b * Hkv + hk) * (size_t)Sk * D;
         const float* v = V + (b * Hkv + hk) * (size_t)Sk * D;
         size_t nvis = causal ? (i + 1 < Sk ? i + 1 : Sk) : Sk;
+        const size_t jlo = win_lo(i, window);
         double m = -INFINITY;
-        for (size_t j = 0; j < nvis; ++j) {
+        for (size_t j = jlo; j < nvis; ++j) {
             double dot = 0.0;
             for (size_t d = 0; d < D; ++d) dot += (double)q[d] * (double)k[j * D + d];
             p[j] = dot * scale;
@@ -286,15 +310,22 @@ int oracle_fwd_rows_f64(const float* Q, const float* K, const float* V,
         }
         double l = 0.0;
         for (size_t d = 0; d < D; ++d) acc[d] = 0.0;
-        for (size_t j = 0; j < nvis; ++j) {
+        for (size_t j = jlo; j < nvis; ++j) {
             const double e = exp(p[j] - m);
             l += e;
             for (size_t d = 0; d < D; ++d) acc[d] += e * (double)v[j * D + d];
         }
-        for (size_t d = 0; d < D; ++d) Orows[(size_t)r * D + d] = (float)(acc[d] / l);
-        if (LSErows) LSErows[r] = (float)(m + log(l));
+        for (size_t d = 0; d < D; ++d) Orows[(size_t)r * D + d] = l > 0.0 ? (float)(acc[d] / l) : 0.0f;
+        if (LSErows) LSErows[r] = l > 0.0 ? (float)(m + log(l)) : -INFINITY;
     }
     free(p);
     free(acc);
     return 0;
+}
+
+int oracle_fwd_rows_f64(const float* Q, const float* K, const float* V,
+                        const int64_t* rows, uint32_t nrows, float* Orows, float* LSErows,
+                        uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t D,
+                        double scale, int causal) {
+    return oracle_fwd_rows_f64_w(Q, K, V, rows, nrows, Orows, LSErows, B, Hq, Hkv, Sq, Sk, D, scale, causal, -1);
 }

@@ -176,7 +176,43 @@ def triton_amd_cases():
         print("triton-amd", name, tuple(out.shape))
 
 
+def triton_amd_window_cases():
+    """Sliding window: the same kernel with window_size > 0 -- visible iff
+    q_pos - k_pos < window_size, on top of the causal rule (triton_flash_amd.py:179-183)."""
+    cases = [  # name, seed, B, Hq, Hkv, Sq, Sk, D, causal, window
+        ("causal_w16_b1h2s128d64", 70, 1, 2, 2, 128, 128, 64, True, 16),
+        ("causal_w100_gqa_b1h4kv2s200d32", 71, 1, 4, 2, 200, 200, 32, True, 100),
+        ("full_w32_mqa_b1h4kv1sq64sk96d128", 72, 1, 4, 1, 64, 96, 128, False, 32),
+        ("causal_w1_b1h2s64d64", 73, 1, 2, 2, 64, 64, 64, True, 1),
+        ("causal_w70_b2h2s300d128", 74, 2, 2, 2, 300, 300, 128, True, 70),
+    ]
+    for name, seed, B, Hq, Hkv, Sq, Sk, D, causal, window in cases:
+        q, k, v = make_inputs(seed, B, Hq, Hkv, Sq, Sk, D)
+        tq, tk, tv = (torch.from_numpy(x).contiguous() for x in (q, k, v))
+        out = torch.empty_like(tq)
+        L = torch.empty(B, Hq, Sq, dtype=torch.float32)
+        sc = 1.0 / math.sqrt(D)
+        BM = BN = 64
+        grid = (triton.cdiv(Sq, BM), B * Hq)
+        ref_amd._flash_attn_fwd_amd.fn[grid](
+            tq, tk, tv, out, L,
+            *tq.stride(), *tk.stride(), *tv.stride(), *out.stride(), *L.stride(),
+            Hq, Hkv, Sq, Sk, D, sc, window,
+            BLOCK_M=BM, BLOCK_N=BN, BLOCK_K=triton.next_power_of_2(D),
+            IS_CAUSAL=causal, STORE_LSE=True)
+        rec = dict(kind="triton_amd_fwd_window", seed=seed, shape=np.array([B, Hq, Hkv, Sq, Sk, D]),
+                   causal=causal, scale=-1.0, dtype="fp32", window=window,
+                   q=q, k=k, v=v, out=out.numpy(), lse=L.numpy())
+        np.savez_compressed(os.path.join(OUT, f"win_{name}.npz"), **rec)
+        print("triton-amd window", name, tuple(out.shape))
+
+
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "window":   # add the window fixtures without touching the others
+        triton_amd_window_cases()
+        sys.exit(0)
     numpy_cases()
     triton_cases()
     triton_amd_cases()
+    triton_amd_window_cases()
