@@ -14,7 +14,9 @@ fallback -- when the library or a HIP device is missing the call raises AuleErro
 
 Also carried: the SDPA shim install() / uninstall() / scaled_dot_product_attention
 (__init__.py:288-442).  Not carried over (out of scope): ComfyUI
-glue, paged/gravity/sort features, fused RoPE, sliding window.
+glue, paged/gravity/sort features, fused RoPE.  Sliding window (window_size > 0) follows the convention of the
+kernel the reference runs on ROCm (triton_flash_amd.py:179-183): key j is visible to query i only if
+i - j < window_size, on top of the causal rule; unlike the reference, the backward honours it too.
 """
 import logging
 import math
@@ -68,7 +70,7 @@ def flash_attention(query, key, value, rot_cos=None, rot_sin=None, causal=True, 
             (the reference's ROCm route drops them too: __init__.py:204).
         causal: top-left aligned causal mask (query i sees keys j <= i)
         scale: softmax scale, default 1/sqrt(head_dim)
-        window_size: only -1 (full attention) is implemented
+        window_size: -1 = full attention; W > 0 = sliding window, key j visible to query i only if i - j < W
 
     Returns: tensor/array shaped like `query`, same container type and dtype.
     Raises: ValueError for invalid shapes; AuleError if the HIP backend is unavailable.
@@ -84,9 +86,7 @@ def flash_attention(query, key, value, rot_cos=None, rot_sin=None, causal=True, 
 
     if rot_cos is not None or rot_sin is not None:
         warnings.warn("RoPE is not fused in the HIP backend, ignoring rot_cos/rot_sin", stacklevel=2)
-    if window_size is not None and window_size > 0:
-        raise NotImplementedError("sliding window attention is not implemented in the HIP backend "
-                                  "(SURVEY.md 8f row N1); pass window_size=-1")
+    window = int(window_size) if window_size is not None and window_size > 0 else -1
 
     from ._torch import flash_attention_hip
 
@@ -97,12 +97,12 @@ def flash_attention(query, key, value, rot_cos=None, rot_sin=None, causal=True, 
         if query.is_cuda:
             if not (key.is_cuda and value.is_cuda):
                 raise ValueError("query, key and value must be on the same device")
-            return flash_attention_hip(query, key, value, causal=causal, scale=scale)
+            return flash_attention_hip(query, key, value, causal=causal, scale=scale, window=window)
         # CPU torch tensor: the reference round-trips through its device backend and
         # returns a tensor on query.device (__init__.py:210-229); same here.
         dev = _hip_device()
         with torch.no_grad():
-            out = flash_attention_hip(query.to(dev), key.to(dev), value.to(dev), causal=causal, scale=scale)
+            out = flash_attention_hip(query.to(dev), key.to(dev), value.to(dev), causal=causal, scale=scale, window=window)
         return out.to(query.device)
 
     # NumPy in -> NumPy out (dtype follows the input, like _cpu_attention: __init__.py:247-271)
@@ -113,7 +113,7 @@ def flash_attention(query, key, value, rot_cos=None, rot_sin=None, causal=True, 
     tk = torch.from_numpy(np.ascontiguousarray(key, dtype=comp)).to(dev)
     tv = torch.from_numpy(np.ascontiguousarray(value, dtype=comp)).to(dev)
     with torch.no_grad():
-        out = flash_attention_hip(tq, tk, tv, causal=causal, scale=scale)
+        out = flash_attention_hip(tq, tk, tv, causal=causal, scale=scale, window=window)
     out_np = out.cpu().numpy()
     return out_np if out_np.dtype == in_dtype else out_np.astype(in_dtype)
 

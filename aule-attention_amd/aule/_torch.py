@@ -76,19 +76,20 @@ def bwd_raw(q, k, v, out, dout, lse, causal, scale, window=-1):
 
 class FlashAttentionHipFunc(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, causal, scale):
+    def forward(ctx, q, k, v, causal, scale, window=-1):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        out, lse = fwd_raw(q, k, v, causal, scale, want_lse=True)
+        out, lse = fwd_raw(q, k, v, causal, scale, want_lse=True, window=window)
         ctx.save_for_backward(q, k, v, out, lse)      # triton_flash_amd.py:436
-        ctx.causal, ctx.scale = causal, scale
+        ctx.causal, ctx.scale, ctx.window = causal, scale, window
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors
         dout = dout.contiguous().to(q.dtype)
-        dq, dk, dv = bwd_raw(q, k, v, out, dout, lse, ctx.causal, ctx.scale)
-        return dq, dk, dv, None, None
+        # (the reference's backward drops the window, triton_flash_amd.py:447-500; here it is the true gradient)
+        dq, dk, dv = bwd_raw(q, k, v, out, dout, lse, ctx.causal, ctx.scale, window=ctx.window)
+        return dq, dk, dv, None, None, None
 
 
 def _pad_head_dim(x, Dp):
@@ -96,7 +97,7 @@ def _pad_head_dim(x, Dp):
     return x if D == Dp else torch.nn.functional.pad(x, (0, Dp - D))
 
 
-def flash_attention_hip(q, k, v, causal=True, scale=None):
+def flash_attention_hip(q, k, v, causal=True, scale=None, window=-1):
     """Device tensors in, device tensor out, autograd-aware.  dtype fp16/bf16/fp32 run
     natively; anything else is computed in fp32 and cast back."""
     D = q.shape[-1]
@@ -112,7 +113,7 @@ def flash_attention_hip(q, k, v, causal=True, scale=None):
     Dp = next(x for x in SUPPORTED_HEAD_DIMS if x >= D)
     if Dp != D:   # zero-padded head dim: dot products and outputs are unchanged
         q, k, v = _pad_head_dim(q, Dp), _pad_head_dim(k, Dp), _pad_head_dim(v, Dp)
-    out = FlashAttentionHipFunc.apply(q, k, v, bool(causal), float(scale))
+    out = FlashAttentionHipFunc.apply(q, k, v, bool(causal), float(scale), int(window))
     if Dp != D:
         out = out[..., :D]
     return out if out.dtype == orig_dtype else out.to(orig_dtype)

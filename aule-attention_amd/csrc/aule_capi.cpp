@@ -127,7 +127,7 @@ bool download_rows(float* dst, const float* src, uint32_t pitch, size_t rows, ui
 int run_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse, uint32_t B, uint32_t Hq,
                 uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t Dlogical, uint32_t Dp, int causal, int window = -1) {
     FwdArgs a;
-    a.window = window;
+    a.window = (window > 0 && (uint32_t)window < Sq) ? window : -1;  // W >= Sq masks nothing
     a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse;
     a.B = (int)B; a.Hq = (int)Hq; a.Hkv = (int)Hkv; a.Sq = (int)Sq; a.Sk = (int)Sk; a.D = (int)Dp;
     a.scale = 1.0f / std::sqrt((float)Dlogical);  // attention_pipeline.zig:329
@@ -623,7 +623,7 @@ int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
     a.dtype = d->dtype;
-    a.window = d->window_size;
+    a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q) ? d->window_size : -1;  // W >= Sq masks nothing
     rc = aule_hip::launch_fwd(a, (hipStream_t)d->stream);
     if (rc != 0) {
         set_error("Attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");
@@ -679,7 +679,7 @@ int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
     a.dtype = d->dtype;
-    a.window = d->window_size;
+    a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q) ? d->window_size : -1;
     rc = aule_hip::launch_bwd(a, (hipStream_t)d->stream);
     if (rc != 0) {
         set_error("Backward failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");

@@ -96,6 +96,7 @@ struct BwdParams {
     int nblk;     // Q blocks (dq kernel) or KV blocks / block pairs (dkdv kernel)
     int gsplit;   // dkdv: the query heads of a GQA group are split over this many workgroups
     float* part;  // dkdv, gsplit > 1: fp32 partials [2 (dK,dV)][gsplit][B,Hkv,Sk,D]
+    int window;   // sliding window: key j visible to query i only if i - j < window (0: off)
 };
 
 // Row-major image swizzle (shared with the forward's K image).
@@ -188,12 +189,13 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
     const int tr_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
 
     u32x4_t kst[CH], vst[CH];
+    int t_lo = 0;  // first KV tile any row of the current Q block can see (sliding window; else 0)
     auto issue_loads = [&](int t) {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if (Cfg::kFull || tid + 512 * i < Cfg::NCHUNK) {
-                kst[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, st_g[i], t * kDqKV * RB, 0);
-                vst[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, st_g[i], t * kDqKV * RB, 0);
+                kst[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, st_g[i], (t_lo + t) * kDqKV * RB, 0);
+                vst[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, st_g[i], (t_lo + t) * kDqKV * RB, 0);
             }
     };
     auto write_tile = [&](int t) {
@@ -215,6 +217,8 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
         const int q0w = qb * kDqQBlock + wave * 32;
         const int qrow = q0w + l31;
         const int qr = qrow < Sq ? qrow : Sq - 1;
+        const int kv_hi = CAUSAL ? min(Sk, qb * kDqQBlock + kDqQBlock) : Sk;
+        t_lo = p.window > 0 ? min(max(0, qb * kDqQBlock - p.window + 1) / kDqKV, (kv_hi + kDqKV - 1) / kDqKV - 1) : 0;
 
         issue_loads(0);
         v8 qf[KS], dof[KS];
@@ -227,10 +231,10 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
         const float delta = p.delta[qbase + qr];
         const int kv_lim = CAUSAL ? min(Sk - 1, qrow) : Sk - 1;  // last key visible to this lane's query row
 
-        const int kv_hi = CAUSAL ? min(Sk, qb * kDqQBlock + kDqQBlock) : Sk;
-        const int nt = (kv_hi + kDqKV - 1) / kDqKV;
+        const int kv_low = p.window > 0 ? qrow - p.window + 1 : -0x40000000;  // first key visible to this lane's row
+        const int nt = (kv_hi + kDqKV - 1) / kDqKV - t_lo;
         const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32) : Sk;
-        const int na = (wave_kv_hi + kDqKV - 1) / kDqKV;
+        const int na = max(1, (wave_kv_hi + kDqKV - 1) / kDqKV - t_lo);
 
         f32x16_t acc[DB];
 #pragma unroll
@@ -292,10 +296,12 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
             }
         };
         auto softmax = [&](int kv0) {  // P^T = exp2(S^T c - LSE log2e) (0 where masked) ; dS^T = P^T o (dP^T - delta)
-            const bool need_mask = (CAUSAL && (kv0 + kDqKV - 1 > q0w)) || (kv0 + kDqKV > Sk);
+            const bool need_mask = (CAUSAL && (kv0 + kDqKV - 1 > q0w)) || (kv0 + kDqKV > Sk) ||
+                                   (p.window > 0 && q0w + 31 - kv0 >= p.window);
             const f32x2_t c2 = {c, c}, nl2 = {nlse2, nlse2}, dl2 = {delta, delta};
             int rel = kv0 - kv_lim;  // key index relative to the last visible key of this lane's row
-            asm volatile("" : "+v"(rel));  // (opaque: otherwise hipcc hoists 32 per-element constants out of the loop and spills them)
+            int rlo = kv0 - kv_low;  // ... and to the first visible one (sliding window)
+            asm volatile("" : "+v"(rel), "+v"(rlo));  // (opaque: otherwise hipcc hoists 32 per-element constants out of the loop and spills them)
             u32x4_t du[2][2];
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
@@ -310,8 +316,9 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
                         t2[1] = fast_exp2(t2[1]);
                         if (need_mask) {  // visible iff kv <= kv_lim (one compare per element, no branches)
                             const int kvr = rel + sb * 32 + crow(r, hi);
-                            t2[0] = kvr <= 0 ? t2[0] : 0.f;
-                            t2[1] = kvr < 0 ? t2[1] : 0.f;
+                            const int kvl = rlo + sb * 32 + crow(r, hi);
+                            t2[0] = (kvr <= 0 && kvl >= 0) ? t2[0] : 0.f;
+                            t2[1] = (kvr < 0 && kvl >= -1) ? t2[1] : 0.f;
                         }
                         const f32x2_t dpv = {dp[sb][r], dp[sb][r + 1]};
                         const f32x2_t dsv = t2 * (dpv - dl2);
@@ -345,7 +352,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
             // ---- V-phase(j): staging, then P/dS of tile j
             if (j + 1 + grp < nt) write_tile(j + 1 + grp);
             if (j + 2 + grp < nt) issue_loads(j + 2 + grp);
-            if constexpr (MODE >= 1) softmax(j * kDqKV);
+            if constexpr (MODE >= 1) softmax((t_lo + j) * kDqKV);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
@@ -465,7 +472,10 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
         }
 
         // query tiles that can see this KV block (top-left causal: q >= kv)
-        const int ntq_all = (Sq + kQT - 1) / kQT;
+        // (sliding window: and q - kv < window, i.e. q <= last key of the block + window - 1)
+        const int W = p.window;
+        int ntq_all = (Sq + kQT - 1) / kQT;
+        if (W > 0) ntq_all = min(ntq_all, (kb * kKvBlock + kKvBlock - 1 + W + kQT - 1) / kQT);
         const int first_qt = CAUSAL ? (kb * kKvBlock) / kQT : 0;
         const int ntq = ntq_all > first_qt ? ntq_all - first_qt : 0;
         const int nit = ntq * gh;  // flattened (group head, q tile) loop
@@ -516,7 +526,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
             const int q0 = (first_qt + it % ntq) * kQT;
             if (it + 1 < nit) issue_loads(it + 1);
             // the tile contributes to this wave's keys iff some query row q >= key row exists
-            if (!CAUSAL || q0 + kQT - 1 >= n0w) {
+            if ((!CAUSAL || q0 + kQT - 1 >= n0w) && (W <= 0 || q0 < n0w + 31 + W)) {
                 const char* base = stage0 + cur * STAGE;
                 const char* qrm = base + a_base;
                 const char* qtr = base + RM + tr_off;
@@ -536,7 +546,8 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                     s = T::mfma(as_v8<T>(qa), kf[ks], ks == 0 ? z : s);              // S  = Q  . K^T
                     dp = T::mfma(as_v8<T>(da), as_v8<T>(vb), ks == 0 ? z : dp);      // dP = dO . V^T
                 }
-                const bool need_mask = (CAUSAL && (q0 < n0w + 31)) || (q0 + kQT > Sq) || (n0w + 32 > Sk);
+                const bool need_mask = (CAUSAL && (q0 < n0w + 31)) || (q0 + kQT > Sq) || (n0w + 32 > Sk) ||
+                                       (W > 0 && q0 + kQT - 1 - n0w >= W);
                 const f32x2_t c2 = {c, c};
                 v8 pb[2], dsb[2];
 #pragma unroll
@@ -558,8 +569,8 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                             if (need_mask) {
                                 const int q = q0 + crow(r, hi);
                                 const bool okc = kvrow < Sk;
-                                t[0] = (okc && q < Sq && (!CAUSAL || kvrow <= q)) ? t[0] : 0.f;
-                                t[1] = (okc && q + 1 < Sq && (!CAUSAL || kvrow <= q + 1)) ? t[1] : 0.f;
+                                t[0] = (okc && q < Sq && (!CAUSAL || kvrow <= q) && (W <= 0 || q - kvrow < W)) ? t[0] : 0.f;
+                                t[1] = (okc && q + 1 < Sq && (!CAUSAL || kvrow <= q + 1) && (W <= 0 || q + 1 - kvrow < W)) ? t[1] : 0.f;
                             }
                             const f32x2_t dpv = {dp[r] - d4[2 * j2], dp[r + 1] - d4[2 * j2 + 1]};
                             const f32x2_t dsv = t * dpv;
@@ -686,6 +697,7 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
     p.c = a.scale * kLog2e;
     p.scale = a.scale;
+    p.window = a.window > 0 ? a.window : 0;
     {
         const int nqb = (a.Sq + kDqQBlock - 1) / kDqQBlock;
         p.nblk = a.causal ? (nqb + 1) / 2 : nqb;  // causal: one workgroup per Q-block pair (i, n-1-i)

@@ -69,8 +69,10 @@ void aule_tensor_clear_all(void);                              /* src/lib.zig:39
 
 /* ---- handle-based forward: GQA (Hkv from K's shape), cross-attn, causal ---- */
 /* src/lib.zig:496-529 -> backend.zig:318-370 -> attention_gpu.zig:360-453.     */
-/* rot_cos/rot_sin handles must be 0 and window_size must be <= 0 (RoPE /      */
-/* sliding window are "next" rows): otherwise -3 + error text.   */
+/* rot_cos/rot_sin handles must be 0 (fused RoPE: -3 + error text).             */
+/* window_size > 0: sliding window, key j visible to query i only if            */
+/* i - j < window_size, on top of the causal rule (the convention of the kernel */
+/* the reference runs on ROCm, python/aule/triton_flash_amd.py:179-183).        */
 int32_t aule_attention_forward_gpu(aule_tensor_handle q, aule_tensor_handle k, aule_tensor_handle v,
                                    aule_tensor_handle output, aule_tensor_handle rot_cos,
                                    aule_tensor_handle rot_sin, int32_t causal, int32_t window_size);
@@ -123,7 +125,7 @@ typedef struct aule_attn_desc {
     uint32_t batch, heads_q, heads_kv, seq_q, seq_k, head_dim;
     float scale;           /* softmax scale; 0 or NaN => 1/sqrt(head_dim) */
     int32_t causal;
-    int32_t window_size;   /* must be <= 0 (full attention) */
+    int32_t window_size;   /* <= 0: full attention; W > 0: key j visible to query i only if i - j < W */
     int32_t device;        /* HIP device ordinal; -1 = current device */
     void* stream;          /* hipStream_t; NULL = default stream */
     const void* q;

@@ -42,10 +42,17 @@ def test_validation_applies_to_torch_too():
         aule.flash_attention(torch.zeros(2, 3, 4), torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 4))
 
 
-def test_window_not_implemented(small_qkv):
+def test_window_is_accepted_and_reaches_the_backend(small_qkv):
+    """window_size > 0 is a supported option: it passes validation and, on a box without a
+    ROCm device, fails like every other call -- with AuleError, not NotImplementedError."""
+    import torch
     q, k, v = small_qkv
-    with pytest.raises(NotImplementedError):
-        aule.flash_attention(q, k, v, window_size=16)
+    if torch.cuda.is_available():
+        out = aule.flash_attention(q, k, v, window_size=16)
+        assert out.shape == q.shape
+    else:
+        with pytest.raises(aule.AuleError):
+            aule.flash_attention(q, k, v, window_size=16)
 
 
 def test_version_and_exports():

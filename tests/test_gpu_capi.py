@@ -74,7 +74,7 @@ def test_out_of_scope_stubs_return_minus3(A):
     assert lib.aule_spatial_sort(h, h, h, 0) == -3
     assert lib.aule_attention_forward_gravity(h, h, h, h, 0, 0, h, 0, 4, -1) == -3
     assert lib.aule_attention_forward_gpu(h, h, h, h, h, h, 0, -1) == -3        # RoPE handles
-    assert lib.aule_attention_forward_gpu(h, h, h, h, 0, 0, 0, 8) == -3         # window
+    assert lib.aule_attention_forward_gpu(h, h, h, h, 0, 0, 0, 8) == 0          # sliding window is supported
     assert lib.aule_attention_forward_gpu(h, h, h, 99, 0, 0, 0, -1) == -1       # bad handle
     lib.aule_tensor_destroy(h)
 
@@ -160,8 +160,6 @@ def test_ex_rejects_bad_arguments(A):
     d.head_dim = 48
     assert lib.aule_attention_forward_ex(ctypes.byref(d)) == -3                # head_dim
     d.head_dim = 64
-    d.window_size = 4
-    assert lib.aule_attention_forward_ex(ctypes.byref(d)) == -3                # window
-    d.window_size = -1
+    d.window_size = 4                                                          # accepted (sliding window)
     assert lib.aule_attention_forward_ex(ctypes.byref(d)) == -3                # null pointers
     assert b"null" in lib.aule_get_error()

@@ -1,0 +1,113 @@
+"""Sliding window on the GPU: key j is visible to query i only if i - j < W, on top of the
+causal rule (the convention of the kernel the reference runs on ROCm, triton_flash_amd.py:179-183).
+
+  * golden vectors recorded from that kernel (tests/golden/win_*.npz, gen_golden.py window), fp32;
+  * forward AND backward against the windowed fp64 oracle for 16-bit and fp32 I/O (the reference's own
+    backward ignores the window, so there is no reference golden for the gradients);
+  * size-independent properties: W >= Sk is full attention bit for bit; W = 1 under a causal mask makes every
+    row attend to itself only (O = V, dQ = dK = 0 to rounding, dV = dO summed over the group);
+  * the C-ABI handle path (aule_attention_forward_gpu with window_size).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden
+from util import BWD_TOL, LSE_TOL, assert_close, fwd_tol, quantize, torch_dtype
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(torch, a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", torch_dtype(dtype))
+
+
+@pytest.mark.parametrize("path", golden_files("win_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_window_goldens(path):
+    import torch
+    import aule
+    g = load_golden(path)
+    W = int(np.load(path)["window"])
+    out = aule.flash_attention(g["q"], g["k"], g["v"], causal=g["causal"], window_size=W)       # numpy in/out
+    assert isinstance(out, np.ndarray)
+    assert_close(out, g["out"], 1e-5, 1e-5, g["name"])
+    from aule import _torch as at
+    D = g["q"].shape[-1]
+    o, lse = at.fwd_raw(_dev(torch, g["q"], "fp32"), _dev(torch, g["k"], "fp32"), _dev(torch, g["v"], "fp32"),
+                        g["causal"], 1 / math.sqrt(D), window=W)
+    assert_close(o.cpu().numpy(), g["out"], 1e-5, 1e-5, g["name"] + " out")
+    assert_close(lse.cpu().numpy(), g["lse"], 1e-5, 1e-5, g["name"] + " lse")
+
+
+CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, causal, window
+    ("bf16", 1, 4, 2, 512, 512, 128, True, 100),
+    ("bf16", 1, 2, 2, 1000, 1000, 128, True, 300),
+    ("bf16", 1, 2, 1, 333, 500, 64, False, 77),
+    ("fp16", 1, 2, 2, 700, 700, 64, True, 64),
+    ("bf16", 2, 2, 2, 2048, 2048, 128, True, 512),
+    ("fp32", 1, 2, 2, 300, 300, 32, True, 50),
+    ("bf16", 1, 2, 2, 600, 200, 128, True, 64),     # rows beyond Sk + W - 1 see no key: O = 0
+    ("fp16", 1, 3, 3, 130, 130, 32, True, 7),
+    ("bf16", 1, 8, 1, 257, 257, 128, True, 255),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(x) for x in c))
+def test_window_forward_backward_vs_oracle(case, oracle_mod):
+    import torch
+    from aule import _torch as at
+    dtype, B, Hq, Hkv, Sq, Sk, D, causal, W = case
+    rng = np.random.RandomState(11)
+    q, k, v, do = (quantize(rng.randn(*s).astype(np.float32), dtype)
+                   for s in ((B, Hq, Sq, D), (B, Hkv, Sk, D), (B, Hkv, Sk, D), (B, Hq, Sq, D)))
+    sc = 1 / math.sqrt(D)
+    tq, tk, tv, tdo = (_dev(torch, x, dtype) for x in (q, k, v, do))
+    out, lse = at.fwd_raw(tq, tk, tv, causal, sc, window=W)
+    ref, ref_lse = oracle_mod.fwd_f64(q, k, v, causal, None, W)
+    atol, rtol = fwd_tol(dtype, np.abs(v).max())
+    assert_close(out.float().cpu().numpy(), ref, atol, rtol, "out")
+    fin = np.isfinite(ref_lse)
+    got_lse = lse.cpu().numpy()
+    assert_close(got_lse[fin], ref_lse[fin], LSE_TOL[dtype], 1e-5, "lse")
+    assert np.all(np.isneginf(got_lse[~fin]))          # rows without a visible key
+    dq, dk, dv = at.bwd_raw(tq, tk, tv, out, tdo, lse, causal, sc, window=W)
+    rq, rk, rv = oracle_mod.bwd_f64(q, k, v, do, causal, None, W)
+    a, r = BWD_TOL[dtype]
+    for name, got, want in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+        assert_close(got.float().cpu().numpy(), want, a * max(1.0, float(np.abs(want).max())), r, name)
+
+
+def test_window_properties():
+    import torch
+    import aule
+    torch.manual_seed(3)
+    q = torch.randn(1, 4, 384, 128, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(1, 2, 384, 128, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(1, 2, 384, 128, device="cuda", dtype=torch.bfloat16)
+    full = aule.flash_attention(q, k, v, causal=True)
+    assert torch.equal(aule.flash_attention(q, k, v, causal=True, window_size=384), full)     # W >= Sk: no effect
+    assert torch.equal(aule.flash_attention(q, k, v, causal=True, window_size=10 ** 6), full)
+    # W = 1 + causal: every row attends to itself only
+    qa, ka, va = (x.clone().requires_grad_(True) for x in (q, k, v))
+    o1 = aule.flash_attention(qa, ka, va, causal=True, window_size=1)
+    want = v.repeat_interleave(2, dim=1)
+    assert torch.equal(o1, want)
+    do = torch.randn_like(o1)
+    o1.backward(do)
+    # dS = p (dP - delta) with p = 1: zero up to the rounding difference between dP and delta = rowsum(O dO)
+    assert float(qa.grad.abs().max()) < 1e-4 and float(ka.grad.abs().max()) < 1e-4
+    want_dv = do.float().view(1, 2, 2, 384, 128).sum(dim=2)
+    assert torch.allclose(va.grad.float(), want_dv, atol=2e-2, rtol=2e-2)
+
+
+def test_window_through_the_c_abi_handles(oracle_mod):
+    from aule.hip import Aule
+    rng = np.random.RandomState(2)
+    q = rng.randn(1, 4, 96, 64).astype(np.float32)
+    k = rng.randn(1, 2, 160, 64).astype(np.float32)
+    v = rng.randn(1, 2, 160, 64).astype(np.float32)
+    with Aule() as a:
+        out = a.attention(q, k, v, causal=True, window_size=40)
+    ref, _ = oracle_mod.fwd_f64(q, k, v, True, None, 40)
+    assert_close(out, ref, 1e-5, 1e-5, "forward_gpu window")

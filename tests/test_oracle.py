@@ -137,6 +137,37 @@ def test_triton_goldens_backward(oracle_mod, path):
     np.testing.assert_allclose(dv, g["dv"], rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize("path", golden_files("win_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_window_goldens_pin_the_windowed_oracle(oracle_mod, path):
+    """Sliding window (row N1): the reference's ROCm kernel with window_size > 0 (triton_flash_amd.py:179-183,
+    interpreted; fixtures from gen_golden.py window) vs the C judge and its NumPy twin."""
+    g = load_golden(path)
+    W = int(np.load(path)["window"])
+    o, lse = oracle_mod.fwd_f64(g["q"], g["k"], g["v"], g["causal"], g["scale"], W)
+    np.testing.assert_allclose(o, g["out"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lse, g["lse"], rtol=1e-5, atol=2e-5)
+    o2, lse2 = oracle_mod.np_fwd_f64(g["q"], g["k"], g["v"], g["causal"], g["scale"], W)
+    np.testing.assert_allclose(o2, g["out"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lse2, g["lse"], rtol=1e-5, atol=2e-5)
+
+
+def test_windowed_backward_judges_agree(oracle_mod):
+    """No reference golden exists for the windowed gradients (the reference's backward drops the window):
+    the C judge and the NumPy judge are two independent restatements of Appendix B with the window added."""
+    rng = np.random.RandomState(4)
+    q, do = rng.randn(1, 4, 70, 16).astype(np.float32), rng.randn(1, 4, 70, 16).astype(np.float32)
+    k, v = rng.randn(1, 2, 90, 16).astype(np.float32), rng.randn(1, 2, 90, 16).astype(np.float32)
+    for causal in (True, False):
+        for W in (1, 7, 33, 200):
+            a = oracle_mod.bwd_f64(q, k, v, do, causal, None, W)
+            b = oracle_mod.np_bwd_f64(q, k, v, do, causal, None, W)
+            for x, y in zip(a, b):
+                np.testing.assert_allclose(x, y, rtol=1e-5, atol=1e-6)
+    # a window that masks nothing is the unwindowed judge
+    for x, y in zip(oracle_mod.bwd_f64(q, k, v, do, True, None, 10 ** 6), oracle_mod.bwd_f64(q, k, v, do, True)):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_c1_fixture_is_reference_config():
     g = load_golden([p for p in golden_files("np_") if "c1_" in p][0])
     assert [int(x) for x in g["shape"]] == [1, 8, 8, 256, 256, 64] and g["causal"] and g["dtype"] == "fp32"
