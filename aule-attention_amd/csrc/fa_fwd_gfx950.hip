@@ -330,8 +330,21 @@ static int fwd_kernel_choice() {
 }
 static bool use_v1() { return fwd_kernel_choice() == 1; }
 
+bool splitkv_applicable(const FwdArgs& a);                      // fa_fwd_splitkv_gfx950.hip
+int launch_fwd_splitkv(const FwdArgs& a, hipStream_t stream);
+
+// AULE_HIP_FWD_SPLITKV=0 keeps short-query shapes on the tiled kernels (A/B measurements)
+static bool splitkv_enabled() {
+    static const int v = [] {
+        const char* e = getenv("AULE_HIP_FWD_SPLITKV");
+        return (e != nullptr && e[0] == '0') ? 0 : 1;
+    }();
+    return v == 1;
+}
+
 int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (a.dtype == kF32) return launch_fwd_f32(a, stream);
+    if (splitkv_enabled() && splitkv_applicable(a)) return launch_fwd_splitkv(a, stream);
     if (fwd_kernel_choice() == 2 && a.window <= 0) {
         const int rc = launch_fwd_iw(a, stream);
         if (rc != -1) return rc;

@@ -1,0 +1,295 @@
+// fa_fwd_splitkv_gfx950.hip -- forward for SHORT query sequences against long K/V (decode-like cross-attention,
+// SURVEY.md 8d points C5b / C5c): the regime where the tiled kernels cannot fill the chip -- a 256-row Q block per
+// workgroup leaves B*Hq*ceil(Sq/256) workgroups, 32 for C5b -- and the bound is HBM (K and V are read once,
+// arithmetic intensity ~32 FLOP/B at Sq = 1).
+//
+//   * GQA/MQA packing: the Hq/Hkv query heads that share one K/V head are stacked into the ROW dimension
+//     (row r of a (batch, kv-head) unit = (head r / Sq of the group, query r % Sq)), so MQA decode with 32 heads
+//     is exactly one 32-row MFMA tile instead of 32 one-row problems, and K/V are streamed once per unit.
+//   * split-KV: the key range is cut into chunks of `chunk_tiles` 32-key tiles, ONE WAVE per chunk (4 waves per
+//     workgroup); every wave keeps its own online-softmax state and writes an un-normalised partial
+//     (m, l, O) in fp32; fa_fwd_splitkv_combine merges the partials of a row (log-sum-exp merge), casts O and
+//     writes LSE.  ~2048 waves are launched whatever the shape.
+//   * per wave and 32-key tile: K fragments go from global memory straight into the MFMA A operand (row = key,
+//     16 contiguous bytes per lane: no LDS), V goes through a wave-private LDS tile in the [kv/4][d/16][4][16]
+//     sub-tile layout for ds_read_b64_tr_b16 (same layout and operand maps as fa_fwd_pp_gfx950.hip), S^T = K.Q^T
+//     with a lane owning one packed row, O^T += V^T.P^T.
+// Non-causal only (with the reference's top-left causal rule a short query sequence sees only its first Sq keys,
+// which the tiled kernels handle).  Reference semantics: python/aule/triton_flash_amd.py:97-240 (same math,
+// GQA head map :126-127).
+#include "fa_device.h"
+#include "fa_kernels.h"
+
+namespace aule_hip {
+namespace {
+
+struct SplitParams {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* o;
+    float* lse;
+    float* part;   // [npart][rows_total][D + 2] fp32: O (un-normalised), m (log2 units), l
+    int B, Hq, Hkv, Sq, Sk;
+    float c;       // |scale| * log2(e); the sign goes into Q
+    int negq;
+    int nrt;          // 32-row tiles per (batch, kv-head) unit
+    int chunk_tiles;  // 32-key tiles per wave
+    int npart;        // partials per row = 4 * gridDim.x
+    int rows_total;   // B * Hkv * nrt * 32
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t skv_srd(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+template <class T, int D>
+__global__ void __launch_bounds__(256) fa_fwd_splitkv_kernel(const SplitParams p) {
+    using v8 = typename T::v8;
+    constexpr int RB = D * 2, KS = D / 16, DB = D / 32, CPR = RB / 16;
+    constexpr int VT = 32 * RB;           // one wave's V tile
+    constexpr int NV = (32 * CPR) / 64;   // 16-byte chunks per lane and tile
+    __shared__ __attribute__((aligned(16))) char smem[4 * VT];
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* const Vw = smem + wave * VT;
+
+    const int g = p.Hq / p.Hkv;
+    const int unit = blockIdx.y / p.nrt, rt = blockIdx.y % p.nrt;
+    const int b = unit / p.Hkv, hk = unit % p.Hkv;
+    const int Sq = p.Sq, Sk = p.Sk;
+    const int row = rt * 32 + l31;                 // packed row of this lane inside the unit
+    const bool valid = row < g * Sq;
+    const int head = hk * g + (valid ? row / Sq : 0), qi = valid ? row % Sq : 0;
+
+    const size_t kvoff = (size_t)(b * p.Hkv + hk) * Sk * RB;
+    const __amdgpu_buffer_rsrc_t krs = skv_srd(reinterpret_cast<const char*>(p.k) + kvoff, (unsigned)Sk * RB);
+    const __amdgpu_buffer_rsrc_t vrs = skv_srd(reinterpret_cast<const char*>(p.v) + kvoff, (unsigned)Sk * RB);
+
+    // Q fragments (B operand of S^T = K.Q^T): lane (row, hi) holds d = 16ks + 8hi .. +7; rows beyond the unit are 0
+    v8 qf[KS];
+    {
+        const char* qrow = reinterpret_cast<const char*>(p.q) + ((size_t)(b * p.Hq + head) * Sq + qi) * RB;
+        const unsigned flip = p.negq ? 0x80008000u : 0u;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4_t x = {0u, 0u, 0u, 0u};
+            if (valid) x = *reinterpret_cast<const u32x4_t*>(qrow + (2 * ks + hi) * 16);
+            x[0] ^= flip; x[1] ^= flip; x[2] ^= flip; x[3] ^= flip;
+            qf[ks] = as_v8<T>(x);
+        }
+    }
+
+    // V staging map (sub-tiled image filled linearly by lane id) and transpose-read offset: fa_fwd_pp_gfx950.hip
+    int v_g[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int bidx = (lane >> 3) + 8 * i;  // sub-tile index = kv4 * (D/16) + d16
+        v_g[i] = ((bidx / (D / 16)) * 4 + ((lane >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (lane & 1)) * 16;
+    }
+    const int tr_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
+
+    f32x16_t o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const float c = p.c;
+
+    const int ntiles = (Sk + 31) / 32;
+    const int t0 = (blockIdx.x * 4 + wave) * p.chunk_tiles;
+    const int t1 = min(t0 + p.chunk_tiles, ntiles);
+    f32x16_t z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+
+    for (int t = t0; t < t1; ++t) {
+        const int kv0 = t * 32;
+        u32x4_t ka[KS], vx[NV];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            ka[ks] = __builtin_amdgcn_raw_buffer_load_b128(krs, (kv0 + l31) * RB + (2 * ks + hi) * 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) vx[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], kv0 * RB, 0);
+        f32x16_t s;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s = T::mfma(as_v8<T>(ka[ks]), qf[ks], ks == 0 ? z : s);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<u32x4_t*>(Vw + lane * 16 + i * 1024) = vx[i];
+
+        // online softmax over this tile's 32 keys (16 per lane half), exp2 domain
+        const bool ragged = kv0 + 32 > Sk;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float x = s[r] * c;
+            if (ragged && kv0 + crow(r, hi) >= Sk) x = -INFINITY;
+            s[r] = x;
+            mx = fmaxf(mx, x);
+        }
+        mx = fmaxf(mx, xhalf(mx));
+        const float m_new = fmaxf(m, mx);   // finite: every tile has at least one key < Sk
+        const float alpha = fast_exp2(m - m_new);
+        m = m_new;
+        float ls = 0.f;
+        u32x4_t pu[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float p0 = fast_exp2(s[2 * i] - m_new), p1 = fast_exp2(s[2 * i + 1] - m_new);
+            ls += p0 + p1;
+            pu[i >> 2][i & 3] = T::pack2(p0, p1);
+        }
+        l = l * alpha + ls;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        // O^T += V^T . P^T  (A by transpose read from the wave's LDS tile; k-slot order = S accumulator order)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const int off = ((4 * kk) * (D / 16) + 2 * d) * 128;
+                const s16x4_t a0 = lds_tr16(Vw + tr_off + off);
+                const s16x4_t a1 = lds_tr16(Vw + tr_off + off + 2 * (D / 16) * 128);
+                o[d] = T::mfma(as_v8<T>(a0, a1), as_v8<T>(pu[kk]), o[d]);
+            }
+    }
+
+    // partial of this wave: O (un-normalised), m, l of the lane's row (both lane halves hold the same row)
+    const float lt = l + xhalf(l);
+    const int pi = blockIdx.x * 4 + wave;
+    const size_t prow = (size_t)pi * p.rows_total + (size_t)blockIdx.y * 32 + l31;
+    float* dst = p.part + prow * (D + 2);
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4_t x = {o[d][4 * g4], o[d][4 * g4 + 1], o[d][4 * g4 + 2], o[d][4 * g4 + 3]};
+            *reinterpret_cast<f32x4_t*>(dst + 32 * d + 8 * g4 + 4 * hi) = x;
+        }
+    if (hi == 0) {
+        dst[D] = m;
+        dst[D + 1] = lt;
+    }
+}
+
+// One workgroup per packed row: log-sum-exp merge of the row's partials (there can be hundreds -- a serial loop per
+// thread made this kernel, not the split kernel, the bottleneck: 230 us for C5b), cast, LSE.  Threads are arranged as
+// G groups x D/4 column chunks; group j merges partials j, j+G, ...; the groups are then summed through LDS.
+template <class T, int D>
+__global__ void __launch_bounds__(256) fa_fwd_splitkv_combine(const SplitParams p) {
+    constexpr int C4 = D / 4, G = 256 / C4;
+    __shared__ float red[256];
+    __shared__ __attribute__((aligned(16))) float accs[G][D];
+    __shared__ float lsum[G];
+    const int prow = blockIdx.x, tid = threadIdx.x;
+    const int g = p.Hq / p.Hkv;
+    const int unit = prow / (p.nrt * 32), row = prow % (p.nrt * 32);
+    if (row >= g * p.Sq) return;
+    const int b = unit / p.Hkv, hk = unit % p.Hkv, head = hk * g + row / p.Sq, qi = row % p.Sq;
+    const float* base = p.part + (size_t)prow * (D + 2);
+    const size_t pstride = (size_t)p.rows_total * (D + 2);
+    // M = max over the partials' maxima
+    float mx = -INFINITY;
+    for (int i = tid; i < p.npart; i += 256) mx = fmaxf(mx, base[i * pstride + D]);
+    red[tid] = mx;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) red[tid] = fmaxf(red[tid], red[tid + st]);
+        __syncthreads();
+    }
+    const float M = red[0];
+    const int grp = tid / C4, c4 = tid % C4;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    float L = 0.f;
+#pragma unroll 4
+    for (int i = grp; i < p.npart; i += G) {
+        const float* src = base + i * pstride;
+        const float w = fast_exp2(src[D] - M);   // empty partial: m = -inf -> 0
+        const f32x4_t x = *reinterpret_cast<const f32x4_t*>(src + 4 * c4);
+        acc += x * w;
+        if (c4 == 0) L += w * src[D + 1];
+    }
+    *reinterpret_cast<f32x4_t*>(&accs[grp][4 * c4]) = acc;
+    if (c4 == 0) lsum[grp] = L;
+    __syncthreads();
+    if (tid < C4) {
+        f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+        float Lt = 0.f;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            t += *reinterpret_cast<const f32x4_t*>(&accs[j][4 * tid]);
+            Lt += lsum[j];
+        }
+        const float inv = 1.0f / Lt;
+        const size_t orow = ((size_t)(b * p.Hq + head) * p.Sq + qi);
+        u32x2_t u;
+        u[0] = T::pack2(t[0] * inv, t[1] * inv);
+        u[1] = T::pack2(t[2] * inv, t[3] * inv);
+        *reinterpret_cast<u32x2_t*>(reinterpret_cast<char*>(p.o) + orow * (D * 2) + tid * 8) = u;
+        if (tid == 0 && p.lse != nullptr) p.lse[orow] = (M + fast_log2(Lt)) * kLn2;
+    }
+}
+
+template <class T, int D>
+int launch_split(const FwdArgs& a, hipStream_t stream) {
+    SplitParams p;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o; p.lse = a.lse;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
+    float c = a.scale * kLog2e;
+    p.negq = c < 0.f;
+    p.c = c < 0.f ? -c : c;
+    if (p.c == 0.f) p.c = 1e-30f;
+    const int g = a.Hq / a.Hkv;
+    p.nrt = (g * a.Sq + 31) / 32;
+    const int units = a.B * a.Hkv * p.nrt;
+    const int ntiles = (a.Sk + 31) / 32;
+    const int want_waves = (2048 + units - 1) / units;            // ~8 waves per CU over the whole launch
+    p.chunk_tiles = (ntiles + want_waves - 1) / want_waves;
+    if (p.chunk_tiles < 1) p.chunk_tiles = 1;
+    const int nwaves = (ntiles + p.chunk_tiles - 1) / p.chunk_tiles;
+    const int nsplit = (nwaves + 3) / 4;
+    p.npart = nsplit * 4;
+    p.rows_total = units * 32;
+    const size_t bytes = (size_t)p.npart * p.rows_total * (D + 2) * sizeof(float);
+    void* ws = nullptr;
+    hipError_t e = hipMallocAsync(&ws, bytes, stream);   // stream-ordered: safe with concurrent caller streams
+    if (e != hipSuccess) return (int)e;
+    p.part = static_cast<float*>(ws);
+    hipLaunchKernelGGL((fa_fwd_splitkv_kernel<T, D>), dim3((unsigned)nsplit, (unsigned)units), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((fa_fwd_splitkv_combine<T, D>), dim3((unsigned)p.rows_total), dim3(256), 0, stream, p);
+    const int rc = (int)hipGetLastError();
+    (void)hipFreeAsync(ws, stream);
+    return rc;
+}
+
+}  // namespace
+
+// Shapes the split-KV path takes over from the tiled kernels: 16-bit, non-causal, no window, short queries against
+// long K/V -- few enough Q blocks that the tiled kernels would leave most CUs idle.
+bool splitkv_applicable(const FwdArgs& a) {
+    if (a.dtype != kBF16 && a.dtype != kF16) return false;
+    if (a.causal || a.window > 0) return false;
+    if (a.D != 32 && a.D != 64 && a.D != 128) return false;
+    if (a.Sq > 64 || a.Sk < 1024) return false;
+    const long long tiled_wgs = (long long)a.B * a.Hq * ((a.Sq + 255) / 256);
+    return tiled_wgs < 512;   // less than two workgroups per CU
+}
+
+int launch_fwd_splitkv(const FwdArgs& a, hipStream_t stream) {
+    if (a.dtype == kBF16) {
+        if (a.D == 128) return launch_split<Bf16Traits, 128>(a, stream);
+        if (a.D == 64) return launch_split<Bf16Traits, 64>(a, stream);
+        if (a.D == 32) return launch_split<Bf16Traits, 32>(a, stream);
+    } else if (a.dtype == kF16) {
+        if (a.D == 128) return launch_split<F16Traits, 128>(a, stream);
+        if (a.D == 64) return launch_split<F16Traits, 64>(a, stream);
+        if (a.D == 32) return launch_split<F16Traits, 32>(a, stream);
+    }
+    return -1;
+}
+
+}  // namespace aule_hip

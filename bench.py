@@ -34,7 +34,12 @@ CONFIGS = {
     "c3": (4, 32, 8, 2048, 2048, 128, "bf16", True, "fwdbwd"),    # configs[2] (B=4 assumed)
     "c4": (8, 32, 32, 8192, 8192, 128, "bf16", True, "fwd"),      # configs[3]: B=64 over 8 GPUs
     "c5": (1, 32, 1, 16384, 16384, 64, "fp16", False, "fwd"),     # configs[4]
+    # SURVEY 8d note: the genuinely HBM-bound cross-attention points that bracket the regime configs[4] is labelled with
+    "c5b": (1, 32, 1, 1, 16384, 64, "fp16", False, "fwd"),        # decode-like: AI = 32 FLOP/B
+    "c5c": (1, 32, 1, 64, 16384, 64, "fp16", False, "fwd"),       # AI ~ 1800 FLOP/B
 }
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+RIDGE = 315.0           # FLOP/B where the bf16/fp16 MFMA roof meets the HBM roof
 
 
 def causal_pairs(Sq, Sk):
@@ -182,6 +187,9 @@ def main():
     value = f_step * n_gpus * args.steps / wall / 1e12
     kern_ms = dev_ms / args.steps          # HIP events on the launch stream, per step
     achieved = f_step / (kern_ms * 1e-3) / 1e12
+    elt = 2 if dtype != "fp32" else 4
+    alg_bytes = elt * (2 * B * Hq * Sq * D + 2 * B * Hkv * Sk * D) + 4 * B * Hq * Sq
+    hbm_bound = mode == "fwd" and f_step / alg_bytes < RIDGE
 
     result = {
         "metric": "attention TFLOPS/GPU (fwd, fwd+bwd) + % MFMA roofline at S=4096,D=128",
@@ -201,14 +209,18 @@ def main():
             "global_batch": B * n_gpus, "parallelism": "batch-sharded dp%d, no data-path collective" % n_gpus,
             "flop_convention": "4*B*Hq*D*sum_i min(i+1,Sk) (causal), bwd=2.5x fwd"},
         "per_gpu_tflops": value / n_gpus,
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_TFLOPS[dtype], "traffic": hbm_traffic(args.config, mode),
-                     "kernel_ms": kern_ms,
-                     "note": "achieved = algorithmic FLOPs per step / HIP-event time per step on the launch "
-                             "stream; traffic = HBM bytes per launch from the rocprofv3 PMC passes in "
-                             "profiles/ (FETCH_SIZE x2 + WRITE_SIZE), algorithmic bytes %d" % int(
-                                 (2 if dtype != "fp32" else 4) * (2 * B * Hq * Sq * D + 2 * B * Hkv * Sk * D)
-                                 + 4 * B * Hq * Sq)},
+        "roofline": ({"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": hbm_traffic(args.config, mode),
+                      "kernel_ms": kern_ms,
+                      "note": "arithmetic intensity %.0f FLOP/B < ridge %.0f: achieved = algorithmic bytes (%d) / HIP-event "
+                              "time per step" % (f_step / alg_bytes, RIDGE, int(alg_bytes))}
+                     if hbm_bound else
+                     {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                      "frac": achieved / PEAK_TFLOPS[dtype], "traffic": hbm_traffic(args.config, mode),
+                      "kernel_ms": kern_ms,
+                      "note": "achieved = algorithmic FLOPs per step / HIP-event time per step on the launch "
+                              "stream; traffic = HBM bytes per launch from the rocprofv3 PMC passes in "
+                              "profiles/ (FETCH_SIZE x2 + WRITE_SIZE), algorithmic bytes %d" % int(alg_bytes)}),
     }
 
     if dist is not None and (n_gpus > 1 or os.environ.get("AULE_BENCH_FORCE_GATHER")):

@@ -1,0 +1,54 @@
+"""Short-query / long-KV forward (split-KV kernel, csrc/fa_fwd_splitkv_gfx950.hip; SURVEY.md 8d points C5b, C5c):
+non-causal 16-bit problems with Sq <= 64 and Sk >= 1024 that would leave the tiled kernels most of the chip idle.
+Parity vs the fp64 oracle on shapes covering MQA/GQA/MHA packing, partial row tiles, ragged Sk, every head_dim,
+negative scale, and the autograd round trip (the backward consumes the LSE the split-KV path wrote)."""
+import math
+
+import numpy as np
+import pytest
+
+from util import BWD_TOL, LSE_TOL, assert_close, fwd_tol, quantize, torch_dtype
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, scale
+    ("fp16", 1, 32, 1, 1, 16384, 64, None),      # C5b
+    ("fp16", 1, 32, 1, 64, 16384, 64, None),     # C5c
+    ("bf16", 2, 8, 2, 1, 4096, 128, None),
+    ("bf16", 1, 4, 4, 3, 1500, 128, None),       # MHA: 3 rows per unit, ragged Sk
+    ("fp16", 2, 6, 3, 17, 2049, 32, 0.3),
+    ("bf16", 1, 16, 2, 9, 1024, 64, -0.2),       # 72 packed rows = 3 row tiles (last partial), negative scale
+    ("bf16", 3, 2, 2, 64, 5000, 128, None),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(x) for x in c))
+def test_splitkv_forward_vs_oracle(case, oracle_mod):
+    import torch
+    from aule import _torch as at
+    dtype, B, Hq, Hkv, Sq, Sk, D, scale = case
+    rng = np.random.RandomState(21)
+    q, k, v = (quantize(rng.randn(*s).astype(np.float32), dtype) for s in ((B, Hq, Sq, D), (B, Hkv, Sk, D), (B, Hkv, Sk, D)))
+    sc = (1 / math.sqrt(D)) if scale is None else scale
+    dev = lambda a: torch.from_numpy(a).to("cuda", torch_dtype(dtype))
+    out, lse = at.fwd_raw(dev(q), dev(k), dev(v), False, sc)
+    ref, ref_lse = oracle_mod.fwd_f64(q, k, v, False, scale)
+    atol, rtol = fwd_tol(dtype, np.abs(v).max())
+    assert_close(out.float().cpu().numpy(), ref, atol, rtol, "out")
+    assert_close(lse.cpu().numpy(), ref_lse, LSE_TOL[dtype], 1e-5, "lse")
+
+
+def test_splitkv_feeds_the_backward(oracle_mod):
+    import torch
+    import aule
+    rng = np.random.RandomState(22)
+    B, Hq, Hkv, Sq, Sk, D = 1, 8, 2, 5, 1536, 64
+    q, k, v, do = (quantize(rng.randn(*s).astype(np.float32), "bf16")
+                   for s in ((B, Hq, Sq, D), (B, Hkv, Sk, D), (B, Hkv, Sk, D), (B, Hq, Sq, D)))
+    tq, tk, tv = (torch.from_numpy(x).to("cuda", torch.bfloat16).requires_grad_(True) for x in (q, k, v))
+    out = aule.flash_attention(tq, tk, tv, causal=False)
+    out.backward(torch.from_numpy(do).to("cuda", torch.bfloat16))
+    rq, rk, rv = oracle_mod.bwd_f64(q, k, v, do, False)
+    a, r = BWD_TOL["bf16"]
+    for name, got, want in (("dq", tq.grad, rq), ("dk", tk.grad, rk), ("dv", tv.grad, rv)):
+        assert_close(got.float().cpu().numpy(), want, a * max(1.0, float(np.abs(want).max())), r, name)
