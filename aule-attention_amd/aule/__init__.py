@@ -122,6 +122,27 @@ def flash_attention(query, key, value, rot_cos=None, rot_sin=None, causal=True, 
 attention = flash_attention
 
 
+def flash_attention_paged_amd(q, k_cache, v_cache, block_tables, context_lens, scale=None, window_size=-1):
+    """PagedAttention for the decode phase (one query token per sequence, vLLM-style block tables); same name,
+    arguments and result as the reference's export (python/aule/triton_flash_amd.py:656-737, __init__.py:59):
+
+        q [batch, heads_q, head_dim]; k_cache, v_cache [num_blocks, block_size, heads_kv, head_dim];
+        block_tables [batch, max_blocks_per_seq]; context_lens [batch]  ->  [batch, heads_q, head_dim]
+
+    window_size > 0 keeps only the last window_size positions of each sequence.  fp16 / bf16 ROCm tensors."""
+    try:
+        import torch  # noqa: F401
+    except ImportError as e:
+        raise AuleError("aule (HIP build) needs PyTorch-ROCm for device memory") from e
+    if not q.is_cuda:
+        raise AuleError("aule (HIP build): paged decode needs ROCm device tensors; there is no CPU fallback")
+    from ._torch import paged_decode
+    return paged_decode(q, k_cache, v_cache, block_tables, context_lens, scale=scale, window_size=window_size)
+
+
+flash_attention_paged = flash_attention_paged_amd
+
+
 # =============================================================================
 # PyTorch SDPA compatibility layer (SURVEY.md 8f row N3; reference __init__.py:288-442)
 # =============================================================================
@@ -226,5 +247,5 @@ def set_verbose(flag=True):
     _verbose = bool(flag)
 
 
-__all__ = ["flash_attention", "attention", "AuleError", "scaled_dot_product_attention", "install", "uninstall",
+__all__ = ["flash_attention", "attention", "flash_attention_paged_amd", "flash_attention_paged", "AuleError", "scaled_dot_product_attention", "install", "uninstall",
            "get_available_backends", "get_backend_errors", "get_backend_info", "set_verbose", "__version__"]

@@ -76,6 +76,30 @@ class AttnBwdDesc(ctypes.Structure):
     ]
 
 
+class PagedDesc(ctypes.Structure):
+    """struct aule_paged_desc (include/aule.h)."""
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("dtype", ctypes.c_int32),
+        ("batch", ctypes.c_uint32),
+        ("heads_q", ctypes.c_uint32),
+        ("heads_kv", ctypes.c_uint32),
+        ("head_dim", ctypes.c_uint32),
+        ("block_size", ctypes.c_uint32),
+        ("max_blocks", ctypes.c_uint32),
+        ("scale", ctypes.c_float),
+        ("window_size", ctypes.c_int32),
+        ("device", ctypes.c_int32),
+        ("stream", ctypes.c_void_p),
+        ("q", ctypes.c_void_p),
+        ("k_cache", ctypes.c_void_p),
+        ("v_cache", ctypes.c_void_p),
+        ("block_tables", ctypes.c_void_p),
+        ("context_lens", ctypes.c_void_p),
+        ("out", ctypes.c_void_p),
+    ]
+
+
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 
 # Every symbol include/aule.h declares: (name, restype, argtypes)
@@ -116,6 +140,7 @@ SIGNATURES = [
     ("aule_attention_forward_ex", _I32, [ctypes.POINTER(AttnDesc)]),
     ("aule_attention_backward_ex", _I32, [ctypes.POINTER(AttnBwdDesc)]),
     ("aule_attention_backward_workspace_size", _U64, [ctypes.POINTER(AttnBwdDesc)]),
+    ("aule_attention_paged_decode_ex", _I32, [ctypes.POINTER(PagedDesc)]),
     ("aule_hip_build_info", ctypes.c_char_p, []),
 ]
 

@@ -117,3 +117,54 @@ def flash_attention_hip(q, k, v, causal=True, scale=None, window=-1):
     if Dp != D:
         out = out[..., :D]
     return out if out.dtype == orig_dtype else out.to(orig_dtype)
+
+
+def paged_decode(q, k_cache, v_cache, block_tables, context_lens, scale=None, window_size=-1):
+    """Paged-KV decode on the HIP backend; counterpart of flash_attention_paged_amd
+    (python/aule/triton_flash_amd.py:656-737), same argument meaning:
+
+        q            [batch, heads_q, head_dim] (or [batch, heads_q, 1, head_dim]) fp16 / bf16
+        k_cache      [num_blocks, block_size, heads_kv, head_dim]     v_cache: same
+        block_tables [batch, max_blocks_per_seq] integer, context_lens [batch] integer
+    Returns [batch, heads_q, head_dim].  No device->host synchronisation (the reference reads
+    context_lens.max() on the host)."""
+    if q.dim() == 4:
+        if q.shape[2] != 1:
+            raise ValueError("PagedAttention only supports single query token")
+        q = q.squeeze(2)
+    if q.dim() != 3 or k_cache.dim() != 4 or v_cache.shape != k_cache.shape:
+        raise ValueError("expected q [B,Hq,D] and k_cache/v_cache [num_blocks, block_size, Hkv, D]")
+    B, Hq, D = q.shape
+    _, block_size, Hkv, Dk = k_cache.shape
+    if Dk != D:
+        raise ValueError(f"head_dim mismatch: query={D}, cache={Dk}")
+    if Hq % Hkv != 0:
+        raise ValueError(f"heads_q ({Hq}) must be divisible by heads_kv ({Hkv})")
+    if q.dtype not in (torch.float16, torch.bfloat16) or k_cache.dtype != q.dtype or v_cache.dtype != q.dtype:
+        raise ValueError("paged decode runs in fp16 or bf16 (query and caches in the same dtype)")
+    if D not in SUPPORTED_HEAD_DIMS:
+        raise ValueError(f"head_dim must be one of {SUPPORTED_HEAD_DIMS} for paged decode, got {D}")
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    lib = _capi.get_lib()
+    q, k_cache, v_cache = q.contiguous(), k_cache.contiguous(), v_cache.contiguous()
+    bt = block_tables.contiguous().to(torch.int32)
+    cl = context_lens.contiguous().to(torch.int32)
+    if bt.dim() != 2 or bt.shape[0] != B or cl.shape != (B,):
+        raise ValueError("block_tables must be [batch, max_blocks] and context_lens [batch]")
+    out = torch.empty_like(q)
+    if B * Hq == 0:
+        return out
+    d = _capi.PagedDesc()
+    d.struct_size = ctypes.sizeof(_capi.PagedDesc)
+    d.dtype = _DTYPES[q.dtype]
+    d.batch, d.heads_q, d.heads_kv, d.head_dim = B, Hq, Hkv, D
+    d.block_size, d.max_blocks = block_size, bt.shape[1]
+    d.scale = float(scale)
+    d.window_size = int(window_size) if window_size is not None and window_size > 0 else -1
+    d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
+    d.stream = _stream_ptr(q.device)
+    d.q, d.k_cache, d.v_cache, d.out = q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr()
+    d.block_tables, d.context_lens = bt.data_ptr(), cl.data_ptr()
+    _capi.check(lib.aule_attention_paged_decode_ex(ctypes.byref(d)), "aule_attention_paged_decode_ex")
+    return out

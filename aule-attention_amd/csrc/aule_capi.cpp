@@ -632,6 +632,56 @@ int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
     return 0;
 }
 
+int32_t aule_attention_paged_decode_ex(const aule_paged_desc* d) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) {
+        set_error("Library not initialized. Call aule_init() first.");
+        return -1;
+    }
+    if (d == nullptr || d->struct_size != sizeof(aule_paged_desc)) {
+        set_error("Paged attention failed: bad descriptor (struct_size mismatch)");
+        return -3;
+    }
+    if (d->dtype != AULE_DTYPE_F16 && d->dtype != AULE_DTYPE_BF16) {
+        set_error("Paged attention failed: dtype must be fp16 or bf16");
+        return -3;
+    }
+    if (d->head_dim != 32 && d->head_dim != 64 && d->head_dim != 128) {
+        set_error("Paged attention failed: head_dim %u unsupported (32, 64 or 128)", d->head_dim);
+        return -3;
+    }
+    if (d->heads_kv == 0 || d->heads_q % d->heads_kv != 0) {
+        set_error("Paged attention failed: heads_q (%u) must be divisible by heads_kv (%u)", d->heads_q, d->heads_kv);
+        return -3;
+    }
+    if (d->block_size == 0 || d->max_blocks == 0 || (uint64_t)d->block_size * d->max_blocks >= (1ull << 30)) {
+        set_error("Paged attention failed: bad block_size / max_blocks");
+        return -3;
+    }
+    if ((uint64_t)d->batch * d->heads_q == 0) return 0;
+    if (!d->q || !d->k_cache || !d->v_cache || !d->block_tables || !d->context_lens || !d->out) {
+        set_error("Paged attention failed: null tensor pointer");
+        return -3;
+    }
+    DeviceGuard g(d->device);
+    int rc = ensure_configured();
+    if (rc) return rc;
+    aule_hip::PagedArgs a;
+    a.q = d->q; a.k_cache = d->k_cache; a.v_cache = d->v_cache; a.out = d->out;
+    a.block_tables = d->block_tables; a.context_lens = d->context_lens;
+    a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv; a.D = (int)d->head_dim;
+    a.block_size = (int)d->block_size; a.max_blocks = (int)d->max_blocks;
+    a.scale = resolve_scale(d->scale, d->head_dim);
+    a.window = d->window_size;
+    a.dtype = d->dtype;
+    rc = aule_hip::launch_paged_decode(a, (hipStream_t)d->stream);
+    if (rc != 0) {
+        set_error("Paged attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");
+        return -4;
+    }
+    return 0;
+}
+
 uint64_t aule_attention_backward_workspace_size(const aule_attn_bwd_desc* d) {
     if (d == nullptr) return 0;
     return aule_hip::bwd_workspace_bytes((int)d->batch, (int)d->heads_q, (int)d->heads_kv, (int)d->seq_q, (int)d->seq_k,

@@ -37,13 +37,18 @@ struct SplitParams {
     int chunk_tiles;  // 32-key tiles per wave
     int npart;        // partials per row = 4 * gridDim.x
     int rows_total;   // B * Hkv * nrt * 32
+    // paged KV cache (decode, Sq = 1; python/aule/triton_flash_amd.py:543-737): K/V = [num_blocks, block_size, Hkv, D]
+    const int* block_tables;   // [B, max_blocks] physical block of each logical block
+    const int* context_lens;   // [B] keys per sequence
+    int block_size, max_blocks;
+    int window;                // > 0: only the last `window` positions (context_len - 1 - pos < window)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t skv_srd(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <class T, int D>
+template <class T, int D, bool PAGED>
 __global__ void __launch_bounds__(256) fa_fwd_splitkv_kernel(const SplitParams p) {
     using v8 = typename T::v8;
     constexpr int RB = D * 2, KS = D / 16, DB = D / 32, CPR = RB / 16;
@@ -58,14 +63,22 @@ __global__ void __launch_bounds__(256) fa_fwd_splitkv_kernel(const SplitParams p
     const int g = p.Hq / p.Hkv;
     const int unit = blockIdx.y / p.nrt, rt = blockIdx.y % p.nrt;
     const int b = unit / p.Hkv, hk = unit % p.Hkv;
-    const int Sq = p.Sq, Sk = p.Sk;
+    const int Sq = p.Sq;
+    const int Sk = PAGED ? p.context_lens[b] : p.Sk;   // paged: keys of this sequence
     const int row = rt * 32 + l31;                 // packed row of this lane inside the unit
     const bool valid = row < g * Sq;
     const int head = hk * g + (valid ? row / Sq : 0), qi = valid ? row % Sq : 0;
 
-    const size_t kvoff = (size_t)(b * p.Hkv + hk) * Sk * RB;
-    const __amdgpu_buffer_rsrc_t krs = skv_srd(reinterpret_cast<const char*>(p.k) + kvoff, (unsigned)Sk * RB);
-    const __amdgpu_buffer_rsrc_t vrs = skv_srd(reinterpret_cast<const char*>(p.v) + kvoff, (unsigned)Sk * RB);
+    const size_t kvoff = PAGED ? 0 : (size_t)(b * p.Hkv + hk) * Sk * RB;
+    const __amdgpu_buffer_rsrc_t krs = skv_srd(reinterpret_cast<const char*>(p.k) + kvoff, PAGED ? 0u : (unsigned)Sk * RB);
+    const __amdgpu_buffer_rsrc_t vrs = skv_srd(reinterpret_cast<const char*>(p.v) + kvoff, PAGED ? 0u : (unsigned)Sk * RB);
+    // paged: byte address of key/value row `kv` of this unit inside the cache (64-bit: caches exceed 4 GiB)
+    const int* const bt = PAGED ? p.block_tables + (size_t)b * p.max_blocks : nullptr;
+    auto paged_row = [&](int kv) -> size_t {
+        const int lb = kv / p.block_size, off = kv - lb * p.block_size;
+        const size_t phys = (size_t)bt[lb];
+        return ((phys * p.block_size + off) * p.Hkv + hk) * (size_t)RB;
+    };
 
     // Q fragments (B operand of S^T = K.Q^T): lane (row, hi) holds d = 16ks + 8hi .. +7; rows beyond the unit are 0
     v8 qf[KS];
@@ -82,11 +95,13 @@ __global__ void __launch_bounds__(256) fa_fwd_splitkv_kernel(const SplitParams p
     }
 
     // V staging map (sub-tiled image filled linearly by lane id) and transpose-read offset: fa_fwd_pp_gfx950.hip
-    int v_g[NV];
+    int v_g[NV], v_row[NV], v_col[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int bidx = (lane >> 3) + 8 * i;  // sub-tile index = kv4 * (D/16) + d16
-        v_g[i] = ((bidx / (D / 16)) * 4 + ((lane >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (lane & 1)) * 16;
+        v_row[i] = (bidx / (D / 16)) * 4 + ((lane >> 1) & 3);
+        v_col[i] = ((bidx % (D / 16)) * 2 + (lane & 1)) * 16;
+        v_g[i] = v_row[i] * RB + v_col[i];
     }
     const int tr_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
 
@@ -99,8 +114,11 @@ __global__ void __launch_bounds__(256) fa_fwd_splitkv_kernel(const SplitParams p
     const float c = p.c;
 
     const int ntiles = (Sk + 31) / 32;
-    const int t0 = (blockIdx.x * 4 + wave) * p.chunk_tiles;
+    int t0 = (blockIdx.x * 4 + wave) * p.chunk_tiles;
     const int t1 = min(t0 + p.chunk_tiles, ntiles);
+    if constexpr (PAGED) {
+        if (p.window > 0) t0 = max(t0, max(0, Sk - p.window) / 32);   // tiles entirely before the window
+    }
     f32x16_t z;
 #pragma unroll
     for (int r = 0; r < 16; ++r) z[r] = 0.f;
@@ -108,11 +126,24 @@ __global__ void __launch_bounds__(256) fa_fwd_splitkv_kernel(const SplitParams p
     for (int t = t0; t < t1; ++t) {
         const int kv0 = t * 32;
         u32x4_t ka[KS], vx[NV];
+        if constexpr (PAGED) {
+            const u32x4_t zero = {0u, 0u, 0u, 0u};
+            const bool kin = kv0 + l31 < Sk;
+            const char* krow = reinterpret_cast<const char*>(p.k) + (kin ? paged_row(kv0 + l31) : 0);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            ka[ks] = __builtin_amdgcn_raw_buffer_load_b128(krs, (kv0 + l31) * RB + (2 * ks + hi) * 16, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) ka[ks] = kin ? *reinterpret_cast<const u32x4_t*>(krow + (2 * ks + hi) * 16) : zero;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) vx[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], kv0 * RB, 0);
+            for (int i = 0; i < NV; ++i) {
+                const bool vin = kv0 + v_row[i] < Sk;
+                vx[i] = vin ? *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.v) + paged_row(kv0 + v_row[i]) + v_col[i]) : zero;
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                ka[ks] = __builtin_amdgcn_raw_buffer_load_b128(krs, (kv0 + l31) * RB + (2 * ks + hi) * 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) vx[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], kv0 * RB, 0);
+        }
         f32x16_t s;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) s = T::mfma(as_v8<T>(ka[ks]), qf[ks], ks == 0 ? z : s);
@@ -120,12 +151,15 @@ __global__ void __launch_bounds__(256) fa_fwd_splitkv_kernel(const SplitParams p
         for (int i = 0; i < NV; ++i) *reinterpret_cast<u32x4_t*>(Vw + lane * 16 + i * 1024) = vx[i];
 
         // online softmax over this tile's 32 keys (16 per lane half), exp2 domain
-        const bool ragged = kv0 + 32 > Sk;
+        const bool ragged = kv0 + 32 > Sk || (PAGED && p.window > 0 && Sk - 1 - kv0 >= p.window);
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float x = s[r] * c;
-            if (ragged && kv0 + crow(r, hi) >= Sk) x = -INFINITY;
+            if (ragged) {
+                const int kv = kv0 + crow(r, hi);
+                if (kv >= Sk || (PAGED && p.window > 0 && Sk - 1 - kv >= p.window)) x = -INFINITY;
+            }
             s[r] = x;
             mx = fmaxf(mx, x);
         }
@@ -208,7 +242,7 @@ __global__ void __launch_bounds__(256) fa_fwd_splitkv_combine(const SplitParams 
 #pragma unroll 4
     for (int i = grp; i < p.npart; i += G) {
         const float* src = base + i * pstride;
-        const float w = fast_exp2(src[D] - M);   // empty partial: m = -inf -> 0
+        const float w = (M == -INFINITY) ? 0.f : fast_exp2(src[D] - M);   // empty partial: m = -inf -> 0
         const f32x4_t x = *reinterpret_cast<const f32x4_t*>(src + 4 * c4);
         acc += x * w;
         if (c4 == 0) L += w * src[D + 1];
@@ -224,7 +258,7 @@ __global__ void __launch_bounds__(256) fa_fwd_splitkv_combine(const SplitParams 
             t += *reinterpret_cast<const f32x4_t*>(&accs[j][4 * tid]);
             Lt += lsum[j];
         }
-        const float inv = 1.0f / Lt;
+        const float inv = Lt > 0.f ? 1.0f / Lt : 0.f;   // paged: a sequence with context_len 0 has no key -> O = 0
         const size_t orow = ((size_t)(b * p.Hq + head) * p.Sq + qi);
         u32x2_t u;
         u[0] = T::pack2(t[0] * inv, t[1] * inv);
@@ -254,12 +288,50 @@ int launch_split(const FwdArgs& a, hipStream_t stream) {
     const int nsplit = (nwaves + 3) / 4;
     p.npart = nsplit * 4;
     p.rows_total = units * 32;
+    p.block_tables = nullptr; p.context_lens = nullptr; p.block_size = 0; p.max_blocks = 0; p.window = 0;
     const size_t bytes = (size_t)p.npart * p.rows_total * (D + 2) * sizeof(float);
     void* ws = nullptr;
     hipError_t e = hipMallocAsync(&ws, bytes, stream);   // stream-ordered: safe with concurrent caller streams
     if (e != hipSuccess) return (int)e;
     p.part = static_cast<float*>(ws);
-    hipLaunchKernelGGL((fa_fwd_splitkv_kernel<T, D>), dim3((unsigned)nsplit, (unsigned)units), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((fa_fwd_splitkv_kernel<T, D, false>), dim3((unsigned)nsplit, (unsigned)units), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((fa_fwd_splitkv_combine<T, D>), dim3((unsigned)p.rows_total), dim3(256), 0, stream, p);
+    const int rc = (int)hipGetLastError();
+    (void)hipFreeAsync(ws, stream);
+    return rc;
+}
+
+// Paged decode: one query token per sequence, K/V gathered through the block table; the key range is bounded by
+// max_blocks * block_size on the host (no device->host sync for max(context_lens)); waves past a sequence's
+// context_len leave an empty partial.
+template <class T, int D>
+int launch_paged(const PagedArgs& a, hipStream_t stream) {
+    SplitParams p;
+    p.q = a.q; p.k = a.k_cache; p.v = a.v_cache; p.o = a.out; p.lse = nullptr;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = 1; p.Sk = a.max_blocks * a.block_size;
+    float c = a.scale * kLog2e;
+    p.negq = c < 0.f;
+    p.c = c < 0.f ? -c : c;
+    if (p.c == 0.f) p.c = 1e-30f;
+    const int g = a.Hq / a.Hkv;
+    p.nrt = (g + 31) / 32;
+    const int units = a.B * a.Hkv * p.nrt;
+    const int ntiles = (p.Sk + 31) / 32;
+    const int want_waves = (2048 + units - 1) / units;
+    p.chunk_tiles = (ntiles + want_waves - 1) / want_waves;
+    if (p.chunk_tiles < 1) p.chunk_tiles = 1;
+    const int nwaves = (ntiles + p.chunk_tiles - 1) / p.chunk_tiles;
+    const int nsplit = (nwaves + 3) / 4;
+    p.npart = nsplit * 4;
+    p.rows_total = units * 32;
+    p.block_tables = a.block_tables; p.context_lens = a.context_lens;
+    p.block_size = a.block_size; p.max_blocks = a.max_blocks; p.window = a.window > 0 ? a.window : 0;
+    const size_t bytes = (size_t)p.npart * p.rows_total * (D + 2) * sizeof(float);
+    void* ws = nullptr;
+    hipError_t e = hipMallocAsync(&ws, bytes, stream);
+    if (e != hipSuccess) return (int)e;
+    p.part = static_cast<float*>(ws);
+    hipLaunchKernelGGL((fa_fwd_splitkv_kernel<T, D, true>), dim3((unsigned)nsplit, (unsigned)units), dim3(256), 0, stream, p);
     hipLaunchKernelGGL((fa_fwd_splitkv_combine<T, D>), dim3((unsigned)p.rows_total), dim3(256), 0, stream, p);
     const int rc = (int)hipGetLastError();
     (void)hipFreeAsync(ws, stream);
@@ -267,6 +339,19 @@ int launch_split(const FwdArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+int launch_paged_decode(const PagedArgs& a, hipStream_t stream) {
+    if (a.dtype == kBF16) {
+        if (a.D == 128) return launch_paged<Bf16Traits, 128>(a, stream);
+        if (a.D == 64) return launch_paged<Bf16Traits, 64>(a, stream);
+        if (a.D == 32) return launch_paged<Bf16Traits, 32>(a, stream);
+    } else if (a.dtype == kF16) {
+        if (a.D == 128) return launch_paged<F16Traits, 128>(a, stream);
+        if (a.D == 64) return launch_paged<F16Traits, 64>(a, stream);
+        if (a.D == 32) return launch_paged<F16Traits, 32>(a, stream);
+    }
+    return -1;
+}
 
 // Shapes the split-KV path takes over from the tiled kernels: 16-bit, non-causal, no window, short queries against
 // long K/V -- few enough Q blocks that the tiled kernels would leave most CUs idle.

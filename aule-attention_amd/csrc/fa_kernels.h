@@ -47,8 +47,26 @@ struct BwdArgs {
     int window = -1;  // as FwdArgs::window (the reference's backward ignores it; this one honours it)
 };
 
+// Paged-KV decode (python/aule/triton_flash_amd.py:543-737): one query token per sequence.
+//   q, out : [B, Hq, D]      k_cache, v_cache : [num_blocks, block_size, Hkv, D]   (16-bit dtypes)
+//   block_tables : [B, max_blocks] int32 (physical block of each logical block), context_lens : [B] int32
+struct PagedArgs {
+    const void* q;
+    const void* k_cache;
+    const void* v_cache;
+    void* out;
+    const int* block_tables;
+    const int* context_lens;
+    int B, Hq, Hkv, D;
+    int block_size, max_blocks;
+    float scale;
+    int window;   // > 0: attend only to the last `window` positions (context_len - 1 - pos < window)
+    int dtype;
+};
+
 // Returns 0 on success, a hipError_t value on launch failure, -1 for an
 // unsupported (dtype, D) combination.
+int launch_paged_decode(const PagedArgs& a, hipStream_t stream);
 int launch_fwd(const FwdArgs& a, hipStream_t stream);
 int launch_bwd(const BwdArgs& a, hipStream_t stream);
 

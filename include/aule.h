@@ -160,6 +160,29 @@ typedef struct aule_attn_bwd_desc {
 /* 0 ok; -1 uninitialised; -3 invalid/unsupported arguments; -4 launch failure. Asynchronous. */
 int32_t aule_attention_forward_ex(const aule_attn_desc* desc);
 int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* desc);
+/* Paged-KV decode (additive).  Replaces python/aule/triton_flash_amd.py:543-737            */
+/* (_paged_attention_fwd_amd / flash_attention_paged_amd): one query token per sequence, vLLM-style block tables.  */
+/* Asynchronous on `stream`; device pointers.                                                                     */
+typedef struct aule_paged_desc {
+    uint32_t struct_size;      /* = sizeof(aule_paged_desc) */
+    int32_t dtype;             /* AULE_DTYPE_F16 or AULE_DTYPE_BF16 */
+    uint32_t batch, heads_q, heads_kv, head_dim;   /* head_dim 32, 64 or 128 */
+    uint32_t block_size;       /* tokens per cache block */
+    uint32_t max_blocks;       /* columns of block_tables */
+    float scale;               /* 0 -> 1/sqrt(head_dim) */
+    int32_t window_size;       /* > 0: only the last window_size positions (context_len - 1 - pos < window_size) */
+    int32_t device;            /* HIP device ordinal, -1 = current */
+    void* stream;              /* hipStream_t */
+    const void* q;             /* [batch, heads_q, head_dim] */
+    const void* k_cache;       /* [num_blocks, block_size, heads_kv, head_dim] */
+    const void* v_cache;       /* same layout */
+    const int32_t* block_tables;   /* [batch, max_blocks]: physical block of each logical block */
+    const int32_t* context_lens;   /* [batch]: keys per sequence (0 -> output row of zeros) */
+    void* out;                 /* [batch, heads_q, head_dim] */
+} aule_paged_desc;
+/* 0 ok; -1 uninitialised; -3 invalid/unsupported arguments; -4 launch failure. */
+int32_t aule_attention_paged_decode_ex(const aule_paged_desc* desc);
+
 uint64_t aule_attention_backward_workspace_size(const aule_attn_bwd_desc* desc);
 
 /* Build/ABI identification: "aule-hip gfx950 <abi>" */

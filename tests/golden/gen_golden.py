@@ -207,8 +207,42 @@ def triton_amd_window_cases():
         print("triton-amd window", name, tuple(out.shape))
 
 
+def paged_cases():
+    """Paged-KV decode: flash_attention_paged_amd (triton_flash_amd.py:656-737), interpreted."""
+    cases = [  # name, seed, B, Hq, Hkv, D, block_size, num_blocks, context_lens, window, dtype
+        ("gqa_b3h8kv2d64_bs16", 80, 3, 8, 2, 64, 16, 24, [37, 100, 1], -1, "fp16"),
+        ("mqa_b2h4kv1d128_bs32_w20", 81, 2, 4, 1, 128, 32, 12, [150, 64], 20, "fp16"),
+        ("mha_b2h2kv2d32_bs8", 82, 2, 2, 2, 32, 8, 40, [129, 17], -1, "fp16"),
+    ]
+    for name, seed, B, Hq, Hkv, D, bs, nb, lens, window, dt in cases:
+        rng = np.random.RandomState(seed)
+        tdt = TORCH_DT[dt]
+        q = torch.from_numpy(rng.randn(B, Hq, D).astype(np.float32)).to(tdt)
+        kc = torch.from_numpy(rng.randn(nb, bs, Hkv, D).astype(np.float32)).to(tdt)
+        vc = torch.from_numpy(rng.randn(nb, bs, Hkv, D).astype(np.float32)).to(tdt)
+        max_blocks = (max(lens) + bs - 1) // bs
+        bt = np.zeros((B, max_blocks), dtype=np.int32)
+        perm = rng.permutation(nb)
+        used = 0
+        for b in range(B):
+            n = (lens[b] + bs - 1) // bs
+            bt[b, :n] = perm[used:used + n]
+            used += n
+        assert used <= nb
+        out = ref_amd.flash_attention_paged_amd(q, kc, vc, torch.from_numpy(bt), torch.tensor(lens, dtype=torch.int32),
+                                                scale=None, window_size=window)
+        rec = dict(kind="triton_amd_paged", seed=seed, dtype=dt, window=window, block_size=bs,
+                   q=q.float().numpy(), k_cache=kc.float().numpy(), v_cache=vc.float().numpy(),
+                   block_tables=bt, context_lens=np.array(lens, dtype=np.int32), out=out.float().numpy())
+        np.savez_compressed(os.path.join(OUT, f"paged_{name}.npz"), **rec)
+        print("paged", name, tuple(out.shape))
+
+
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "paged":
+        paged_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "window":   # add the window fixtures without touching the others
         triton_amd_window_cases()
         sys.exit(0)
@@ -216,3 +250,4 @@ if __name__ == "__main__":
     triton_cases()
     triton_amd_cases()
     triton_amd_window_cases()
+    paged_cases()

@@ -1,0 +1,83 @@
+"""Paged-KV decode on the GPU (csrc/fa_fwd_splitkv_gfx950.hip PAGED variant behind
+aule.flash_attention_paged_amd / aule_attention_paged_decode_ex): golden vectors recorded from the reference's
+flash_attention_paged_amd, the fp64 judge on larger seeded problems (GQA, MQA, ragged context lengths including 0
+and 1, shuffled block tables, block sizes 8..128, window), and agreement with the contiguous kernel."""
+import numpy as np
+import pytest
+
+from conftest import golden_files
+from util import assert_close, fwd_tol, quantize, torch_dtype
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(torch, q, kc, vc, bt, cl, dtype, scale=None, window=-1):
+    import aule
+    dt = torch_dtype(dtype)
+    out = aule.flash_attention_paged_amd(torch.from_numpy(q).to("cuda", dt), torch.from_numpy(kc).to("cuda", dt),
+                                         torch.from_numpy(vc).to("cuda", dt), torch.from_numpy(bt).cuda(),
+                                         torch.from_numpy(cl).cuda(), scale=scale, window_size=window)
+    return out.float().cpu().numpy()
+
+
+@pytest.mark.parametrize("path", golden_files("paged_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_paged_goldens(path):
+    import torch
+    z = np.load(path)
+    out = _run(torch, z["q"], z["k_cache"], z["v_cache"], z["block_tables"], z["context_lens"], str(z["dtype"]),
+               None, int(z["window"]))
+    atol, rtol = fwd_tol(str(z["dtype"]), np.abs(z["v_cache"]).max(), sides=2)
+    assert_close(out, z["out"], atol, rtol, "paged golden")
+
+
+CASES = [  # dtype, B, Hq, Hkv, D, block_size, context lens, window
+    ("bf16", 4, 32, 8, 128, 16, [1000, 37, 4096, 1], -1),
+    ("fp16", 2, 32, 1, 64, 128, [5000, 129], -1),
+    ("bf16", 3, 8, 8, 128, 8, [0, 77, 300], -1),          # a sequence with no key: zeros
+    ("fp16", 2, 16, 4, 32, 32, [2048, 2047], 256),        # sliding window over the last 256 positions
+    ("bf16", 1, 64, 8, 128, 64, [20000], -1),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-B{c[1]}-H{c[2]}kv{c[3]}-D{c[4]}-bs{c[5]}-w{c[7]}")
+def test_paged_vs_oracle(case, oracle_mod):
+    import torch
+    dtype, B, Hq, Hkv, D, bs, lens, window = case
+    rng = np.random.RandomState(31)
+    nblk = [(n + bs - 1) // bs for n in lens]
+    num_blocks = sum(nblk) + 3
+    q = quantize(rng.randn(B, Hq, D).astype(np.float32), dtype)
+    kc = quantize(rng.randn(num_blocks, bs, Hkv, D).astype(np.float32), dtype)
+    vc = quantize(rng.randn(num_blocks, bs, Hkv, D).astype(np.float32), dtype)
+    bt = np.full((B, max(max(nblk), 1) + 2), 0, dtype=np.int32)    # unused columns point at block 0
+    perm = rng.permutation(num_blocks)
+    used = 0
+    for b in range(B):
+        bt[b, :nblk[b]] = perm[used:used + nblk[b]]
+        used += nblk[b]
+    cl = np.array(lens, dtype=np.int32)
+    out = _run(torch, q, kc, vc, bt, cl, dtype, None, window)
+    ref = oracle_mod.paged_decode_f64(q, kc, vc, bt, cl, None, window)
+    atol, rtol = fwd_tol(dtype, np.abs(vc).max())
+    assert_close(out, ref, atol, rtol, "paged")
+
+
+def test_paged_equals_contiguous_decode():
+    """Identity block table + one context length = the non-paged short-query kernel on K/V [B,Hkv,Sk,D]."""
+    import torch
+    import aule
+    torch.manual_seed(5)
+    B, Hq, Hkv, D, bs, n = 2, 16, 4, 128, 32, 2048
+    k = torch.randn(B, Hkv, n, D, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(B, Hkv, n, D, device="cuda", dtype=torch.bfloat16)
+    q = torch.randn(B, Hq, 1, D, device="cuda", dtype=torch.bfloat16)
+    dense = aule.flash_attention(q, k, v, causal=False)                      # [B,Hq,1,D]
+    # cache [num_blocks, bs, Hkv, D] holding sequence b in blocks b*nb .. (b+1)*nb-1
+    nb = n // bs
+    kc = k.permute(0, 2, 1, 3).reshape(B * nb, bs, Hkv, D).contiguous()
+    vc = v.permute(0, 2, 1, 3).reshape(B * nb, bs, Hkv, D).contiguous()
+    bt = torch.arange(B * nb, device="cuda", dtype=torch.int32).view(B, nb)
+    cl = torch.full((B,), n, device="cuda", dtype=torch.int32)
+    paged = aule.flash_attention_paged_amd(q, kc, vc, bt, cl)
+    assert paged.shape == (B, Hq, D)
+    assert torch.equal(paged, dense.squeeze(2))                              # same arithmetic in the same order
