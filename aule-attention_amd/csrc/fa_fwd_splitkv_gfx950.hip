@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) fa_fwd_splitkv_combine(const SplitParams 
     const int grp = tid / C4, c4 = tid % C4;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     float L = 0.f;
-#pragma unroll 4
+#pragma unroll 8
     for (int i = grp; i < p.npart; i += G) {
         const float* src = base + i * pstride;
         const float w = (M == -INFINITY) ? 0.f : fast_exp2(src[D] - M);   // empty partial: m = -inf -> 0
