@@ -36,26 +36,8 @@ struct DeltaParams {
     long long rows;  // B*Hq*Sq
 };
 
+// (16-bit I/O: delta is computed inside the dQ kernel, see fa_bwd_dq_kernel; fp32 I/O keeps a separate kernel)
 // CPR 16-byte chunks per row; one lane per chunk, CPR-lane groups reduce by shuffle.
-template <class T, int D>
-__global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const DeltaParams p) {
-    constexpr int CPR = D * 2 / 16;
-    constexpr int RPB = 256 / CPR;  // rows per block
-    const int tid = threadIdx.x;
-    const int sub = tid % CPR;
-    const long long row = (long long)blockIdx.x * RPB + tid / CPR;
-    float acc = 0.f;
-    if (row < p.rows) {
-        const u32x4_t a = reinterpret_cast<const u32x4_t*>(p.o)[row * CPR + sub];
-        const u32x4_t b = reinterpret_cast<const u32x4_t*>(p.dout)[row * CPR + sub];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc += T::lo(a[j]) * T::lo(b[j]) + T::hi(a[j]) * T::hi(b[j]);
-    }
-#pragma unroll
-    for (int off = CPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (row < p.rows && sub == 0) p.delta[row] = acc;
-}
-
 template <int D>
 __global__ void __launch_bounds__(256) fa_bwd_delta_f32_kernel(const DeltaParams p) {
     constexpr int CPR = D * 4 / 16;  // 8, 16 or 32 lanes per row
@@ -86,7 +68,9 @@ struct BwdParams {
     const void* v;
     const void* dout;
     const float* lse;
-    const float* delta;
+    const float* delta;   // dkdv kernel: read (written by the dQ kernel)
+    const void* o;        // dQ kernel: forward output, for delta = rowsum(O * dO)
+    float* delta_out;     // dQ kernel: where it publishes delta for the dK/dV kernel
     void* dq;
     void* dk;
     void* dv;
@@ -228,7 +212,23 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
             dof[ks] = as_v8<T>(__builtin_amdgcn_raw_buffer_load_b128(grs, qrow * RB + (2 * ks + hi) * 16, 0, 0));
         }
         const float nlse2 = -p.lse[qbase + qr] * kLog2e;
-        const float delta = p.delta[qbase + qr];
+        // delta_i = sum_d O[i,d] dO[i,d] (triton_flash.py:353-379), fused here: the lane already holds its half of
+        // the dO row; the O row is read once, multiplied in fp32, and the two lane halves are added.  Published for
+        // the dK/dV kernel, which runs after this one on the same stream.
+        float delta;
+        {
+            const __amdgpu_buffer_rsrc_t ors = make_srd_b(reinterpret_cast<const char*>(p.o) + qbase * RB, (unsigned)Sq * RB);
+            float part = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4_t ov = __builtin_amdgcn_raw_buffer_load_b128(ors, qrow * RB + (2 * ks + hi) * 16, 0, 0);
+                const u32x4_t gv = __builtin_bit_cast(u32x4_t, dof[ks]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) part += T::lo(ov[i]) * T::lo(gv[i]) + T::hi(ov[i]) * T::hi(gv[i]);
+            }
+            delta = part + xhalf(part);
+            if (hi == 0 && qrow < Sq) p.delta_out[qbase + qrow] = delta;
+        }
         const int kv_lim = CAUSAL ? min(Sk - 1, qrow) : Sk - 1;  // last key visible to this lane's query row
 
         const int kv_low = p.window > 0 ? qrow - p.window + 1 : -0x40000000;  // first key visible to this lane's row
@@ -681,18 +681,10 @@ inline uint64_t delta_bytes(int B, int Hq, int Sq) {
 
 template <class T, int D>
 int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
-    {
-        DeltaParams dp;
-        dp.o = a.o; dp.dout = a.dout; dp.delta = a.delta;
-        dp.rows = (long long)a.B * a.Hq * a.Sq;
-        constexpr int RPB = 256 / (D * 2 / 16);
-        const dim3 grid((unsigned)((dp.rows + RPB - 1) / RPB)), block(256);
-        hipLaunchKernelGGL((fa_bwd_delta_kernel<T, D>), grid, block, 0, stream, dp);
-        int rc = (int)hipGetLastError();
-        if (rc) return rc;
-    }
+    // (delta = rowsum(O * dO) is computed inside the dQ kernel)
     BwdParams p;
     p.q = a.q; p.k = a.k; p.v = a.v; p.dout = a.dout; p.lse = a.lse; p.delta = a.delta;
+    p.o = a.o; p.delta_out = a.delta;
     p.dq = a.dq; p.dk = a.dk; p.dv = a.dv;
     p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
     p.c = a.scale * kLog2e;
