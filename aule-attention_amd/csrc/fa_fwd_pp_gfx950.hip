@@ -299,11 +299,12 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
 
             // Both MFMA loops are software-pipelined by hand: a wave issues in order, so an MFMA whose LDS
             // operands were requested just before it stalls for the whole LDS latency (measured: 16 MFMAs
-            // took ~950 cycles instead of 512).  Operands are requested kAhead steps early; the
+            // took ~950 cycles instead of 512).  Operands are requested kAhead steps early (about two MFMA
+            // operands ahead is the measured optimum for both loops: deeper look-ahead costs 3-4 %); the
             // sched_group_barrier sequence pins "1 MFMA, then the reads of a later step" in the final code.
             auto qk = [&](int buf) __attribute__((always_inline)) {  // S^T = K_tile . Q^T   (all LDS offsets are immediates)
                 const char* kb = Ks + buf * KTILE + ka_base;
-                constexpr int kAhead = 2;
+                constexpr int kAhead = 1;
                 u32x4_t kf[KS][2];
                 auto rd = [&](int ks) __attribute__((always_inline)) {
                     kf[ks][0] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32);
@@ -328,7 +329,7 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
             auto pv = [&](int buf) __attribute__((always_inline)) {  // O^T += V^T . P^T
                 const char* vb = Vs + buf * VTILE + va_off;
                 constexpr int NST = 4 * DB;  // MFMA steps: (sb, kk) outer, d inner
-                constexpr int kAhead = 3;
+                constexpr int kAhead = 2;
                 s16x4_t a0[NST], a1[NST];
                 auto rd = [&](int st) __attribute__((always_inline)) {
                     const int sk = st / DB, d = st % DB;  // sk = 2*sb + kk
