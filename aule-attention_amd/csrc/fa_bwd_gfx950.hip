@@ -400,6 +400,10 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
 // dV^T += dO^T.P and dK^T += Q^T.dS).
 constexpr int kKvBlock = 256;  // 8 waves x 32 key rows
 constexpr int kQT = 32;        // query rows per tile
+#ifndef AULE_DKV_AHEAD
+#define AULE_DKV_AHEAD 1
+#endif
+constexpr int kDkvAhead = AULE_DKV_AHEAD;  // operand look-ahead of the dK/dV kernel's MFMA loops (steps)
 
 template <int D>
 struct DkvCfg {
@@ -538,13 +542,25 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                 f32x16_t s, dp, z;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                {   // operands requested kDkvAhead k-steps early (hand-pipelined like the forward's M-phase loops)
+                    u32x4_t qa[KS], da[KS], vb[KS];
+                    auto rd = [&](int ks) __attribute__((always_inline)) {
+                        qa[ks] = *reinterpret_cast<const u32x4_t*>(qrm + ks * 32);
+                        da[ks] = *reinterpret_cast<const u32x4_t*>(grm + ks * 32);
+                        vb[ks] = *reinterpret_cast<const u32x4_t*>(vsl + ks * 32);
+                    };
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const u32x4_t qa = *reinterpret_cast<const u32x4_t*>(qrm + ks * 32);
-                    const u32x4_t da = *reinterpret_cast<const u32x4_t*>(grm + ks * 32);
-                    const u32x4_t vb = *reinterpret_cast<const u32x4_t*>(vsl + ks * 32);
-                    s = T::mfma(as_v8<T>(qa), kf[ks], ks == 0 ? z : s);              // S  = Q  . K^T
-                    dp = T::mfma(as_v8<T>(da), as_v8<T>(vb), ks == 0 ? z : dp);      // dP = dO . V^T
+                    for (int ks = 0; ks < kDkvAhead && ks < KS; ++ks) rd(ks);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3 * (kDkvAhead < KS ? kDkvAhead : KS), 0);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        if (ks + kDkvAhead < KS) rd(ks + kDkvAhead);
+                        s = T::mfma(as_v8<T>(qa[ks]), kf[ks], ks == 0 ? z : s);                  // S  = Q  . K^T
+                        dp = T::mfma(as_v8<T>(da[ks]), as_v8<T>(vb[ks]), ks == 0 ? z : dp);      // dP = dO . V^T
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (ks + kDkvAhead < KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
                 }
                 const bool need_mask = (CAUSAL && (q0 < n0w + 31)) || (q0 + kQT > Sq) || (n0w + 32 > Sk) ||
                                        (W > 0 && q0 + kQT - 1 - n0w >= W);
@@ -582,18 +598,31 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                     dsb[kk] = as_v8<T>(du);
                 }
                 // dV^T += dO^T . P ; dK^T += Q^T . dS   (A by transpose read, k-slot = query row)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int d = 0; d < DB; ++d) {
+                {
+                    constexpr int NST = 2 * DB;   // step = (kk, d): one dV and one dK MFMA
+                    s16x4_t x0[NST], x1[NST], y0[NST], y1[NST];
+                    auto rd = [&](int st) __attribute__((always_inline)) {
+                        const int kk = st / DB, d = st % DB;
                         const int off = ((4 * kk) * (D / 16) + 2 * d) * 128;
-                        const s16x4_t x0 = lds_tr16(gtr + off);
-                        const s16x4_t x1 = lds_tr16(gtr + off + 2 * (D / 16) * 128);
-                        dv[d] = T::mfma(as_v8<T>(x0, x1), pb[kk], dv[d]);
-                        const s16x4_t y0 = lds_tr16(qtr + off);
-                        const s16x4_t y1 = lds_tr16(qtr + off + 2 * (D / 16) * 128);
-                        dk[d] = T::mfma(as_v8<T>(y0, y1), dsb[kk], dk[d]);
+                        x0[st] = lds_tr16(gtr + off);
+                        x1[st] = lds_tr16(gtr + off + 2 * (D / 16) * 128);
+                        y0[st] = lds_tr16(qtr + off);
+                        y1[st] = lds_tr16(qtr + off + 2 * (D / 16) * 128);
+                    };
+#pragma unroll
+                    for (int st = 0; st < kDkvAhead && st < NST; ++st) rd(st);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4 * (kDkvAhead < NST ? kDkvAhead : NST), 0);
+#pragma unroll
+                    for (int st = 0; st < NST; ++st) {
+                        if (st + kDkvAhead < NST) rd(st + kDkvAhead);
+                        const int kk = st / DB, d = st % DB;
+                        dv[d] = T::mfma(as_v8<T>(x0[st], x1[st]), pb[kk], dv[d]);
+                        dk[d] = T::mfma(as_v8<T>(y0[st], y1[st]), dsb[kk], dk[d]);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (st + kDkvAhead < NST) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     }
+                }
             }
             if (it + 1 < nit) write_stage(cur ^ 1);
             __syncthreads();
