@@ -125,6 +125,36 @@ __device__ __forceinline__ unsigned softmax_pair_bf16(float s0, float s1, float 
 #endif
     return packed;
 }
+// Eight scores (half an S tuple) per asm statement: x = S*c - m_ref, P = exp2(x), two row-sum chains, bf16 pack.
+// Inputs and temporaries are separate operands (tying them made hipcc copy the MFMA result tuple register by
+// register): 8 inputs + 8 temporaries + 4 packed outputs + c, nm + the two accumulators = 24 operands (limit 30).
+// Every v_exp result is first read at least two instructions later (inline asm is invisible to the hazard recogniser).
+#define AULE_SM_PAIR(S0, S1, X0, X1, PK)         \
+    "v_fma_f32 " X0 ", " S0 ", %22, %23\n\t"     \
+    "v_fma_f32 " X1 ", " S1 ", %22, %23\n\t"     \
+    "v_exp_f32 " X0 ", " X0 "\n\t"               \
+    "v_exp_f32 " X1 ", " X1 "\n\t"               \
+    "v_add_f32 %12, %12, " X0 "\n\t"             \
+    "v_add_f32 %13, %13, " X1 "\n\t"             \
+    "v_cvt_pk_bf16_f32 " PK ", " X0 ", " X1 "\n\t"
+__device__ __forceinline__ u32x4_t softmax_oct_bf16(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7,
+                                                    float c, float nm, float& a0, float& a1) {
+    u32x4_t pk = {0u, 0u, 0u, 0u};
+#if defined(__HIP_DEVICE_COMPILE__)
+    float x0, x1, x2, x3, x4, x5, x6, x7;
+    unsigned k0, k1, k2, k3;
+    asm volatile(
+        AULE_SM_PAIR("%14", "%15", "%0", "%1", "%8") AULE_SM_PAIR("%16", "%17", "%2", "%3", "%9")
+        AULE_SM_PAIR("%18", "%19", "%4", "%5", "%10") AULE_SM_PAIR("%20", "%21", "%6", "%7", "%11")
+        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7),
+          "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3), "+v"(a0), "+v"(a1)
+        : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7), "v"(c), "v"(nm));
+    pk = u32x4_t{k0, k1, k2, k3};
+#else
+    (void)s0; (void)s1; (void)s2; (void)s3; (void)s4; (void)s5; (void)s6; (void)s7; (void)c; (void)nm; (void)a0; (void)a1;
+#endif
+    return pk;
+}
 __device__ __forceinline__ float fma_pinned(float a, float b, float c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float r;
@@ -372,13 +402,10 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
 #pragma unroll
                     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            // ONE asm statement per element pair (hipcc pads separate asm statements with s_nop):
-                            // x = S*c - m_ref, P = exp2(x), row-sum adds (two chains), pack.  The order keeps one
-                            // independent instruction between each v_exp and the first use of its result -- inline
-                            // asm is invisible to the hazard recogniser.
-                            pr[sb][i >> 2][i & 3] = softmax_pair_bf16(s[sb][2 * i], s[sb][2 * i + 1], c, nm, a0, a1);
-                        }
+                        for (int kk = 0; kk < 2; ++kk)
+                            pr[sb][kk] = softmax_oct_bf16(s[sb][8 * kk], s[sb][8 * kk + 1], s[sb][8 * kk + 2], s[sb][8 * kk + 3],
+                                                          s[sb][8 * kk + 4], s[sb][8 * kk + 5], s[sb][8 * kk + 6], s[sb][8 * kk + 7],
+                                                          c, nm, a0, a1);
                     l += a0 + a1;  // (two asm adds behind the last v_exp)
                     asm volatile("" : "+v"(pr[0][0]), "+v"(pr[0][1]), "+v"(pr[1][0]), "+v"(pr[1][1]), "+v"(l));
 #pragma unroll
