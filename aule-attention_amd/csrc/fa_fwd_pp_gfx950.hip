@@ -129,26 +129,29 @@ __device__ __forceinline__ unsigned softmax_pair_bf16(float s0, float s1, float 
 // Inputs and temporaries are separate operands (tying them made hipcc copy the MFMA result tuple register by
 // register): 8 inputs + 8 temporaries + 4 packed outputs + c, nm + the two accumulators = 24 operands (limit 30).
 // Every v_exp result is first read at least two instructions later (inline asm is invisible to the hazard recogniser).
-#define AULE_SM_PAIR(S0, S1, X0, X1, PK)         \
+#define AULE_SM_PAIR(CVT, S0, S1, X0, X1, PK)    \
     "v_fma_f32 " X0 ", " S0 ", %22, %23\n\t"     \
     "v_fma_f32 " X1 ", " S1 ", %22, %23\n\t"     \
     "v_exp_f32 " X0 ", " X0 "\n\t"               \
     "v_exp_f32 " X1 ", " X1 "\n\t"               \
     "v_add_f32 %12, %12, " X0 "\n\t"             \
     "v_add_f32 %13, %13, " X1 "\n\t"             \
-    "v_cvt_pk_bf16_f32 " PK ", " X0 ", " X1 "\n\t"
-__device__ __forceinline__ u32x4_t softmax_oct_bf16(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7,
+    CVT " " PK ", " X0 ", " X1 "\n\t"
+#define AULE_SM_OCT(CVT)                                                                                              \
+    asm volatile(AULE_SM_PAIR(CVT, "%14", "%15", "%0", "%1", "%8") AULE_SM_PAIR(CVT, "%16", "%17", "%2", "%3", "%9")    \
+                 AULE_SM_PAIR(CVT, "%18", "%19", "%4", "%5", "%10") AULE_SM_PAIR(CVT, "%20", "%21", "%6", "%7", "%11")  \
+                 : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7), "=&v"(k0),   \
+                   "=&v"(k1), "=&v"(k2), "=&v"(k3), "+v"(a0), "+v"(a1)                                                  \
+                 : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7), "v"(c), "v"(nm))
+template <class T>
+__device__ __forceinline__ u32x4_t softmax_oct(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7,
                                                     float c, float nm, float& a0, float& a1) {
     u32x4_t pk = {0u, 0u, 0u, 0u};
 #if defined(__HIP_DEVICE_COMPILE__)
     float x0, x1, x2, x3, x4, x5, x6, x7;
     unsigned k0, k1, k2, k3;
-    asm volatile(
-        AULE_SM_PAIR("%14", "%15", "%0", "%1", "%8") AULE_SM_PAIR("%16", "%17", "%2", "%3", "%9")
-        AULE_SM_PAIR("%18", "%19", "%4", "%5", "%10") AULE_SM_PAIR("%20", "%21", "%6", "%7", "%11")
-        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7),
-          "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3), "+v"(a0), "+v"(a1)
-        : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7), "v"(c), "v"(nm));
+    if constexpr (T::kDType == 2) AULE_SM_OCT("v_cvt_pk_bf16_f32");
+    else AULE_SM_OCT("v_cvt_pk_f16_f32");   // round-to-nearest-even, like the (_Float16) casts of F16Traits::pack2
     pk = u32x4_t{k0, k1, k2, k3};
 #else
     (void)s0; (void)s1; (void)s2; (void)s3; (void)s4; (void)s5; (void)s6; (void)s7; (void)c; (void)nm; (void)a0; (void)a1;
@@ -403,7 +406,7 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk)
-                            pr[sb][kk] = softmax_oct_bf16(s[sb][8 * kk], s[sb][8 * kk + 1], s[sb][8 * kk + 2], s[sb][8 * kk + 3],
+                            pr[sb][kk] = softmax_oct<T>(s[sb][8 * kk], s[sb][8 * kk + 1], s[sb][8 * kk + 2], s[sb][8 * kk + 3],
                                                           s[sb][8 * kk + 4], s[sb][8 * kk + 5], s[sb][8 * kk + 6], s[sb][8 * kk + 7],
                                                           c, nm, a0, a1);
                     l += a0 + a1;  // (two asm adds behind the last v_exp)
@@ -445,23 +448,19 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
                 }
-                const f32x2_t c2 = {c, c};
+                // the same fused statement as the fixed-reference form, against the (lazily raised) running maximum
                 const float m_sub = (WIN && m == -INFINITY) ? 0.f : m;  // (-inf) - (-inf) would be NaN; P = exp2(-inf) = 0
-                const f32x2_t nm2 = {-m_sub, -m_sub};
-                f32x2_t ls[2] = {{0.f, 0.f}, {0.f, 0.f}};
+                const float nmv = -m_sub;
+                float a0 = 0.f, a1 = 0.f;
                 u32x4_t pu[2][2];
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        f32x2_t t = {s[sb][2 * i], s[sb][2 * i + 1]};
-                        t = __builtin_elementwise_fma(t, c2, nm2);   // v_pk_fma_f32
-                        t[0] = fast_exp2(t[0]);
-                        t[1] = fast_exp2(t[1]);
-                        ls[i & 1] += t;                                // v_pk_add_f32, two chains
-                        pu[sb][i >> 2][i & 3] = T::pack2(t[0], t[1]);
-                    }
-                const f32x2_t lt2 = ls[0] + ls[1];
+                    for (int kk = 0; kk < 2; ++kk)
+                        pu[sb][kk] = softmax_oct<T>(s[sb][8 * kk], s[sb][8 * kk + 1], s[sb][8 * kk + 2], s[sb][8 * kk + 3],
+                                                    s[sb][8 * kk + 4], s[sb][8 * kk + 5], s[sb][8 * kk + 6], s[sb][8 * kk + 7],
+                                                    c, nmv, a0, a1);
+                const f32x2_t lt2 = {a0, a1};
                 l += lt2[0] + lt2[1];
                 // Pin the results of this phase HERE: the softmax is register-only code that LLVM otherwise
                 // sinks past the barrier into the block that consumes P (next to this wave's own MFMAs).
