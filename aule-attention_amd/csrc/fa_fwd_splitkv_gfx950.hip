@@ -104,6 +104,22 @@ __global__ void __launch_bounds__(256) fa_fwd_splitkv_kernel(const SplitParams p
         v_g[i] = v_row[i] * RB + v_col[i];
     }
     const int tr_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
+    // paged fast path (power-of-two block size >= 8): block index inside the tile and byte offset inside the block
+    const bool pow2 = PAGED && p.block_size >= 8 && (p.block_size & (p.block_size - 1)) == 0;
+    const int bs_log2 = PAGED ? 31 - __builtin_clz(p.block_size | 1) : 0;
+    const size_t blk_bytes = PAGED ? (size_t)p.block_size * p.Hkv * RB : 0;
+    int k_jb = 0, k_off = 0, v_jb[NV], v_off[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v_jb[i] = 0; v_off[i] = 0; }
+    if (pow2) {
+        k_jb = l31 >> bs_log2;
+        k_off = ((l31 & (p.block_size - 1)) * p.Hkv + hk) * RB + hi * 16;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v_jb[i] = v_row[i] >> bs_log2;
+            v_off[i] = ((v_row[i] & (p.block_size - 1)) * p.Hkv + hk) * RB + v_col[i];
+        }
+    }
 
     f32x16_t o[DB];
 #pragma unroll
@@ -128,6 +144,26 @@ __global__ void __launch_bounds__(256) fa_fwd_splitkv_kernel(const SplitParams p
         u32x4_t ka[KS], vx[NV];
         if constexpr (PAGED) {
             const u32x4_t zero = {0u, 0u, 0u, 0u};
+            if (pow2) {
+                // power-of-two block sizes >= 8 (the usual 16/32/64/128): the tile's <= 4 logical blocks are looked up
+                // ONCE per tile with wave-uniform (scalar) loads; each lane picks its block with selects and adds a
+                // 32-bit in-block offset computed once per launch -- no per-lane table lookups or 64-bit multiplies
+                const int lb0 = kv0 >> bs_log2;
+                size_t pb[4];
+                const size_t tile_off = (size_t)(kv0 & (p.block_size - 1)) * p.Hkv * RB;   // blocks larger than a tile
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) pb[jb] = (size_t)bt[min(lb0 + jb, p.max_blocks - 1)] * blk_bytes + tile_off;
+                auto pick = [&](int jb) -> size_t { return jb == 0 ? pb[0] : (jb == 1 ? pb[1] : (jb == 2 ? pb[2] : pb[3])); };
+                const bool kin = kv0 + l31 < Sk;
+                const char* krow = reinterpret_cast<const char*>(p.k) + pick(k_jb) + k_off;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) ka[ks] = kin ? *reinterpret_cast<const u32x4_t*>(krow + ks * 32) : zero;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const bool vin = kv0 + v_row[i] < Sk;
+                    vx[i] = vin ? *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.v) + pick(v_jb[i]) + v_off[i]) : zero;
+                }
+            } else {
             const bool kin = kv0 + l31 < Sk;
             const char* krow = reinterpret_cast<const char*>(p.k) + (kin ? paged_row(kv0 + l31) : 0);
 #pragma unroll
@@ -136,6 +172,7 @@ __global__ void __launch_bounds__(256) fa_fwd_splitkv_kernel(const SplitParams p
             for (int i = 0; i < NV; ++i) {
                 const bool vin = kv0 + v_row[i] < Sk;
                 vx[i] = vin ? *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(p.v) + paged_row(kv0 + v_row[i]) + v_col[i]) : zero;
+            }
             }
         } else {
 #pragma unroll
