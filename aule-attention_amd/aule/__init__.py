@@ -68,7 +68,9 @@ def flash_attention(query, key, value, rot_cos=None, rot_sin=None, causal=True, 
         key, value: [batch, heads_kv, seq_len_k, head_dim]
         rot_cos, rot_sin: accepted for signature compatibility; ignored with a warning
             (the reference's ROCm route drops them too: __init__.py:204).
-        causal: top-left aligned causal mask (query i sees keys j <= i)
+        causal: True = top-left aligned causal mask (query i sees keys j <= i), the reference's rule;
+            "bottom-right" = query i sits at position i + seq_len_k - seq_len_q (the last query sees every
+            key; needs seq_len_k >= seq_len_q) -- an additive option, not in the reference
         scale: softmax scale, default 1/sqrt(head_dim)
         window_size: -1 = full attention; W > 0 = sliding window, key j visible to query i only if i - j < W
 

@@ -22,6 +22,24 @@ def _stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def causal_code(causal):
+    """The C-ABI's AULE_CAUSAL_* code for the Python-level `causal` argument: False/None -> 0,
+    True or "top-left" -> 1 (the reference's rule), "bottom-right" or 2 -> 2."""
+    if isinstance(causal, str):
+        try:
+            return {"none": 0, "top-left": 1, "bottom-right": 2}[causal]
+        except KeyError:
+            raise ValueError(f"causal must be a bool, 'top-left' or 'bottom-right', got {causal!r}") from None
+    if causal is None or causal is False:
+        return 0
+    if causal is True:
+        return 1
+    c = int(causal)
+    if c not in (0, 1, 2):
+        raise ValueError(f"causal code must be 0, 1 or 2, got {causal!r}")
+    return c
+
+
 def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1):
     """q [B,Hq,Sq,D], k/v [B,Hkv,Sk,D]: contiguous device tensors, D in SUPPORTED_HEAD_DIMS.
     Returns (out, lse or None).  Asynchronous on the current stream."""
@@ -37,7 +55,7 @@ def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1):
     d.dtype = _DTYPES[q.dtype]
     d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
     d.scale = float(scale)
-    d.causal = 1 if causal else 0
+    d.causal = causal_code(causal)
     d.window_size = int(window) if window is not None and window > 0 else -1
     d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
     d.stream = _stream_ptr(q.device)
@@ -59,7 +77,7 @@ def bwd_raw(q, k, v, out, dout, lse, causal, scale, window=-1):
     d.dtype = _DTYPES[q.dtype]
     d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
     d.scale = float(scale)
-    d.causal = 1 if causal else 0
+    d.causal = causal_code(causal)
     d.window_size = int(window) if window is not None and window > 0 else -1
     d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
     d.stream = _stream_ptr(q.device)
@@ -113,7 +131,10 @@ def flash_attention_hip(q, k, v, causal=True, scale=None, window=-1):
     Dp = next(x for x in SUPPORTED_HEAD_DIMS if x >= D)
     if Dp != D:   # zero-padded head dim: dot products and outputs are unchanged
         q, k, v = _pad_head_dim(q, Dp), _pad_head_dim(k, Dp), _pad_head_dim(v, Dp)
-    out = FlashAttentionHipFunc.apply(q, k, v, bool(causal), float(scale), int(window))
+    code = causal_code(causal)
+    if code == 2 and k.shape[2] < q.shape[2]:
+        raise ValueError(f"bottom-right causal alignment needs seq_len_k >= seq_len_q, got {k.shape[2]} < {q.shape[2]}")
+    out = FlashAttentionHipFunc.apply(q, k, v, code, float(scale), int(window))
     if Dp != D:
         out = out[..., :D]
     return out if out.dtype == orig_dtype else out.to(orig_dtype)

@@ -563,7 +563,15 @@ int32_t aule_attention_forward_gravity(aule_tensor_handle, aule_tensor_handle, a
 
 /* ------------------------------------------------------------ _ex entries */
 static int check_common(int32_t dtype, uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk,
-                        uint32_t D, int32_t window) {
+                        uint32_t D, int32_t window, int32_t causal) {
+    if (causal < 0 || causal > AULE_CAUSAL_BOTTOM_RIGHT) {
+        set_error("Attention failed: unknown causal mode %d (0 none, 1 top-left, 2 bottom-right)", causal);
+        return -3;
+    }
+    if (causal == AULE_CAUSAL_BOTTOM_RIGHT && Sk < Sq) {
+        set_error("Attention failed: bottom-right causal alignment needs seq_k (%u) >= seq_q (%u)", Sk, Sq);
+        return -3;
+    }
     if (dtype < 0 || dtype > 2) {
         set_error("Attention failed: unknown dtype %d", dtype);
         return -3;
@@ -602,7 +610,7 @@ int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
         return -3;
     }
     int rc = check_common(d->dtype, d->batch, d->heads_q, d->heads_kv, d->seq_q, d->seq_k, d->head_dim,
-                          d->window_size);
+                          d->window_size, d->causal);
     if (rc) return rc;
     if ((uint64_t)d->batch * d->heads_q * d->seq_q == 0) return 0;  // empty output
     if (d->seq_k == 0) {
@@ -622,8 +630,10 @@ int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
     a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
+    a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? (int)d->seq_k - (int)d->seq_q : 0;
     a.dtype = d->dtype;
-    a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q) ? d->window_size : -1;  // W >= Sq masks nothing
+    // W >= Sq + coff masks nothing (the last query sits at position Sq - 1 + coff)
+    a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
     rc = aule_hip::launch_fwd(a, (hipStream_t)d->stream);
     if (rc != 0) {
         set_error("Attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");
@@ -699,7 +709,7 @@ int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
         return -3;
     }
     int rc = check_common(d->dtype, d->batch, d->heads_q, d->heads_kv, d->seq_q, d->seq_k, d->head_dim,
-                          d->window_size);
+                          d->window_size, d->causal);
     if (rc) return rc;
     if ((uint64_t)d->batch * d->heads_q * d->seq_q == 0 && (uint64_t)d->batch * d->heads_kv * d->seq_k == 0)
         return 0;
@@ -728,8 +738,9 @@ int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
     a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
+    a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? (int)d->seq_k - (int)d->seq_q : 0;
     a.dtype = d->dtype;
-    a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q) ? d->window_size : -1;
+    a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
     rc = aule_hip::launch_bwd(a, (hipStream_t)d->stream);
     if (rc != 0) {
         set_error("Backward failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");

@@ -34,6 +34,7 @@ struct BwdF32Params {
     float scale;
     int nblk;
     int window;   // sliding window: key j visible to query i only if i - j < window (0: off)
+    int coff;     // causal position offset (query i sits at position i + coff)
 };
 
 constexpr int kRows = 128;  // rows per workgroup (4 waves x 32)
@@ -112,12 +113,13 @@ __global__ void __launch_bounds__(256) fa_bwd_dq_f32_kernel(const BwdF32Params p
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
-    const int kv_hi = CAUSAL ? min(Sk, w.blk * kRows + kRows) : Sk;
+    const int coff = p.coff;
+    const int kv_hi = CAUSAL ? min(Sk, w.blk * kRows + kRows + coff) : Sk;
     const int nt = (kv_hi + kTile - 1) / kTile;
-    const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32) : Sk;
+    const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32 + coff) : Sk;
     const int W = p.window;
-    const int t_lo = W > 0 ? max(0, w.blk * kRows - W + 1) / kTile : 0;  // tiles before the block's window: skipped
-    const int wave_kv_lo = W > 0 ? q0w - W + 1 : 0;
+    const int t_lo = W > 0 ? max(0, w.blk * kRows + coff - W + 1) / kTile : 0;  // tiles before the block's window: skipped
+    const int wave_kv_lo = W > 0 ? q0w + coff - W + 1 : 0;
 
     for (int t = t_lo; t < nt; ++t) {
         const int kv0 = t * kTile;
@@ -133,13 +135,13 @@ __global__ void __launch_bounds__(256) fa_bwd_dq_f32_kernel(const BwdF32Params p
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[(2 * st + hi) * 32 + l31], qf[st], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[(2 * st + hi) * 32 + l31], dof[st], dp, 0, 0, 0);
             }
-            const bool need_mask = (CAUSAL && (kv0 + kTile - 1 > q0w)) || (kv0 + kTile > Sk) || (W > 0 && q0w + 31 - kv0 >= W);
+            const bool need_mask = (CAUSAL && (kv0 + kTile - 1 > q0w + coff)) || (kv0 + kTile > Sk) || (W > 0 && q0w + coff + 31 - kv0 >= W);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float pv = fast_exp2(__builtin_fmaf(s[r], c, -lse2));
                 if (need_mask) {
                     const int kv = kv0 + crow(r, hi);
-                    const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow) && (W <= 0 || qrow - kv < W);
+                    const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow + coff) && (W <= 0 || qrow + coff - kv < W);
                     pv = vis ? pv : 0.f;
                 }
                 s[r] = pv * (dp[r] - delta);  // dS^T (scale applied in the epilogue)
@@ -207,9 +209,10 @@ __global__ void __launch_bounds__(256) fa_bwd_dkdv_f32_kernel(const BwdF32Params
         for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
 
     const int W = p.window;
+    const int coff = p.coff;   // query q sits at position q + coff
     int ntq_all = (Sq + kTile - 1) / kTile;
-    if (W > 0) ntq_all = min(ntq_all, (w.blk * kRows + kRows - 1 + W + kTile - 1) / kTile);  // q - kv < W
-    const int first_qt = CAUSAL ? (w.blk * kRows) / kTile : 0;
+    if (W > 0) ntq_all = min(ntq_all, max(0, w.blk * kRows + kRows - 1 + W - coff + kTile - 1) / kTile);  // q + coff - kv < W
+    const int first_qt = CAUSAL ? max(0, w.blk * kRows - coff) / kTile : 0;
 
     for (int hh = 0; hh < g; ++hh) {
         const size_t qb = (size_t)(w.b * p.Hq + w.hk * g + hh) * Sq;
@@ -223,7 +226,7 @@ __global__ void __launch_bounds__(256) fa_bwd_dkdv_f32_kernel(const BwdF32Params
                 scal[tid] = tid < 32 ? p.lse[qb + r] * kLog2e : p.delta[qb + r];
             }
             __syncthreads();
-            if ((!CAUSAL || q0 + kTile - 1 >= n0w) && (W <= 0 || q0 < n0w + 31 + W)) {
+            if ((!CAUSAL || q0 + coff + kTile - 1 >= n0w) && (W <= 0 || q0 + coff < n0w + 31 + W)) {
                 f32x16_t s, dp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -232,14 +235,14 @@ __global__ void __launch_bounds__(256) fa_bwd_dkdv_f32_kernel(const BwdF32Params
                     s = __builtin_amdgcn_mfma_f32_32x32x2f32(Qt[(2 * st + hi) * 32 + l31], kf[st], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Gt[(2 * st + hi) * 32 + l31], vf[st], dp, 0, 0, 0);
                 }
-                const bool need_mask = (CAUSAL && (q0 < n0w + 31)) || (q0 + kTile > Sq) || (n0w + 32 > Sk) || (W > 0 && q0 + kTile - 1 - n0w >= W);
+                const bool need_mask = (CAUSAL && (q0 + coff < n0w + 31)) || (q0 + kTile > Sq) || (n0w + 32 > Sk) || (W > 0 && q0 + coff + kTile - 1 - n0w >= W);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ql = crow(r, hi);
                     float pv = fast_exp2(__builtin_fmaf(s[r], c, -scal[ql]));
                     if (need_mask) {
                         const int q = q0 + ql;
-                        const bool vis = (q < Sq) && (kvrow < Sk) && (!CAUSAL || kvrow <= q) && (W <= 0 || q - kvrow < W);
+                        const bool vis = (q < Sq) && (kvrow < Sk) && (!CAUSAL || kvrow <= q + coff) && (W <= 0 || q + coff - kvrow < W);
                         pv = vis ? pv : 0.f;
                     }
                     s[r] = pv;                              // P
@@ -289,6 +292,7 @@ int launch_bwd_f32_d(const BwdArgs& a, hipStream_t stream) {
     p.c = a.scale * kLog2e;
     p.scale = a.scale;
     p.window = a.window > 0 ? a.window : 0;
+    p.coff = a.causal ? a.coff : 0;
     const dim3 block(256);
     {
         p.nblk = (a.Sq + kRows - 1) / kRows;

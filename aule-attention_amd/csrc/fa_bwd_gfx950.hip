@@ -81,6 +81,7 @@ struct BwdParams {
     int gsplit;   // dkdv: the query heads of a GQA group are split over this many workgroups
     float* part;  // dkdv, gsplit > 1: fp32 partials [2 (dK,dV)][gsplit][B,Hkv,Sk,D]
     int window;   // sliding window: key j visible to query i only if i - j < window (0: off)
+    int coff;     // causal position offset (query i sits at position i + coff; 0 = top-left rule)
 };
 
 // Row-major image swizzle (shared with the forward's K image).
@@ -201,8 +202,9 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
         const int q0w = qb * kDqQBlock + wave * 32;
         const int qrow = q0w + l31;
         const int qr = qrow < Sq ? qrow : Sq - 1;
-        const int kv_hi = CAUSAL ? min(Sk, qb * kDqQBlock + kDqQBlock) : Sk;
-        t_lo = p.window > 0 ? min(max(0, qb * kDqQBlock - p.window + 1) / kDqKV, (kv_hi + kDqKV - 1) / kDqKV - 1) : 0;
+        const int coff = p.coff;
+        const int kv_hi = CAUSAL ? min(Sk, qb * kDqQBlock + kDqQBlock + coff) : Sk;
+        t_lo = p.window > 0 ? min(max(0, qb * kDqQBlock + coff - p.window + 1) / kDqKV, (kv_hi + kDqKV - 1) / kDqKV - 1) : 0;
 
         issue_loads(0);
         v8 qf[KS], dof[KS];
@@ -229,11 +231,11 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
             delta = part + xhalf(part);
             if (hi == 0 && qrow < Sq) p.delta_out[qbase + qrow] = delta;
         }
-        const int kv_lim = CAUSAL ? min(Sk - 1, qrow) : Sk - 1;  // last key visible to this lane's query row
+        const int kv_lim = CAUSAL ? min(Sk - 1, qrow + coff) : Sk - 1;  // last key visible to this lane's query row
 
-        const int kv_low = p.window > 0 ? qrow - p.window + 1 : -0x40000000;  // first key visible to this lane's row
+        const int kv_low = p.window > 0 ? qrow + coff - p.window + 1 : -0x40000000;  // first key visible to this lane's row
         const int nt = (kv_hi + kDqKV - 1) / kDqKV - t_lo;
-        const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32) : Sk;
+        const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32 + coff) : Sk;
         const int na = max(1, (wave_kv_hi + kDqKV - 1) / kDqKV - t_lo);
 
         f32x16_t acc[DB];
@@ -296,8 +298,8 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
             }
         };
         auto softmax = [&](int kv0) {  // P^T = exp2(S^T c - LSE log2e) (0 where masked) ; dS^T = P^T o (dP^T - delta)
-            const bool need_mask = (CAUSAL && (kv0 + kDqKV - 1 > q0w)) || (kv0 + kDqKV > Sk) ||
-                                   (p.window > 0 && q0w + 31 - kv0 >= p.window);
+            const bool need_mask = (CAUSAL && (kv0 + kDqKV - 1 > q0w + coff)) || (kv0 + kDqKV > Sk) ||
+                                   (p.window > 0 && q0w + coff + 31 - kv0 >= p.window);
             const f32x2_t c2 = {c, c}, nl2 = {nlse2, nlse2}, dl2 = {delta, delta};
             int rel = kv0 - kv_lim;  // key index relative to the last visible key of this lane's row
             int rlo = kv0 - kv_low;  // ... and to the first visible one (sliding window)
@@ -478,9 +480,10 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
         // query tiles that can see this KV block (top-left causal: q >= kv)
         // (sliding window: and q - kv < window, i.e. q <= last key of the block + window - 1)
         const int W = p.window;
+        const int coff = p.coff;   // query q sits at position q + coff
         int ntq_all = (Sq + kQT - 1) / kQT;
-        if (W > 0) ntq_all = min(ntq_all, (kb * kKvBlock + kKvBlock - 1 + W + kQT - 1) / kQT);
-        const int first_qt = CAUSAL ? (kb * kKvBlock) / kQT : 0;
+        if (W > 0) ntq_all = min(ntq_all, max(0, kb * kKvBlock + kKvBlock - 1 + W - coff + kQT - 1) / kQT);
+        const int first_qt = CAUSAL ? max(0, kb * kKvBlock - coff) / kQT : 0;
         const int ntq = ntq_all > first_qt ? ntq_all - first_qt : 0;
         const int nit = ntq * gh;  // flattened (group head, q tile) loop
 
@@ -530,7 +533,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
             const int q0 = (first_qt + it % ntq) * kQT;
             if (it + 1 < nit) issue_loads(it + 1);
             // the tile contributes to this wave's keys iff some query row q >= key row exists
-            if ((!CAUSAL || q0 + kQT - 1 >= n0w) && (W <= 0 || q0 < n0w + 31 + W)) {
+            if ((!CAUSAL || q0 + coff + kQT - 1 >= n0w) && (W <= 0 || q0 + coff < n0w + 31 + W)) {
                 const char* base = stage0 + cur * STAGE;
                 const char* qrm = base + a_base;
                 const char* qtr = base + RM + tr_off;
@@ -562,8 +565,8 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     }
                 }
-                const bool need_mask = (CAUSAL && (q0 < n0w + 31)) || (q0 + kQT > Sq) || (n0w + 32 > Sk) ||
-                                       (W > 0 && q0 + kQT - 1 - n0w >= W);
+                const bool need_mask = (CAUSAL && (q0 + coff < n0w + 31)) || (q0 + kQT > Sq) || (n0w + 32 > Sk) ||
+                                       (W > 0 && q0 + coff + kQT - 1 - n0w >= W);
                 const f32x2_t c2 = {c, c};
                 v8 pb[2], dsb[2];
 #pragma unroll
@@ -585,8 +588,9 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                             if (need_mask) {
                                 const int q = q0 + crow(r, hi);
                                 const bool okc = kvrow < Sk;
-                                t[0] = (okc && q < Sq && (!CAUSAL || kvrow <= q) && (W <= 0 || q - kvrow < W)) ? t[0] : 0.f;
-                                t[1] = (okc && q + 1 < Sq && (!CAUSAL || kvrow <= q + 1) && (W <= 0 || q + 1 - kvrow < W)) ? t[1] : 0.f;
+                                const int qp = q + coff;
+                                t[0] = (okc && q < Sq && (!CAUSAL || kvrow <= qp) && (W <= 0 || qp - kvrow < W)) ? t[0] : 0.f;
+                                t[1] = (okc && q + 1 < Sq && (!CAUSAL || kvrow <= qp + 1) && (W <= 0 || qp + 1 - kvrow < W)) ? t[1] : 0.f;
                             }
                             const f32x2_t dpv = {dp[r] - d4[2 * j2], dp[r + 1] - d4[2 * j2 + 1]};
                             const f32x2_t dsv = t * dpv;
@@ -719,6 +723,7 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     p.c = a.scale * kLog2e;
     p.scale = a.scale;
     p.window = a.window > 0 ? a.window : 0;
+    p.coff = a.causal ? a.coff : 0;
     {
         const int nqb = (a.Sq + kDqQBlock - 1) / kDqQBlock;
         p.nblk = a.causal ? (nqb + 1) / 2 : nqb;  // causal: one workgroup per Q-block pair (i, n-1-i)

@@ -30,6 +30,7 @@ struct FwdF32Params {
     float c;   // scale * log2(e)  (sign kept: the max is taken on c*s)
     int nqb;
     int window;  // sliding window: key j visible to query i only if i - j < window (0: off)
+    int coff;    // causal position offset (query i sits at position i + coff)
 };
 
 constexpr int kQB = 128;  // 4 waves x 32 rows
@@ -77,12 +78,13 @@ __global__ void __launch_bounds__(256) fa_fwd_f32_kernel(const FwdF32Params p) {
     float m = -INFINITY, l = 0.f;
     const float c = p.c;
 
-    const int kv_hi = CAUSAL ? min(Sk, w.blk * kQB + kQB) : Sk;
+    const int coff = p.coff;
+    const int kv_hi = CAUSAL ? min(Sk, w.blk * kQB + kQB + coff) : Sk;
     const int nt = (kv_hi + kKV - 1) / kKV;
-    const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32) : Sk;
+    const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32 + coff) : Sk;
     const int W = p.window;
-    const int t_lo = W > 0 ? max(0, w.blk * kQB - W + 1) / kKV : 0;   // tiles before the block's window: skipped
-    const int wave_kv_lo = W > 0 ? q0w - W + 1 : 0;                  // first key any row of this wave can see
+    const int t_lo = W > 0 ? max(0, w.blk * kQB + coff - W + 1) / kKV : 0;   // tiles before the block's window: skipped
+    const int wave_kv_lo = W > 0 ? q0w + coff - W + 1 : 0;                  // first key any row of this wave can see
 
     for (int t = t_lo; t < nt; ++t) {
         const int kv0 = t * kKV;
@@ -119,14 +121,14 @@ __global__ void __launch_bounds__(256) fa_fwd_f32_kernel(const FwdF32Params p) {
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[(2 * st + hi) * 32 + l31], qf[st], s, 0, 0, 0);
 
             // t = c * s ; mask ; online softmax in the exp2 domain
-            const bool need_mask = (CAUSAL && (kv0 + kKV - 1 > q0w)) || (kv0 + kKV > Sk) || (W > 0 && q0w + 31 - kv0 >= W);
+            const bool need_mask = (CAUSAL && (kv0 + kKV - 1 > q0w + coff)) || (kv0 + kKV > Sk) || (W > 0 && q0w + coff + 31 - kv0 >= W);
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float x = s[r] * c;
                 if (need_mask) {
                     const int kv = kv0 + crow(r, hi);
-                    const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow) && (W <= 0 || qrow - kv < W);
+                    const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow + coff) && (W <= 0 || qrow + coff - kv < W);
                     x = vis ? x : -INFINITY;
                 }
                 s[r] = x;
@@ -185,6 +187,7 @@ int launch_f32(const FwdArgs& a, hipStream_t stream) {
     p.c = a.scale * kLog2e;
     p.nqb = (a.Sq + kQB - 1) / kQB;
     p.window = a.window > 0 ? a.window : 0;
+    p.coff = a.causal ? a.coff : 0;
     const dim3 grid((unsigned)(p.nqb * a.B * a.Hq)), block(256);
     if (a.causal)
         hipLaunchKernelGGL((fa_fwd_f32_kernel<D, true>), grid, block, 0, stream, p);

@@ -345,11 +345,12 @@ static bool splitkv_enabled() {
 int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (a.dtype == kF32) return launch_fwd_f32(a, stream);
     if (splitkv_enabled() && splitkv_applicable(a)) return launch_fwd_splitkv(a, stream);
-    if (fwd_kernel_choice() == 2 && a.window <= 0) {
+    const bool pp_only = a.window > 0 || (a.causal && a.coff != 0);  // window / shifted causal live in the ping-pong kernel
+    if (fwd_kernel_choice() == 2 && !pp_only) {
         const int rc = launch_fwd_iw(a, stream);
         if (rc != -1) return rc;
     }
-    if (!use_v1() || a.window > 0) return launch_fwd_pp(a, stream);  // the sliding window lives in the ping-pong kernel
+    if (!use_v1() || pp_only) return launch_fwd_pp(a, stream);
     if (a.dtype == kBF16) {
         if (a.D == 128) return launch_fwd_16<Bf16Traits, 128>(a, stream);
         if (a.D == 64) return launch_fwd_16<Bf16Traits, 64>(a, stream);

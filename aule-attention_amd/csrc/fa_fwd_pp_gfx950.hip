@@ -43,6 +43,7 @@ struct FwdPPParams {
     int nwork;    // work items per head: ceil(nqb/2) when pairing, else nqb
     int pair;     // process Q blocks (i, nqb-1-i) in one workgroup
     int window;   // sliding window: key j visible to query i only if i - j < window (<= 0: off)
+    int coff;     // causal position offset (query i sits at position i + coff; 0 = top-left rule)
     int dbg_flags;            // timeline build only: bit0 = group 1 computes nothing, bit1 = group 0 computes nothing
     unsigned long long* dbg;  // timeline build only: [8 waves][kTLMax] s_memtime stamps of workgroup 0
 };
@@ -271,12 +272,13 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
         const int q0w = qb * kQBlock + wave * 32;
         const int qrow = q0w + l31;
 
-        const int kv_hi = CAUSAL ? min(Sk, qb * kQBlock + kQBlock) : Sk;
+        const int coff = p.coff;                  // position of query row i = i + coff
+        const int kv_hi = CAUSAL ? min(Sk, qb * kQBlock + kQBlock + coff) : Sk;
         int t_lo = 0;  // first tile any row of this Q block can see
-        if constexpr (WIN) t_lo = min(max(0, qb * kQBlock - p.window + 1) / kKVTile, (kv_hi + kKVTile - 1) / kKVTile - 1);
+        if constexpr (WIN) t_lo = min(max(0, qb * kQBlock + coff - p.window + 1) / kKVTile, (kv_hi + kKVTile - 1) / kKVTile - 1);
         kvb = t_lo * kKVTile;
         const int nt = (kv_hi + kKVTile - 1) / kKVTile - t_lo;   // tiles staged by the workgroup (>= 1)
-        const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32) : Sk;  // keys visible to this wave
+        const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32 + coff) : Sk;  // keys visible to this wave
         int na = max(1, (wave_kv_hi + kKVTile - 1) / kKVTile - t_lo);  // tiles this wave computes (a prefix)
         if constexpr (TL) {
             if ((p.dbg_flags >> grp) & 1) na = 0;
@@ -384,15 +386,15 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
             };
             auto softmax = [&](int kv0, auto fixed_tag) __attribute__((always_inline)) {
                 constexpr bool FIXED = decltype(fixed_tag)::value != 0;  // S_j -> P_j (16-bit, in registers); updates m, l, o
-                const bool need_mask = (CAUSAL && (kv0 + kKVTile - 1 > q0w)) || (kv0 + kKVTile > Sk) ||
-                                       (WIN && (q0w + 31 - kv0 >= p.window));
+                const bool need_mask = (CAUSAL && (kv0 + kKVTile - 1 > q0w + coff)) || (kv0 + kKVTile > Sk) ||
+                                       (WIN && (q0w + coff + 31 - kv0 >= p.window));
                 if (need_mask) {
 #pragma unroll
                     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int kv = kv0 + sb * 32 + crow(r, hi);
-                            const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow) && (!WIN || qrow - kv < p.window);
+                            const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow + coff) && (!WIN || qrow + coff - kv < p.window);
                             s[sb][r] = vis ? s[sb][r] : -INFINITY;
                         }
                 }
@@ -634,6 +636,7 @@ int launch_pp(const FwdArgs& a, hipStream_t stream) {
     p.dbg = nullptr;
     p.dbg_flags = 0;
     p.window = a.window > 0 ? a.window : 0;
+    p.coff = a.causal ? a.coff : 0;
     const dim3 grid((unsigned)(p.nwork * a.B * a.Hq)), block(512);
     const size_t lds = Cfg<D>::LDS + 16;
     if (p.window > 0) {  // sliding window: online softmax only
@@ -692,6 +695,7 @@ int launch_fwd_pp_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_
     p.pair = a.causal ? 1 : 0;
     p.nwork = p.pair ? (p.nqb + 1) / 2 : p.nqb;
     p.window = 0;
+    p.coff = 0;
     p.dbg = dbg;
     p.dbg_flags = getenv("AULE_TL_FLAGS") ? atoi(getenv("AULE_TL_FLAGS")) : 0;
     const dim3 grid((unsigned)(p.nwork * a.B * a.Hq)), block(512);

@@ -27,6 +27,8 @@ struct FwdArgs {
     int causal;
     int dtype;
     int window = -1;  // sliding window: key j visible to query i only if i - j < window (<= 0: off)
+    int coff = 0;     // causal position offset: query i sits at position i + coff (0 = the reference's top-left
+                      // rule; Sk - Sq = bottom-right alignment); also shifts the window
 };
 
 struct BwdArgs {
@@ -45,6 +47,7 @@ struct BwdArgs {
     int causal;
     int dtype;
     int window = -1;  // as FwdArgs::window (the reference's backward ignores it; this one honours it)
+    int coff = 0;     // as FwdArgs::coff
 };
 
 // Paged-KV decode (python/aule/triton_flash_amd.py:543-737): one query token per sequence.

@@ -117,14 +117,23 @@ typedef enum aule_dtype {
 
 /* All tensors row-major contiguous: Q,O,dO,dQ [B,Hq,Sq,D]; K,V,dK,dV [B,Hkv,Sk,D];
  * LSE [B,Hq,Sq] fp32.  Pointers are DEVICE pointers on `device`.
- * head_dim in {32, 64, 128}; heads_q % heads_kv == 0; causal mask is top-left
- * aligned (query i sees keys j <= i), as in every reference implementation. */
+ * head_dim in {32, 64, 128}; heads_q % heads_kv == 0.
+ * `causal`: 0 = none; 1 = top-left aligned (query i sees keys j <= i), the rule of
+ * every reference implementation; 2 = bottom-right aligned (query i sits at position
+ * i + seq_k - seq_q, i.e. the last query sees every key; needs seq_k >= seq_q) --
+ * an additive option for chunked prefill / decode against a longer KV history.
+ * With mode 2 the sliding window is measured from the shifted position as well.
+ * The handle-based and host entry points above keep the reference's rule (any
+ * non-zero `causal` = top-left). */
+#define AULE_CAUSAL_NONE 0
+#define AULE_CAUSAL_TOP_LEFT 1
+#define AULE_CAUSAL_BOTTOM_RIGHT 2
 typedef struct aule_attn_desc {
     uint32_t struct_size;  /* = sizeof(aule_attn_desc) */
     int32_t dtype;         /* aule_dtype */
     uint32_t batch, heads_q, heads_kv, seq_q, seq_k, head_dim;
     float scale;           /* softmax scale; 0 or NaN => 1/sqrt(head_dim) */
-    int32_t causal;
+    int32_t causal;        /* AULE_CAUSAL_* */
     int32_t window_size;   /* <= 0: full attention; W > 0: key j visible to query i only if i - j < W */
     int32_t device;        /* HIP device ordinal; -1 = current device */
     void* stream;          /* hipStream_t; NULL = default stream */

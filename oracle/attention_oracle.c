@@ -155,6 +155,12 @@ int oracle_backend_cpu_attention(const float* Q, const float* K, const float* V,
 static size_t win_lo(size_t i, int window) {
     return (window > 0 && i + 1 > (size_t)window) ? i + 1 - (size_t)window : 0;
 }
+/* Causal alignment (a gap in the reference): causal == 1 is the reference's top-left rule   */
+/* (query i sees keys j <= i); causal == 2 is bottom-right (query i sits at position i + Sk - Sq, the rule a    */
+/* KV cache needs; requires Sk >= Sq).  pos(i) is the position used by both the causal and the window test.     */
+static size_t q_pos(size_t i, uint32_t Sq, uint32_t Sk, int causal) {
+    return (causal == 2 && Sk > Sq) ? i + (Sk - Sq) : i;
+}
 
 int oracle_fwd_f64_w(const float* Q, const float* K, const float* V, float* O, float* LSE,
                      uint32_t B, uint32_t Hq, uint32_t Hkv, uint32_t Sq, uint32_t Sk, uint32_t D,
@@ -172,8 +178,9 @@ int oracle_fwd_f64_w(const float* Q, const float* K, const float* V, float* O, f
             const float* v = V + (b * Hkv + hk) * (size_t)Sk * D;
             float* o = O + (b * Hq + h) * (size_t)Sq * D;
             for (size_t i = 0; i < Sq; ++i) {
-                size_t nvis = causal ? (i + 1 < Sk ? i + 1 : Sk) : Sk;
-                const size_t jlo = win_lo(i, window);
+                const size_t pi = q_pos(i, Sq, Sk, causal);
+                size_t nvis = causal ? (pi + 1 < Sk ? pi + 1 : Sk) : Sk;
+                const size_t jlo = win_lo(pi, window);
                 double m = -INFINITY;
                 for (size_t j = jlo; j < nvis; ++j) {
                     double dot = 0.0;
@@ -235,8 +242,9 @@ int oracle_bwd_f64_w(const float* Q, const float* K, const float* V, const float
                 const float* go = dO + (b * Hq + h) * (size_t)Sq * D;
                 float* gq = dQ + (b * Hq + h) * (size_t)Sq * D;
                 for (size_t i = 0; i < Sq; ++i) {
-                    size_t nvis = causal ? (i + 1 < Sk ? i + 1 : Sk) : Sk;
-                    const size_t jlo = win_lo(i, window);
+                    const size_t pi = q_pos(i, Sq, Sk, causal);
+                    size_t nvis = causal ? (pi + 1 < Sk ? pi + 1 : Sk) : Sk;
+                    const size_t jlo = win_lo(pi, window);
                     double m = -INFINITY;
                     for (size_t j = jlo; j < nvis; ++j) {
                         double dot = 0.0;
@@ -299,8 +307,9 @@ int oracle_fwd_rows_f64_w(const float* Q, const float* K, const float* V,
         const float* q = Q + flat * D;
         const float* k = K + (b * Hkv + hk) * (size_t)Sk * D;
         const float* v = V + (b * Hkv + hk) * (size_t)Sk * D;
-        size_t nvis = causal ? (i + 1 < Sk ? i + 1 : Sk) : Sk;
-        const size_t jlo = win_lo(i, window);
+        const size_t pi = q_pos(i, Sq, Sk, causal);
+        size_t nvis = causal ? (pi + 1 < Sk ? pi + 1 : Sk) : Sk;
+        const size_t jlo = win_lo(pi, window);
         double m = -INFINITY;
         for (size_t j = jlo; j < nvis; ++j) {
             double dot = 0.0;

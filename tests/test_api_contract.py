@@ -86,3 +86,13 @@ def test_sdpa_shim_install_uninstall_and_cpu_fallback(capsys):
     assert F.scaled_dot_product_attention is orig
     aule.uninstall()
     assert "Not installed" in capsys.readouterr().out
+
+
+def test_causal_argument_codes():
+    """`causal` keeps the reference's bool meaning; the strings are the additive alignment option (C-ABI AULE_CAUSAL_*)."""
+    from aule._torch import causal_code
+    assert [causal_code(x) for x in (False, None, 0, True, 1, "top-left", "bottom-right", 2, "none")] == \
+        [0, 0, 0, 1, 1, 1, 2, 2, 0]
+    for bad in ("diagonal", 3, -1):
+        with pytest.raises(ValueError):
+            causal_code(bad)

@@ -168,6 +168,46 @@ def test_windowed_backward_judges_agree(oracle_mod):
         np.testing.assert_array_equal(x, y)
 
 
+def test_bottom_right_oracle_pinned_on_torch_lower_right_bias(oracle_mod):
+    """The bottom-right alignment is not in the reference; the oracle's causal=2 mode is pinned on
+    PyTorch's own definition of it (torch.nn.attention.bias.causal_lower_right) through fp64 SDPA with autograd,
+    and on the two judges (C and NumPy) agreeing, with and without a window."""
+    import torch
+    from torch.nn.attention.bias import causal_lower_right
+    rng = np.random.RandomState(8)
+    Sq, Sk, D = 37, 90, 16
+    q, do = rng.randn(1, 4, Sq, D).astype(np.float32), rng.randn(1, 4, Sq, D).astype(np.float32)
+    k, v = rng.randn(1, 2, Sk, D).astype(np.float32), rng.randn(1, 2, Sk, D).astype(np.float32)
+    tq, tk, tv = (torch.from_numpy(x).double().requires_grad_(True) for x in (q, k, v))
+    bias = causal_lower_right(Sq, Sk)._materialize()          # bool [Sq, Sk], True = visible
+    assert bool(bias[0, Sk - Sq]) and not bool(bias[0, Sk - Sq + 1]) and bool(bias[-1].all())
+    ref = torch.nn.functional.scaled_dot_product_attention(
+        tq, tk.repeat_interleave(2, 1), tv.repeat_interleave(2, 1), attn_mask=bias)
+    ref.backward(torch.from_numpy(do).double())
+    out, lse = oracle_mod.fwd_f64(q, k, v, "bottom-right")
+    np.testing.assert_allclose(out, ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    dq, dk, dv = oracle_mod.bwd_f64(q, k, v, do, "bottom-right")
+    np.testing.assert_allclose(dq, tq.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dk, tk.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dv, tv.grad.numpy(), rtol=1e-5, atol=1e-6)
+    for W in (-1, 7, 33):
+        a = oracle_mod.fwd_f64(q, k, v, 2, None, W)
+        b = oracle_mod.np_fwd_f64(q, k, v, 2, None, W)
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-5, atol=1e-5)
+        for x, y in zip(oracle_mod.bwd_f64(q, k, v, do, 2, None, W), oracle_mod.np_bwd_f64(q, k, v, do, 2, None, W)):
+            np.testing.assert_allclose(x, y, rtol=1e-5, atol=1e-6)
+    # Sq == Sk: the two alignments are the same mask, bit for bit
+    qs = rng.randn(1, 4, Sk, D).astype(np.float32)
+    for x, y in zip(oracle_mod.fwd_f64(qs, k, v, 2), oracle_mod.fwd_f64(qs, k, v, True)):
+        np.testing.assert_array_equal(x, y)
+    # the sampled-rows judge follows the same rule
+    rows = np.array([0, 5, Sq - 1, Sq + 3, 4 * Sq - 1], dtype=np.int64)
+    o_r, l_r = oracle_mod.fwd_rows_f64(q, k, v, rows, 2)
+    np.testing.assert_allclose(o_r, out.reshape(-1, D)[rows], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(l_r, lse.reshape(-1)[rows], rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("path", golden_files("paged_"), ids=lambda p: p.split("/")[-1][:-4])
 def test_paged_goldens_pin_the_paged_oracle(oracle_mod, path):
     """Paged-KV decode (row N2): the reference's flash_attention_paged_amd (interpreted, fp16 I/O) vs the judge."""
