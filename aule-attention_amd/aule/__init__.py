@@ -14,7 +14,9 @@ fallback -- when the library or a HIP device is missing the call raises AuleErro
 
 Also carried: the SDPA shim install() / uninstall() / scaled_dot_product_attention
 (__init__.py:288-442).  Not carried over (out of scope): ComfyUI
-glue, paged/gravity/sort features, fused RoPE.  Sliding window (window_size > 0) follows the convention of the
+glue, gravity/sort features.  RoPE: flash_attention_rope / precompute_rope_frequencies / apply_rope_separate
+(triton_flash.py:561-703) run a rotation pass + the attention kernels; flash_attention() itself keeps the
+behaviour of the reference's ROCm route and ignores rot_cos / rot_sin with a warning.  Sliding window (window_size > 0) follows the convention of the
 kernel the reference runs on ROCm (triton_flash_amd.py:179-183): key j is visible to query i only if
 i - j < window_size, on top of the causal rule; unlike the reference, the backward honours it too.
 """
@@ -146,6 +148,54 @@ flash_attention_paged = flash_attention_paged_amd
 
 
 # =============================================================================
+# RoPE (reference python/aule/triton_flash.py:561-703, exported at __init__.py:72-75)
+# =============================================================================
+def flash_attention_rope(q, k, v, cos, sin, causal=True, scale=None, window_size=-1):
+    """RoPE + FlashAttention-2; same name, arguments and result as the reference's export
+    (triton_flash.py:561-603): half-split pairs, x_rot = x * cos + rotate_half(x) * sin, query i at table row i,
+    key j at row j; cos / sin [seq_len, head_dim // 2] or [1, seq_len, head_dim // 2].
+
+    On MI355X the rotation is one HBM-streaming pass over Q and K (csrc/rope_gfx950.hip) ahead of the attention
+    kernels -- K is rotated once, not once per Q block -- and the backward returns the true gradients (rotated back),
+    which the reference's backward does not.  ROCm tensors; autograd-aware."""
+    try:
+        import torch  # noqa: F401
+    except ImportError as e:
+        raise AuleError("aule (HIP build) needs PyTorch-ROCm for device memory") from e
+    _validate(q, k, v)
+    if cos is None or sin is None:
+        raise ValueError("cos and sin are required for RoPE")
+    if not (q.is_cuda and k.is_cuda and v.is_cuda):
+        raise AuleError("aule (HIP build): flash_attention_rope needs ROCm device tensors; there is no CPU fallback")
+    window = int(window_size) if window_size is not None and window_size > 0 else -1
+    from ._torch import flash_attention_rope_hip
+    return flash_attention_rope_hip(q, k, v, cos, sin, causal=causal, scale=scale, window=window, layout="half")
+
+
+def precompute_rope_frequencies(seq_len, head_dim, base=10000.0, device="cuda", dtype=None):
+    """cos, sin [seq_len, head_dim // 2]: theta_p = base^(-p / (head_dim/2)), angle = position * theta_p
+    (same signature and values as triton_flash.py:644-677)."""
+    import torch
+    dtype = torch.float32 if dtype is None else dtype
+    half_dim = head_dim // 2
+    freqs = 1.0 / (base ** (torch.arange(0, half_dim, device=device, dtype=dtype) / half_dim))
+    angles = torch.arange(seq_len, device=device, dtype=dtype)[:, None] * freqs[None, :]
+    return torch.cos(angles), torch.sin(angles)
+
+
+def apply_rope_separate(q, k, cos, sin):
+    """The rotation alone, (q_rot, k_rot), half-split pairs (triton_flash.py:680-703: the table is cut to
+    q's sequence length and applied to both).  ROCm tensors run the HIP rotation pass."""
+    if not (q.is_cuda and k.is_cuda):
+        raise AuleError("aule (HIP build): apply_rope_separate needs ROCm device tensors; there is no CPU fallback")
+    from ._torch import _rope_tables, rope_raw
+    if k.shape[2] != q.shape[2]:
+        raise ValueError(f"apply_rope_separate needs equal sequence lengths, got {q.shape[2]} and {k.shape[2]}")
+    c, s = _rope_tables(cos, sin, q.shape[-1], q.device)
+    return rope_raw(q.contiguous(), c, s, "half"), rope_raw(k.contiguous(), c, s, "half")
+
+
+# =============================================================================
 # PyTorch SDPA compatibility layer (SURVEY.md 8f row N3; reference __init__.py:288-442)
 # =============================================================================
 _original_sdpa = None
@@ -249,5 +299,6 @@ def set_verbose(flag=True):
     _verbose = bool(flag)
 
 
-__all__ = ["flash_attention", "attention", "flash_attention_paged_amd", "flash_attention_paged", "AuleError", "scaled_dot_product_attention", "install", "uninstall",
+__all__ = ["flash_attention", "attention", "flash_attention_paged_amd", "flash_attention_paged",
+           "flash_attention_rope", "precompute_rope_frequencies", "apply_rope_separate", "AuleError", "scaled_dot_product_attention", "install", "uninstall",
            "get_available_backends", "get_backend_errors", "get_backend_info", "set_verbose", "__version__"]

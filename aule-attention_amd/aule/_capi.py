@@ -100,6 +100,30 @@ class PagedDesc(ctypes.Structure):
     ]
 
 
+class RopeDesc(ctypes.Structure):
+    """struct aule_rope_desc (include/aule.h)."""
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("dtype", ctypes.c_int32),
+        ("rows_bh", ctypes.c_uint64),
+        ("seq", ctypes.c_uint32),
+        ("head_dim", ctypes.c_uint32),
+        ("row_pitch", ctypes.c_uint32),
+        ("table_len", ctypes.c_uint32),
+        ("table_pitch", ctypes.c_uint32),
+        ("layout", ctypes.c_int32),
+        ("inverse", ctypes.c_int32),
+        ("pos_offset", ctypes.c_uint32),
+        ("device", ctypes.c_int32),
+        ("stream", ctypes.c_void_p),
+        ("in_", ctypes.c_void_p),
+        ("out", ctypes.c_void_p),
+        ("cos", ctypes.c_void_p),
+        ("sin", ctypes.c_void_p),
+    ]
+
+
+ROPE_HALF, ROPE_INTERLEAVED = 0, 1
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 
 # Every symbol include/aule.h declares: (name, restype, argtypes)
@@ -141,6 +165,7 @@ SIGNATURES = [
     ("aule_attention_backward_ex", _I32, [ctypes.POINTER(AttnBwdDesc)]),
     ("aule_attention_backward_workspace_size", _U64, [ctypes.POINTER(AttnBwdDesc)]),
     ("aule_attention_paged_decode_ex", _I32, [ctypes.POINTER(PagedDesc)]),
+    ("aule_rope_ex", _I32, [ctypes.POINTER(RopeDesc)]),
     ("aule_hip_build_info", ctypes.c_char_p, []),
 ]
 

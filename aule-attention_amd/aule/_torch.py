@@ -140,6 +140,112 @@ def flash_attention_hip(q, k, v, causal=True, scale=None, window=-1):
     return out if out.dtype == orig_dtype else out.to(orig_dtype)
 
 
+_ROPE_LAYOUTS = {"half": _capi.ROPE_HALF, "interleaved": _capi.ROPE_INTERLEAVED}
+
+
+def _rope_tables(cos, sin, D, device):
+    """cos / sin as contiguous fp32 [table_len, D/2] on `device` (the reference takes [S, D/2] or [1, S, D/2]:
+    triton_flash.py:414-424)."""
+    if cos is None or sin is None:
+        raise ValueError("cos and sin are required for RoPE")
+    if cos.shape[-1] != D // 2 or sin.shape[-1] != D // 2:
+        raise ValueError(f"cos/sin must have shape [..., {D // 2}], got {tuple(cos.shape)} / {tuple(sin.shape)}")
+    cos = cos.to(device=device, dtype=torch.float32).reshape(-1, D // 2).contiguous()
+    sin = sin.to(device=device, dtype=torch.float32).reshape(-1, D // 2).contiguous()
+    if cos.shape != sin.shape:
+        raise ValueError("cos and sin must have the same shape")
+    return cos, sin
+
+
+def rope_raw(x, cos, sin, layout="half", inverse=False, pos_offset=0, out=None):
+    """Rotary embedding pass on the HIP backend (csrc/rope_gfx950.hip): x [B,H,S,D] contiguous device tensor
+    (fp32/fp16/bf16), cos/sin fp32 [table_len, D/2]; row s uses table row s + pos_offset.  `out` may be x."""
+    lib = _capi.get_lib()
+    B, H, S, D = x.shape
+    if D % 2:
+        raise ValueError(f"RoPE needs an even head_dim, got {D}")
+    if out is None:
+        out = torch.empty_like(x)
+    if x.numel() == 0:
+        return out
+    if S + pos_offset > cos.shape[0]:
+        raise ValueError(f"RoPE table has {cos.shape[0]} rows, sequence needs {S + pos_offset}")
+    d = _capi.RopeDesc()
+    d.struct_size = ctypes.sizeof(_capi.RopeDesc)
+    d.dtype = _DTYPES[x.dtype]
+    d.rows_bh, d.seq, d.head_dim, d.row_pitch = B * H, S, D, D
+    d.table_len, d.table_pitch = cos.shape[0], 0
+    d.layout, d.inverse, d.pos_offset = _ROPE_LAYOUTS[layout], 1 if inverse else 0, int(pos_offset)
+    d.device = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    d.stream = _stream_ptr(x.device)
+    d.in_, d.out, d.cos, d.sin = x.data_ptr(), out.data_ptr(), cos.data_ptr(), sin.data_ptr()
+    _capi.check(lib.aule_rope_ex(ctypes.byref(d)), "aule_rope_ex")
+    return out
+
+
+class FlashAttentionRopeHipFunc(torch.autograd.Function):
+    """RoPE pass on Q and K, then the attention kernels on the rotated tensors.  The backward rotates dQ', dK' back
+    (the rotation is orthogonal: its transpose is the rotation by the opposite angle) -- the reference's backward
+    ignores the rotation altogether (triton_flash.py:479-526 differentiates the un-rotated q, k)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cos, sin, causal, scale, window, layout, q_pos, Dp):
+        qr = rope_raw(q.contiguous(), cos, sin, layout, False, q_pos)
+        kr = rope_raw(k.contiguous(), cos, sin, layout, False, 0)
+        D = q.shape[-1]
+        if Dp != D:
+            qr, kr, v = _pad_head_dim(qr, Dp), _pad_head_dim(kr, Dp), _pad_head_dim(v, Dp)
+        v = v.contiguous()
+        out, lse = fwd_raw(qr, kr, v, causal, scale, want_lse=True, window=window)
+        ctx.save_for_backward(qr, kr, v, out, lse, cos, sin)
+        ctx.args = (causal, scale, window, layout, q_pos, D)
+        return out[..., :D] if Dp != D else out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qr, kr, v, out, lse, cos, sin = ctx.saved_tensors
+        causal, scale, window, layout, q_pos, D = ctx.args
+        Dp = qr.shape[-1]
+        dout = dout.to(qr.dtype)
+        dout = _pad_head_dim(dout, Dp).contiguous() if Dp != D else dout.contiguous()
+        dq, dk, dv = bwd_raw(qr, kr, v, out, dout, lse, causal, scale, window=window)
+        if Dp != D:
+            dq, dk, dv = dq[..., :D].contiguous(), dk[..., :D].contiguous(), dv[..., :D]
+        rope_raw(dq, cos, sin, layout, True, q_pos, out=dq)
+        rope_raw(dk, cos, sin, layout, True, 0, out=dk)
+        return dq, dk, dv, None, None, None, None, None, None, None, None
+
+
+def flash_attention_rope_hip(q, k, v, cos, sin, causal=True, scale=None, window=-1, layout="half"):
+    """RoPE + attention on device tensors, autograd-aware.  Query i uses table row i (row i + Sk - Sq with
+    causal="bottom-right"), key j row j -- the positions of the reference's kernel (triton_flash.py:119, :169)."""
+    D = q.shape[-1]
+    if D > 128:
+        raise ValueError(f"head_dim must be <= 128 for the HIP backend, got {D}")
+    if D % 2:
+        raise ValueError(f"RoPE needs an even head_dim, got {D}")
+    if layout not in _ROPE_LAYOUTS:
+        raise ValueError(f"layout must be 'half' or 'interleaved', got {layout!r}")
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    orig_dtype = q.dtype
+    if orig_dtype not in _DTYPES:
+        q, k, v = q.float(), k.float(), v.float()
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        k, v = k.to(q.dtype), v.to(q.dtype)
+    cos, sin = _rope_tables(cos, sin, D, q.device)
+    code = causal_code(causal)
+    Sq, Sk = q.shape[2], k.shape[2]
+    if code == 2 and Sk < Sq:
+        raise ValueError(f"bottom-right causal alignment needs seq_len_k >= seq_len_q, got {Sk} < {Sq}")
+    q_pos = Sk - Sq if code == 2 else 0
+    if max(Sq + q_pos, Sk) > cos.shape[0]:
+        raise ValueError(f"RoPE table has {cos.shape[0]} rows, sequences need {max(Sq + q_pos, Sk)}")
+    Dp = next(x for x in SUPPORTED_HEAD_DIMS if x >= D)
+    out = FlashAttentionRopeHipFunc.apply(q, k, v, cos, sin, code, float(scale), int(window), layout, q_pos, Dp)
+    return out if out.dtype == orig_dtype else out.to(orig_dtype)
+
+
 def paged_decode(q, k_cache, v_cache, block_tables, context_lens, scale=None, window_size=-1):
     """Paged-KV decode on the HIP backend; counterpart of flash_attention_paged_amd
     (python/aule/triton_flash_amd.py:656-737), same argument meaning:

@@ -157,14 +157,26 @@ class Aule:
         k = self.tensor(key.shape)
         v = self.tensor(value.shape)
         o = self.tensor(query.shape)
+        extra = []
         try:
             q.upload(query.astype(np.float32, copy=False))
             k.upload(key.astype(np.float32, copy=False))
             v.upload(value.astype(np.float32, copy=False))
-            self.attention_gpu(q, k, v, o, causal=causal, window_size=window_size)
+            if rot_cos is not None and rot_sin is not None:
+                # tables [.., seq, head_dim/2], interleaved pairs (vulkan.py:725-772, attention_f32.comp:98-111)
+                rc, rs = (np.asarray(x, dtype=np.float32) for x in (rot_cos, rot_sin))
+                rc = rc.reshape((1,) * (4 - rc.ndim) + rc.shape)
+                rs = rs.reshape((1,) * (4 - rs.ndim) + rs.shape)
+                tc, ts = self.tensor(rc.shape), self.tensor(rs.shape)
+                extra += [tc, ts]
+                tc.upload(rc)
+                ts.upload(rs)
+                self.attention_gpu(q, k, v, o, tc, ts, causal=causal, window_size=window_size)
+            else:
+                self.attention_gpu(q, k, v, o, causal=causal, window_size=window_size)
             return o.download()
         finally:
-            for t in (q, k, v, o):
+            for t in [q, k, v, o] + extra:
                 t.destroy()
                 if t in self._tensors:
                     self._tensors.remove(t)

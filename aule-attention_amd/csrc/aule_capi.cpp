@@ -395,9 +395,13 @@ int32_t aule_attention_forward_gpu(aule_tensor_handle qh, aule_tensor_handle kh,
     DevTensor* v = lookup(vh);
     DevTensor* o = lookup(oh);
     if (!q || !k || !v || !o) return -1;
+    // rot_cos / rot_sin: both or neither; [.., S, D/2] tables, interleaved pairs (shaders/attention_f32.comp:98-111)
+    DevTensor* rc_t = nullptr;
+    DevTensor* rs_t = nullptr;
     if (rot_cos != 0 || rot_sin != 0) {
-        set_error("Attention failed: fused RoPE is not supported by the HIP backend");
-        return -3;
+        rc_t = lookup(rot_cos);
+        rs_t = lookup(rot_sin);
+        if (!rc_t || !rs_t) return -1;
     }
     // window_size > 0: sliding window, key j visible to query i only if i - j < window_size (the convention of
     // the kernel the reference runs on ROCm, triton_flash_amd.py:179-183; the Vulkan shaders use others)
@@ -421,8 +425,40 @@ int32_t aule_attention_forward_gpu(aule_tensor_handle qh, aule_tensor_handle kh,
         return -3;
     }
     DeviceGuard g(g_device);
-    int rc = run_fwd_f32((const float*)q->ptr, (const float*)k->ptr, (const float*)v->ptr, (float*)o->ptr, nullptr,
+    const float* qp = (const float*)q->ptr;
+    const float* kp = (const float*)k->ptr;
+    float* rot = nullptr;   // rotated copies of Q and K (the handle tensors are the caller's and stay untouched)
+    if (rc_t) {
+        const uint64_t rows_c = (uint64_t)rc_t->shape[0] * rc_t->shape[1] * rc_t->shape[2];
+        const uint64_t rows_s = (uint64_t)rs_t->shape[0] * rs_t->shape[1] * rs_t->shape[2];
+        const uint32_t need = Sq > Sk ? Sq : Sk;
+        if ((D & 1) || rc_t->shape[3] != D / 2 || rs_t->shape[3] != D / 2 || rows_c < need || rows_s < need ||
+            rc_t->pitch != rs_t->pitch) {
+            set_error("Attention failed: error.ShapeMismatch (rot_cos / rot_sin must be [.., seq, head_dim/2])");
+            return -3;
+        }
+        const size_t nq = (size_t)B * Hq * Sq * q->pitch, nk = (size_t)B * Hkv * Sk * k->pitch;
+        if (hipMalloc((void**)&rot, (nq + nk) * sizeof(float)) != hipSuccess) {
+            set_error("Attention failed: error.OutOfDeviceMemory");
+            return -3;
+        }
+        aule_hip::RopeArgs r;
+        r.cos = (const float*)rc_t->ptr; r.sin = (const float*)rs_t->ptr; r.table_pitch = (int)rc_t->pitch;
+        r.D = (int)D; r.layout = AULE_ROPE_INTERLEAVED; r.inverse = 0; r.pos_offset = 0; r.dtype = aule_hip::kF32;
+        r.in = q->ptr; r.out = rot; r.nheads = (long long)B * Hq; r.S = (int)Sq; r.pitch = (int)q->pitch;
+        int e = aule_hip::launch_rope(r, nullptr);
+        r.in = k->ptr; r.out = rot + nq; r.nheads = (long long)B * Hkv; r.S = (int)Sk; r.pitch = (int)k->pitch;
+        if (e == 0) e = aule_hip::launch_rope(r, nullptr);
+        if (e != 0) {
+            (void)hipFree(rot);
+            set_error("Attention failed: RoPE pass: %s", e > 0 ? hipGetErrorString((hipError_t)e) : "unsupported shape");
+            return -3;
+        }
+        qp = rot; kp = rot + nq;
+    }
+    int rc = run_fwd_f32(qp, kp, (const float*)v->ptr, (float*)o->ptr, nullptr,
                          B, Hq, Hkv, Sq, Sk, D, q->pitch, causal, window_size);
+    if (rot) (void)hipFree(rot);   // run_fwd_f32 synchronises
     if (rc != 0) {
         set_error("Attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported shape");
         return -3;
@@ -687,6 +723,59 @@ int32_t aule_attention_paged_decode_ex(const aule_paged_desc* d) {
     rc = aule_hip::launch_paged_decode(a, (hipStream_t)d->stream);
     if (rc != 0) {
         set_error("Paged attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");
+        return -4;
+    }
+    return 0;
+}
+
+int32_t aule_rope_ex(const aule_rope_desc* d) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init) {
+        set_error("Library not initialized. Call aule_init() first.");
+        return -1;
+    }
+    if (d == nullptr || d->struct_size != sizeof(aule_rope_desc)) {
+        set_error("RoPE failed: bad descriptor (struct_size mismatch)");
+        return -3;
+    }
+    if (d->dtype < 0 || d->dtype > 2) {
+        set_error("RoPE failed: unknown dtype %d", d->dtype);
+        return -3;
+    }
+    if (d->head_dim == 0 || (d->head_dim & 1) || d->row_pitch < d->head_dim) {
+        set_error("RoPE failed: head_dim (%u) must be even and <= row_pitch (%u)", d->head_dim, d->row_pitch);
+        return -3;
+    }
+    if (d->layout != AULE_ROPE_HALF && d->layout != AULE_ROPE_INTERLEAVED) {
+        set_error("RoPE failed: unknown layout %d", d->layout);
+        return -3;
+    }
+    if ((uint64_t)d->seq + d->pos_offset > d->table_len) {
+        set_error("RoPE failed: table too short (%u rows < seq %u + pos_offset %u)", d->table_len, d->seq, d->pos_offset);
+        return -3;
+    }
+    if (d->table_pitch != 0 && d->table_pitch < d->head_dim / 2) {
+        set_error("RoPE failed: table_pitch (%u) < head_dim/2", d->table_pitch);
+        return -3;
+    }
+    if (d->rows_bh == 0 || d->seq == 0) return 0;
+    if (d->rows_bh * d->seq >= (1ull << 40) || d->seq >= (1u << 30)) {
+        set_error("RoPE failed: problem too large");
+        return -3;
+    }
+    if (!d->in || !d->out || !d->cos || !d->sin) {
+        set_error("RoPE failed: null pointer");
+        return -3;
+    }
+    DeviceGuard g(d->device);
+    aule_hip::RopeArgs r;
+    r.in = d->in; r.out = d->out; r.cos = d->cos; r.sin = d->sin;
+    r.nheads = (long long)d->rows_bh; r.S = (int)d->seq; r.D = (int)d->head_dim; r.pitch = (int)d->row_pitch;
+    r.layout = d->layout; r.inverse = d->inverse != 0; r.pos_offset = (int)d->pos_offset; r.dtype = d->dtype;
+    r.table_pitch = (int)d->table_pitch;
+    const int rc = aule_hip::launch_rope(r, (hipStream_t)d->stream);
+    if (rc != 0) {
+        set_error("RoPE failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");
         return -4;
     }
     return 0;

@@ -67,6 +67,21 @@ struct PagedArgs {
     int dtype;
 };
 
+// Rotary embedding pass (rope_gfx950.hip): x [nheads, S, D] with `pitch` elements per row, tables [>= S + pos_offset, D/2]
+// fp32; layout 0 = half-split pairs (p, p + D/2), 1 = interleaved pairs (2p, 2p + 1); in == out is allowed.
+struct RopeArgs {
+    const void* in;
+    void* out;
+    const float* cos;
+    const float* sin;
+    long long nheads;   // B * H
+    int S, D, pitch;
+    int layout, inverse, pos_offset;
+    int dtype;
+    int table_pitch = 0;   // floats per table row; 0 = D/2
+};
+int launch_rope(const RopeArgs& a, hipStream_t stream);
+
 // Returns 0 on success, a hipError_t value on launch failure, -1 for an
 // unsupported (dtype, D) combination.
 int launch_paged_decode(const PagedArgs& a, hipStream_t stream);

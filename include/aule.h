@@ -192,6 +192,33 @@ typedef struct aule_paged_desc {
 /* 0 ok; -1 uninitialised; -3 invalid/unsupported arguments; -4 launch failure. */
 int32_t aule_attention_paged_decode_ex(const aule_paged_desc* desc);
 
+/* Rotary position embedding pass (additive; SURVEY.md 8f row N1, second half).  Replaces the rotation the           */
+/* reference fuses into its kernels: python/aule/triton_flash.py:32-52,:112-131,:165-180 (layout HALF) and            */
+/* shaders/attention_f32.comp:98-111,:132-145 (layout INTERLEAVED).  x is [rows_bh, seq, head_dim] with               */
+/* `row_pitch` elements per row; row s uses table row s + pos_offset; `inverse` applies the transposed rotation       */
+/* (dQ', dK' -> dQ, dK).  in == out is allowed.  Asynchronous on `stream`; device pointers.                           */
+#define AULE_ROPE_HALF 0         /* pairs (p, p + head_dim/2) */
+#define AULE_ROPE_INTERLEAVED 1  /* pairs (2p, 2p + 1) */
+typedef struct aule_rope_desc {
+    uint32_t struct_size;      /* = sizeof(aule_rope_desc) */
+    int32_t dtype;             /* aule_dtype */
+    uint64_t rows_bh;          /* batch * heads */
+    uint32_t seq, head_dim;    /* head_dim even (any size; 16-byte vector path when head_dim % 16 == 0) */
+    uint32_t row_pitch;        /* elements per row, >= head_dim */
+    uint32_t table_len;        /* rows of cos / sin; seq + pos_offset <= table_len */
+    uint32_t table_pitch;      /* floats per table row; 0 = head_dim/2 */
+    int32_t layout;            /* AULE_ROPE_* */
+    int32_t inverse;
+    uint32_t pos_offset;
+    int32_t device;
+    void* stream;
+    const void* in;
+    void* out;
+    const float* cos;          /* [table_len, head_dim/2] fp32 */
+    const float* sin;
+} aule_rope_desc;
+int32_t aule_rope_ex(const aule_rope_desc* desc);
+
 uint64_t aule_attention_backward_workspace_size(const aule_attn_bwd_desc* desc);
 
 /* Build/ABI identification: "aule-hip gfx950 <abi>" */

@@ -238,8 +238,39 @@ def paged_cases():
         print("paged", name, tuple(out.shape))
 
 
+def rope_cases():
+    """RoPE.  The reference's fused kernel (triton_flash.py:112-131, :165-180) does not run --
+    it slices register tensors (`q[:, :half_k]`) and builds `tl.arange(0, BLOCK_K // 2)` from a non-constexpr, which
+    Triton rejects on any backend -- so the fixtures record what its own self-test (:788-806) holds the fused path
+    to: the tables of precompute_rope_frequencies (:644-677), the half-split rotation apply_rope_separate
+    (:680-703; pairs (i, i + D/2), position = sequence index) and attention over the rotated Q, K by the
+    reference's FA-2 kernel (:386-476, interpreted)."""
+    from aule.triton_flash import precompute_rope_frequencies, apply_rope_separate
+    cases = [  # name, seed, B, Hq, Hkv, S, D, causal, table_len
+        ("mha_b2h8s64d64_causal", 90, 2, 8, 8, 64, 64, True, 64),        # triton_flash.py:808
+        ("mha_b1h8s32d128_causal", 91, 1, 8, 8, 32, 128, True, 32),      # :809
+        ("mha_b1h4s64d64_full", 92, 1, 4, 4, 64, 64, False, 64),         # :810
+        ("gqa_b1h4kv2s100d32_full", 93, 1, 4, 2, 100, 32, False, 128),
+        ("mqa_b1h4kv1s70d64_causal", 94, 1, 4, 1, 70, 64, True, 96),
+    ]
+    for name, seed, B, Hq, Hkv, S, D, causal, tlen in cases:
+        q, k, v = make_inputs(seed, B, Hq, Hkv, S, S, D)
+        tq, tk, tv = (torch.from_numpy(x) for x in (q, k, v))
+        cos, sin = precompute_rope_frequencies(tlen, D, device="cpu")
+        qr, kr = apply_rope_separate(tq, tk, cos, sin)
+        out = FlashAttentionTritonFunc.apply(qr.contiguous(), kr.contiguous(), tv, causal, None, -1, None, None)
+        rec = dict(kind="triton_rope", seed=seed, shape=np.array([B, Hq, Hkv, S, S, D]), causal=causal,
+                   scale=-1.0, dtype="fp32", q=q, k=k, v=v, cos=cos.numpy(), sin=sin.numpy(),
+                   q_rot=qr.numpy(), k_rot=kr.numpy(), out=out.numpy())
+        np.savez_compressed(os.path.join(OUT, f"rope_{name}.npz"), **rec)
+        print("rope", name, tuple(out.shape))
+
+
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "rope":
+        rope_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "paged":
         paged_cases()
         sys.exit(0)
@@ -251,3 +282,4 @@ if __name__ == "__main__":
     triton_amd_cases()
     triton_amd_window_cases()
     paged_cases()
+    rope_cases()

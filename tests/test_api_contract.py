@@ -96,3 +96,22 @@ def test_causal_argument_codes():
     for bad in ("diagonal", 3, -1):
         with pytest.raises(ValueError):
             causal_code(bad)
+
+
+def test_rope_exports_match_reference_signatures():
+    """flash_attention_rope / precompute_rope_frequencies / apply_rope_separate: triton_flash.py:561-570, :644-650,
+    :680 (exported by the reference at __init__.py:72-75)."""
+    assert list(inspect.signature(aule.flash_attention_rope).parameters) == \
+        ["q", "k", "v", "cos", "sin", "causal", "scale", "window_size"]
+    p = inspect.signature(aule.flash_attention_rope).parameters
+    assert p["causal"].default is True and p["scale"].default is None and p["window_size"].default == -1
+    assert list(inspect.signature(aule.precompute_rope_frequencies).parameters) == \
+        ["seq_len", "head_dim", "base", "device", "dtype"]
+    assert inspect.signature(aule.precompute_rope_frequencies).parameters["base"].default == 10000.0
+    assert list(inspect.signature(aule.apply_rope_separate).parameters) == ["q", "k", "cos", "sin"]
+    cos, sin = aule.precompute_rope_frequencies(8, 16, device="cpu")
+    assert tuple(cos.shape) == (8, 8) and float(cos[0].min()) == 1.0 and float(sin[0].abs().max()) == 0.0
+    import torch
+    x = torch.zeros(1, 1, 8, 16)
+    with pytest.raises(aule.AuleError):          # CPU tensors: no fallback
+        aule.flash_attention_rope(x, x, x, cos, sin)

@@ -208,6 +208,48 @@ def test_bottom_right_oracle_pinned_on_torch_lower_right_bias(oracle_mod):
     np.testing.assert_allclose(l_r, lse.reshape(-1)[rows], rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("path", golden_files("rope_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_rope_goldens_pin_the_rope_oracle(oracle_mod, path):
+    """tests/golden/rope_*: the reference's tables (triton_flash.py:644-677), its half-split rotation (:680-703) and
+    its FA-2 kernel over the rotated Q, K (what its self-test :788-806 expects of the fused path)."""
+    g = np.load(path)
+    D = g["q"].shape[-1]
+    c, s = oracle_mod.rope_tables(g["cos"].shape[0], D)
+    np.testing.assert_allclose(c, g["cos"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(s, g["sin"], rtol=0, atol=1e-5)
+    qr = oracle_mod.rope_f64(g["q"], g["cos"], g["sin"], "half")
+    kr = oracle_mod.rope_f64(g["k"], g["cos"], g["sin"], "half")
+    np.testing.assert_allclose(qr, g["q_rot"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(kr, g["k_rot"], rtol=1e-6, atol=1e-6)
+    out, _ = oracle_mod.fwd_f64(qr, kr, g["v"], bool(g["causal"]))
+    np.testing.assert_allclose(out, g["out"], rtol=1e-5, atol=1e-5)
+
+
+def test_rope_oracle_layouts_and_inverse(oracle_mod):
+    """Interleaved pairs restated from the reference's own test oracle (tests/test_rope_unit.py:76-86: view
+    [.., D/2, 2], x1' = x1 c - x2 s, x2' = x1 s + x2 c), the two layouts agreeing up to the pair permutation,
+    and the inverse being the transpose."""
+    rng = np.random.RandomState(12)
+    x = rng.randn(2, 3, 11, 16).astype(np.float32)
+    cos, sin = oracle_mod.rope_tables(20, 16)
+    got = oracle_mod.rope_f64(x, cos, sin, "interleaved", pos_offset=4)
+    xr = x.astype(np.float64).reshape(2, 3, 11, 8, 2)
+    c, s = cos[4:15].astype(np.float64), sin[4:15].astype(np.float64)
+    want = np.stack([xr[..., 0] * c - xr[..., 1] * s, xr[..., 0] * s + xr[..., 1] * c], axis=-1).reshape(x.shape)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+    perm = np.concatenate([np.arange(0, 16, 2), np.arange(1, 16, 2)])         # interleaved -> half-split order
+    half = oracle_mod.rope_f64(x[..., perm], cos, sin, "half", pos_offset=4)
+    np.testing.assert_allclose(half, got[..., perm], rtol=1e-6, atol=1e-6)
+    for layout in ("half", "interleaved"):
+        y = oracle_mod.rope_f64(x, cos, sin, layout)
+        np.testing.assert_allclose(oracle_mod.rope_f64(y, cos, sin, layout, inverse=True), x, rtol=1e-5, atol=1e-6)
+        # <R a, b> = <a, R^T b>
+        b = rng.randn(*x.shape).astype(np.float32)
+        lhs = (y.astype(np.float64) * b).sum()
+        rhs = (x.astype(np.float64) * oracle_mod.rope_f64(b, cos, sin, layout, inverse=True)).sum()
+        assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
 @pytest.mark.parametrize("path", golden_files("paged_"), ids=lambda p: p.split("/")[-1][:-4])
 def test_paged_goldens_pin_the_paged_oracle(oracle_mod, path):
     """Paged-KV decode (row N2): the reference's flash_attention_paged_amd (interpreted, fp16 I/O) vs the judge."""
