@@ -442,6 +442,13 @@ int32_t aule_attention_forward_gpu(aule_tensor_handle qh, aule_tensor_handle kh,
             set_error("Attention failed: error.OutOfDeviceMemory");
             return -3;
         }
+        // The pass writes columns [0, D) only; the fp32 kernels run at the padded width and need pad = 0
+        // (handle tensors are zero-padded on upload), so the copies must not carry allocator garbage there.
+        if (q->pitch != D && hipMemset(rot, 0, (nq + nk) * sizeof(float)) != hipSuccess) {
+            (void)hipFree(rot);
+            set_error("Attention failed: RoPE pass: could not clear the workspace");
+            return -3;
+        }
         aule_hip::RopeArgs r;
         r.cos = (const float*)rc_t->ptr; r.sin = (const float*)rs_t->ptr; r.table_pitch = (int)rc_t->pitch;
         r.D = (int)D; r.layout = AULE_ROPE_INTERLEAVED; r.inverse = 0; r.pos_offset = 0; r.dtype = aule_hip::kF32;

@@ -152,6 +152,15 @@ def test_rope_through_the_c_abi_handles(oracle_mod):
     emb = np.outer(np.arange(S, dtype=np.float32), freqs)
     cos, sin = np.cos(emb).astype(np.float32), np.sin(emb).astype(np.float32)
     with Aule() as a:
+        # Dirty the allocator first: head_dim 48 is stored with a row pitch of 64 and the kernels need the pad to be
+        # zero, so the rotated copies must not inherit freed memory (this passed by luck on fresh zero pages once).
+        for _ in range(4):
+            junk = [a.tensor((1, 4, 96, 64)) for _ in range(6)]
+            for t in junk:
+                t.upload(np.full((1, 4, 96, 64), np.nan, dtype=np.float32))
+            for t in junk:
+                t.destroy()
+                a._tensors.remove(t)
         out = a.attention(q, k, v, rot_cos=cos.reshape(1, 1, S, half), rot_sin=sin.reshape(1, 1, S, half), causal=False)
         base = a.attention(q, k, v, causal=False)
         # a GQA / cross-attention case with a longer table and a 2-D table
