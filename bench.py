@@ -35,6 +35,8 @@ CONFIGS = {
     "c4": (8, 32, 32, 8192, 8192, 128, "bf16", True, "fwd"),      # configs[3]: B=64 over 8 GPUs
     "c5": (1, 32, 1, 16384, 16384, 64, "fp16", False, "fwd"),     # configs[4]
     # SURVEY 8d note: the genuinely HBM-bound cross-attention points that bracket the regime configs[4] is labelled with
+    # c5b / c5c: K+V is 4 MB, resident in L2 / the Infinity Cache across steps -- their "hbm" roofline entry is the
+    # algorithmic byte rate of a launch-bound call, not DRAM traffic (tools/bench_decode_ws.py has the HBM rates)
     "c5b": (1, 32, 1, 1, 16384, 64, "fp16", False, "fwd"),        # decode-like: AI = 32 FLOP/B
     "c5c": (1, 32, 1, 64, 16384, 64, "fp16", False, "fwd"),       # AI ~ 1800 FLOP/B
 }
