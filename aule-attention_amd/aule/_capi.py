@@ -167,6 +167,7 @@ SIGNATURES = [
     ("aule_attention_paged_decode_ex", _I32, [ctypes.POINTER(PagedDesc)]),
     ("aule_rope_ex", _I32, [ctypes.POINTER(RopeDesc)]),
     ("aule_hip_build_info", ctypes.c_char_p, []),
+    ("aule_hip_debug_forward_route", _I32, [ctypes.POINTER(AttnDesc)]),
 ]
 
 _lib = None

@@ -847,6 +847,23 @@ int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
 
 const char* aule_hip_build_info(void) { return "aule-hip gfx950 abi1"; }
 
+/* Debug hook (not part of the drop-in ABI): the forward kernel aule_attention_forward_ex would launch for `d`
+ * -- 0 fp32, 1 ping-pong, 2 in-wave, 3 lock-step, 4 split-KV; -3 for a bad descriptor.  Pure host logic: no
+ * device, no aule_init() needed.  Used by the tests to pin which kernel a shape exercises. */
+int32_t aule_hip_debug_forward_route(const aule_attn_desc* d) {
+    if (d == nullptr || d->struct_size != sizeof(aule_attn_desc)) return -3;
+    if (d->causal < 0 || d->causal > AULE_CAUSAL_BOTTOM_RIGHT) return -3;
+    FwdArgs a;
+    a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv;
+    a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
+    if (a.Hkv <= 0 || a.Hq % a.Hkv != 0) return -3;
+    a.causal = d->causal != 0;
+    a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? a.Sk - a.Sq : 0;
+    a.dtype = d->dtype;
+    a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
+    return aule_hip::fwd_route(a);
+}
+
 /* Debug hook (not part of the drop-in ABI): bf16 D=128 forward with per-phase s_memtime stamps of
  * workgroup 0 written to `stamps` (device pointer, 8 * 256 uint64).  Used by tools/timeline.py. */
 int32_t aule_hip_debug_forward_timeline(const aule_attn_desc* d, unsigned long long* stamps) {

@@ -342,6 +342,18 @@ static bool splitkv_enabled() {
     return v == 1;
 }
 
+// Which kernel launch_fwd() picks for `a` (host logic only, no device work): 0 fp32, 1 ping-pong, 2 in-wave,
+// 3 lock-step v1, 4 split-KV.  Lets the tests pin the path a shape exercises (the in-wave kernel can still decline
+// a shape at launch and fall through to the ping-pong kernel).
+int fwd_route(const FwdArgs& a) {
+    if (a.dtype == kF32) return 0;
+    if (splitkv_enabled() && splitkv_applicable(a)) return 4;
+    const bool pp_only = a.window > 0 || (a.causal && a.coff != 0);
+    if (fwd_kernel_choice() == 2 && !pp_only) return 2;
+    if (!use_v1() || pp_only) return 1;
+    return 3;
+}
+
 int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (a.dtype == kF32) return launch_fwd_f32(a, stream);
     if (splitkv_enabled() && splitkv_applicable(a)) return launch_fwd_splitkv(a, stream);

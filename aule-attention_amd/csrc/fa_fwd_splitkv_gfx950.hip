@@ -390,6 +390,9 @@ int launch_paged_decode(const PagedArgs& a, hipStream_t stream) {
     return -1;
 }
 
+#ifndef AULE_SPLITKV_MAX_UNITS
+#define AULE_SPLITKV_MAX_UNITS 128   // (A/B builds override it: tools/split_ab.py)
+#endif
 // Shapes the split-KV path takes over from the tiled kernels: 16-bit, non-causal, no window, short queries against
 // long K/V -- few enough Q blocks that the tiled kernels would leave most CUs idle.
 bool splitkv_applicable(const FwdArgs& a) {
@@ -398,7 +401,14 @@ bool splitkv_applicable(const FwdArgs& a) {
     if (a.D != 32 && a.D != 64 && a.D != 128) return false;
     if (a.Sq > 64 || a.Sk < 1024) return false;
     const long long tiled_wgs = (long long)a.B * a.Hq * ((a.Sq + 255) / 256);
-    return tiled_wgs < 512;   // less than two workgroups per CU
+    if (tiled_wgs >= 512) return false;   // two workgroups per CU: the tiled kernel fills the chip
+    // K/V is streamed once per 32-row tile of packed rows, so `units` of them re-read it that many times and every
+    // one adds partials to combine.  Measured (tools/split_grid.py, bf16 D128, Sk 2048 / 8192): units <= 128 wins
+    // in every case (2-8x at B = 1); units = 256 is break-even (-20..25 % at Sk 2048, +4..7 % at 8192); units >= 512
+    // loses (B8 Hq32 Hkv8 Sq64 Sk8192: 318 vs 194 us).
+    const int g = a.Hq / a.Hkv;
+    const long long units = (long long)a.B * a.Hkv * ((g * a.Sq + 31) / 32);
+    return units <= AULE_SPLITKV_MAX_UNITS;
 }
 
 int launch_fwd_splitkv(const FwdArgs& a, hipStream_t stream) {

@@ -86,6 +86,7 @@ int launch_rope(const RopeArgs& a, hipStream_t stream);
 // unsupported (dtype, D) combination.
 int launch_paged_decode(const PagedArgs& a, hipStream_t stream);
 int launch_fwd(const FwdArgs& a, hipStream_t stream);
+int fwd_route(const FwdArgs& a);   // 0 fp32, 1 ping-pong, 2 in-wave, 3 v1, 4 split-KV (host logic only)
 int launch_bwd(const BwdArgs& a, hipStream_t stream);
 
 // Bytes of device workspace launch_bwd needs: delta [B,Hq,Sq] fp32, plus (16-bit GQA/MQA problems that

@@ -223,6 +223,9 @@ uint64_t aule_attention_backward_workspace_size(const aule_attn_bwd_desc* desc);
 
 /* Build/ABI identification: "aule-hip gfx950 <abi>" */
 const char* aule_hip_build_info(void);
+/* Debug (not part of the drop-in ABI): forward kernel aule_attention_forward_ex would pick for `desc` --        */
+/* 0 fp32, 1 ping-pong, 2 in-wave, 3 lock-step, 4 split-KV; -3 bad descriptor.  Host logic only, no aule_init(). */
+int32_t aule_hip_debug_forward_route(const aule_attn_desc* desc);
 
 #ifdef __cplusplus
 }

@@ -97,3 +97,43 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "import oracle" not in txt and "liboracle" not in txt and "oracle/" not in txt, (dp, f)
+
+
+def _route(B, Hq, Hkv, Sq, Sk, D, dtype=2, causal=0, window=-1):
+    lib = ctypes.CDLL(_capi.find_library())
+    lib.aule_hip_debug_forward_route.restype = ctypes.c_int32
+    lib.aule_hip_debug_forward_route.argtypes = [ctypes.POINTER(_capi.AttnDesc)]
+    d = _capi.AttnDesc()
+    d.struct_size = ctypes.sizeof(_capi.AttnDesc)
+    d.dtype = dtype
+    d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
+    d.causal, d.window_size = causal, window
+    return lib.aule_hip_debug_forward_route(ctypes.byref(d))
+
+
+def test_forward_routing_rule(monkeypatch):
+    """The dispatcher is host logic (no device needed).  Split-KV (4) only where tools/split_grid.py measured it
+    ahead of the tiled kernel: 16-bit, non-causal, no window, Sq <= 64, Sk >= 1024, < 512 tiled workgroups and at
+    most 128 units = B * Hkv * ceil(g * Sq / 32); everything else 16-bit goes to the ping-pong kernel (1), fp32 to 0."""
+    for var in ("AULE_HIP_FWD_KERNEL", "AULE_HIP_FWD_SPLITKV"):
+        monkeypatch.delenv(var, raising=False)
+    SPLIT, PP, F32 = 4, 1, 0
+    assert _route(1, 32, 1, 1, 16384, 64, dtype=1) == SPLIT          # C5b
+    assert _route(1, 32, 1, 64, 16384, 64, dtype=1) == SPLIT         # C5c: 64 units
+    assert _route(8, 32, 8, 1, 8192, 128) == SPLIT                   # batch-8 GQA decode: 64 units
+    assert _route(8, 32, 8, 16, 8192, 128) == SPLIT                  # 128 units: the last winning point
+    assert _route(8, 32, 8, 32, 8192, 128) == PP                     # 256 units: break-even, tiled
+    assert _route(8, 32, 8, 64, 8192, 128) == PP                     # 512 units: split-KV measured 318 vs 194 us
+    assert _route(8, 32, 32, 1, 2048, 128) == PP                     # MHA decode, 256 units: 69 vs 53 us
+    assert _route(16, 32, 8, 1, 8192, 128) == PP                     # 512 tiled workgroups fill the chip
+    assert _route(1, 32, 8, 1, 512, 128) == PP                       # short K/V
+    assert _route(1, 32, 8, 65, 8192, 128) == PP                     # Sq > 64
+    assert _route(1, 32, 8, 1, 8192, 128, causal=1) == PP            # causal
+    assert _route(1, 32, 8, 1, 8192, 128, causal=2) == PP            # bottom-right: shifted causal lives in pp
+    assert _route(1, 32, 8, 8, 8192, 128, window=4) == PP            # window
+    assert _route(1, 32, 8, 8, 8192, 128, window=64) == SPLIT        # W >= Sq masks nothing: dropped
+    assert _route(1, 32, 8, 1, 8192, 128, dtype=0) == F32
+    assert _route(4, 32, 32, 4096, 4096, 128, causal=1) == PP        # the headline shape
+    assert _route(1, 3, 2, 1, 8192, 128) == -3                       # heads not divisible
+    # (AULE_HIP_FWD_SPLITKV=0 is read once per process into a static, so the off-switch is not testable here;
+    #  tools/split_grid.py exercises it in a process of its own)

@@ -22,6 +22,20 @@ CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, scale
 ]
 
 
+def _route(case):
+    """Kernel the dispatcher picks for `case` (aule_hip_debug_forward_route: 4 = split-KV)."""
+    import ctypes
+    from aule import _capi
+    dtype, B, Hq, Hkv, Sq, Sk, D, _ = case
+    lib = _capi.get_lib()
+    d = _capi.AttnDesc()
+    d.struct_size = ctypes.sizeof(_capi.AttnDesc)
+    d.dtype = {"fp32": 0, "fp16": 1, "bf16": 2}[dtype]
+    d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
+    d.causal, d.window_size = 0, -1
+    return lib.aule_hip_debug_forward_route(ctypes.byref(d))
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(x) for x in c))
 def test_splitkv_forward_vs_oracle(case, oracle_mod):
     import torch
@@ -31,6 +45,7 @@ def test_splitkv_forward_vs_oracle(case, oracle_mod):
     q, k, v = (quantize(rng.randn(*s).astype(np.float32), dtype) for s in ((B, Hq, Sq, D), (B, Hkv, Sk, D), (B, Hkv, Sk, D)))
     sc = (1 / math.sqrt(D)) if scale is None else scale
     dev = lambda a: torch.from_numpy(a).to("cuda", torch_dtype(dtype))
+    assert _route(case) == 4, "this shape no longer takes the split-KV kernel: the test would cover the tiled one"
     out, lse = at.fwd_raw(dev(q), dev(k), dev(v), False, sc)
     ref, ref_lse = oracle_mod.fwd_f64(q, k, v, False, scale)
     atol, rtol = fwd_tol(dtype, np.abs(v).max())
