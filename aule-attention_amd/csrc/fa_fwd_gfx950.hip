@@ -312,6 +312,8 @@ int set_attr_16() {
 int launch_fwd_f32(const FwdArgs& a, hipStream_t stream);  // fa_fwd_f32.hip
 int configure_fwd_f32();
 int launch_fwd_pp(const FwdArgs& a, hipStream_t stream);   // fa_fwd_pp_gfx950.hip
+int launch_fwd_pp_split(const FwdArgs& a, hipStream_t stream);
+bool pp_split_applicable(const FwdArgs& a);
 int configure_fwd_pp();
 int launch_fwd_iw(const FwdArgs& a, hipStream_t stream);   // fa_fwd_iw_gfx950.hip (-1: shape not covered)
 int configure_fwd_iw();
@@ -342,12 +344,32 @@ static bool splitkv_enabled() {
     return v == 1;
 }
 
+// Non-causal problems that the plain tiled launch would run badly (few workgroups, or Q blocks mostly without rows):
+// 4 = wave-per-chunk split-KV kernel, 5 = tiled kernel with packed rows + KV splits, 0 = neither.  Measured on one
+// box per comparison (tools/ppsplit_grid.py, tools/ppsplit_decode.py): the tiled variant wins almost
+// everywhere, including Sq = 1 (its combine merges <= 32 partials per row, the wave kernel's hundreds); the wave kernel
+// keeps the pure streaming corner -- many units, at most half a row tile of packed rows, K+V beyond ~100 MB -- where
+// it is 10-15 % ahead at D = 128 and 35-55 % at D = 64.  Differences below ~8 % on these kernels are noise.
+static int short_query_route(const FwdArgs& a) {
+    if (a.dtype == kF32 || a.causal || a.window > 0) return 0;
+    const bool wave_ok = splitkv_enabled() && splitkv_applicable(a);
+    const bool tiled_ok = pp_split_applicable(a) && !use_v1() && fwd_kernel_choice() != 2;
+    if (wave_ok && tiled_ok) {
+        const long long units = (long long)a.B * a.Hkv;
+        const long long rows = (long long)(a.Hq / a.Hkv) * a.Sq;
+        const double kv_bytes = 2.0 * (double)units * a.Sk * a.D * 2.0;
+        return (units >= 32 && rows <= 16 && kv_bytes >= 100e6) ? 4 : 5;
+    }
+    return wave_ok ? 4 : (tiled_ok ? 5 : 0);
+}
+
 // Which kernel launch_fwd() picks for `a` (host logic only, no device work): 0 fp32, 1 ping-pong, 2 in-wave,
-// 3 lock-step v1, 4 split-KV.  Lets the tests pin the path a shape exercises (the in-wave kernel can still decline
+// 3 lock-step v1, 4 split-KV, 5 tiled kernel with packed rows + KV splits.  Lets the tests pin the path a shape exercises (the in-wave kernel can still decline
 // a shape at launch and fall through to the ping-pong kernel).
 int fwd_route(const FwdArgs& a) {
     if (a.dtype == kF32) return 0;
-    if (splitkv_enabled() && splitkv_applicable(a)) return 4;
+    const int sq = short_query_route(a);
+    if (sq) return sq;
     const bool pp_only = a.window > 0 || (a.causal && a.coff != 0);
     if (fwd_kernel_choice() == 2 && !pp_only) return 2;
     if (!use_v1() || pp_only) return 1;
@@ -356,7 +378,9 @@ int fwd_route(const FwdArgs& a) {
 
 int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (a.dtype == kF32) return launch_fwd_f32(a, stream);
-    if (splitkv_enabled() && splitkv_applicable(a)) return launch_fwd_splitkv(a, stream);
+    const int sq = short_query_route(a);
+    if (sq == 4) return launch_fwd_splitkv(a, stream);
+    if (sq == 5) return launch_fwd_pp_split(a, stream);
     const bool pp_only = a.window > 0 || (a.causal && a.coff != 0);  // window / shifted causal live in the ping-pong kernel
     if (fwd_kernel_choice() == 2 && !pp_only) {
         const int rc = launch_fwd_iw(a, stream);

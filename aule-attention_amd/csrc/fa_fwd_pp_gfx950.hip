@@ -44,11 +44,23 @@ struct FwdPPParams {
     int pair;     // process Q blocks (i, nqb-1-i) in one workgroup
     int window;   // sliding window: key j visible to query i only if i - j < window (<= 0: off)
     int coff;     // causal position offset (query i sits at position i + coff; 0 = top-left rule)
+    // SPLIT kernels only (short packed queries against long K/V, launch_pp_split): workgroup = (base work item, KV split)
+    int nbase;          // base work items = nwork * B * Hq; blockIdx.x = split * nbase + base item
+    int chunk;          // keys per split (multiple of kKVTile)
+    int part_rows;      // rows of one partial plane = units * prow_per_unit
+    int prow_per_unit;  // packed rows reserved per (batch, kv-head) unit (multiple of 32)
+    float* part;        // [nsplit][part_rows][D + 2] fp32: un-normalised O, m (log2 units), l -- fa_fwd_splitkv_combine
     int dbg_flags;            // timeline build only: bit0 = group 1 computes nothing, bit1 = group 0 computes nothing
     unsigned long long* dbg;  // timeline build only: [8 waves][kTLMax] s_memtime stamps of workgroup 0
 };
 
 constexpr int kTLMax = 256;
+
+// Which shapes take the SPLIT instances: to be set from measurements (tools/ppsplit_grid.py); until then every shape
+// that passes the structural tests in pp_split_applicable() does.
+#ifndef AULE_PPSPLIT_RULE
+#define AULE_PPSPLIT_RULE true
+#endif
 
 #ifndef AULE_MPRIO
 #define AULE_MPRIO 1
@@ -183,9 +195,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, uns
 // WIN: sliding window (the convention of triton_flash_amd.py:179-183: on top of the causal rule,
 // key j is visible to query i only if i - j < window).  KV tiles entirely before the window of the Q block's first
 // row are skipped by the whole workgroup; the online softmax tolerates rows whose keys in a tile are all masked.
-template <class T, int D, bool CAUSAL, bool TL = false, bool RAWOK = false, bool WIN = false>
+template <class T, int D, bool CAUSAL, bool TL = false, bool RAWOK = false, bool WIN = false, bool SPLIT = false>
 __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
     static_assert(!(RAWOK && WIN), "the fixed-reference pass needs a visible key in the first tile of every row");
+    static_assert(!SPLIT || (!CAUSAL && !WIN && !TL), "KV splits: position-independent masks only");
     using C = Cfg<D>;
     using v8 = typename T::v8;
     constexpr int RB = C::RB, RBP = C::RBP, CPR = C::CPR, KTILE = C::KTILE, VTILE = C::VTILE;
@@ -214,11 +227,15 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
         }
     };
 
-    const WorkItem w = decode_work(blockIdx.x, p.B, p.Hq, p.Hkv, p.nwork, false);
-    const int Sq = p.Sq, Sk = p.Sk;
+    // SPLIT: this workgroup sees keys [kv_begin, kv_begin + Sk) of its head as if they were the whole K/V (the
+    // masks are position-independent), and leaves an un-normalised partial instead of O / LSE.
+    const int split = SPLIT ? (int)(blockIdx.x / (unsigned)p.nbase) : 0;
+    const WorkItem w = decode_work(SPLIT ? (int)(blockIdx.x % (unsigned)p.nbase) : (int)blockIdx.x, p.B, p.Hq, p.Hkv, p.nwork, false);
+    const int kv_begin = SPLIT ? split * p.chunk : 0;
+    const int Sq = p.Sq, Sk = SPLIT ? min(p.chunk, p.Sk - kv_begin) : p.Sk;
     const float c = p.c;
 
-    const size_t kvhead = (size_t)(w.b * p.Hkv + w.hk) * Sk * RB;
+    const size_t kvhead = ((size_t)(w.b * p.Hkv + w.hk) * p.Sk + kv_begin) * RB;
     const __amdgpu_buffer_rsrc_t krs = make_srd(reinterpret_cast<const char*>(p.k) + kvhead, (unsigned)Sk * RB);
     const __amdgpu_buffer_rsrc_t vrs = make_srd(reinterpret_cast<const char*>(p.v) + kvhead, (unsigned)Sk * RB);
 
@@ -584,6 +601,42 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
         //      global stores are whole 16-byte chunks of full rows (the direct form is 16 row-strided
         //      8-byte stores per lane and was ~16k cycles per Q block); LSE = (m + log2 l) * ln2
         const float lt = l + xhalf(l);
+        if constexpr (SPLIT) {
+            // partial (O^T un-normalised, m, l) in fp32; rows go through the wave's Q slab like the O epilogue below,
+            // half a row (D/2 floats = RB bytes) per pass, so that the global stores are whole rows
+            float* const prow0 = p.part + ((size_t)split * p.part_rows + (size_t)(w.b * p.Hkv + w.hk) * p.prow_per_unit) * (D + 2);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        constexpr int HALF = D / 2;
+                        const int d0 = 32 * d + 8 * g4;   // this lane holds columns d0 + 4 hi .. + 3
+                        if (d0 / HALF == h) {
+                            const f32x4_t x = {o[d][4 * g4 + 0], o[d][4 * g4 + 1], o[d][4 * g4 + 2], o[d][4 * g4 + 3]};
+                            *reinterpret_cast<f32x4_t*>(Qs + l31 * RBP + ((d0 % HALF) + 4 * hi) * 4) = x;
+                        }
+                    }
+#pragma unroll
+                for (int i = 0; i < (32 * CPR) / 64; ++i) {
+                    const int cidx = lane + 64 * i;
+                    const int row = cidx / CPR, cc = cidx % CPR;
+                    const f32x4_t x = *reinterpret_cast<const f32x4_t*>(Qs + row * RBP + cc * 16);
+                    if (q0w + row < Sq) {
+                        float* dst = prow0 + (size_t)(q0w + row) * (D + 2) + h * (D / 2) + cc * 4;
+                        // rows are (D + 2) floats apart: 8-byte aligned, not 16
+                        *reinterpret_cast<f32x2_t*>(dst) = f32x2_t{x[0], x[1]};
+                        *reinterpret_cast<f32x2_t*>(dst + 2) = f32x2_t{x[2], x[3]};
+                    }
+                }
+            }
+            if (qrow < Sq && hi == 0) {
+                prow0[(size_t)qrow * (D + 2) + D] = m;
+                prow0[(size_t)qrow * (D + 2) + D + 1] = lt;
+            }
+            continue;
+        }
         const float inv = (WIN && !(lt > 0.f)) ? 0.f : 1.0f / lt;  // a row with no visible key at all: O = 0, LSE = -inf
 #pragma unroll
         for (int d = 0; d < DB; ++d)
@@ -662,6 +715,70 @@ int launch_pp(const FwdArgs& a, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// ---- short packed queries against long K/V on the tiled kernel (SPLIT instances) -------------------------------
+// Non-causal, no window: masks do not depend on the query position, so (1) the g = Hq/Hkv query heads that share a
+// K/V head are contiguous in Q / O / LSE and can be read as ONE head with g*Sq rows (B' = B*Hkv, Hq' = Hkv' = 1):
+// a 256-row Q block is then full of real rows and K/V is streamed once per group; (2) the key range is cut into
+// `nsplit` chunks, one workgroup each, so that B'*nqb'*nsplit workgroups fill the chip; every workgroup leaves an
+// fp32 partial and fa_fwd_splitkv_combine (fa_fwd_splitkv_gfx950.hip) merges them.  Complements the wave-per-chunk
+// split-KV kernel, which wins while a unit has few packed rows (it is HBM-bound; this one is MFMA-bound).
+struct PPSplitPlan {
+    int g, rows, nqb, nbase, ntiles, nsplit, chunk, nrt;
+};
+
+static PPSplitPlan pp_split_plan(const FwdArgs& a) {
+    PPSplitPlan s;
+    s.g = a.Hq / a.Hkv;
+    s.rows = s.g * a.Sq;
+    s.nqb = (s.rows + kQBlock - 1) / kQBlock;
+    s.nbase = a.B * a.Hkv * s.nqb;
+    s.ntiles = (a.Sk + kKVTile - 1) / kKVTile;
+    int want = 256 / (s.nbase > 0 ? s.nbase : 1);          // one workgroup per CU (137 KB of LDS each)
+    const int most = s.ntiles / 4;                          // at least 4 tiles per split: the prologue costs ~3
+    if (want > most) want = most;
+    if (want < 1) want = 1;
+    const int tiles_per = (s.ntiles + want - 1) / want;
+    s.chunk = tiles_per * kKVTile;
+    s.nsplit = (a.Sk + s.chunk - 1) / s.chunk;
+    s.nrt = (s.rows + 31) / 32;
+    return s;
+}
+
+template <class T, int D>
+int launch_pp_split(const FwdArgs& a, hipStream_t stream) {
+    const PPSplitPlan s = pp_split_plan(a);
+    FwdPPParams p;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.o = nullptr; p.lse = nullptr;
+    p.B = a.B * a.Hkv; p.Hq = 1; p.Hkv = 1; p.Sq = s.rows; p.Sk = a.Sk;
+    float c = a.scale * kLog2e;
+    p.negq = c < 0.f;
+    c = c < 0.f ? -c : c;
+    if (c == 0.f) c = 1e-30f;
+    p.c = c;
+    p.nqb = s.nqb; p.pair = 0; p.nwork = s.nqb;
+    p.dbg = nullptr; p.dbg_flags = 0; p.window = 0; p.coff = 0;
+    p.nbase = s.nbase; p.chunk = s.chunk;
+    p.prow_per_unit = s.nrt * 32;
+    p.part_rows = a.B * a.Hkv * p.prow_per_unit;
+    const size_t bytes = (size_t)s.nsplit * p.part_rows * (D + 2) * sizeof(float);
+    void* ws = nullptr;
+    hipError_t e = hipMallocAsync(&ws, bytes, stream);   // stream-ordered, like the split-KV kernel's workspace
+    if (e != hipSuccess) return (int)e;
+    p.part = static_cast<float*>(ws);
+    const dim3 grid((unsigned)(s.nbase * s.nsplit)), block(512);
+    const size_t lds = Cfg<D>::LDS + 16;
+    bool raw = false;
+    if constexpr (std::is_same<T, Bf16Traits>::value) raw = raw_softmax_enabled();
+    if constexpr (std::is_same<T, Bf16Traits>::value) {
+        if (raw) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false, false, true, false, true>), grid, block, lds, stream, p);
+    }
+    if (!raw) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false, false, false, false, true>), grid, block, lds, stream, p);
+    int rc = (int)hipGetLastError();
+    if (rc == 0) rc = launch_splitkv_combine(a, p.part, s.nsplit, s.nrt, stream);
+    (void)hipFreeAsync(ws, stream);
+    return rc;
+}
+
 template <class T, int D>
 int set_attr_pp() {
     int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, true>),
@@ -672,7 +789,11 @@ int set_attr_pp() {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, false, false, false, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, false, false, false, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
     if constexpr (std::is_same<T, Bf16Traits>::value) {
+        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, false, false, true, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
         rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, true, false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
         rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, false, false, true>),
@@ -723,6 +844,48 @@ int launch_fwd_pp(const FwdArgs& a, hipStream_t stream) {
         if (a.D == 128) return launch_pp<F16Traits, 128>(a, stream);
         if (a.D == 64) return launch_pp<F16Traits, 64>(a, stream);
         if (a.D == 32) return launch_pp<F16Traits, 32>(a, stream);
+    }
+    return -1;
+}
+
+// Shapes for the SPLIT instances.  AULE_HIP_FWD_PPSPLIT=0 turns the path off (A/B measurements).
+bool pp_split_applicable(const FwdArgs& a) {
+    static const int on = [] {
+        const char* e = getenv("AULE_HIP_FWD_PPSPLIT");
+        return (e != nullptr && e[0] == '0') ? 0 : 1;
+    }();
+    if (!on) return false;
+    if (a.dtype != kBF16 && a.dtype != kF16) return false;
+    if (a.causal || a.window > 0) return false;
+    if (a.D != 32 && a.D != 64 && a.D != 128) return false;
+    if ((long long)a.Hq / a.Hkv * a.Sq >= (1 << 24)) return false;
+    const PPSplitPlan s = pp_split_plan(a);
+    const long long tiled_wgs = (long long)a.B * a.Hq * ((a.Sq + kQBlock - 1) / kQBlock);
+    // worth it when the plain launch leaves most CUs idle or most waves of a Q block without rows, and the split
+    // launch does not: at least two splits, or packing alone folds >= 2 heads into one block
+    if (tiled_wgs >= 256 && s.nsplit < 2 && s.nbase * 2 > tiled_wgs) return false;
+    if (s.nsplit < 2 && s.nbase == tiled_wgs) return false;   // nothing to gain: same workgroups, plus a combine
+    // The path costs a second launch, a stream-ordered allocation and a combine with one workgroup per output row:
+    // a floor of ~18 us, and a cost that grows with the rows while the gain grows with Sk.  Measured edges
+    // (tools/ppsplit_edges.py, previous behaviour -> this path):
+    //   Sk <= 512, B <= 8:  9-16 us -> 18-21 us (loses);  B = 32 (1024 plain workgroups): 62 -> 36 us at Sk 512 (wins)
+    //   16 k rows: Sk 1024 27 -> 47 us, Sk 2048 47 -> 54 us (loses); Sk 4096 89 -> 65 us, Sk 8192 166 -> 93 us (wins)
+    //   32 k rows: Sk 1024 19 -> 61 us, Sk 4096 67 -> 88 us (loses); Sk 8192 178 -> 165 us (wins)
+    // rows <= 4 Sk separates all of these; it is a fit to this sample, not a model.
+    if (a.Sk < 1024 && tiled_wgs < 1024) return false;
+    if ((long long)a.B * a.Hq * a.Sq > 4LL * a.Sk) return false;
+    return AULE_PPSPLIT_RULE;
+}
+
+int launch_fwd_pp_split(const FwdArgs& a, hipStream_t stream) {
+    if (a.dtype == kBF16) {
+        if (a.D == 128) return launch_pp_split<Bf16Traits, 128>(a, stream);
+        if (a.D == 64) return launch_pp_split<Bf16Traits, 64>(a, stream);
+        if (a.D == 32) return launch_pp_split<Bf16Traits, 32>(a, stream);
+    } else if (a.dtype == kF16) {
+        if (a.D == 128) return launch_pp_split<F16Traits, 128>(a, stream);
+        if (a.D == 64) return launch_pp_split<F16Traits, 64>(a, stream);
+        if (a.D == 32) return launch_pp_split<F16Traits, 32>(a, stream);
     }
     return -1;
 }

@@ -411,6 +411,33 @@ bool splitkv_applicable(const FwdArgs& a) {
     return units <= AULE_SPLITKV_MAX_UNITS;
 }
 
+// The combine pass on its own, for partials written by another kernel (fa_fwd_pp_gfx950.hip SPLIT instances) in
+// the same layout: part [npart][B*Hkv*nrt*32][D + 2] fp32, packed row r of a unit = (head r / Sq of the group, query r % Sq).
+template <class T, int D>
+static int combine_only(const FwdArgs& a, float* part, int npart, int nrt, hipStream_t stream) {
+    SplitParams p;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o; p.lse = a.lse; p.part = part;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
+    p.c = 1.f; p.negq = 0; p.nrt = nrt; p.chunk_tiles = 0; p.npart = npart;
+    p.rows_total = a.B * a.Hkv * nrt * 32;
+    p.block_tables = nullptr; p.context_lens = nullptr; p.block_size = 0; p.max_blocks = 0; p.window = 0;
+    hipLaunchKernelGGL((fa_fwd_splitkv_combine<T, D>), dim3((unsigned)p.rows_total), dim3(256), 0, stream, p);
+    return (int)hipGetLastError();
+}
+
+int launch_splitkv_combine(const FwdArgs& a, float* part, int npart, int nrt, hipStream_t stream) {
+    if (a.dtype == kBF16) {
+        if (a.D == 128) return combine_only<Bf16Traits, 128>(a, part, npart, nrt, stream);
+        if (a.D == 64) return combine_only<Bf16Traits, 64>(a, part, npart, nrt, stream);
+        if (a.D == 32) return combine_only<Bf16Traits, 32>(a, part, npart, nrt, stream);
+    } else if (a.dtype == kF16) {
+        if (a.D == 128) return combine_only<F16Traits, 128>(a, part, npart, nrt, stream);
+        if (a.D == 64) return combine_only<F16Traits, 64>(a, part, npart, nrt, stream);
+        if (a.D == 32) return combine_only<F16Traits, 32>(a, part, npart, nrt, stream);
+    }
+    return -1;
+}
+
 int launch_fwd_splitkv(const FwdArgs& a, hipStream_t stream) {
     if (a.dtype == kBF16) {
         if (a.D == 128) return launch_split<Bf16Traits, 128>(a, stream);

@@ -86,7 +86,9 @@ int launch_rope(const RopeArgs& a, hipStream_t stream);
 // unsupported (dtype, D) combination.
 int launch_paged_decode(const PagedArgs& a, hipStream_t stream);
 int launch_fwd(const FwdArgs& a, hipStream_t stream);
-int fwd_route(const FwdArgs& a);   // 0 fp32, 1 ping-pong, 2 in-wave, 3 v1, 4 split-KV (host logic only)
+// merge partials [npart][B*Hkv*nrt*32][D+2] fp32 (un-normalised O, m in log2 units, l) into O / LSE (fa_fwd_splitkv_gfx950.hip)
+int launch_splitkv_combine(const FwdArgs& a, float* part, int npart, int nrt, hipStream_t stream);
+int fwd_route(const FwdArgs& a);   // 0 fp32, 1 ping-pong, 2 in-wave, 3 v1, 4 split-KV, 5 tiled + packed rows + KV splits (host logic only)
 int launch_bwd(const BwdArgs& a, hipStream_t stream);
 
 // Bytes of device workspace launch_bwd needs: delta [B,Hq,Sq] fp32, plus (16-bit GQA/MQA problems that

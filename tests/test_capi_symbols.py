@@ -112,26 +112,34 @@ def _route(B, Hq, Hkv, Sq, Sk, D, dtype=2, causal=0, window=-1):
 
 
 def test_forward_routing_rule(monkeypatch):
-    """The dispatcher is host logic (no device needed).  Split-KV (4) only where tools/split_grid.py measured it
-    ahead of the tiled kernel: 16-bit, non-causal, no window, Sq <= 64, Sk >= 1024, < 512 tiled workgroups and at
-    most 128 units = B * Hkv * ceil(g * Sq / 32); everything else 16-bit goes to the ping-pong kernel (1), fp32 to 0."""
-    for var in ("AULE_HIP_FWD_KERNEL", "AULE_HIP_FWD_SPLITKV"):
+    """The dispatcher is host logic (no device needed).  Non-causal 16-bit problems that the plain tiled launch would
+    run badly go to one of two kernels by a MEASURED rule (tools/ppsplit_grid.py, tools/ppsplit_decode.py):
+    5 = tiled kernel with packed rows + KV splits (most shapes), 4 = wave-per-chunk split-KV kernel (>= 32 units,
+    <= 16 packed rows, K+V >= 100 MB); everything else 16-bit goes to the ping-pong kernel (1), fp32 to 0."""
+    for var in ("AULE_HIP_FWD_KERNEL", "AULE_HIP_FWD_SPLITKV", "AULE_HIP_FWD_PPSPLIT"):
         monkeypatch.delenv(var, raising=False)
-    SPLIT, PP, F32 = 4, 1, 0
-    assert _route(1, 32, 1, 1, 16384, 64, dtype=1) == SPLIT          # C5b
-    assert _route(1, 32, 1, 64, 16384, 64, dtype=1) == SPLIT         # C5c: 64 units
-    assert _route(8, 32, 8, 1, 8192, 128) == SPLIT                   # batch-8 GQA decode: 64 units
-    assert _route(8, 32, 8, 16, 8192, 128) == SPLIT                  # 128 units: the last winning point
-    assert _route(8, 32, 8, 32, 8192, 128) == PP                     # 256 units: break-even, tiled
-    assert _route(8, 32, 8, 64, 8192, 128) == PP                     # 512 units: split-KV measured 318 vs 194 us
-    assert _route(8, 32, 32, 1, 2048, 128) == PP                     # MHA decode, 256 units: 69 vs 53 us
-    assert _route(16, 32, 8, 1, 8192, 128) == PP                     # 512 tiled workgroups fill the chip
-    assert _route(1, 32, 8, 1, 512, 128) == PP                       # short K/V
-    assert _route(1, 32, 8, 65, 8192, 128) == PP                     # Sq > 64
+    WAVE, TILED_SPLIT, PP, F32 = 4, 5, 1, 0
+    assert _route(1, 32, 1, 1, 16384, 64, dtype=1) == TILED_SPLIT    # C5b: 32 -> 17 us
+    assert _route(1, 32, 1, 64, 16384, 64, dtype=1) == TILED_SPLIT   # C5c: 44 -> 28 us
+    assert _route(8, 32, 8, 1, 2048, 128) == TILED_SPLIT             # 67 MB of K+V: below the streaming corner
+    assert _route(8, 32, 8, 1, 8192, 128) == WAVE                    # 64 units, 4 rows, 268 MB
+    assert _route(8, 32, 8, 1, 32768, 128) == WAVE                   # 209 vs 243 us
+    assert _route(8, 32, 8, 1, 8192, 64) == WAVE                     # D = 64 streaming: 35 vs 47 us
+    assert _route(4, 64, 8, 1, 65536, 128) == WAVE                   # 32 units, 8 rows
+    assert _route(1, 32, 8, 1, 131072, 128) == TILED_SPLIT           # 8 units: 133 vs 117 us
+    assert _route(8, 32, 8, 16, 8192, 128) == TILED_SPLIT            # 64 packed rows: 103 -> 67 us
+    assert _route(8, 32, 8, 64, 8192, 128) == TILED_SPLIT            # 194 -> 100 us (the wave kernel: 318)
+    assert _route(16, 32, 8, 1, 8192, 128) == TILED_SPLIT            # large-batch decode: 376 -> 117 us
+    assert _route(64, 32, 8, 1, 8192, 128) == TILED_SPLIT            # 1506 -> 461 us
+    assert _route(1, 8, 8, 300, 8192, 128) == TILED_SPLIT            # Sq > 64, 16 tiled workgroups: 162 -> 34 us
+    assert _route(8, 32, 32, 1, 2048, 128) == PP                     # MHA decode: nothing to pack, chip already full
+    assert _route(16, 32, 32, 1, 8192, 128) == PP
+    assert _route(1, 32, 32, 2048, 2048, 128) == PP                  # 256 full Q blocks
+    assert _route(4, 32, 32, 4096, 4096, 128) == PP                  # C2 shape, non-causal
     assert _route(1, 32, 8, 1, 8192, 128, causal=1) == PP            # causal
     assert _route(1, 32, 8, 1, 8192, 128, causal=2) == PP            # bottom-right: shifted causal lives in pp
     assert _route(1, 32, 8, 8, 8192, 128, window=4) == PP            # window
-    assert _route(1, 32, 8, 8, 8192, 128, window=64) == SPLIT        # W >= Sq masks nothing: dropped
+    assert _route(1, 32, 8, 8, 8192, 128, window=64) == TILED_SPLIT  # W >= Sq masks nothing: dropped
     assert _route(1, 32, 8, 1, 8192, 128, dtype=0) == F32
     assert _route(4, 32, 32, 4096, 4096, 128, causal=1) == PP        # the headline shape
     assert _route(1, 3, 2, 1, 8192, 128) == -3                       # heads not divisible
