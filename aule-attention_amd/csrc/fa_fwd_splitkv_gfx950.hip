@@ -411,6 +411,68 @@ bool splitkv_applicable(const FwdArgs& a) {
     return units <= AULE_SPLITKV_MAX_UNITS;
 }
 
+// Combine for FEW partials per row (the tiled kernel's SPLIT instances leave at most a few dozen): one WAVE per packed
+// row, four rows per workgroup, no LDS and no block-wide reduction.  Lane i first weighs partial i (w_i = 2^(m_i - M),
+// M the row's maximum; wave reductions), then every lane accumulates its D/64 columns over the partials with w_i
+// broadcast from lane i.  The one-workgroup-per-row kernel above spends 256 threads and two block reductions on a row
+// with 4 partials: 26 us for B8 Hq32 Hkv8 Sq64 (34 MB, 1.3 TB/s) -- a quarter of that shape's time.  Used for <= 16
+// partials per row only: beyond that the serial walk over the partials is slower than the kernel above.
+template <class T, int D>
+__global__ void __launch_bounds__(256) fa_fwd_splitkv_combine_rows(const SplitParams p) {
+    constexpr int CPL = (D + 63) / 64;            // columns per lane (D = 32: lanes 32..63 carry no column)
+    const int lane = threadIdx.x & 63;
+    const int prow = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (prow >= p.rows_total) return;
+    const int g = p.Hq / p.Hkv;
+    const int unit = prow / (p.nrt * 32), row = prow % (p.nrt * 32);
+    if (row >= g * p.Sq) return;
+    const int b = unit / p.Hkv, hk = unit % p.Hkv, head = hk * g + row / p.Sq, qi = row % p.Sq;
+    const float* base = p.part + (size_t)prow * (D + 2);
+    const size_t pstride = (size_t)p.rows_total * (D + 2);
+    float acc[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+    float L = 0.f, M = -INFINITY;
+    const bool has_col = lane * CPL < D;
+    for (int i0 = 0; i0 < p.npart; i0 += 64) {     // (one trip unless there are more than 64 partials)
+        const int n = min(64, p.npart - i0);
+        const float mi = lane < n ? base[(size_t)(i0 + lane) * pstride + D] : -INFINITY;
+        const float li = lane < n ? base[(size_t)(i0 + lane) * pstride + D + 1] : 0.f;
+        float mx = mi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float Mn = fmaxf(M, mx);
+        const float rescale = (M == -INFINITY) ? 0.f : fast_exp2(M - Mn);   // earlier trips (if any) move to the new maximum
+        const float w = (mi == -INFINITY) ? 0.f : fast_exp2(mi - Mn);       // empty partial: weight 0
+        float wl = w * li;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wl += __shfl_xor(wl, o, 64);
+        L = L * rescale + wl;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c] *= rescale;
+        M = Mn;
+        for (int i = 0; i < n; ++i) {
+            const float wi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), i));
+            if (has_col) {
+                const float* src = base + (size_t)(i0 + i) * pstride + lane * CPL;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) acc[c] += wi * src[c];
+            }
+        }
+    }
+    const float inv = L > 0.f ? 1.0f / L : 0.f;
+    const size_t orow = ((size_t)(b * p.Hq + head) * p.Sq + qi);
+    if (has_col) {
+        if constexpr (CPL == 2) {
+            reinterpret_cast<unsigned*>(p.o)[orow * (D / 2) + lane] = T::pack2(acc[0] * inv, acc[1] * inv);
+        } else {
+            const unsigned u = T::pack2(acc[0] * inv, 0.f);
+            reinterpret_cast<unsigned short*>(p.o)[orow * D + lane] = (unsigned short)(u & 0xffffu);
+        }
+    }
+    if (lane == 0 && p.lse != nullptr) p.lse[orow] = L > 0.f ? (M + fast_log2(L)) * kLn2 : -INFINITY;
+}
+
 // The combine pass on its own, for partials written by another kernel (fa_fwd_pp_gfx950.hip SPLIT instances) in
 // the same layout: part [npart][B*Hkv*nrt*32][D + 2] fp32, packed row r of a unit = (head r / Sq of the group, query r % Sq).
 template <class T, int D>
@@ -421,7 +483,17 @@ static int combine_only(const FwdArgs& a, float* part, int npart, int nrt, hipSt
     p.c = 1.f; p.negq = 0; p.nrt = nrt; p.chunk_tiles = 0; p.npart = npart;
     p.rows_total = a.B * a.Hkv * nrt * 32;
     p.block_tables = nullptr; p.context_lens = nullptr; p.block_size = 0; p.max_blocks = 0; p.window = 0;
-    hipLaunchKernelGGL((fa_fwd_splitkv_combine<T, D>), dim3((unsigned)p.rows_total), dim3(256), 0, stream, p);
+    static const int lean = [] {   // AULE_HIP_FWD_COMBINE=wg selects the workgroup-per-row kernel (A/B measurements)
+        const char* e = getenv("AULE_HIP_FWD_COMBINE");
+        return (e != nullptr && e[0] == 'w') ? 0 : 1;
+    }();
+    // Same-box A/B (tools/combine_ab.py, two passes): with <= 16 partials per row the wave-per-row kernel is ahead or
+    // level (B8 Hq32 Hkv8 Sq64 Sk8192 101 -> 87 us, B4 Sq128 Sk4096 65.5 -> 52.4 us); with >= 32 its serial walk over the
+    // partials loses to the kernel that spreads them over thread groups (C5b 21.7 -> 29.0 us, C5c 29.8 -> 36.2 us).
+    if (lean && npart <= 16)
+        hipLaunchKernelGGL((fa_fwd_splitkv_combine_rows<T, D>), dim3((unsigned)((p.rows_total + 3) / 4)), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((fa_fwd_splitkv_combine<T, D>), dim3((unsigned)p.rows_total), dim3(256), 0, stream, p);
     return (int)hipGetLastError();
 }
 
