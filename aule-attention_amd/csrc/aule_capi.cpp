@@ -637,6 +637,15 @@ static int check_common(int32_t dtype, uint32_t B, uint32_t Hq, uint32_t Hkv, ui
     return 0;
 }
 
+// One query at the bottom-right position sees every key: with no window the causal mask masks nothing, and the
+// problem is the non-causal one (which has the faster short-query paths).
+static void drop_trivial_causal(int& causal, int& coff, int Sq, int window) {
+    if (causal && Sq == 1 && coff > 0 && window <= 0) {
+        causal = 0;
+        coff = 0;
+    }
+}
+
 static float resolve_scale(float scale, uint32_t D) {
     if (scale == 0.0f || std::isnan(scale)) return 1.0f / std::sqrt((float)D);
     return scale;
@@ -677,6 +686,7 @@ int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
     a.dtype = d->dtype;
     // W >= Sq + coff masks nothing (the last query sits at position Sq - 1 + coff)
     a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
+    drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
     rc = aule_hip::launch_fwd(a, (hipStream_t)d->stream);
     if (rc != 0) {
         set_error("Attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");
@@ -837,6 +847,7 @@ int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
     a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? (int)d->seq_k - (int)d->seq_q : 0;
     a.dtype = d->dtype;
     a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
+    drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
     rc = aule_hip::launch_bwd(a, (hipStream_t)d->stream);
     if (rc != 0) {
         set_error("Backward failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");
@@ -861,6 +872,7 @@ int32_t aule_hip_debug_forward_route(const aule_attn_desc* d) {
     a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? a.Sk - a.Sq : 0;
     a.dtype = d->dtype;
     a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
+    drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
     return aule_hip::fwd_route(a);
 }
 

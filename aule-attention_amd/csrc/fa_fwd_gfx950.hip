@@ -351,8 +351,8 @@ static bool splitkv_enabled() {
 // keeps the pure streaming corner -- many units, at most half a row tile of packed rows, K+V beyond ~100 MB -- where
 // it is 10-15 % ahead at D = 128 and 35-55 % at D = 64.  Differences below ~8 % on these kernels are noise.
 static int short_query_route(const FwdArgs& a) {
-    if (a.dtype == kF32 || a.causal || a.window > 0) return 0;
-    const bool wave_ok = splitkv_enabled() && splitkv_applicable(a);
+    if (a.dtype == kF32 || a.window > 0) return 0;
+    const bool wave_ok = !a.causal && splitkv_enabled() && splitkv_applicable(a);   // (the wave kernel has no mask)
     const bool tiled_ok = pp_split_applicable(a) && !use_v1() && fwd_kernel_choice() != 2;
     if (wave_ok && tiled_ok) {
         const long long units = (long long)a.B * a.Hkv;

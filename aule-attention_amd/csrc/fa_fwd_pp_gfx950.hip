@@ -49,6 +49,7 @@ struct FwdPPParams {
     int chunk;          // keys per split (multiple of kKVTile)
     int part_rows;      // rows of one partial plane = units * prow_per_unit
     int prow_per_unit;  // packed rows reserved per (batch, kv-head) unit (multiple of 32)
+    int sq_orig;        // queries per head before packing (packed row r is query r % sq_orig of its head)
     float* part;        // [nsplit][part_rows][D + 2] fp32: un-normalised O, m (log2 units), l -- fa_fwd_splitkv_combine
     int dbg_flags;            // timeline build only: bit0 = group 1 computes nothing, bit1 = group 0 computes nothing
     unsigned long long* dbg;  // timeline build only: [8 waves][kTLMax] s_memtime stamps of workgroup 0
@@ -198,7 +199,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, uns
 template <class T, int D, bool CAUSAL, bool TL = false, bool RAWOK = false, bool WIN = false, bool SPLIT = false>
 __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
     static_assert(!(RAWOK && WIN), "the fixed-reference pass needs a visible key in the first tile of every row");
-    static_assert(!SPLIT || (!CAUSAL && !WIN && !TL), "KV splits: position-independent masks only");
+    static_assert(!SPLIT || !TL, "no timeline build of the SPLIT instances");
+    static_assert(!(SPLIT && CAUSAL) || WIN, "a split can hide every key from a row: needs the -inf guards of the WIN softmax");
     using C = Cfg<D>;
     using v8 = typename T::v8;
     constexpr int RB = C::RB, RBP = C::RBP, CPR = C::CPR, KTILE = C::KTILE, VTILE = C::VTILE;
@@ -290,12 +292,16 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
         const int qrow = q0w + l31;
 
         const int coff = p.coff;                  // position of query row i = i + coff
-        const int kv_hi = CAUSAL ? min(Sk, qb * kQBlock + kQBlock + coff) : Sk;
+        // SPLIT: rows are packed (row r = query r % sq_orig of some head of the group) and key indices are local to
+        // this split, so positions are taken per lane and the block / wave bounds cover every head's queries
+        const int qposv = SPLIT ? (qrow % p.sq_orig) + coff - kv_begin : qrow + coff;      // this lane's query position
+        const int blk_pos_lo = SPLIT ? coff - kv_begin : qb * kQBlock + coff;               // first position in the block
+        const int kv_hi = CAUSAL ? max(1, min(Sk, SPLIT ? p.sq_orig + coff - kv_begin : qb * kQBlock + kQBlock + coff)) : Sk;
         int t_lo = 0;  // first tile any row of this Q block can see
-        if constexpr (WIN) t_lo = min(max(0, qb * kQBlock + coff - p.window + 1) / kKVTile, (kv_hi + kKVTile - 1) / kKVTile - 1);
+        if constexpr (WIN) t_lo = min(max(0, blk_pos_lo - p.window + 1) / kKVTile, (kv_hi + kKVTile - 1) / kKVTile - 1);
         kvb = t_lo * kKVTile;
         const int nt = (kv_hi + kKVTile - 1) / kKVTile - t_lo;   // tiles staged by the workgroup (>= 1)
-        const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32 + coff) : Sk;  // keys visible to this wave
+        const int wave_kv_hi = CAUSAL ? (SPLIT ? kv_hi : min(Sk, q0w + 32 + coff)) : Sk;  // keys visible to this wave
         int na = max(1, (wave_kv_hi + kKVTile - 1) / kKVTile - t_lo);  // tiles this wave computes (a prefix)
         if constexpr (TL) {
             if ((p.dbg_flags >> grp) & 1) na = 0;
@@ -403,15 +409,15 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
             };
             auto softmax = [&](int kv0, auto fixed_tag) __attribute__((always_inline)) {
                 constexpr bool FIXED = decltype(fixed_tag)::value != 0;  // S_j -> P_j (16-bit, in registers); updates m, l, o
-                const bool need_mask = (CAUSAL && (kv0 + kKVTile - 1 > q0w + coff)) || (kv0 + kKVTile > Sk) ||
-                                       (WIN && (q0w + coff + 31 - kv0 >= p.window));
+                const bool need_mask = (CAUSAL && (kv0 + kKVTile - 1 > (SPLIT ? blk_pos_lo : q0w + coff))) || (kv0 + kKVTile > Sk) ||
+                                       (WIN && ((SPLIT ? blk_pos_lo + p.sq_orig - 1 : q0w + coff + 31) - kv0 >= p.window));
                 if (need_mask) {
 #pragma unroll
                     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int kv = kv0 + sb * 32 + crow(r, hi);
-                            const bool vis = (kv < Sk) && (!CAUSAL || kv <= qrow + coff) && (!WIN || qrow + coff - kv < p.window);
+                            const bool vis = (kv < Sk) && (!CAUSAL || kv <= qposv) && (!WIN || qposv - kv < p.window);
                             s[sb][r] = vis ? s[sb][r] : -INFINITY;
                         }
                 }
@@ -690,6 +696,7 @@ int launch_pp(const FwdArgs& a, hipStream_t stream) {
     p.dbg_flags = 0;
     p.window = a.window > 0 ? a.window : 0;
     p.coff = a.causal ? a.coff : 0;
+    p.sq_orig = a.Sq; p.nbase = 1; p.chunk = 0; p.part_rows = 0; p.prow_per_unit = 0; p.part = nullptr;
     const dim3 grid((unsigned)(p.nwork * a.B * a.Hq)), block(512);
     const size_t lds = Cfg<D>::LDS + 16;
     if (p.window > 0) {  // sliding window: online softmax only
@@ -757,6 +764,7 @@ int launch_pp_split(const FwdArgs& a, hipStream_t stream) {
     p.c = c;
     p.nqb = s.nqb; p.pair = 0; p.nwork = s.nqb;
     p.dbg = nullptr; p.dbg_flags = 0; p.window = 0; p.coff = 0;
+    p.sq_orig = a.Sq;
     p.nbase = s.nbase; p.chunk = s.chunk;
     p.prow_per_unit = s.nrt * 32;
     p.part_rows = a.B * a.Hkv * p.prow_per_unit;
@@ -767,6 +775,15 @@ int launch_pp_split(const FwdArgs& a, hipStream_t stream) {
     p.part = static_cast<float*>(ws);
     const dim3 grid((unsigned)(s.nbase * s.nsplit)), block(512);
     const size_t lds = Cfg<D>::LDS + 16;
+    if (a.causal) {   // bottom-right chunk: guarded online softmax (rows can be fully masked inside a split), no window
+        p.coff = a.coff;
+        p.window = 0x3fffffff;
+        hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, true, false, false, true, true>), grid, block, lds, stream, p);
+        int rcc = (int)hipGetLastError();
+        if (rcc == 0) rcc = launch_splitkv_combine(a, p.part, s.nsplit, s.nrt, stream);
+        (void)hipFreeAsync(ws, stream);
+        return rcc;
+    }
     bool raw = false;
     if constexpr (std::is_same<T, Bf16Traits>::value) raw = raw_softmax_enabled();
     if constexpr (std::is_same<T, Bf16Traits>::value) {
@@ -790,6 +807,8 @@ int set_attr_pp() {
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, false, false, false, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, false, false, false, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, true, false, false, true, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<D>::LDS + 16);
     if constexpr (std::is_same<T, Bf16Traits>::value) {
         rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_pp_kernel<T, D, false, false, true, false, true>),
@@ -817,6 +836,7 @@ int launch_fwd_pp_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_
     p.nwork = p.pair ? (p.nqb + 1) / 2 : p.nqb;
     p.window = 0;
     p.coff = 0;
+    p.sq_orig = a.Sq; p.nbase = 1; p.chunk = 0; p.part_rows = 0; p.prow_per_unit = 0; p.part = nullptr;
     p.dbg = dbg;
     p.dbg_flags = getenv("AULE_TL_FLAGS") ? atoi(getenv("AULE_TL_FLAGS")) : 0;
     const dim3 grid((unsigned)(p.nwork * a.B * a.Hq)), block(512);
@@ -856,7 +876,10 @@ bool pp_split_applicable(const FwdArgs& a) {
     }();
     if (!on) return false;
     if (a.dtype != kBF16 && a.dtype != kF16) return false;
-    if (a.causal || a.window > 0) return false;
+    if (a.window > 0) return false;
+    // causal: only the bottom-right aligned short chunk (decode / speculative verification / chunked prefill against a
+    // KV history): every split then has full work; a top-left mask with Sq < Sk sees only the first Sq keys
+    if (a.causal && !(a.coff == a.Sk - a.Sq && a.coff > 0 && a.Sq <= 256)) return false;
     if (a.D != 32 && a.D != 64 && a.D != 128) return false;
     if ((long long)a.Hq / a.Hkv * a.Sq >= (1 << 24)) return false;
     const PPSplitPlan s = pp_split_plan(a);

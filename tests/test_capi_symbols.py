@@ -137,7 +137,16 @@ def test_forward_routing_rule(monkeypatch):
     assert _route(1, 32, 32, 2048, 2048, 128) == PP                  # 256 full Q blocks
     assert _route(4, 32, 32, 4096, 4096, 128) == PP                  # C2 shape, non-causal
     assert _route(1, 32, 8, 1, 8192, 128, causal=1) == PP            # causal
-    assert _route(1, 32, 8, 1, 8192, 128, causal=2) == PP            # bottom-right: shifted causal lives in pp
+    # bottom-right aligned causal (additive mode): one query sees every key -> the non-causal problem; short chunks
+    # (Sq <= 256, no window) take the tiled kernel's SPLIT instances with a mask; the rest stays on the plain kernel
+    assert _route(1, 32, 8, 1, 8192, 128, causal=2) == TILED_SPLIT   # = non-causal, 8 units
+    assert _route(8, 32, 8, 1, 8192, 128, causal=2) == WAVE          # = non-causal, the streaming corner
+    assert _route(8, 32, 8, 64, 8192, 128, causal=2) == TILED_SPLIT  # 210 -> 94 us
+    assert _route(1, 32, 8, 8, 32768, 128, causal=2) == TILED_SPLIT  # 641 -> 44 us
+    assert _route(4, 32, 8, 1024, 4096, 128, causal=2) == PP         # Sq > 256
+    assert _route(8, 32, 8, 64, 8192, 128, causal=2, window=16) == PP
+    assert _route(8, 32, 8, 64, 8192, 128, causal=1) == PP           # top-left: sees the first Sq keys only
+    assert _route(1, 32, 8, 1, 8192, 128, causal=2, window=128) == PP   # a window from the end needs the mask
     assert _route(1, 32, 8, 8, 8192, 128, window=4) == PP            # window
     assert _route(1, 32, 8, 8, 8192, 128, window=64) == TILED_SPLIT  # W >= Sq masks nothing: dropped
     assert _route(1, 32, 8, 1, 8192, 128, dtype=0) == F32

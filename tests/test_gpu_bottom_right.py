@@ -37,7 +37,31 @@ CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, window
     ("fp16", 1, 2, 1, 200, 1000, 128, 64),
     ("fp32", 1, 2, 2, 150, 400, 64, 33),
     ("bf16", 1, 2, 2, 2048, 2048 + 517, 128, -1),
+    # short chunks against a long history: the tiled kernel's SPLIT instances with the causal mask (route 5) --
+    # packed rows whose waves span several heads, rows that see no key in the later key splits
+    ("bf16", 2, 8, 2, 64, 8192, 128, -1),
+    ("fp16", 1, 8, 2, 17, 3000, 64, -1),            # 68 packed rows
+    ("fp16", 2, 6, 3, 33, 2049, 32, -1),            # 66 packed rows, ragged Sk
+    ("bf16", 1, 32, 1, 5, 4100, 128, -1),           # MQA: 160 packed rows
+    ("bf16", 8, 32, 8, 1, 4096, 128, -1),           # one query per sequence: routed as the non-causal problem
 ]
+
+ROUTES = {  # forward kernel each of these shapes is meant to exercise (aule_hip_debug_forward_route)
+    ("bf16", 2, 8, 2, 64, 8192, 128, -1): 5, ("fp16", 1, 8, 2, 17, 3000, 64, -1): 5, ("fp16", 2, 6, 3, 33, 2049, 32, -1): 5,
+    ("bf16", 1, 32, 1, 5, 4100, 128, -1): 5, ("bf16", 8, 32, 8, 1, 4096, 128, -1): 4, ("bf16", 1, 8, 1, 64, 2048, 128, -1): 5,
+    ("bf16", 2, 2, 2, 1000, 1500, 128, -1): 1, ("bf16", 1, 4, 2, 512, 1024, 128, 100): 1, ("fp32", 1, 2, 1, 300, 420, 32, -1): 0,
+}
+
+
+def _route(case):
+    from aule import _capi
+    dtype, B, Hq, Hkv, Sq, Sk, D, W = case
+    d = _capi.AttnDesc()
+    d.struct_size = ctypes.sizeof(_capi.AttnDesc)
+    d.dtype = {"fp32": 0, "fp16": 1, "bf16": 2}[dtype]
+    d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
+    d.causal, d.window_size = 2, W
+    return _capi.get_lib().aule_hip_debug_forward_route(ctypes.byref(d))
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(x) for x in c))
@@ -45,6 +69,8 @@ def test_bottom_right_forward_backward_vs_oracle(case, oracle_mod):
     import torch
     from aule import _torch as at
     dtype, B, Hq, Hkv, Sq, Sk, D, W = case
+    if case in ROUTES:
+        assert _route(case) == ROUTES[case], "the dispatch rule moved this shape off the kernel it was written for"
     rng = np.random.RandomState(23)
     q, k, v, do = (quantize(rng.randn(*s).astype(np.float32), dtype)
                    for s in ((B, Hq, Sq, D), (B, Hkv, Sk, D), (B, Hkv, Sk, D), (B, Hq, Sq, D)))
