@@ -43,6 +43,8 @@ class AttnDesc(ctypes.Structure):
         ("v", ctypes.c_void_p),
         ("out", ctypes.c_void_p),
         ("lse", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p),
+        ("workspace_bytes", ctypes.c_uint64),
     ]
 
 
@@ -97,6 +99,8 @@ class PagedDesc(ctypes.Structure):
         ("block_tables", ctypes.c_void_p),
         ("context_lens", ctypes.c_void_p),
         ("out", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p),
+        ("workspace_bytes", ctypes.c_uint64),
     ]
 
 
@@ -166,6 +170,8 @@ SIGNATURES = [
     ("aule_attention_backward_workspace_size", _U64, [ctypes.POINTER(AttnBwdDesc)]),
     ("aule_attention_paged_decode_ex", _I32, [ctypes.POINTER(PagedDesc)]),
     ("aule_rope_ex", _I32, [ctypes.POINTER(RopeDesc)]),
+    ("aule_attention_forward_workspace_size", ctypes.c_uint64, [ctypes.POINTER(AttnDesc)]),
+    ("aule_attention_paged_decode_workspace_size", ctypes.c_uint64, [ctypes.POINTER(PagedDesc)]),
     ("aule_hip_build_info", ctypes.c_char_p, []),
     ("aule_hip_debug_forward_route", _I32, [ctypes.POINTER(AttnDesc)]),
 ]

@@ -40,6 +40,15 @@ def causal_code(causal):
     return c
 
 
+def _workspace(nbytes, device):
+    """Partials of the two-launch short-query paths from torch's caching allocator: stream-ordered like the library's own
+    hipMallocAsync fallback, but graph-aware -- under torch.cuda.graph capture it adds no alloc / free nodes (which cost
+    more than the kernels of a decode step).  Freed by reference count after the launch; the allocator keeps the block
+    on the launch stream's free list, so reuse is ordered behind the kernels that read it."""
+    nbytes = int(nbytes)
+    return torch.empty((nbytes,), device=device, dtype=torch.uint8) if nbytes > 0 else None
+
+
 def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1):
     """q [B,Hq,Sq,D], k/v [B,Hkv,Sk,D]: contiguous device tensors, D in SUPPORTED_HEAD_DIMS.
     Returns (out, lse or None).  Asynchronous on the current stream."""
@@ -61,6 +70,9 @@ def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1):
     d.stream = _stream_ptr(q.device)
     d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
     d.lse = lse.data_ptr() if lse is not None else None
+    ws = _workspace(lib.aule_attention_forward_workspace_size(ctypes.byref(d)), q.device)
+    if ws is not None:
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     _capi.check(lib.aule_attention_forward_ex(ctypes.byref(d)), "aule_attention_forward_ex")
     return out, lse
 
@@ -292,6 +304,9 @@ def paged_decode(q, k_cache, v_cache, block_tables, context_lens, scale=None, wi
     d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
     d.stream = _stream_ptr(q.device)
     d.q, d.k_cache, d.v_cache, d.out = q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr()
+    ws = _workspace(lib.aule_attention_paged_decode_workspace_size(ctypes.byref(d)), q.device)
+    if ws is not None:
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     d.block_tables, d.context_lens = bt.data_ptr(), cl.data_ptr()
     _capi.check(lib.aule_attention_paged_decode_ex(ctypes.byref(d)), "aule_attention_paged_decode_ex")
     return out

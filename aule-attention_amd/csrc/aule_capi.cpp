@@ -17,12 +17,17 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <mutex>
 
 #include "fa_kernels.h"
 
-static_assert(sizeof(aule_attn_desc) == 96, "aule_attn_desc layout is part of the ABI");
+// abi2: optional workspace / workspace_bytes appended to the forward and paged descriptors (96 -> 112, 104 -> 120)
+static_assert(sizeof(aule_attn_desc) == 112 && offsetof(aule_attn_desc, lse) == 88 && offsetof(aule_attn_desc, workspace) == 96,
+              "aule_attn_desc layout is part of the ABI");
+static_assert(sizeof(aule_paged_desc) == 120 && offsetof(aule_paged_desc, workspace) == 104,
+              "aule_paged_desc layout is part of the ABI");
 static_assert(sizeof(aule_attn_bwd_desc) == 144, "aule_attn_bwd_desc layout is part of the ABI");
 
 namespace {
@@ -687,6 +692,7 @@ int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
     // W >= Sq + coff masks nothing (the last query sits at position Sq - 1 + coff)
     a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
     drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
+    a.ws = d->workspace; a.ws_bytes = d->workspace ? d->workspace_bytes : 0;
     rc = aule_hip::launch_fwd(a, (hipStream_t)d->stream);
     if (rc != 0) {
         set_error("Attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");
@@ -737,6 +743,7 @@ int32_t aule_attention_paged_decode_ex(const aule_paged_desc* d) {
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.window = d->window_size;
     a.dtype = d->dtype;
+    a.ws = d->workspace; a.ws_bytes = d->workspace ? d->workspace_bytes : 0;
     rc = aule_hip::launch_paged_decode(a, (hipStream_t)d->stream);
     if (rc != 0) {
         set_error("Paged attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");
@@ -856,7 +863,42 @@ int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
     return 0;
 }
 
-const char* aule_hip_build_info(void) { return "aule-hip gfx950 abi1"; }
+const char* aule_hip_build_info(void) { return "aule-hip gfx950 abi2"; }   // abi2: workspace fields in the fwd / paged descriptors
+
+uint64_t aule_attention_forward_workspace_size(const aule_attn_desc* d) {
+    if (d == nullptr || d->struct_size != sizeof(aule_attn_desc)) return 0;
+    if (d->dtype < 0 || d->dtype > 2 || d->causal < 0 || d->causal > AULE_CAUSAL_BOTTOM_RIGHT) return 0;
+    if (d->heads_kv == 0 || d->heads_q % d->heads_kv != 0 || d->seq_k == 0) return 0;
+    if ((uint64_t)d->batch * d->heads_q * d->seq_q == 0) return 0;
+    if (d->head_dim != 32 && d->head_dim != 64 && d->head_dim != 128) return 0;
+    if (d->causal == AULE_CAUSAL_BOTTOM_RIGHT && d->seq_k < d->seq_q) return 0;
+    FwdArgs a;
+    a.q = a.k = a.v = nullptr; a.o = nullptr; a.lse = nullptr;
+    a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv;
+    a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
+    a.scale = 1.0f;
+    a.causal = d->causal != 0;
+    a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? a.Sk - a.Sq : 0;
+    a.dtype = d->dtype;
+    a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
+    drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
+    return aule_hip::fwd_workspace_bytes(a);
+}
+
+uint64_t aule_attention_paged_decode_workspace_size(const aule_paged_desc* d) {
+    if (d == nullptr || d->struct_size != sizeof(aule_paged_desc)) return 0;
+    if (d->dtype != AULE_DTYPE_F16 && d->dtype != AULE_DTYPE_BF16) return 0;
+    if (d->head_dim != 32 && d->head_dim != 64 && d->head_dim != 128) return 0;
+    if (d->heads_kv == 0 || d->heads_q % d->heads_kv != 0) return 0;
+    if (d->block_size == 0 || d->max_blocks == 0 || (uint64_t)d->block_size * d->max_blocks >= (1ull << 30)) return 0;
+    if ((uint64_t)d->batch * d->heads_q == 0) return 0;
+    aule_hip::PagedArgs a;
+    a.q = a.k_cache = a.v_cache = nullptr; a.out = nullptr; a.block_tables = nullptr; a.context_lens = nullptr;
+    a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv; a.D = (int)d->head_dim;
+    a.block_size = (int)d->block_size; a.max_blocks = (int)d->max_blocks;
+    a.scale = 1.0f; a.window = d->window_size; a.dtype = d->dtype;
+    return aule_hip::paged_workspace_bytes(a);
+}
 
 /* Debug hook (not part of the drop-in ABI): the forward kernel aule_attention_forward_ex would launch for `d`
  * -- 0 fp32, 1 ping-pong, 2 in-wave, 3 lock-step, 4 split-KV; -3 for a bad descriptor.  Pure host logic: no

@@ -376,11 +376,27 @@ int fwd_route(const FwdArgs& a) {
     return 3;
 }
 
+uint64_t fwd_workspace_bytes(FwdArgs a) {
+    uint64_t bytes = 0;
+    a.query_ws = &bytes;
+    (void)launch_fwd(a, nullptr);   // dry run: the two-launch paths report their plan, the others launch nothing
+    return bytes;
+}
+
+uint64_t paged_workspace_bytes(PagedArgs a) {
+    uint64_t bytes = 0;
+    a.query_ws = &bytes;
+    (void)launch_paged_decode(a, nullptr);
+    return bytes;
+}
+
 int launch_fwd(const FwdArgs& a, hipStream_t stream) {
-    if (a.dtype == kF32) return launch_fwd_f32(a, stream);
-    const int sq = short_query_route(a);
+    if (a.query_ws != nullptr) *a.query_ws = 0;
+    const int sq = a.dtype == kF32 ? 0 : short_query_route(a);
     if (sq == 4) return launch_fwd_splitkv(a, stream);
     if (sq == 5) return launch_fwd_pp_split(a, stream);
+    if (a.query_ws != nullptr) return 0;   // single-launch paths need no workspace
+    if (a.dtype == kF32) return launch_fwd_f32(a, stream);
     const bool pp_only = a.window > 0 || (a.causal && a.coff != 0);  // window / shifted causal live in the ping-pong kernel
     if (fwd_kernel_choice() == 2 && !pp_only) {
         const int rc = launch_fwd_iw(a, stream);

@@ -769,30 +769,29 @@ int launch_pp_split(const FwdArgs& a, hipStream_t stream) {
     p.prow_per_unit = s.nrt * 32;
     p.part_rows = a.B * a.Hkv * p.prow_per_unit;
     const size_t bytes = (size_t)s.nsplit * p.part_rows * (D + 2) * sizeof(float);
-    void* ws = nullptr;
-    hipError_t e = hipMallocAsync(&ws, bytes, stream);   // stream-ordered, like the split-KV kernel's workspace
-    if (e != hipSuccess) return (int)e;
-    p.part = static_cast<float*>(ws);
+    if (a.query_ws != nullptr) {
+        *a.query_ws = bytes;
+        return 0;
+    }
+    ScopedWorkspace ws(bytes, a.ws, a.ws_bytes, stream);   // caller's buffer, or stream-ordered like the split-KV kernel's
+    if (ws.err != hipSuccess) return (int)ws.err;
+    p.part = static_cast<float*>(ws.ptr);
     const dim3 grid((unsigned)(s.nbase * s.nsplit)), block(512);
     const size_t lds = Cfg<D>::LDS + 16;
     if (a.causal) {   // bottom-right chunk: guarded online softmax (rows can be fully masked inside a split), no window
         p.coff = a.coff;
         p.window = 0x3fffffff;
         hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, true, false, false, true, true>), grid, block, lds, stream, p);
-        int rcc = (int)hipGetLastError();
-        if (rcc == 0) rcc = launch_splitkv_combine(a, p.part, s.nsplit, s.nrt, stream);
-        (void)hipFreeAsync(ws, stream);
-        return rcc;
+    } else {
+        bool raw = false;
+        if constexpr (std::is_same<T, Bf16Traits>::value) {
+            raw = raw_softmax_enabled();
+            if (raw) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false, false, true, false, true>), grid, block, lds, stream, p);
+        }
+        if (!raw) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false, false, false, false, true>), grid, block, lds, stream, p);
     }
-    bool raw = false;
-    if constexpr (std::is_same<T, Bf16Traits>::value) raw = raw_softmax_enabled();
-    if constexpr (std::is_same<T, Bf16Traits>::value) {
-        if (raw) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false, false, true, false, true>), grid, block, lds, stream, p);
-    }
-    if (!raw) hipLaunchKernelGGL((fa_fwd_pp_kernel<T, D, false, false, false, false, true>), grid, block, lds, stream, p);
     int rc = (int)hipGetLastError();
     if (rc == 0) rc = launch_splitkv_combine(a, p.part, s.nsplit, s.nrt, stream);
-    (void)hipFreeAsync(ws, stream);
     return rc;
 }
 

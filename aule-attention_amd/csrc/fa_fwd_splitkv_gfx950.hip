@@ -327,15 +327,16 @@ int launch_split(const FwdArgs& a, hipStream_t stream) {
     p.rows_total = units * 32;
     p.block_tables = nullptr; p.context_lens = nullptr; p.block_size = 0; p.max_blocks = 0; p.window = 0;
     const size_t bytes = (size_t)p.npart * p.rows_total * (D + 2) * sizeof(float);
-    void* ws = nullptr;
-    hipError_t e = hipMallocAsync(&ws, bytes, stream);   // stream-ordered: safe with concurrent caller streams
-    if (e != hipSuccess) return (int)e;
-    p.part = static_cast<float*>(ws);
+    if (a.query_ws != nullptr) {
+        *a.query_ws = bytes;
+        return 0;
+    }
+    ScopedWorkspace ws(bytes, a.ws, a.ws_bytes, stream);   // caller's buffer, or stream-ordered (safe with concurrent streams)
+    if (ws.err != hipSuccess) return (int)ws.err;
+    p.part = static_cast<float*>(ws.ptr);
     hipLaunchKernelGGL((fa_fwd_splitkv_kernel<T, D, false>), dim3((unsigned)nsplit, (unsigned)units), dim3(256), 0, stream, p);
     hipLaunchKernelGGL((fa_fwd_splitkv_combine<T, D>), dim3((unsigned)p.rows_total), dim3(256), 0, stream, p);
-    const int rc = (int)hipGetLastError();
-    (void)hipFreeAsync(ws, stream);
-    return rc;
+    return (int)hipGetLastError();
 }
 
 // Paged decode: one query token per sequence, K/V gathered through the block table; the key range is bounded by
@@ -364,15 +365,16 @@ int launch_paged(const PagedArgs& a, hipStream_t stream) {
     p.block_tables = a.block_tables; p.context_lens = a.context_lens;
     p.block_size = a.block_size; p.max_blocks = a.max_blocks; p.window = a.window > 0 ? a.window : 0;
     const size_t bytes = (size_t)p.npart * p.rows_total * (D + 2) * sizeof(float);
-    void* ws = nullptr;
-    hipError_t e = hipMallocAsync(&ws, bytes, stream);
-    if (e != hipSuccess) return (int)e;
-    p.part = static_cast<float*>(ws);
+    if (a.query_ws != nullptr) {
+        *a.query_ws = bytes;
+        return 0;
+    }
+    ScopedWorkspace ws(bytes, a.ws, a.ws_bytes, stream);
+    if (ws.err != hipSuccess) return (int)ws.err;
+    p.part = static_cast<float*>(ws.ptr);
     hipLaunchKernelGGL((fa_fwd_splitkv_kernel<T, D, true>), dim3((unsigned)nsplit, (unsigned)units), dim3(256), 0, stream, p);
     hipLaunchKernelGGL((fa_fwd_splitkv_combine<T, D>), dim3((unsigned)p.rows_total), dim3(256), 0, stream, p);
-    const int rc = (int)hipGetLastError();
-    (void)hipFreeAsync(ws, stream);
-    return rc;
+    return (int)hipGetLastError();
 }
 
 }  // namespace

@@ -29,6 +29,33 @@ struct FwdArgs {
     int window = -1;  // sliding window: key j visible to query i only if i - j < window (<= 0: off)
     int coff = 0;     // causal position offset: query i sits at position i + coff (0 = the reference's top-left
                       // rule; Sk - Sq = bottom-right alignment); also shifts the window
+    // Partials of the two-launch short-query paths: the caller's buffer when it is large enough (no allocation at
+    // all -- what a hipGraph capture wants: hipMallocAsync / hipFreeAsync become graph nodes that cost more than the
+    // kernels of a decode step), otherwise a stream-ordered allocation.
+    void* ws = nullptr;
+    uint64_t ws_bytes = 0;
+    uint64_t* query_ws = nullptr;   // dry run: the launcher stores the bytes it would need and launches nothing
+};
+
+// The workspace of one launch: the caller's buffer, or hipMallocAsync / hipFreeAsync on the launch stream.
+struct ScopedWorkspace {
+    void* ptr = nullptr;
+    bool owned = false;
+    hipStream_t stream;
+    hipError_t err = hipSuccess;
+    ScopedWorkspace(size_t bytes, void* user, uint64_t user_bytes, hipStream_t s) : stream(s) {
+        if (user != nullptr && user_bytes >= bytes && (reinterpret_cast<uintptr_t>(user) & 15) == 0) {
+            ptr = user;
+            return;
+        }
+        err = hipMallocAsync(&ptr, bytes, s);
+        owned = err == hipSuccess;
+    }
+    ~ScopedWorkspace() {
+        if (owned) (void)hipFreeAsync(ptr, stream);
+    }
+    ScopedWorkspace(const ScopedWorkspace&) = delete;
+    ScopedWorkspace& operator=(const ScopedWorkspace&) = delete;
 };
 
 struct BwdArgs {
@@ -65,6 +92,9 @@ struct PagedArgs {
     float scale;
     int window;   // > 0: attend only to the last `window` positions (context_len - 1 - pos < window)
     int dtype;
+    void* ws = nullptr;             // as FwdArgs::ws / ws_bytes / query_ws
+    uint64_t ws_bytes = 0;
+    uint64_t* query_ws = nullptr;
 };
 
 // Rotary embedding pass (rope_gfx950.hip): x [nheads, S, D] with `pitch` elements per row, tables [>= S + pos_offset, D/2]
@@ -88,7 +118,10 @@ int launch_paged_decode(const PagedArgs& a, hipStream_t stream);
 int launch_fwd(const FwdArgs& a, hipStream_t stream);
 // merge partials [npart][B*Hkv*nrt*32][D+2] fp32 (un-normalised O, m in log2 units, l) into O / LSE (fa_fwd_splitkv_gfx950.hip)
 int launch_splitkv_combine(const FwdArgs& a, float* part, int npart, int nrt, hipStream_t stream);
-int fwd_route(const FwdArgs& a);   // 0 fp32, 1 ping-pong, 2 in-wave, 3 v1, 4 split-KV, 5 tiled + packed rows + KV splits (host logic only)
+int fwd_route(const FwdArgs& a);
+// bytes of workspace launch_fwd / launch_paged_decode would allocate for these arguments (0: single-launch path)
+uint64_t fwd_workspace_bytes(FwdArgs a);
+uint64_t paged_workspace_bytes(PagedArgs a);   // 0 fp32, 1 ping-pong, 2 in-wave, 3 v1, 4 split-KV, 5 tiled + packed rows + KV splits (host logic only)
 int launch_bwd(const BwdArgs& a, hipStream_t stream);
 
 // Bytes of device workspace launch_bwd needs: delta [B,Hq,Sq] fp32, plus (16-bit GQA/MQA problems that

@@ -142,6 +142,9 @@ typedef struct aule_attn_desc {
     const void* v;
     void* out;
     float* lse;            /* optional (NULL to skip) */
+    void* workspace;       /* optional device buffer, 16-byte aligned, >= aule_attention_forward_workspace_size()  */
+    uint64_t workspace_bytes;  /* bytes; NULL / too small: the library allocates stream-ordered (hipMallocAsync), which */
+                           /* is correct everywhere but adds costly alloc/free nodes under hipGraph capture         */
 } aule_attn_desc;
 
 typedef struct aule_attn_bwd_desc {
@@ -188,9 +191,15 @@ typedef struct aule_paged_desc {
     const int32_t* block_tables;   /* [batch, max_blocks]: physical block of each logical block */
     const int32_t* context_lens;   /* [batch]: keys per sequence (0 -> output row of zeros) */
     void* out;                 /* [batch, heads_q, head_dim] */
+    void* workspace;           /* optional, as aule_attn_desc.workspace; size from aule_attention_paged_decode_workspace_size() */
+    uint64_t workspace_bytes;
 } aule_paged_desc;
 /* 0 ok; -1 uninitialised; -3 invalid/unsupported arguments; -4 launch failure. */
 int32_t aule_attention_paged_decode_ex(const aule_paged_desc* desc);
+/* Bytes of optional workspace the forward / paged decode would otherwise allocate itself for this descriptor   */
+/* (0: single-launch path, nothing needed).  Host logic only; pointers in the descriptor are not read.           */
+uint64_t aule_attention_forward_workspace_size(const aule_attn_desc* desc);
+uint64_t aule_attention_paged_decode_workspace_size(const aule_paged_desc* desc);
 
 /* Rotary position embedding pass (additive; SURVEY.md 8f row N1, second half).  Replaces the rotation the           */
 /* reference fuses into its kernels: python/aule/triton_flash.py:32-52,:112-131,:165-180 (layout HALF) and            */

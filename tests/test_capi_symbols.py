@@ -47,8 +47,11 @@ def test_binding_covers_header():
 
 def test_descriptor_layout():
     # x86-64 SysV layout of the structs in include/aule.h
-    assert ctypes.sizeof(_capi.AttnDesc) == 96
+    # abi2: optional workspace / workspace_bytes appended to the forward and paged descriptors
+    assert ctypes.sizeof(_capi.AttnDesc) == 112
     assert _capi.AttnDesc.stream.offset == 48 and _capi.AttnDesc.lse.offset == 88
+    assert _capi.AttnDesc.workspace.offset == 96 and _capi.AttnDesc.workspace_bytes.offset == 104
+    assert ctypes.sizeof(_capi.PagedDesc) == 120 and _capi.PagedDesc.workspace.offset == 104
     assert ctypes.sizeof(_capi.AttnBwdDesc) == 144
     assert _capi.AttnBwdDesc.workspace_bytes.offset == 136
 
