@@ -9,6 +9,7 @@ streams, autograd graph); the arithmetic is in aule-attention_amd/csrc/*.hip.
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -16,6 +17,9 @@ from . import _capi
 
 _DTYPES = {torch.float32: _capi.DTYPE_F32, torch.float16: _capi.DTYPE_F16, torch.bfloat16: _capi.DTYPE_BF16}
 SUPPORTED_HEAD_DIMS = (32, 64, 128)
+
+
+_ALWAYS_AUTOGRAD = os.environ.get("AULE_HIP_ALWAYS_AUTOGRAD", "0") == "1"
 
 
 def _stream_ptr(device):
@@ -146,7 +150,16 @@ def flash_attention_hip(q, k, v, causal=True, scale=None, window=-1):
     code = causal_code(causal)
     if code == 2 and k.shape[2] < q.shape[2]:
         raise ValueError(f"bottom-right causal alignment needs seq_len_k >= seq_len_q, got {k.shape[2]} < {q.shape[2]}")
-    out = FlashAttentionHipFunc.apply(q, k, v, code, float(scale), int(window))
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        out = FlashAttentionHipFunc.apply(q, k, v, code, float(scale), int(window))
+    else:
+        # inference: no autograd node (its apply() costs more CPU time than a decode kernel runs) and no LSE,
+        # which only the backward reads.  AULE_HIP_ALWAYS_AUTOGRAD=1 restores the old route (A/B measurements).
+        if _ALWAYS_AUTOGRAD:
+            out = FlashAttentionHipFunc.apply(q, k, v, code, float(scale), int(window))
+        else:
+            out, _ = fwd_raw(q.contiguous(), k.contiguous(), v.contiguous(), code, float(scale), want_lse=False,
+                             window=int(window))
     if Dp != D:
         out = out[..., :D]
     return out if out.dtype == orig_dtype else out.to(orig_dtype)
