@@ -209,7 +209,10 @@ def main():
         "config": {"workload": "%s: B=%d/GPU Hq=%d Hkv=%d Sq=%d Sk=%d D=%d %s %s %s" % (
             args.config, B, Hq, Hkv, Sq, Sk, D, dtype, "causal" if causal else "non-causal", mode),
             "global_batch": B * n_gpus, "parallelism": "batch-sharded dp%d, no data-path collective" % n_gpus,
-            "flop_convention": "4*B*Hq*D*sum_i min(i+1,Sk) (causal), bwd=2.5x fwd"},
+            "flop_convention": "4*B*Hq*D*sum_i min(i+1,Sk) (causal), bwd=2.5x fwd",
+            "lse": ("stored (autograd saves it for the backward)" if mode == "fwdbwd" else
+                    "not stored: forward-only steps run under no_grad and take the API's inference path "
+                    "(B*Hq*Sq fp32 = 0.4 % of the output bytes at C2)")},
         "per_gpu_tflops": value / n_gpus,
         "roofline": ({"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": hbm_traffic(args.config, mode),
