@@ -62,6 +62,9 @@ constexpr int kTLMax = 256;
 #ifndef AULE_PPSPLIT_RULE
 #define AULE_PPSPLIT_RULE true
 #endif
+#ifndef AULE_PPSPLIT_ROWS_PER_KEY
+#define AULE_PPSPLIT_ROWS_PER_KEY 4   // total rows <= this x Sk (A/B builds override it: tools/ppsplit_edges.py)
+#endif
 
 #ifndef AULE_MPRIO
 #define AULE_MPRIO 1
@@ -895,7 +898,7 @@ bool pp_split_applicable(const FwdArgs& a) {
     //   32 k rows: Sk 1024 19 -> 61 us, Sk 4096 67 -> 88 us (loses); Sk 8192 178 -> 165 us (wins)
     // rows <= 4 Sk separates all of these; it is a fit to this sample, not a model.
     if (a.Sk < 1024 && tiled_wgs < 1024) return false;
-    if ((long long)a.B * a.Hq * a.Sq > 4LL * a.Sk) return false;
+    if ((long long)a.B * a.Hq * a.Sq > (long long)AULE_PPSPLIT_ROWS_PER_KEY * a.Sk) return false;
     return AULE_PPSPLIT_RULE;
 }
 
