@@ -282,10 +282,22 @@ __global__ void __launch_bounds__(512) fa_fwd_pp_kernel(const FwdPPParams p) {
                 *reinterpret_cast<u32x4_t*>(Ks + buf * KTILE + k_lds[i]) = kst[i];
     };
     auto write_v = [&](int buf) __attribute__((always_inline)) {
+        // The non-causal fixed-reference D = 128 kernels sit one register over the 256 of two waves per SIMD, and hipcc
+        // spilled exactly this address (tid * 16): a scratch reload + s_waitcnt vmcnt(0) at the top of every tile
+        // iteration.  There it is rebuilt from the lane id (two mbcnt) and the scalar wave id instead of staying live
+        // across the loop: -0.3 .. -0.9 % in three same-box passes (tools/noncausal_ab.py).  Confined to exactly the
+        // instantiations that spilled: applied to every non-causal kernel it made bf16 D = 64 3.2 % SLOWER (a kernel
+        // that never spilled -- the extra instructions moved hipcc's allocation), and the causal kernels are left
+        // byte-identical.
+        int t16 = tid * 16;
+        if constexpr (!CAUSAL && RAWOK && D == 128) {
+            const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            t16 = (ln << 4) + wave * 1024;
+        }
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if (C::kFull || tid + 512 * i < C::NCHUNK)
-                *reinterpret_cast<u32x4_t*>(Vs + buf * VTILE + tid * 16 + i * 8192) = vst[i];
+                *reinterpret_cast<u32x4_t*>(Vs + buf * VTILE + t16 + i * 8192) = vst[i];
     };
 
     const int nparts = (p.pair && (p.nqb - 1 - w.blk) != w.blk) ? 2 : 1;
