@@ -36,6 +36,13 @@ CASES = [  # dtype, B, Hq, Hkv, D, block_size, context lens, window
     ("bf16", 3, 8, 8, 128, 8, [0, 77, 300], -1),          # a sequence with no key: zeros
     ("fp16", 2, 16, 4, 32, 32, [2048, 2047], 256),        # sliding window over the last 256 positions
     ("bf16", 1, 64, 8, 128, 64, [20000], -1),
+    # block sizes that are NOT powers of two take the general address path (divide / modulo per key row; the
+    # power-of-two sizes above take the shift / mask fast path), and 32-key tiles straddle their block boundaries
+    ("bf16", 3, 16, 4, 128, 48, [1000, 47, 4000], -1),
+    ("fp16", 2, 32, 8, 64, 24, [3001, 25], -1),
+    ("fp16", 2, 8, 2, 32, 100, [2500, 99], 300),
+    ("bf16", 2, 8, 8, 128, 1, [700, 3], -1),             # one token per block
+    ("bf16", 2, 32, 4, 64, 33, [5000, 1], 64),
 ]
 
 
