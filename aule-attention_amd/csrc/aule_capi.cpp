@@ -900,6 +900,24 @@ uint64_t aule_attention_paged_decode_workspace_size(const aule_paged_desc* d) {
     return aule_hip::paged_workspace_bytes(a);
 }
 
+/* Debug hook (not part of the drop-in ABI): aule_attention_backward_ex with the dK/dV kernel's timeline build --
+ * per-phase s_memtime stamps of its workgroup 0 into `stamps` (device pointer, 8 * 384 uint64; bf16 D128 causal only,
+ * otherwise the ordinary kernels run and nothing is written).  Used by tools/timeline_bwd.py. */
+int32_t aule_hip_debug_backward_timeline(const aule_attn_bwd_desc* d, unsigned long long* stamps) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_init || d == nullptr || d->struct_size != sizeof(aule_attn_bwd_desc)) return -1;
+    BwdArgs a;
+    a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->out; a.dout = d->dout; a.lse = d->lse;
+    a.dq = d->dq; a.dk = d->dk; a.dv = d->dv; a.delta = (float*)d->workspace;
+    a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv;
+    a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
+    a.scale = resolve_scale(d->scale, d->head_dim);
+    a.causal = d->causal != 0;
+    a.dtype = d->dtype;
+    a.dbg = stamps;
+    return aule_hip::launch_bwd(a, (hipStream_t)d->stream);
+}
+
 /* Debug hook (not part of the drop-in ABI): the forward kernel aule_attention_forward_ex would launch for `d`
  * -- 0 fp32, 1 ping-pong, 2 in-wave, 3 lock-step, 4 split-KV; -3 for a bad descriptor.  Pure host logic: no
  * device, no aule_init() needed.  Used by the tests to pin which kernel a shape exercises. */

@@ -82,7 +82,62 @@ struct BwdParams {
     float* part;  // dkdv, gsplit > 1: fp32 partials [2 (dK,dV)][gsplit][B,Hkv,Sk,D]
     int window;   // sliding window: key j visible to query i only if i - j < window (0: off)
     int coff;     // causal position offset (query i sits at position i + coff; 0 = top-left rule)
+    unsigned long long* dbg;  // timeline build of the dK/dV kernel only: [8 waves][kBwdTLMax] s_memtime stamps of workgroup 0
 };
+
+constexpr int kBwdTLMax = 384;   // 6 stamps per tile
+
+#ifndef AULE_DKV_PINNED
+#define AULE_DKV_PINNED 1        // 0: the plain-IR P/dS arithmetic (A/B builds)
+#endif
+constexpr bool kDkvPinned = AULE_DKV_PINNED != 0;
+
+// P and dS of four scores (consecutive query rows of one key column) as single-issue instructions in a fixed order:
+//   x = S*c - LSE', P = exp2(x), dS = P * (dP - delta), packs of (P0,P1) (P2,P3) (dS0,dS1) (dS2,dS3).
+// As plain IR on f32x2 hipcc emits v_pk_fma / v_pk_mul / v_pk_add, the forms that run ~3.6x slower beside the SIMD
+// partner's MFMA stream (tools/probe_issue.hip); the dK/dV timeline had this phase at 1050-1900 cycles of a ~5000-cycle
+// tile, longer than either MFMA phase.  Inputs, temporaries and outputs are separate operands (29 of the 30 allowed;
+// tying them makes hipcc copy the MFMA result tuples); every v_exp result is first read >= 2 instructions later
+// (inline asm is invisible to the hazard recogniser).
+#define AULE_PDS_QUAD(CVT)                                                                                         \
+    asm volatile("v_fma_f32 %4, %12, %28, -%20\n\t"                                                                \
+                 "v_fma_f32 %5, %13, %28, -%21\n\t"                                                                \
+                 "v_fma_f32 %6, %14, %28, -%22\n\t"                                                                \
+                 "v_fma_f32 %7, %15, %28, -%23\n\t"                                                                \
+                 "v_exp_f32 %4, %4\n\t"                                                                            \
+                 "v_exp_f32 %5, %5\n\t"                                                                            \
+                 "v_exp_f32 %6, %6\n\t"                                                                            \
+                 "v_exp_f32 %7, %7\n\t"                                                                            \
+                 "v_sub_f32 %8, %16, %24\n\t"                                                                      \
+                 "v_sub_f32 %9, %17, %25\n\t"                                                                      \
+                 "v_sub_f32 %10, %18, %26\n\t"                                                                     \
+                 "v_sub_f32 %11, %19, %27\n\t"                                                                     \
+                 CVT " %0, %4, %5\n\t"                                                                             \
+                 CVT " %1, %6, %7\n\t"                                                                             \
+                 "v_mul_f32 %8, %8, %4\n\t"                                                                        \
+                 "v_mul_f32 %9, %9, %5\n\t"                                                                        \
+                 "v_mul_f32 %10, %10, %6\n\t"                                                                      \
+                 "v_mul_f32 %11, %11, %7\n\t"                                                                      \
+                 CVT " %2, %8, %9\n\t"                                                                             \
+                 CVT " %3, %10, %11\n\t"                                                                           \
+                 : "=&v"(p01), "=&v"(p23), "=&v"(d01), "=&v"(d23), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3),     \
+                   "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)                                                      \
+                 : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(g0), "v"(g1), "v"(g2), "v"(g3), "v"(l0), "v"(l1),        \
+                   "v"(l2), "v"(l3), "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(c))
+template <class T>
+__device__ __forceinline__ void pds_quad(float s0, float s1, float s2, float s3, float g0, float g1, float g2, float g3,
+                                         float l0, float l1, float l2, float l3, float e0, float e1, float e2, float e3,
+                                         float c, unsigned& p01, unsigned& p23, unsigned& d01, unsigned& d23) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float t0, t1, t2, t3, u0, u1, u2, u3;
+    if constexpr (T::kDType == 2) AULE_PDS_QUAD("v_cvt_pk_bf16_f32");
+    else AULE_PDS_QUAD("v_cvt_pk_f16_f32");   // round-to-nearest-even, like F16Traits::pack2
+#else
+    (void)s0; (void)s1; (void)s2; (void)s3; (void)g0; (void)g1; (void)g2; (void)g3; (void)l0; (void)l1; (void)l2; (void)l3;
+    (void)e0; (void)e1; (void)e2; (void)e3; (void)c;
+    p01 = p23 = d01 = d23 = 0u;
+#endif
+}
 
 // Row-major image swizzle (shared with the forward's K image).
 template <int D>
@@ -420,9 +475,25 @@ struct DkvCfg {
     static constexpr int LDS = 8 * VSLAB + 2 * STAGE;
 };
 
-template <class T, int D, bool CAUSAL>
+template <class T, int D, bool CAUSAL, bool TL = false>
 __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
     using Cfg = DkvCfg<D>;
+    // TL: s_memtime stamps of workgroup 0 at the phase boundaries of every tile (tools/timeline_bwd.py):
+    //   0 loop top (next tile's loads issued)   1 S / dP MFMAs retired   2 P / dS arithmetic done
+    //   3 dV / dK MFMAs retired                 4 next tile written to LDS   5 barrier passed
+    int tl_n = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if constexpr (TL) {
+            if (blockIdx.x == 0 && tl_n < kBwdTLMax) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if ((threadIdx.x & 63) == 0) p.dbg[(threadIdx.x >> 6) * kBwdTLMax + tl_n] = t;
+                ++tl_n;
+            }
+        }
+    };
+    auto retire = [&](f32x16_t& a, f32x16_t& b) __attribute__((always_inline)) {   // make the MFMA results "used" before a stamp
+        if constexpr (TL) asm volatile("s_nop 0" : "+v"(a), "+v"(b));
+    };
     using v8 = typename T::v8;
     constexpr int RB = Cfg::RB, RBP = Cfg::RBP, CPR = Cfg::CPR, RM = Cfg::RM, ST = Cfg::ST;
     constexpr int KS = Cfg::KS, DB = Cfg::DB, STAGE = Cfg::STAGE;
@@ -502,7 +573,10 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
             if (tid < 64) {
                 int r = q0 + (tid & 31);
                 r = r < Sq ? r : Sq - 1;
-                sc_st = tid < 32 ? p.lse[qb + r] * kLog2e : p.delta[qb + r];
+                // raw value: scaling the LSE here made the compiler wait for this load inside the loop top -- a full
+                // memory round trip (~760 cycles per tile) on wave 0, which the other waves then wait for at the
+                // barrier (tools/timeline_bwd.py); it is scaled when it is written to LDS, a tile later
+                sc_st = tid < 32 ? p.lse[qb + r] : p.delta[qb + r];
             }
         };
         auto write_stage = [&](int buf) {
@@ -513,7 +587,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                 *reinterpret_cast<u32x4_t*>(base + RM + ST + st_rm) = dst;
                 *reinterpret_cast<u32x4_t*>(base + 2 * RM + ST + tid * 16) = dst;
             }
-            if (tid < 64) reinterpret_cast<float*>(base + 2 * RM + 2 * ST)[tid] = sc_st;
+            if (tid < 64) reinterpret_cast<float*>(base + 2 * RM + 2 * ST)[tid] = tid < 32 ? sc_st * kLog2e : sc_st;
         };
 
         f32x16_t dk[DB], dv[DB];
@@ -532,6 +606,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
             const int cur = it & 1;
             const int q0 = (first_qt + it % ntq) * kQT;
             if (it + 1 < nit) issue_loads(it + 1);
+            stamp();   // 0
             // the tile contributes to this wave's keys iff some query row q >= key row exists
             if ((!CAUSAL || q0 + coff + kQT - 1 >= n0w) && (W <= 0 || q0 + coff < n0w + 31 + W)) {
                 const char* base = stage0 + cur * STAGE;
@@ -565,6 +640,8 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     }
                 }
+                retire(s, dp);
+                stamp();   // 1
                 const bool need_mask = (CAUSAL && (q0 + coff < n0w + 31)) || (q0 + kQT > Sq) || (n0w + 32 > Sk) ||
                                        (W > 0 && q0 + coff + kQT - 1 - n0w >= W);
                 const f32x2_t c2 = {c, c};
@@ -577,6 +654,14 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                         const int r0 = 8 * kk + 4 * g4;  // registers r0..r0+3 = 4 consecutive query rows
                         const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(scal + 2 * r0 + 4 * hi);
                         const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(scal + 32 + 2 * r0 + 4 * hi);
+                        if (kDkvPinned && !need_mask) {   // (wave-uniform) steady state: the pinned single-issue form
+                            unsigned p01, p23, d01, d23;   // (a vector element cannot bind to the asm's reference)
+                            pds_quad<T>(s[r0], s[r0 + 1], s[r0 + 2], s[r0 + 3], dp[r0], dp[r0 + 1], dp[r0 + 2], dp[r0 + 3],
+                                        l4[0], l4[1], l4[2], l4[3], d4[0], d4[1], d4[2], d4[3], c, p01, p23, d01, d23);
+                            pu[2 * g4] = p01; pu[2 * g4 + 1] = p23;
+                            du[2 * g4] = d01; du[2 * g4 + 1] = d23;
+                            continue;
+                        }
 #pragma unroll
                         for (int j2 = 0; j2 < 2; ++j2) {
                             const int r = r0 + 2 * j2;
@@ -601,6 +686,8 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                     pb[kk] = as_v8<T>(pu);
                     dsb[kk] = as_v8<T>(du);
                 }
+                if constexpr (TL) asm volatile("" : "+v"(pb[0]), "+v"(pb[1]), "+v"(dsb[0]), "+v"(dsb[1]));
+                stamp();   // 2
                 // dV^T += dO^T . P ; dK^T += Q^T . dS   (A by transpose read, k-slot = query row)
                 {
                     constexpr int NST = 2 * DB;   // step = (kk, d): one dV and one dK MFMA
@@ -628,8 +715,15 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                     }
                 }
             }
+            else {
+                stamp(); stamp();   // (tile skipped by this wave: keep six stamps per tile)
+            }
+            retire(dv[DB - 1], dk[DB - 1]);
+            stamp();   // 3
             if (it + 1 < nit) write_stage(cur ^ 1);
+            stamp();   // 4
             __syncthreads();
+            stamp();   // 5
         }
 
         if (kvrow < Sk) {
@@ -743,7 +837,18 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
         p.gsplit = dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal);
         p.part = reinterpret_cast<float*>(reinterpret_cast<char*>(a.delta) + delta_bytes(a.B, a.Hq, a.Sq));
         const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv * p.gsplit)), block(512);
-        if (a.causal)
+        p.dbg = a.dbg;
+        bool tl_done = false;
+        if constexpr (std::is_same<T, Bf16Traits>::value && D == 128) {
+            if (a.dbg != nullptr && a.causal) {   // timeline build (tools/timeline_bwd.py): bf16 D128 causal only
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkdv_kernel<T, D, true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, DkvCfg<D>::LDS);
+                hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, true, true>), grid, block, DkvCfg<D>::LDS, stream, p);
+                tl_done = true;
+            }
+        }
+        if (tl_done) {
+        } else if (a.causal)
             hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, true>), grid, block, DkvCfg<D>::LDS, stream, p);
         else
             hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, false>), grid, block, DkvCfg<D>::LDS, stream, p);

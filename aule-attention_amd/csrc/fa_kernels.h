@@ -75,6 +75,7 @@ struct BwdArgs {
     int dtype;
     int window = -1;  // as FwdArgs::window (the reference's backward ignores it; this one honours it)
     int coff = 0;     // as FwdArgs::coff
+    unsigned long long* dbg = nullptr;   // debug: s_memtime stamps of the dK/dV kernel's workgroup 0 (bf16 D128 causal)
 };
 
 // Paged-KV decode (python/aule/triton_flash_amd.py:543-737): one query token per sequence.
