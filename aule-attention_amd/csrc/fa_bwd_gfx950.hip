@@ -91,6 +91,9 @@ constexpr int kBwdTLMax = 384;   // 6 stamps per tile
 #define AULE_DKV_PINNED 1        // 0: the plain-IR P/dS arithmetic (A/B builds)
 #endif
 constexpr bool kDkvPinned = AULE_DKV_PINNED != 0;
+#ifndef AULE_DKV_MPRIO
+#define AULE_DKV_MPRIO 0         // s_setprio level around the dK/dV kernel's MFMA loops (A/B builds)
+#endif
 
 // P and dS of four scores (consecutive query rows of one key column) as single-issue instructions in a fixed order:
 //   x = S*c - LSE', P = exp2(x), dS = P * (dP - delta), packs of (P0,P1) (P2,P3) (dS0,dS1) (dS2,dS3).
@@ -629,6 +632,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                     };
 #pragma unroll
                     for (int ks = 0; ks < kDkvAhead && ks < KS; ++ks) rd(ks);
+                    if constexpr (AULE_DKV_MPRIO != 0) __builtin_amdgcn_s_setprio(AULE_DKV_MPRIO);
                     __builtin_amdgcn_sched_group_barrier(0x100, 3 * (kDkvAhead < KS ? kDkvAhead : KS), 0);
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
@@ -640,6 +644,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     }
                 }
+                if constexpr (AULE_DKV_MPRIO != 0) __builtin_amdgcn_s_setprio(0);
                 retire(s, dp);
                 stamp();   // 1
                 const bool need_mask = (CAUSAL && (q0 + coff < n0w + 31)) || (q0 + kQT > Sq) || (n0w + 32 > Sk) ||
@@ -702,6 +707,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                     };
 #pragma unroll
                     for (int st = 0; st < kDkvAhead && st < NST; ++st) rd(st);
+                    if constexpr (AULE_DKV_MPRIO != 0) __builtin_amdgcn_s_setprio(AULE_DKV_MPRIO);
                     __builtin_amdgcn_sched_group_barrier(0x100, 4 * (kDkvAhead < NST ? kDkvAhead : NST), 0);
 #pragma unroll
                     for (int st = 0; st < NST; ++st) {
@@ -718,6 +724,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
             else {
                 stamp(); stamp();   // (tile skipped by this wave: keep six stamps per tile)
             }
+            if constexpr (AULE_DKV_MPRIO != 0) __builtin_amdgcn_s_setprio(0);
             retire(dv[DB - 1], dk[DB - 1]);
             stamp();   // 3
             if (it + 1 < nit) write_stage(cur ^ 1);
