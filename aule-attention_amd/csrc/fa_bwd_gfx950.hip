@@ -91,6 +91,10 @@ constexpr int kBwdTLMax = 384;   // 6 stamps per tile
 #define AULE_DKV_PINNED 1        // 0: the plain-IR P/dS arithmetic (A/B builds)
 #endif
 constexpr bool kDkvPinned = AULE_DKV_PINNED != 0;
+#ifndef AULE_DQ_PINNED
+#define AULE_DQ_PINNED 1         // 0: the plain-IR P/dS arithmetic of the dQ kernel (A/B builds)
+#endif
+constexpr bool kDqPinned = AULE_DQ_PINNED != 0;
 #ifndef AULE_DKV_MPRIO
 #define AULE_DKV_MPRIO 0         // s_setprio level around the dK/dV kernel's MFMA loops (A/B builds)
 #endif
@@ -140,6 +144,32 @@ __device__ __forceinline__ void pds_quad(float s0, float s1, float s2, float s3,
     (void)e0; (void)e1; (void)e2; (void)e3; (void)c;
     p01 = p23 = d01 = d23 = 0u;
 #endif
+}
+
+// The dQ kernel's variant: only dS is needed there, and LSE' / delta are per lane (a lane owns a query row).
+#define AULE_DS_PAIR(CVT)                                                                          \
+    asm volatile("v_fma_f32 %1, %5, %9, %10\n\t"                                                   \
+                 "v_fma_f32 %2, %6, %9, %10\n\t"                                                   \
+                 "v_sub_f32 %3, %7, %11\n\t"                                                       \
+                 "v_exp_f32 %1, %1\n\t"                                                            \
+                 "v_exp_f32 %2, %2\n\t"                                                            \
+                 "v_sub_f32 %4, %8, %11\n\t"                                                       \
+                 "v_mul_f32 %3, %3, %1\n\t"                                                        \
+                 "v_mul_f32 %4, %4, %2\n\t"                                                        \
+                 CVT " %0, %3, %4\n\t"                                                             \
+                 : "=&v"(d01), "=&v"(t0), "=&v"(t1), "=&v"(u0), "=&v"(u1)                          \
+                 : "v"(s0), "v"(s1), "v"(g0), "v"(g1), "v"(c), "v"(nl), "v"(dl))
+template <class T>
+__device__ __forceinline__ unsigned ds_pair(float s0, float s1, float g0, float g1, float c, float nl, float dl) {
+    unsigned d01 = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    float t0, t1, u0, u1;
+    if constexpr (T::kDType == 2) AULE_DS_PAIR("v_cvt_pk_bf16_f32");
+    else AULE_DS_PAIR("v_cvt_pk_f16_f32");
+#else
+    (void)s0; (void)s1; (void)g0; (void)g1; (void)c; (void)nl; (void)dl;
+#endif
+    return d01;
 }
 
 // Row-major image swizzle (shared with the forward's K image).
@@ -363,6 +393,17 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
             int rlo = kv0 - kv_low;  // ... and to the first visible one (sliding window)
             asm volatile("" : "+v"(rel), "+v"(rlo));  // (opaque: otherwise hipcc hoists 32 per-element constants out of the loop and spills them)
             u32x4_t du[2][2];
+            if (kDqPinned && !need_mask) {   // (wave-uniform) steady state: pinned single-issue form, two scores a statement
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int r = 8 * kk + 2 * j;
+                            du[sb][kk][j] = ds_pair<T>(s[sb][r], s[sb][r + 1], dp[sb][r], dp[sb][r + 1], c, nlse2, delta);
+                        }
+            } else
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
