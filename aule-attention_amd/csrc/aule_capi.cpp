@@ -903,7 +903,7 @@ uint64_t aule_attention_paged_decode_workspace_size(const aule_paged_desc* d) {
 /* Debug hook (not part of the drop-in ABI): aule_attention_backward_ex with the dK/dV kernel's timeline build --
  * per-phase s_memtime stamps of its workgroup 0 into `stamps` (device pointer, 8 * 384 uint64; bf16 D128 causal only,
  * otherwise the ordinary kernels run and nothing is written).  Used by tools/timeline_bwd.py. */
-int32_t aule_hip_debug_backward_timeline(const aule_attn_bwd_desc* d, unsigned long long* stamps) {
+static int32_t backward_timeline(const aule_attn_bwd_desc* d, unsigned long long* stamps, bool dq) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_init || d == nullptr || d->struct_size != sizeof(aule_attn_bwd_desc)) return -1;
     BwdArgs a;
@@ -914,8 +914,15 @@ int32_t aule_hip_debug_backward_timeline(const aule_attn_bwd_desc* d, unsigned l
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
     a.dtype = d->dtype;
-    a.dbg = stamps;
+    if (dq) a.dbg_dq = stamps; else a.dbg = stamps;
     return aule_hip::launch_bwd(a, (hipStream_t)d->stream);
+}
+int32_t aule_hip_debug_backward_timeline(const aule_attn_bwd_desc* d, unsigned long long* stamps) {
+    return backward_timeline(d, stamps, false);
+}
+/* ... the same for the dQ kernel (8 stamps per tile). */
+int32_t aule_hip_debug_backward_timeline_dq(const aule_attn_bwd_desc* d, unsigned long long* stamps) {
+    return backward_timeline(d, stamps, true);
 }
 
 /* Debug hook (not part of the drop-in ABI): the forward kernel aule_attention_forward_ex would launch for `d`

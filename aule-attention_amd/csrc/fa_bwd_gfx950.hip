@@ -223,8 +223,21 @@ struct DqCfg {
     static constexpr int LDS = 4 * RM + 3 * ST;  // Krm x2, Vrm x2, Kst x3
 };
 
-template <class T, int D, bool CAUSAL>
+template <class T, int D, bool CAUSAL, bool TL = false>
 __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
+    // TL: s_memtime stamps of workgroup 0, eight per tile (tools/timeline_bwd.py dq):
+    //   0 V-phase start  1 next tile written to LDS  2 loads issued  3 dS arithmetic done  4 barrier passed (M-phase start)
+    //   5 dQ MFMAs (16) retired  6 S/dP MFMAs of the next tile (32) retired  7 barrier passed
+    int tl_n = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if constexpr (TL) {
+            if (blockIdx.x == 0 && tl_n < kBwdTLMax) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if ((threadIdx.x & 63) == 0) p.dbg[(threadIdx.x >> 6) * kBwdTLMax + tl_n] = t;
+                ++tl_n;
+            }
+        }
+    };
     using Cfg = DqCfg<D>;
     using v8 = typename T::v8;
     constexpr int RB = Cfg::RB, RBP = Cfg::RBP, RM = Cfg::RM, ST = Cfg::ST, CH = Cfg::CH, KS = Cfg::KS, DB = Cfg::DB;
@@ -451,23 +464,33 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
         auto tile_step = [&](int j, auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
             // ---- V-phase(j): staging, then P/dS of tile j
+            stamp();   // 0
             if (j + 1 + grp < nt) write_tile(j + 1 + grp);
+            stamp();   // 1
             if (j + 2 + grp < nt) issue_loads(j + 2 + grp);
+            stamp();   // 2
             if constexpr (MODE >= 1) softmax((t_lo + j) * kDqKV);
+            stamp();   // 3
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
+            stamp();   // 4
             // ---- M-phase(j): dQ^T += K_j^T.dS_j^T ; S^T_{j+1}, dP^T_{j+1}
             __builtin_amdgcn_s_setprio(1);
             if constexpr (MODE >= 1) dq_mm(j);
+            if constexpr (TL) asm volatile("s_nop 0" : "+v"(acc[0]), "+v"(acc[DB - 1]));
+            stamp();   // 5
             if constexpr (MODE == 2) {
                 __builtin_amdgcn_sched_barrier(0);
                 sdp(j + 1);
             }
+            if constexpr (TL) asm volatile("s_nop 0" : "+v"(s[1]), "+v"(dp[1]));
+            stamp();   // 6
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
+            stamp();   // 7
         };
         int j = 0;
         for (; j + 1 < na; ++j) tile_step(j, std::integral_constant<int, 2>{});
@@ -872,7 +895,18 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
         p.gsplit = 1;
         p.part = nullptr;
         const dim3 grid((unsigned)(p.nblk * a.B * a.Hq)), block(512);
-        if (a.causal)
+        p.dbg = a.dbg_dq;
+        bool tl_done = false;
+        if constexpr (std::is_same<T, Bf16Traits>::value && D == 128) {
+            if (a.dbg_dq != nullptr && a.causal) {   // timeline build (tools/timeline_bwd.py dq): bf16 D128 causal only
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dq_kernel<T, D, true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, DqCfg<D>::LDS);
+                hipLaunchKernelGGL((fa_bwd_dq_kernel<T, D, true, true>), grid, block, DqCfg<D>::LDS, stream, p);
+                tl_done = true;
+            }
+        }
+        if (tl_done) {
+        } else if (a.causal)
             hipLaunchKernelGGL((fa_bwd_dq_kernel<T, D, true>), grid, block, DqCfg<D>::LDS, stream, p);
         else
             hipLaunchKernelGGL((fa_bwd_dq_kernel<T, D, false>), grid, block, DqCfg<D>::LDS, stream, p);

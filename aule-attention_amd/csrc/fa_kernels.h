@@ -76,6 +76,7 @@ struct BwdArgs {
     int window = -1;  // as FwdArgs::window (the reference's backward ignores it; this one honours it)
     int coff = 0;     // as FwdArgs::coff
     unsigned long long* dbg = nullptr;   // debug: s_memtime stamps of the dK/dV kernel's workgroup 0 (bf16 D128 causal)
+    unsigned long long* dbg_dq = nullptr;   // ... of the dQ kernel's workgroup 0
 };
 
 // Paged-KV decode (python/aule/triton_flash_amd.py:543-737): one query token per sequence.

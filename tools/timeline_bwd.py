@@ -31,7 +31,8 @@ d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
 n = int(lib.aule_attention_backward_workspace_size(ctypes.byref(d)))
 ws = torch.empty(n, device="cuda", dtype=torch.uint8); d.workspace, d.workspace_bytes = ws.data_ptr(), n
 stamps = torch.zeros(NW * MAX, device="cuda", dtype=torch.int64)
-fn = lib.aule_hip_debug_backward_timeline
+DQ = len(sys.argv) > 1 and sys.argv[1] == "dq"
+fn = lib.aule_hip_debug_backward_timeline_dq if DQ else lib.aule_hip_debug_backward_timeline
 fn.restype = ctypes.c_int32; fn.argtypes = [ctypes.POINTER(_capi.AttnBwdDesc), ctypes.c_void_p]
 for _ in range(3):
     rc = fn(ctypes.byref(d), ctypes.c_void_p(stamps.data_ptr()))
@@ -39,8 +40,25 @@ for _ in range(3):
 torch.cuda.synchronize()
 # the instrumented kernel still computes the right thing
 rq, rk, rv = at.bwd_raw(q, k, v, out, do, lse, True, sc)
-print("TL build == production kernels: dK %s dV %s" % (torch.equal(dk, rk), torch.equal(dv, rv)))
+print("TL build == production kernels: dQ %s dK %s dV %s" % (torch.equal(dq, rq), torch.equal(dk, rk), torch.equal(dv, rv)))
 t = stamps.cpu().numpy().reshape(NW, MAX).astype(np.int64)
+if DQ:
+    # dQ kernel: 8 stamps per 64-key tile; waves 0-3 = group 0, waves 4-7 = group 1 (one phase behind)
+    nt8 = MAX // 8
+    t = t[:, :nt8 * 8].reshape(NW, nt8, 8)
+    nm = ["0>1 write next K/V tile to LDS", "1>2 issue loads", "2>3 dS arithmetic", "3>4 barrier wait (end of V-phase)",
+          "4>5 dQ MFMAs (16: ideal 512)", "5>6 S/dP MFMAs of next tile (32: ideal 1024)", "6>7 barrier wait (end of M-phase)", "7>0' (loop)"]
+    lo, hi = 6, nt8 - 3
+    print(f"dQ kernel, tiles {lo}..{hi-1} of workgroup 0; cycles, median per wave (waves 0-3 group 0, 4-7 group 1)")
+    for ph in range(8):
+        dl = (t[:, lo:hi, ph + 1] - t[:, lo:hi, ph]) if ph < 7 else (t[:, lo + 1:hi + 1, 0] - t[:, lo:hi, 7])
+        med = np.median(dl, axis=1)
+        print(f"  {nm[ph]:46s} " + " ".join(f"{int(m):5d}" for m in med) + f"   | all: {int(np.median(dl))} [{int(np.percentile(dl,10))} .. {int(np.percentile(dl,90))}]")
+    per = np.median(t[:, lo + 1:hi + 1, 0] - t[:, lo:hi, 0], axis=1)
+    print("  tile period                                    " + " ".join(f"{int(m):5d}" for m in per) + f"   | own MFMAs (48 x 32 = 1536) / period = {1536/np.median(per):.2f}; two groups per SIMD: {2*1536/np.median(per):.2f}")
+    g0v = t[0, lo:hi, 0]; g1v = t[4, lo:hi, 0]
+    print("  group 1's V-phase starts this many cycles after group 0's (median):", int(np.median(g1v - g0v)))
+    sys.exit(0)
 ntile = MAX // 6
 t = t[:, :ntile * 6].reshape(NW, ntile, 6)
 names = ["0>1 S/dP MFMA phase (ideal 512..1024)", "1>2 P/dS arithmetic", "2>3 dV/dK MFMA phase (ideal 512..1024)",
