@@ -95,6 +95,9 @@ constexpr bool kDkvPinned = AULE_DKV_PINNED != 0;
 #define AULE_DQ_PINNED 1         // 0: the plain-IR P/dS arithmetic of the dQ kernel (A/B builds)
 #endif
 constexpr bool kDqPinned = AULE_DQ_PINNED != 0;
+#ifndef AULE_DQ_SDP_AHEAD
+#define AULE_DQ_SDP_AHEAD 0       // k-steps of operand look-ahead in the dQ kernel's S/dP product (A/B builds)
+#endif
 #ifndef AULE_DKV_MPRIO
 #define AULE_DKV_MPRIO 0         // s_setprio level around the dK/dV kernel's MFMA loops (A/B builds)
 #endif
@@ -355,7 +358,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
             f32x16_t z;
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
-            constexpr int kAhead = 0;
+            constexpr int kAhead = AULE_DQ_SDP_AHEAD;
             u32x4_t ka[KS][2], va[KS][2];
             auto rd = [&](int ks) {
 #pragma unroll
