@@ -96,7 +96,12 @@ constexpr bool kDkvPinned = AULE_DKV_PINNED != 0;
 #endif
 constexpr bool kDqPinned = AULE_DQ_PINNED != 0;
 #ifndef AULE_DQ_SDP_AHEAD
-#define AULE_DQ_SDP_AHEAD 0       // k-steps of operand look-ahead in the dQ kernel's S/dP product (A/B builds)
+#define AULE_DQ_SDP_AHEAD 1       // k-steps of operand look-ahead in the dQ kernel's S/dP product.  Without the pinned
+                                  // order below 0/1/2 measure the same (hipcc reorders the unrolled block); pinned, 1 is
+                                  // -2.5..3 % on the whole causal-D128 backward and 2 is +10 % (92 B/lane of scratch)
+#endif
+#ifndef AULE_DQ_SDP_PIN
+#define AULE_DQ_SDP_PIN 1         // pin the read / MFMA interleave of that block with sched_group_barrier (needs AHEAD > 0)
 #endif
 #ifndef AULE_DKV_MPRIO
 #define AULE_DKV_MPRIO 0         // s_setprio level around the dK/dV kernel's MFMA loops (A/B builds)
@@ -369,6 +374,8 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
             };
 #pragma unroll
             for (int ks = 0; ks < kAhead && ks < KS; ++ks) rd(ks);
+            if constexpr (AULE_DQ_SDP_PIN != 0 && kAhead > 0)
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 * (kAhead < KS ? kAhead : KS), 0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (kAhead == 0) rd(ks);
@@ -377,6 +384,11 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
                 for (int sb = 0; sb < 2; ++sb) {
                     s[sb] = T::mfma(as_v8<T>(ka[ks][sb]), qf[ks], ks == 0 ? z : s[sb]);
                     dp[sb] = T::mfma(as_v8<T>(va[ks][sb]), dof[ks], ks == 0 ? z : dp[sb]);
+                }
+                if constexpr (AULE_DQ_SDP_PIN != 0 && kAhead > 0) {   // order pinned: next step's reads, then this step's MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (ks + kAhead < KS) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
                 }
             }
         };
