@@ -103,6 +103,12 @@ constexpr bool kDqPinned = AULE_DQ_PINNED != 0;
 #ifndef AULE_DQ_SDP_PIN
 #define AULE_DQ_SDP_PIN 1         // pin the read / MFMA interleave of that block with sched_group_barrier (needs AHEAD > 0)
 #endif
+#ifndef AULE_DQ_MM_AHEAD
+#define AULE_DQ_MM_AHEAD 2         // operand look-ahead of the dQ product (transpose reads)
+#endif
+#ifndef AULE_DQ_MM_PIN
+#define AULE_DQ_MM_PIN 0           // 1: pin its read / MFMA interleave (A/B builds)
+#endif
 #ifndef AULE_DKV_MPRIO
 #define AULE_DKV_MPRIO 0         // s_setprio level around the dK/dV kernel's MFMA loops (A/B builds)
 #endif
@@ -396,7 +402,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
             int kofs = 4 * RM + (t % 3) * ST + tr_off;
             asm volatile("" : "+v"(kofs));  // one base register + 16-bit immediates (else 32 hoisted addresses spill)
             const char* ktr = smem + kofs;
-            constexpr int NST = 4 * DB, kAhead = 2;
+            constexpr int NST = 4 * DB, kAhead = AULE_DQ_MM_AHEAD;
             s16x4_t a0[NST], a1[NST];
             auto rd = [&](int st) {
                 const int sk = st / DB, d = st % DB;  // sk = 2*sb + kk
@@ -406,11 +412,16 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
             };
 #pragma unroll
             for (int st = 0; st < kAhead && st < NST; ++st) rd(st);
+            if constexpr (AULE_DQ_MM_PIN != 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * (kAhead < NST ? kAhead : NST), 0);
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
                 if (st + kAhead < NST) rd(st + kAhead);
                 const int sk = st / DB, d = st % DB;
                 acc[d] = T::mfma(as_v8<T>(a0[st], a1[st]), dsb[sk >> 1][sk & 1], acc[d]);
+                if constexpr (AULE_DQ_MM_PIN != 0) {   // order pinned: one MFMA, then the two transpose reads of step st + kAhead
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (st + kAhead < NST) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
             }
         };
         auto softmax = [&](int kv0) {  // P^T = exp2(S^T c - LSE log2e) (0 where masked) ; dS^T = P^T o (dP^T - delta)
