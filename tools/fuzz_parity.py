@@ -79,7 +79,75 @@ def run(cfg, seed):
         if (np.abs(gg - want) > tol + r * np.abs(want)).any(): errs.append(f"{name} err {np.abs(gg-want).max():.3e} (tol {tol:.1e})")
     return route(dtype, B, Hq, Hkv, Sq, Sk, D, code, W), errs
 
+def run_paged(rng, i):
+    """Random paged-decode problem against oracle.paged_decode_f64: shuffled block tables, ragged lengths (0 and 1
+    included), power-of-two and other block sizes, GQA ratios, window."""
+    import aule
+    dtype = rng.choice(["bf16", "fp16"])
+    D = int(rng.choice([32, 64, 128])); Hkv = int(rng.choice([1, 2, 4, 8])); g = int(rng.choice([1, 2, 4, 8, 16])); Hq = Hkv * g
+    B = int(rng.choice([1, 2, 3, 5, 8])); bs = int(rng.choice([1, 3, 8, 16, 24, 32, 33, 64, 100, 128]))
+    lens = [int(rng.choice([0, 1, 2, bs, bs + 1, 31, 32, 33, 100, 777, 1500, 4000])) for _ in range(B)]
+    W = int(rng.choice([-1, -1, 1, 17, 256]))
+    scale = None if rng.rand() < 0.7 else float(rng.choice([0.3, -0.2]))
+    nblk = [(n + bs - 1) // bs for n in lens]
+    num_blocks = sum(nblk) + int(rng.choice([0, 1, 5]))
+    num_blocks = max(num_blocks, 1)
+    r2 = np.random.RandomState(5000 + i)
+    q = quantize(r2.randn(B, Hq, D).astype(np.float32), dtype)
+    kc = quantize(r2.randn(num_blocks, bs, Hkv, D).astype(np.float32), dtype)
+    vc = quantize(r2.randn(num_blocks, bs, Hkv, D).astype(np.float32), dtype)
+    bt = np.zeros((B, max(max(nblk), 1) + int(rng.choice([0, 2]))), dtype=np.int32)
+    perm = r2.permutation(num_blocks); used = 0
+    for b in range(B):
+        bt[b, :nblk[b]] = perm[used:used + nblk[b]]; used += nblk[b]
+    cl = np.array(lens, dtype=np.int32)
+    dt = torch_dtype(dtype)
+    out = aule.flash_attention_paged_amd(torch.from_numpy(q).to("cuda", dt), torch.from_numpy(kc).to("cuda", dt),
+                                         torch.from_numpy(vc).to("cuda", dt), torch.from_numpy(bt).cuda(), torch.from_numpy(cl).cuda(),
+                                         scale=scale, window_size=W).float().cpu().numpy()
+    ref = oracle.paged_decode_f64(q, kc, vc, bt, cl, scale, W)
+    atol, rtol = fwd_tol(dtype, float(np.abs(vc).max()))
+    cfg = (dtype, B, Hq, Hkv, D, bs, lens, W, scale)
+    if not np.isfinite(out).all(): return cfg, ["non-finite"]
+    bad = np.abs(out - ref) > atol + rtol * np.abs(ref)
+    return cfg, ([f"err {np.abs(out-ref).max():.3e}"] if bad.any() else [])
+
+
+def run_rope(rng, i):
+    """Random RoPE pass against oracle.rope_f64: dtype, layout, inverse, offset, vector and scalar head dims, in place."""
+    dtype = rng.choice(["bf16", "fp16", "fp32"])
+    B, H, S = int(rng.choice([1, 2, 3])), int(rng.choice([1, 2, 5, 8])), int(rng.choice([1, 2, 31, 64, 100, 333]))
+    D = int(rng.choice([2, 6, 16, 20, 32, 48, 64, 80, 96, 128]))
+    layout = rng.choice(["half", "interleaved"]); inverse = bool(rng.rand() < 0.4); off = int(rng.choice([0, 0, 1, 7, 50]))
+    r2 = np.random.RandomState(7000 + i)
+    x = quantize(r2.randn(B, H, S, D).astype(np.float32), dtype)
+    cos, sin = oracle.rope_tables(S + off + int(rng.choice([0, 3])), D)
+    want = oracle.rope_f64(x, cos, sin, layout, inverse, off)
+    dev = lambda a, d="fp32": torch.from_numpy(np.ascontiguousarray(a)).to("cuda", torch_dtype(d))
+    tx = dev(x, dtype)
+    got = at.rope_raw(tx, dev(cos), dev(sin), layout, inverse, off)
+    at.rope_raw(tx, dev(cos), dev(sin), layout, inverse, off, out=tx)
+    tol = {"fp32": 2e-6, "fp16": 2e-3, "bf16": 1.6e-2}[dtype] * max(1.0, float(np.abs(want).max()))
+    cfg = (dtype, B, H, S, D, layout, inverse, off)
+    errs = []
+    if np.abs(got.float().cpu().numpy() - want).max() > tol: errs.append(f"err {np.abs(got.float().cpu().numpy()-want).max():.3e}")
+    if not torch.equal(tx, got): errs.append("in place != out of place")
+    return cfg, errs
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] in ("paged", "rope"):
+        mode = sys.argv[1]; n = int(sys.argv[2]) if len(sys.argv) > 2 else 200; seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+        rng = np.random.RandomState(seed); bad = 0
+        for i in range(n):
+            try:
+                cfg, errs = (run_paged if mode == "paged" else run_rope)(rng, i)
+            except Exception as e:  # noqa: BLE001
+                cfg, errs = ("?",), [f"EXCEPTION {type(e).__name__}: {str(e)[:160]}"]
+            if errs:
+                bad += 1; print(f"FAIL {mode} #{i} cfg={cfg}: {'; '.join(errs)}", flush=True)
+        print(f"{mode}: {n} configurations, {bad} failing")
+        sys.exit(0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.RandomState(seed)
