@@ -109,6 +109,12 @@ constexpr bool kDqPinned = AULE_DQ_PINNED != 0;
 #ifndef AULE_DQ_MM_PIN
 #define AULE_DQ_MM_PIN 0           // 1: pin its read / MFMA interleave (A/B builds)
 #endif
+#ifndef AULE_DKV_SCAL_EARLY
+#define AULE_DKV_SCAL_EARLY 0      // 1: request the LSE' / delta quads one arithmetic block ahead.  Measured: the phase
+                                   // 1140 -> 1080 cycles and the tile 4670 -> 4535, but the whole backward flat within noise in
+                                   // three passes, for 12 B/lane of scratch on causal D128 -- off
+#endif
+constexpr bool kDkvScalEarly = AULE_DKV_SCAL_EARLY != 0;
 #ifndef AULE_DKV_MPRIO
 #define AULE_DKV_MPRIO 0         // s_setprio level around the dK/dV kernel's MFMA loops (A/B builds)
 #endif
@@ -735,6 +741,18 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                     }
                 }
                 if constexpr (AULE_DKV_MPRIO != 0) __builtin_amdgcn_s_setprio(0);
+                // LSE' and delta of the tile's query rows, one block ahead: inside the (kk, g4) loop each pair of reads
+                // was issued right before its block and waited for with lgkmcnt(0) -- four exposed LDS round trips per
+                // tile (the masked path's branches keep hipcc from hoisting them).  The first pair now overlaps the tail
+                // of the S / dP MFMAs and pair i + 1 is requested before block i runs.  (All eight at once is too many
+                // registers: the D128 kernels went from 253 VGPRs / no scratch to 256 + 72 B/lane.)
+                auto scal_rd = [&](int i, f32x4_t& l, f32x4_t& d) __attribute__((always_inline)) {
+                    const int r0 = 8 * (i >> 1) + 4 * (i & 1);
+                    l = *reinterpret_cast<const f32x4_t*>(scal + 2 * r0 + 4 * hi);
+                    d = *reinterpret_cast<const f32x4_t*>(scal + 32 + 2 * r0 + 4 * hi);
+                };
+                f32x4_t l4n = {0.f, 0.f, 0.f, 0.f}, d4n = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (kDkvScalEarly) scal_rd(0, l4n, d4n);
                 retire(s, dp);
                 stamp();   // 1
                 const bool need_mask = (CAUSAL && (q0 + coff < n0w + 31)) || (q0 + kQT > Sq) || (n0w + 32 > Sk) ||
@@ -747,8 +765,14 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
 #pragma unroll
                     for (int g4 = 0; g4 < 2; ++g4) {
                         const int r0 = 8 * kk + 4 * g4;  // registers r0..r0+3 = 4 consecutive query rows
-                        const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(scal + 2 * r0 + 4 * hi);
-                        const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(scal + 32 + 2 * r0 + 4 * hi);
+                        f32x4_t l4, d4;
+                        if constexpr (kDkvScalEarly) {
+                            l4 = l4n; d4 = d4n;
+                            if (2 * kk + g4 < 3) scal_rd(2 * kk + g4 + 1, l4n, d4n);
+                        } else {
+                            l4 = *reinterpret_cast<const f32x4_t*>(scal + 2 * r0 + 4 * hi);
+                            d4 = *reinterpret_cast<const f32x4_t*>(scal + 32 + 2 * r0 + 4 * hi);
+                        }
                         if (kDkvPinned && !need_mask) {   // (wave-uniform) steady state: the pinned single-issue form
                             unsigned p01, p23, d01, d23;   // (a vector element cannot bind to the asm's reference)
                             pds_quad<T>(s[r0], s[r0 + 1], s[r0 + 2], s[r0 + 3], dp[r0], dp[r0 + 1], dp[r0 + 2], dp[r0 + 3],
