@@ -148,6 +148,7 @@ int run_fwd_f32(const float* q, const float* k, const float* v, float* o, float*
 namespace aule_hip {
 int launch_fwd_pp_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
 int launch_fwd_iw_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
+int launch_fwd_ps_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
 int configure_fwd();
 int configure_bwd();
 int configure_kernels() {
@@ -955,6 +956,9 @@ int32_t aule_hip_debug_forward_timeline(const aule_attn_desc* d, unsigned long l
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
     a.dtype = d->dtype;
+    if (const char* e = getenv("AULE_TL"))
+        if (e[0] == 'p' && e[1] == 's')  // persistent tile stream: 8 waves x 2048 tagged stamps (tools/timeline_ps.py)
+            return aule_hip::launch_fwd_ps_timeline(a, stamps, (hipStream_t)d->stream);
     if (const char* e = getenv("AULE_HIP_FWD_KERNEL"))
         if (e[0] == 'i' && e[1] == 'w')  // 4 waves x 512 stamps
             return aule_hip::launch_fwd_iw_timeline(a, stamps, (hipStream_t)d->stream);

@@ -317,6 +317,9 @@ bool pp_split_applicable(const FwdArgs& a);
 int configure_fwd_pp();
 int launch_fwd_iw(const FwdArgs& a, hipStream_t stream);   // fa_fwd_iw_gfx950.hip (-1: shape not covered)
 int configure_fwd_iw();
+int launch_fwd_ps(const FwdArgs& a, hipStream_t stream);   // fa_fwd_ps_gfx950.hip (persistent tile stream)
+bool fwd_ps_applicable(const FwdArgs& a);
+int configure_fwd_ps();
 
 // AULE_HIP_FWD_KERNEL = "pp" (8-wave ping-pong schedule) | "iw" (4-wave in-wave ping-pong, D = 128) |
 // "v1" (one barrier per tile, all waves in the same phase); the non-default ones are kept for A/B measurements
@@ -325,12 +328,13 @@ static int fwd_kernel_choice() {
         const char* e = getenv("AULE_HIP_FWD_KERNEL");
         if (e != nullptr && e[0] == 'v' && e[1] == '1') return 1;
         if (e != nullptr && e[0] == 'i' && e[1] == 'w') return 2;
-        if (e != nullptr && e[0] == 'p' && e[1] == 'p') return 0;
+        if (e != nullptr && e[0] == 'p' && e[1] == 'p') return 4;   // one workgroup per Q-block pair (the stream's predecessor)
         return 0;
     }();
     return v;
 }
 static bool use_v1() { return fwd_kernel_choice() == 1; }
+static bool use_ps(const FwdArgs& a) { return fwd_kernel_choice() == 0 && fwd_ps_applicable(a); }
 
 bool splitkv_applicable(const FwdArgs& a);                      // fa_fwd_splitkv_gfx950.hip
 int launch_fwd_splitkv(const FwdArgs& a, hipStream_t stream);
@@ -370,6 +374,7 @@ int fwd_route(const FwdArgs& a) {
     if (a.dtype == kF32) return 0;
     const int sq = short_query_route(a);
     if (sq) return sq;
+    if (use_ps(a)) return 6;
     const bool pp_only = a.window > 0 || (a.causal && a.coff != 0);
     if (fwd_kernel_choice() == 2 && !pp_only) return 2;
     if (!use_v1() || pp_only) return 1;
@@ -397,6 +402,7 @@ int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (sq == 5) return launch_fwd_pp_split(a, stream);
     if (a.query_ws != nullptr) return 0;   // single-launch paths need no workspace
     if (a.dtype == kF32) return launch_fwd_f32(a, stream);
+    if (use_ps(a)) return launch_fwd_ps(a, stream);
     const bool pp_only = a.window > 0 || (a.causal && a.coff != 0);  // window / shifted causal live in the ping-pong kernel
     if (fwd_kernel_choice() == 2 && !pp_only) {
         const int rc = launch_fwd_iw(a, stream);
@@ -425,6 +431,7 @@ int configure_fwd() {
     rc |= set_attr_16<F16Traits, 32>();
     rc |= configure_fwd_f32();
     rc |= configure_fwd_pp();
+    rc |= configure_fwd_ps();
     rc |= configure_fwd_iw();
     return rc;
 }

@@ -1,0 +1,719 @@
+// fa_fwd_ps_gfx950.hip -- FlashAttention-2 forward (16-bit I/O) as a PERSISTENT TILE STREAM.
+//
+// Same arithmetic, MFMA layouts, LDS images and two-group ping-pong phases as fa_fwd_pp_gfx950.hip (read its header
+// and DESIGN.md 3.2 first).  What changes is everything AROUND the tile loop.  The ping-pong kernel runs one
+// workgroup per causal Q-block pair and pays, per 256-row Q block, an epilogue (2.5 k cycles), a cold prologue (an
+// HBM round trip of ~3.8 k cycles with every CU at a boundary at the same moment), a pre-phase and three alignment
+// barriers: 10-14 k cycles in which the matrix pipes idle, against ~65 k cycles of tile work for an average block of
+// the headline shape.  Here
+//
+//   * the grid is one workgroup per CU (LDS allows only one anyway) and every workgroup walks a LIST of Q blocks
+//     ("parts"; the (i, n-1-i) pairs of the causal load balance, items g, g+G, g+2G, ... of the launch);
+//   * the K/V tile stream does not stop at a Q-block boundary ("seam"): tile positions are numbered through the
+//     whole list, the staging cursors (which tile to request next, from which head) simply run on into the next
+//     part, so the first tiles of the next block are in LDS when the last tile of this one retires;
+//   * at a seam a wave's M-phase is [PV of the last tile | QK^T of the NEXT block's first tile], i.e. the normal
+//     M-phase with a different Q: the next block's Q rows are requested into the (dead) Q registers one phase
+//     earlier, right after the wave's last QK^T of the block;
+//   * a wave's epilogue for a block (normalise, transpose through its LDS slab, whole-row stores, LSE) follows its last PV
+//     of the block directly, inside that M-phase: register pressure is lowest there (S and P are dead, the next S is not
+//     born yet -- in the next block's first V-phase the same code spilled the K/V staging registers and the Q
+//     fragments), and on causal blocks six of the eight waves finish early and do it while they would idle;
+//   * no barrier beyond the two per tile step: the two groups stay one phase apart across seams.
+//
+// The fixed-reference softmax (bf16) keeps its per-block range verdict, but a failed block is no longer re-run on the
+// spot (that would stall the stream): verdicts are posted per part and, after the stream, the workgroup runs the
+// flagged parts again as a second, sparse stream with the online softmax.
+//
+// Covers: bf16 / fp16, D = 32 / 64 / 128, causal (top-left or shifted by `coff`) and non-causal, any Sq, every part
+// with at least 4 KV tiles, no sliding window, no KV split -- everything else stays on fa_fwd_pp_gfx950.hip.
+#include <cstdlib>
+#include <type_traits>
+
+#include "fa_device.h"
+#include "fa_kernels.h"
+#include "fa_fwd_tile.h"
+
+namespace aule_hip {
+namespace {
+
+struct FwdPSParams {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* o;
+    float* lse;
+    int B, Hq, Hkv, Sq, Sk;
+    float c;      // |scale| * log2(e)
+    int negq;     // scale < 0
+    int nqb;      // 256-row Q blocks
+    int nwork;    // work items per head: ceil(nqb/2) when pairing, else nqb
+    int pair;     // item = Q blocks (nqb-1-i, i)
+    int coff;     // causal position offset (query i sits at position i + coff)
+    int nitems;   // nwork * B * Hq; workgroup g takes items g, g + gridDim.x, ...
+    unsigned long long* dbg;   // timeline build only: [8 waves][kPSTLMax] tagged s_memtime stamps of workgroup 0
+};
+
+constexpr int kPSTLMax = 2048;
+
+// s_setprio levels of the two phases.  Same-box A/B (tools/ps_check.py bench, build/variants): M-phase 0 / V-phase 0 beats
+// the predecessor's M-phase 1 by ~1 % on C2 and 3 % on the small shapes; raising the V-phase is within noise of that.
+#ifndef AULE_PS_MPRIO
+#define AULE_PS_MPRIO 0
+#endif
+#ifndef AULE_PS_VPRIO
+#define AULE_PS_VPRIO 0
+#endif
+
+constexpr int kMaxItems = 64;            // per workgroup (the host sizes the grid accordingly)
+constexpr int kMaxSlot = 2 * kMaxItems;  // parts: two per item (the second one invalid for an unpaired block)
+
+__device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// D <= 64: the workgroup needs <= 75 KB of LDS, so two fit a CU if the kernel stays within 128 VGPRs (4 waves per SIMD);
+// the second workgroup fills the first one's barrier and seam bubbles (the predecessor's D = 64 instances do run that way).
+template <class T, int D, bool CAUSAL, bool RAWOK, bool TL = false>
+__global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const FwdPSParams p) {
+    using C = Cfg<D>;
+    using v8 = typename T::v8;
+    using std::integral_constant;
+    constexpr int RB = C::RB, RBP = C::RBP, CPR = C::CPR, KTILE = C::KTILE, VTILE = C::VTILE;
+    constexpr int CH = C::CH, KS = C::KS, DB = C::DB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Ks = smem;
+    char* const Vs = smem + 2 * KTILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = rfl(tid >> 6);
+    const int grp = wave >> 2;  // 0: leads, 1: runs one phase behind
+    const int l31 = lane & 31, hi = lane >> 5;
+    char* const Qs = smem + 2 * KTILE + 2 * VTILE + wave * C::QSLAB;
+    int4* const tab = reinterpret_cast<int4*>(smem + C::LDS);                     // [kMaxSlot] {q row offset, kv row offset, qb | -1, -}
+    int* const redo = reinterpret_cast<int*>(smem + C::LDS + kMaxSlot * 16);      // [kMaxSlot] range verdicts, [kMaxSlot] = any
+
+    const int Sq = p.Sq, Sk = p.Sk, coff = p.coff;
+    const float c = p.c;
+    int tl_n = 0;
+    auto stamp = [&](int tag) __attribute__((always_inline)) {   // timeline build: (tag << 56) | shader clock
+        if constexpr (TL) {
+            if (blockIdx.x == 0 && tl_n < kPSTLMax) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0) p.dbg[wave * kPSTLMax + tl_n] = (t & 0x00ffffffffffffffull) | ((unsigned long long)tag << 56);
+                ++tl_n;
+            }
+        }
+    };
+
+    // ---- part table: thread t describes part (t & 1) of this workgroup's item t >> 1
+    const int G = (int)gridDim.x;
+    const int nit = (p.nitems - (int)blockIdx.x + G - 1) / G;
+    const int nslot = 2 * nit;
+    if (tid < nslot) {
+        const WorkItem w = decode_work((int)blockIdx.x + (tid >> 1) * G, p.B, p.Hq, p.Hkv, p.nwork, false);
+        int qb = -1;
+        if (p.pair) {
+            const int far = p.nqb - 1 - w.blk;       // the larger block of the pair goes first
+            if ((tid & 1) == 0) qb = far;
+            else if (far != w.blk) qb = w.blk;
+        } else if ((tid & 1) == 0) {
+            qb = w.blk;
+        }
+        tab[tid] = int4{(w.b * p.Hq + w.h) * Sq, (w.b * p.Hkv + w.hk) * Sk, qb, 0};
+        redo[tid] = 0;
+    }
+    if (tid == 0) redo[kMaxSlot] = 0;
+    __syncthreads();
+
+    auto next_valid = [&](int slot) __attribute__((always_inline)) {
+        do {
+            ++slot;
+        } while (slot < nslot && rfl(tab[slot].z) < 0);
+        return slot;
+    };
+    auto nt_of = [&](int qb) __attribute__((always_inline)) {
+        const int kv_hi = CAUSAL ? max(1, min(Sk, qb * kQBlock + kQBlock + coff)) : Sk;
+        return (kv_hi + kKVTile - 1) / kKVTile;
+    };
+    auto head_srd = [&](const void* base, int rowoff, int rows) __attribute__((always_inline)) {
+        return make_srd(reinterpret_cast<const char*>(base) + (size_t)(unsigned)rowoff * RB, (unsigned)rows * RB);
+    };
+
+    // ---- staging maps (as fa_fwd_pp_gfx950.hip)
+    int k_g[CH], k_lds[CH], v_g[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int cidx = tid + 512 * i;
+        const int row = cidx / CPR, cc = cidx % CPR;
+        k_g[i] = row * RB + cc * 16;
+        k_lds[i] = row * RBP + cc * 16;
+        const int bidx = (tid >> 3) + 64 * i;
+        v_g[i] = ((bidx / (D / 16)) * 4 + ((tid >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (tid & 1)) * 16;
+    }
+    const int ka_base = l31 * RBP + hi * 16;
+    const int va_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
+
+    u32x4_t kst[CH], vst[CH];
+    auto write_k = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (C::kFull || tid + 512 * i < C::NCHUNK)
+                *reinterpret_cast<u32x4_t*>(Ks + buf * KTILE + k_lds[i]) = kst[i];
+    };
+    auto write_v = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (C::kFull || tid + 512 * i < C::NCHUNK)
+                *reinterpret_cast<u32x4_t*>(Vs + buf * VTILE + tid * 16 + i * 8192) = vst[i];
+    };
+
+    auto run_stream = [&](auto raw_tag) __attribute__((always_inline)) {
+        constexpr bool RAW = decltype(raw_tag)::value != 0;
+        int cs = next_valid(-1);   // compute cursor: the part being computed
+        if (cs >= nslot) return;
+
+        // ---- staging cursors: the tile each of them requests next (slot, tile in the part, tiles of the part, head)
+        int ks_slot = cs, ks_t = 0, ks_nt, vs_slot = cs, vs_t = 0, vs_nt;
+        __amdgpu_buffer_rsrc_t krs, vrs;
+        {
+            const int4 e = tab[cs];
+            ks_nt = vs_nt = nt_of(rfl(e.z));
+            krs = head_srd(p.k, rfl(e.y), Sk);
+            vrs = head_srd(p.v, rfl(e.y), Sk);
+        }
+        auto adv_k = [&]() __attribute__((always_inline)) {
+            if (++ks_t < ks_nt) return;
+            ks_slot = next_valid(ks_slot);
+            ks_t = 0;
+            if (ks_slot < nslot) {
+                const int4 e = tab[ks_slot];
+                ks_nt = nt_of(rfl(e.z));
+                krs = head_srd(p.k, rfl(e.y), Sk);
+            }
+        };
+        auto adv_v = [&]() __attribute__((always_inline)) {
+            if (++vs_t < vs_nt) return;
+            vs_slot = next_valid(vs_slot);
+            vs_t = 0;
+            if (vs_slot < nslot) {
+                const int4 e = tab[vs_slot];
+                vs_nt = nt_of(rfl(e.z));
+                vrs = head_srd(p.v, rfl(e.y), Sk);
+            }
+        };
+        auto issue_k = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if (C::kFull || tid + 512 * i < C::NCHUNK)
+                    kst[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], ks_t * (kKVTile * RB), 0);
+        };
+        auto issue_v = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if (C::kFull || tid + 512 * i < C::NCHUNK)
+                    vst[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], vs_t * (kKVTile * RB), 0);
+        };
+        bool have_k = true, have_v = true;   // kst / vst hold a requested tile that is not in LDS yet
+
+        // ---- compute-side state
+        f32x16_t o[DB];
+        f32x16_t s[2];
+        v8 pb[2][2];
+        u32x4_t qx[KS];   // Q fragments (B operand of S^T = K.Q^T): lane (q, hi) holds d = 16ks+8hi..+7.  ONE variable for the
+                          // fragments in use and the next part's in flight: their lifetimes are disjoint (see tile_step)
+        float m = 0.f, l = 0.f;
+        const unsigned flip = p.negq ? 0x80008000u : 0u;
+
+        auto issue_q = [&](int qoff, int q0) __attribute__((always_inline)) {   // rows >= Sq read as 0
+            const __amdgpu_buffer_rsrc_t qrs = head_srd(p.q, qoff, Sq);
+            // (opaque lane id: a row offset hoisted to kernel entry gets spilled, and the reload's vmcnt(0) would sit
+            // between this step's K/V requests and these loads)
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int qoffs = (q0 + (lane_o & 31)) * RB + (lane_o >> 5) * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qx[ks] = __builtin_amdgcn_raw_buffer_load_b128(qrs, qoffs + ks * 32, 0, 0);
+        };
+        auto take_q = [&]() __attribute__((always_inline)) {   // negative scale: flip the sign of Q once, in place
+            if (flip != 0u) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    qx[ks][0] ^= flip; qx[ks][1] ^= flip; qx[ks][2] ^= flip; qx[ks][3] ^= flip;
+                }
+            }
+        };
+
+        auto qk = [&](int buf) __attribute__((always_inline)) {  // S^T = K_tile . Q^T
+            const char* kb = Ks + buf * KTILE + ka_base;
+            constexpr int kAhead = 1;
+            u32x4_t kf[KS][2];
+            auto rd = [&](int ks) __attribute__((always_inline)) {
+                kf[ks][0] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32);
+                kf[ks][1] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32 + 32 * RBP);
+            };
+            f32x16_t z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < kAhead && ks < KS; ++ks) rd(ks);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (kAhead < KS ? kAhead : KS), 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + kAhead < KS) rd(ks + kAhead);
+                s[0] = T::mfma(as_v8<T>(kf[ks][0]), as_v8<T>(qx[ks]), ks == 0 ? z : s[0]);
+                s[1] = T::mfma(as_v8<T>(kf[ks][1]), as_v8<T>(qx[ks]), ks == 0 ? z : s[1]);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (ks + kAhead < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+        };
+        auto pv = [&](int buf) __attribute__((always_inline)) {  // O^T += V^T . P^T
+            const char* vb = Vs + buf * VTILE + va_off;
+            constexpr int NST = 4 * DB;
+            constexpr int kAhead = 2;
+            s16x4_t a0[NST], a1[NST];
+            auto rd = [&](int st) __attribute__((always_inline)) {
+                const int sk = st / DB, d = st % DB;
+                const int off = ((4 * sk) * (D / 16) + 2 * d) * 128;
+                a0[st] = lds_tr16(vb + off);
+                a1[st] = lds_tr16(vb + off + 2 * (D / 16) * 128);
+            };
+#pragma unroll
+            for (int st = 0; st < kAhead && st < NST; ++st) rd(st);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (kAhead < NST ? kAhead : NST), 0);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                if (st + kAhead < NST) rd(st + kAhead);
+                const int sk = st / DB, d = st % DB;
+                o[d] = T::mfma(as_v8<T>(a0[st], a1[st]), pb[sk >> 1][sk & 1], o[d]);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (st + kAhead < NST) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        };
+
+        // ---- part scalars of the compute side
+        int qoff, qb, nt, na, q0w, qposv, P0 = 0;
+        int n_slot, n_qoff = 0, n_qb = 0;          // the part after this one (n_slot == nslot: none)
+        auto enter_part = [&](int slot) __attribute__((always_inline)) {
+            const int4 e = tab[slot];
+            qoff = rfl(e.x);
+            qb = rfl(e.z);
+            nt = nt_of(qb);
+            q0w = qb * kQBlock + wave * 32;
+            qposv = q0w + l31 + coff;
+            const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32 + coff) : Sk;
+            na = max(1, (wave_kv_hi + kKVTile - 1) / kKVTile);
+            n_slot = next_valid(slot);
+            if (n_slot < nslot) {
+                const int4 en = tab[n_slot];
+                n_qoff = rfl(en.x);
+                n_qb = rfl(en.z);
+            }
+        };
+
+        // ---- epilogue of a part, in two pieces.
+        // (a) epilogue_pack, in the M-phase right behind the wave's last PV of the part: O = O^T / l, rounded and written
+        //     transposed into the wave's slab; LSE; range verdict.  Frees the 64 accumulators for the next part.
+        // (b) drain_rows, two 16-byte row chunks per lane in each of the following V-phases (D = 128: four steps): slab
+        //     -> registers -> whole-row global stores.  Spreading them keeps (a) short -- all eight stores at once cost
+        //     2-4 k cycles inside an M-phase the partner group waits for -- and keeps the store queue shallow.
+        //     Buffer stores against a descriptor of the head's Sq rows: rows >= Sq are dropped by the bounds check.
+        // No division, no LDS-based lane exchange (this runs beside the partner's LDS traffic).
+        constexpr int NR = (32 * CPR) / 64;      // row chunks per lane (CPR / 2)
+        constexpr int kDrain = NR >= 2 ? 2 : 1;  // per V-phase
+        int ep_left = 0, ep_qoff = 0, ep_q0w = 0;
+        auto drain_rows = [&](int n) __attribute__((always_inline)) {
+            int lane_o = lane;   // opaque copy: keeps the slab / row addresses from being hoisted out of the part loop and spilled
+            asm volatile("" : "+v"(lane_o));
+            const __amdgpu_buffer_rsrc_t ors = head_srd(p.o, ep_qoff, Sq);
+            const int i0 = NR - ep_left;                                  // first chunk of this call
+            const int row0 = lane_o / CPR + (64 / CPR) * i0, cc = lane_o % CPR;   // chunk i covers rows lane / CPR + (64 / CPR) i
+            const char* src = Qs + row0 * RBP + cc * 16;
+            const int dst = (ep_q0w + row0) * RB + cc * 16;
+            u32x4_t x[kDrain];
+#pragma unroll
+            for (int i = 0; i < kDrain; ++i)
+                if (i < n) x[i] = *reinterpret_cast<const u32x4_t*>(src + i * (64 / CPR) * RBP);
+#pragma unroll
+            for (int i = 0; i < kDrain; ++i)
+                if (i < n) __builtin_amdgcn_raw_buffer_store_b128(x[i], ors, dst + i * (64 / CPR) * RB, 0, 0);
+            ep_left -= n;
+        };
+        auto epilogue_pack = [&](int eqoff, int eq0w) __attribute__((always_inline)) {
+            while (ep_left > 0) drain_rows(ep_left < kDrain ? ep_left : kDrain);   // (only when two epilogues come < NR / 2 steps apart)
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int l31 = lane_o & 31, hi = lane_o >> 5;
+            stamp(0xd0);
+            const float lt = l + xhalf_fast(l);
+            float inv = __builtin_amdgcn_rcpf(lt);   // 1 ulp; O is rounded to 8 / 11 bits right after
+            if constexpr (TL) { asm volatile("s_nop 0" : "+v"(inv)); stamp(0xd1); }
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    u32x2_t u;
+                    u[0] = T::pack2(o[d][4 * g4 + 0] * inv, o[d][4 * g4 + 1] * inv);
+                    u[1] = T::pack2(o[d][4 * g4 + 2] * inv, o[d][4 * g4 + 3] * inv);
+                    *reinterpret_cast<u32x2_t*>(Qs + l31 * RBP + (32 * d + 8 * g4 + 4 * hi) * 2) = u;
+                }
+            if constexpr (TL) { __builtin_amdgcn_s_waitcnt(0xc07f); stamp(0xd2); }
+            {   // LSE: lanes of the upper half and a null pointer fall outside the descriptor
+                const __amdgpu_buffer_rsrc_t lrs = make_srd(p.lse + (size_t)(unsigned)eqoff, p.lse != nullptr ? (unsigned)Sq * 4u : 0u);
+                const float lse = (m + fast_log2(lt)) * kLn2;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lse), lrs, hi == 0 ? (eq0w + l31) * 4 : 0x7ffffff0, 0, 0);
+            }
+            if constexpr (RAW) {   // range verdict of the fixed-reference pass (NaN fails it too)
+                const bool ok = (lt > 0x1p-100f) && (lt < 0x1p110f);
+                if (__builtin_amdgcn_ballot_w64(!ok) != 0 && lane == 0) redo[cs] = redo[kMaxSlot] = 1;
+            }
+            ep_left = NR; ep_qoff = eqoff; ep_q0w = eq0w;
+            stamp(0xd4);
+        };
+
+        auto softmax = [&](int kv0, auto sm_tag) __attribute__((always_inline)) {
+            constexpr int SM = decltype(sm_tag)::value;   // 0 online (lazy rescale), 1 fixed reference, 2 first tile of a part
+            const bool need_mask = (CAUSAL && (kv0 + kKVTile - 1 > q0w + coff)) || (kv0 + kKVTile > Sk);
+            if (need_mask) {
+                // (opaque copy: without it LICM hoists the 32 per-lane key indices and compare masks out of the part
+                // loop and spills them around every seam)
+                int hi_o = hi;
+                asm volatile("" : "+v"(hi_o));
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = kv0 + sb * 32 + crow(r, hi_o);
+                        const bool vis = (kv < Sk) && (!CAUSAL || kv <= qposv);
+                        s[sb][r] = vis ? s[sb][r] : -INFINITY;
+                    }
+            }
+            if constexpr (SM != 1) {
+                float mx4[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int sb = q4 >> 1, b0 = 8 * (q4 & 1);
+                    mx4[q4] = max3(s[sb][b0], s[sb][b0 + 1], s[sb][b0 + 2]);
+                    mx4[q4] = max3(mx4[q4], s[sb][b0 + 3], s[sb][b0 + 4]);
+                    mx4[q4] = max3(mx4[q4], s[sb][b0 + 5], s[sb][b0 + 6]);
+                }
+                float mx = max3(mx4[0], mx4[1], s[0][7]);
+                mx = max3(mx, mx4[2], s[0][15]);
+                mx = max3(mx, mx4[3], s[1][7]);
+                mx = fmaxf(mx, s[1][15]);
+                mx = fmaxf(mx, xhalf_fast(mx));
+                const float mxc = mx * c;
+                if constexpr (SM == 2) {
+                    m = mxc;   // first tile: O = 0 (zeroed behind the previous epilogue), nothing to rescale (key 0 is visible
+                    l = 0.f;   // to every row: mxc is finite)
+                } else {
+                    if (__builtin_amdgcn_ballot_w64(mxc > m + kRescaleThr) != 0) {
+                        const float m_new = fmaxf(m, mxc);
+                        const float alpha = fast_exp2(m - m_new);
+                        m = m_new;
+                        l *= alpha;
+#pragma unroll
+                        for (int d = 0; d < DB; ++d)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                    }
+                }
+            }
+            const float nm = -m;
+            float a0 = 0.f, a1 = 0.f;
+            u32x4_t pr[2][2];
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    pr[sb][kk] = softmax_oct<T>(s[sb][8 * kk], s[sb][8 * kk + 1], s[sb][8 * kk + 2], s[sb][8 * kk + 3],
+                                                  s[sb][8 * kk + 4], s[sb][8 * kk + 5], s[sb][8 * kk + 6], s[sb][8 * kk + 7],
+                                                  c, nm, a0, a1);
+            l += a0 + a1;
+            // pin the results of this phase HERE (register-only code is otherwise sunk past the barrier)
+            asm volatile("" : "+v"(pr[0][0]), "+v"(pr[0][1]), "+v"(pr[1][0]), "+v"(pr[1][1]), "+v"(l), "+v"(m));
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) pb[sb][kk] = as_v8<T>(pr[sb][kk]);
+        };
+
+        // ---- one tile step = V-phase + barrier + M-phase + barrier, for stream position P (tile j = P - P0 of the part).
+        //      MODE 2 = softmax, PV, QK^T of the next tile; 1 = softmax, PV (the wave's last active tile of the part);
+        //      0 = tile fully masked for this wave (staging and barriers only).  SM as in softmax().  FIRST: first tile
+        //      of a part (finish the previous part's O first).  TAIL steps (MODE <= 1) also carry the seam duties:
+        //      request the next part's Q after the wave's last QK^T, and compute the next part's S_0 at its last tile.
+        auto tile_step = [&](int P, auto mode_tag, auto sm_tag, auto first_tag) __attribute__((always_inline)) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value != 0;
+            const int j = P - P0;
+            const int tlt = 8 * MODE + (FIRST ? 32 : 0) + ((MODE <= 1 && j == nt - 1 && n_slot < nslot) ? 64 : 0);
+            stamp(tlt + 1);
+            // ---- V-phase: staging.  Group d writes the tiles it requested one step ago (V of position P + d,
+            //      K of position P + 1 + d) and requests the next ones (hazards: DESIGN.md "forward schedule";
+            //      positions run through the seams, so nothing changes there).
+            if (have_v) write_v((P + grp) & 1);
+            if (have_k) write_k((P + 1 + grp) & 1);
+            have_v = vs_slot < nslot;
+            if (have_v) { issue_v(); adv_v(); }
+            have_k = ks_slot < nslot;
+            if (have_k) { issue_k(); adv_k(); }
+            if (ep_left > 0) drain_rows(kDrain);
+            stamp(tlt + 2);
+            if constexpr (MODE == 1) {
+                // the wave's last QK^T of this part is behind it (M-phase of step na - 2): the Q registers are free
+                if (n_slot < nslot) issue_q(n_qoff, n_qb * kQBlock + wave * 32);
+            }
+            stamp(tlt + 3);
+            __builtin_amdgcn_s_setprio(AULE_PS_VPRIO);
+            if constexpr (MODE >= 1) softmax(j * kKVTile, sm_tag);
+            __builtin_amdgcn_s_setprio(0);
+            stamp(tlt + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(tlt + 5);
+            // ---- M-phase
+            __builtin_amdgcn_s_setprio(AULE_PS_MPRIO);
+            if constexpr (MODE >= 1) pv(P & 1);
+            if constexpr (TL && MODE >= 1) { keep_live(o[0], o[DB - 1]); stamp(tlt + 6); }
+            if constexpr (MODE == 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                qk((P + 1) & 1);
+            }
+            if constexpr (MODE == 1) {   // this wave's O of the part is final
+                __builtin_amdgcn_sched_barrier(0);
+                epilogue_pack(qoff, q0w);
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+            }
+            if constexpr (MODE <= 1) {
+                if (j == nt - 1 && n_slot < nslot) {   // seam: S_0 of the next part, with its Q
+                    __builtin_amdgcn_sched_barrier(0);
+                    take_q();
+                    if constexpr (TL) { asm volatile("s_nop 0" : "+v"(qx[0]), "+v"(qx[KS - 1])); stamp(tlt + 6); }
+                    qk((P + 1) & 1);
+                }
+            }
+            if constexpr (TL) { keep_live(s[0], s[1]); stamp(tlt + 7); }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        // ---- prologue of the stream: tiles 0, 1, 2 of the first part (it has >= 4) and its Q, in one HBM round trip.
+        //      Entry state of step 0: K_0 in LDS; group 0 holds (V_0, K_1), group 1 has written them and holds (V_1, K_2).
+        stamp(0xe0);
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+        enter_part(cs);
+        issue_k(); adv_k();      // K_0
+        issue_v(); adv_v();      // V_0
+        u32x4_t kpre1[CH], vpre1[CH], kpre2[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (C::kFull || tid + 512 * i < C::NCHUNK) {
+                kpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], 1 * (kKVTile * RB), 0);
+                if (grp == 1) {
+                    vpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], 1 * (kKVTile * RB), 0);
+                    kpre2[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], 2 * (kKVTile * RB), 0);
+                }
+            }
+        adv_k();                 // K_1 requested: the K cursor stands at tile 2, the V cursor at tile 1
+        if (grp == 1) { adv_k(); adv_v(); }
+        issue_q(qoff, q0w);
+        take_q();
+        write_k(0);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) kst[i] = kpre1[i];
+        if (grp == 1) {
+            write_v(0);
+            write_k(1);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                vst[i] = vpre1[i];
+                kst[i] = kpre2[i];
+            }
+        }
+        __syncthreads();
+        if (grp == 1) __syncthreads();  // group 1 starts one phase late
+        stamp(0xe1);
+        qk(0);                          // pre-phase: S_0
+        if constexpr (TL) { keep_live(s[0], s[1]); stamp(0xe2); }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- the stream
+        for (;;) {
+            int P = P0;
+            constexpr int SMF = RAW ? 1 : 0;
+            if (na > 1) {
+                tile_step(P, integral_constant<int, 2>{}, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+                for (++P; P + 1 < P0 + na; ++P)
+                    tile_step(P, integral_constant<int, 2>{}, integral_constant<int, SMF>{}, integral_constant<int, 0>{});
+                tile_step(P, integral_constant<int, 1>{}, integral_constant<int, SMF>{}, integral_constant<int, 0>{});
+            } else {
+                tile_step(P, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+            }
+            for (++P; P < P0 + nt; ++P)
+                tile_step(P, integral_constant<int, 0>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+            if (n_slot >= nslot) break;
+            P0 += nt;
+            cs = n_slot;
+            enter_part(cs);
+        }
+        stamp(0xf0);
+        while (ep_left > 0) drain_rows(ep_left < kDrain ? ep_left : kDrain);
+        if (grp == 0) __syncthreads();  // pairs with group 1's last phase barrier: all waves aligned again
+        stamp(0xf1);
+    };
+
+    if constexpr (RAWOK) {
+        run_stream(std::integral_constant<int, 1>{});
+        __syncthreads();   // every verdict posted, every LDS tile buffer idle
+        if (rfl(redo[kMaxSlot]) != 0) {
+            __syncthreads();
+            if (tid < nslot && redo[tid] == 0) tab[tid].z = -1;   // second, sparse stream: only the flagged parts
+            __syncthreads();
+            run_stream(std::integral_constant<int, 0>{});
+        }
+    } else {
+        run_stream(std::integral_constant<int, 0>{});
+    }
+}
+
+static int cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    return n;
+}
+
+template <class T, int D, bool RAWOK>
+int launch_ps(const FwdArgs& a, hipStream_t stream) {
+    FwdPSParams p;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o; p.lse = a.lse;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
+    float c = a.scale * kLog2e;
+    p.negq = c < 0.f;
+    c = c < 0.f ? -c : c;
+    if (c == 0.f) c = 1e-30f;
+    p.c = c;
+    p.nqb = (a.Sq + kQBlock - 1) / kQBlock;
+    p.pair = a.causal ? 1 : 0;
+    p.nwork = p.pair ? (p.nqb + 1) / 2 : p.nqb;
+    p.coff = a.causal ? a.coff : 0;
+    p.nitems = p.nwork * a.B * a.Hq;
+    p.dbg = nullptr;
+    // one workgroup per CU (two for D <= 64); more only when a workgroup's list would not fit its part table
+    const long long ncu = (long long)cu_count() * (D <= 64 ? 2 : 1);
+    const long long rounds = (p.nitems + ncu * kMaxItems - 1) / (ncu * kMaxItems);
+    long long G = ncu * rounds;
+    if (G > p.nitems) G = p.nitems;
+    const dim3 grid((unsigned)G), block(512);
+    const size_t lds = Cfg<D>::LDS + kMaxSlot * 20 + 16;
+    if (a.causal)
+        hipLaunchKernelGGL((fa_fwd_ps_kernel<T, D, true, RAWOK>), grid, block, lds, stream, p);
+    else
+        hipLaunchKernelGGL((fa_fwd_ps_kernel<T, D, false, RAWOK>), grid, block, lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+template <class T, int D, bool RAWOK>
+int set_attr_ps() {
+    const int lds = Cfg<D>::LDS + kMaxSlot * 20 + 16;
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, true, RAWOK>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, false, RAWOK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return rc;
+}
+
+static bool raw_softmax_enabled() {
+    static const int v = [] {
+        const char* e = getenv("AULE_HIP_FWD_SOFTMAX");
+        return (e != nullptr && e[0] == 'c') ? 0 : 1;
+    }();
+    return v == 1;
+}
+
+}  // namespace
+
+// Debug: the bf16 D = 128 kernel with tagged s_memtime stamps of workgroup 0 (tools/timeline_ps.py).
+int launch_fwd_ps_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream) {
+    if (a.dtype != kBF16 || a.D != 128) return -1;
+    FwdPSParams p;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o; p.lse = a.lse;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
+    p.c = a.scale * kLog2e; p.negq = 0;
+    p.nqb = (a.Sq + kQBlock - 1) / kQBlock;
+    p.pair = a.causal ? 1 : 0;
+    p.nwork = p.pair ? (p.nqb + 1) / 2 : p.nqb;
+    p.coff = a.causal ? a.coff : 0;
+    p.nitems = p.nwork * a.B * a.Hq;
+    p.dbg = dbg;
+    const long long ncu = cu_count();
+    const long long rounds = (p.nitems + ncu * kMaxItems - 1) / (ncu * kMaxItems);
+    long long G = ncu * rounds;
+    if (G > p.nitems) G = p.nitems;
+    const dim3 grid((unsigned)G), block(512);
+    const size_t lds = Cfg<128>::LDS + kMaxSlot * 20 + 16;
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    };
+    if (a.causal) go(&fa_fwd_ps_kernel<Bf16Traits, 128, true, true, true>);
+    else go(&fa_fwd_ps_kernel<Bf16Traits, 128, false, true, true>);
+    return (int)hipGetLastError();
+}
+
+// Shapes the persistent tile stream takes (everything else: fa_fwd_pp_gfx950.hip).
+bool fwd_ps_applicable(const FwdArgs& a) {
+    if (a.dtype != kBF16 && a.dtype != kF16) return false;
+    if (a.D != 32 && a.D != 64 && a.D != 128) return false;
+    if (a.window > 0) return false;
+    if (a.causal && a.coff < 0) return false;
+    // every part needs >= 4 KV tiles (the staging cursors run at most three tiles ahead of the compute cursor and may
+    // cross one seam, not two): the shortest part is the first Q block
+    const long long first = a.causal ? ((long long)kQBlock + a.coff < a.Sk ? (long long)kQBlock + a.coff : a.Sk) : a.Sk;
+    if (first <= 3 * kKVTile) return false;
+    // row offsets are 32-bit in the part table, byte offsets inside one head 32-bit in the buffer descriptors
+    if ((long long)a.B * a.Hq * a.Sq >= (1LL << 31) || (long long)a.B * a.Hkv * a.Sk >= (1LL << 31)) return false;
+    if ((long long)a.Sq * a.D * 2 >= (1LL << 32) || (long long)a.Sk * a.D * 2 >= (1LL << 32)) return false;
+    return true;
+}
+
+int launch_fwd_ps(const FwdArgs& a, hipStream_t stream) {
+    if (a.dtype == kBF16) {
+        if (raw_softmax_enabled()) {
+            if (a.D == 128) return launch_ps<Bf16Traits, 128, true>(a, stream);
+            if (a.D == 64) return launch_ps<Bf16Traits, 64, true>(a, stream);
+            if (a.D == 32) return launch_ps<Bf16Traits, 32, true>(a, stream);
+        } else {
+            if (a.D == 128) return launch_ps<Bf16Traits, 128, false>(a, stream);
+            if (a.D == 64) return launch_ps<Bf16Traits, 64, false>(a, stream);
+            if (a.D == 32) return launch_ps<Bf16Traits, 32, false>(a, stream);
+        }
+    } else if (a.dtype == kF16) {
+        if (a.D == 128) return launch_ps<F16Traits, 128, false>(a, stream);
+        if (a.D == 64) return launch_ps<F16Traits, 64, false>(a, stream);
+        if (a.D == 32) return launch_ps<F16Traits, 32, false>(a, stream);
+    }
+    return -1;
+}
+
+int configure_fwd_ps() {
+    return set_attr_ps<Bf16Traits, 128, true>() | set_attr_ps<Bf16Traits, 64, true>() | set_attr_ps<Bf16Traits, 32, true>() |
+           set_attr_ps<Bf16Traits, 128, false>() | set_attr_ps<Bf16Traits, 64, false>() | set_attr_ps<Bf16Traits, 32, false>() |
+           set_attr_ps<F16Traits, 128, false>() | set_attr_ps<F16Traits, 64, false>() | set_attr_ps<F16Traits, 32, false>();
+}
+
+}  // namespace aule_hip
