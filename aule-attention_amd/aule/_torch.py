@@ -44,6 +44,20 @@ def causal_code(causal):
     return c
 
 
+def _abi_scale(scale):
+    """The `_ex` descriptors read scale == 0 as "default 1/sqrt(D)" (a zero-initialised struct must work); this layer always
+    resolves the default itself, so an explicit 0.0 -- uniform attention in the reference and in the oracle -- is passed
+    as the smallest value the kernels treat the same way (they clamp |scale * log2 e| to 1e-30 anyway)."""
+    scale = float(scale)
+    return scale if scale != 0.0 else 1e-30
+
+
+def _same_device(what, ref, *tensors):
+    for t in tensors:
+        if t.device != ref.device:
+            raise ValueError(f"{what}: every tensor must live on {ref.device}, got one on {t.device}")
+
+
 def _workspace(nbytes, device):
     """Partials of the two-launch short-query paths from torch's caching allocator: stream-ordered like the library's own
     hipMallocAsync fallback, but graph-aware -- under torch.cuda.graph capture it adds no alloc / free nodes (which cost
@@ -57,6 +71,7 @@ def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1):
     """q [B,Hq,Sq,D], k/v [B,Hkv,Sk,D]: contiguous device tensors, D in SUPPORTED_HEAD_DIMS.
     Returns (out, lse or None).  Asynchronous on the current stream."""
     lib = _capi.get_lib()
+    _same_device("flash attention forward", q, k, v)
     B, Hq, Sq, D = q.shape
     Hkv, Sk = k.shape[1], k.shape[2]
     out = torch.empty_like(q)
@@ -67,7 +82,7 @@ def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1):
     d.struct_size = ctypes.sizeof(_capi.AttnDesc)
     d.dtype = _DTYPES[q.dtype]
     d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
-    d.scale = float(scale)
+    d.scale = _abi_scale(scale)
     d.causal = causal_code(causal)
     d.window_size = int(window) if window is not None and window > 0 else -1
     d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
@@ -83,6 +98,7 @@ def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1):
 
 def bwd_raw(q, k, v, out, dout, lse, causal, scale, window=-1):
     lib = _capi.get_lib()
+    _same_device("flash attention backward", q, k, v, out, dout, lse)
     B, Hq, Sq, D = q.shape
     Hkv, Sk = k.shape[1], k.shape[2]
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
@@ -92,7 +108,7 @@ def bwd_raw(q, k, v, out, dout, lse, causal, scale, window=-1):
     d.struct_size = ctypes.sizeof(_capi.AttnBwdDesc)
     d.dtype = _DTYPES[q.dtype]
     d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
-    d.scale = float(scale)
+    d.scale = _abi_scale(scale)
     d.causal = causal_code(causal)
     d.window_size = int(window) if window is not None and window > 0 else -1
     d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
@@ -300,8 +316,10 @@ def paged_decode(q, k_cache, v_cache, block_tables, context_lens, scale=None, wi
         scale = 1.0 / math.sqrt(D)
     lib = _capi.get_lib()
     q, k_cache, v_cache = q.contiguous(), k_cache.contiguous(), v_cache.contiguous()
-    bt = block_tables.contiguous().to(torch.int32)
-    cl = context_lens.contiguous().to(torch.int32)
+    _same_device("paged decode", q, k_cache, v_cache)
+    # block tables / lengths are read by the kernel: a CPU (or other-GPU) tensor would hand it a foreign pointer
+    bt = block_tables.to(device=q.device, dtype=torch.int32).contiguous()
+    cl = context_lens.to(device=q.device, dtype=torch.int32).contiguous()
     if bt.dim() != 2 or bt.shape[0] != B or cl.shape != (B,):
         raise ValueError("block_tables must be [batch, max_blocks] and context_lens [batch]")
     out = torch.empty_like(q)
@@ -312,7 +330,7 @@ def paged_decode(q, k_cache, v_cache, block_tables, context_lens, scale=None, wi
     d.dtype = _DTYPES[q.dtype]
     d.batch, d.heads_q, d.heads_kv, d.head_dim = B, Hq, Hkv, D
     d.block_size, d.max_blocks = block_size, bt.shape[1]
-    d.scale = float(scale)
+    d.scale = _abi_scale(scale)
     d.window_size = int(window_size) if window_size is not None and window_size > 0 else -1
     d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
     d.stream = _stream_ptr(q.device)

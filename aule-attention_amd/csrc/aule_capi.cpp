@@ -146,9 +146,10 @@ int run_fwd_f32(const float* q, const float* k, const float* v, float* o, float*
 }  // namespace
 
 namespace aule_hip {
+#ifdef AULE_DEBUG_HOOKS
 int launch_fwd_pp_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
-int launch_fwd_iw_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
 int launch_fwd_ps_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
+#endif
 int configure_fwd();
 int configure_bwd();
 int configure_kernels() {
@@ -435,12 +436,13 @@ int32_t aule_attention_forward_gpu(aule_tensor_handle qh, aule_tensor_handle kh,
     const float* kp = (const float*)k->ptr;
     float* rot = nullptr;   // rotated copies of Q and K (the handle tensors are the caller's and stay untouched)
     if (rc_t) {
-        const uint64_t rows_c = (uint64_t)rc_t->shape[0] * rc_t->shape[1] * rc_t->shape[2];
-        const uint64_t rows_s = (uint64_t)rs_t->shape[0] * rs_t->shape[1] * rs_t->shape[2];
+        // one table shared by every batch and head, indexed by position: [1, 1, >= max(Sq, Sk), D/2].  (A [B, H, S', D/2]
+        // tensor with S' < seq used to pass a flattened-row count check and was then read across head boundaries.)
         const uint32_t need = Sq > Sk ? Sq : Sk;
-        if ((D & 1) || rc_t->shape[3] != D / 2 || rs_t->shape[3] != D / 2 || rows_c < need || rows_s < need ||
+        if ((D & 1) || rc_t->shape[3] != D / 2 || rs_t->shape[3] != D / 2 || rc_t->shape[0] != 1 || rc_t->shape[1] != 1 ||
+            rs_t->shape[0] != 1 || rs_t->shape[1] != 1 || rc_t->shape[2] < need || rs_t->shape[2] < need ||
             rc_t->pitch != rs_t->pitch) {
-            set_error("Attention failed: error.ShapeMismatch (rot_cos / rot_sin must be [.., seq, head_dim/2])");
+            set_error("Attention failed: error.ShapeMismatch (rot_cos / rot_sin must be [1, 1, >= seq, head_dim/2])");
             return -3;
         }
         const size_t nq = (size_t)B * Hq * Sq * q->pitch, nk = (size_t)B * Hkv * Sk * k->pitch;
@@ -901,12 +903,16 @@ uint64_t aule_attention_paged_decode_workspace_size(const aule_paged_desc* d) {
     return aule_hip::paged_workspace_bytes(a);
 }
 
+#ifdef AULE_DEBUG_HOOKS
+/* The timeline hooks exist only in the debug library (`make dbg` -> build/variants/libaule_dbg.so, -DAULE_DEBUG_HOOKS):
+ * they launch instrumented kernel instances on caller-supplied pointers and are not part of the product libaule.so. */
 /* Debug hook (not part of the drop-in ABI): aule_attention_backward_ex with the dK/dV kernel's timeline build --
  * per-phase s_memtime stamps of its workgroup 0 into `stamps` (device pointer, 8 * 384 uint64; bf16 D128 causal only,
  * otherwise the ordinary kernels run and nothing is written).  Used by tools/timeline_bwd.py. */
 static int32_t backward_timeline(const aule_attn_bwd_desc* d, unsigned long long* stamps, bool dq) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_init || d == nullptr || d->struct_size != sizeof(aule_attn_bwd_desc)) return -1;
+    if (!g_init || d == nullptr || d->struct_size != sizeof(aule_attn_bwd_desc) || stamps == nullptr) return -1;
+    if (d->dtype != AULE_DTYPE_BF16 || d->head_dim != 128 || d->heads_kv == 0 || d->heads_q % d->heads_kv != 0) return -3;
     BwdArgs a;
     a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->out; a.dout = d->dout; a.lse = d->lse;
     a.dq = d->dq; a.dk = d->dk; a.dv = d->dv; a.delta = (float*)d->workspace;
@@ -925,9 +931,10 @@ int32_t aule_hip_debug_backward_timeline(const aule_attn_bwd_desc* d, unsigned l
 int32_t aule_hip_debug_backward_timeline_dq(const aule_attn_bwd_desc* d, unsigned long long* stamps) {
     return backward_timeline(d, stamps, true);
 }
+#endif  // AULE_DEBUG_HOOKS
 
 /* Debug hook (not part of the drop-in ABI): the forward kernel aule_attention_forward_ex would launch for `d`
- * -- 0 fp32, 1 ping-pong, 2 in-wave, 3 lock-step, 4 split-KV; -3 for a bad descriptor.  Pure host logic: no
+ * -- 0 fp32, 1 ping-pong, 4 split-KV, 5 ping-pong with packed rows + KV splits, 6 persistent tile stream; -3 for a bad descriptor.  Pure host logic: no
  * device, no aule_init() needed.  Used by the tests to pin which kernel a shape exercises. */
 int32_t aule_hip_debug_forward_route(const aule_attn_desc* d) {
     if (d == nullptr || d->struct_size != sizeof(aule_attn_desc)) return -3;
@@ -944,11 +951,14 @@ int32_t aule_hip_debug_forward_route(const aule_attn_desc* d) {
     return aule_hip::fwd_route(a);
 }
 
-/* Debug hook (not part of the drop-in ABI): bf16 D=128 forward with per-phase s_memtime stamps of
- * workgroup 0 written to `stamps` (device pointer, 8 * 256 uint64).  Used by tools/timeline.py. */
+#ifdef AULE_DEBUG_HOOKS
+/* Debug hook (debug library only): bf16 D=128 forward with per-phase s_memtime stamps of workgroup 0 written to
+ * `stamps` (device pointer; 8 * 256 uint64 for the ping-pong kernel, 8 * 2048 with AULE_TL=ps for the tile stream).
+ * Used by tools/timeline.py / tools/timeline_ps.py. */
 int32_t aule_hip_debug_forward_timeline(const aule_attn_desc* d, unsigned long long* stamps) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_init || d == nullptr) return -1;
+    if (!g_init || d == nullptr || d->struct_size != sizeof(aule_attn_desc) || stamps == nullptr) return -1;
+    if (d->dtype != AULE_DTYPE_BF16 || d->head_dim != 128 || d->heads_kv == 0 || d->heads_q % d->heads_kv != 0) return -3;
     FwdArgs a;
     a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->out; a.lse = d->lse;
     a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv;
@@ -959,10 +969,8 @@ int32_t aule_hip_debug_forward_timeline(const aule_attn_desc* d, unsigned long l
     if (const char* e = getenv("AULE_TL"))
         if (e[0] == 'p' && e[1] == 's')  // persistent tile stream: 8 waves x 2048 tagged stamps (tools/timeline_ps.py)
             return aule_hip::launch_fwd_ps_timeline(a, stamps, (hipStream_t)d->stream);
-    if (const char* e = getenv("AULE_HIP_FWD_KERNEL"))
-        if (e[0] == 'i' && e[1] == 'w')  // 4 waves x 512 stamps
-            return aule_hip::launch_fwd_iw_timeline(a, stamps, (hipStream_t)d->stream);
     return aule_hip::launch_fwd_pp_timeline(a, stamps, (hipStream_t)d->stream);
 }
+#endif  // AULE_DEBUG_HOOKS
 
 }  // extern "C"

@@ -947,6 +947,7 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
         const dim3 grid((unsigned)(p.nblk * a.B * a.Hq)), block(512);
         p.dbg = a.dbg_dq;
         bool tl_done = false;
+#ifdef AULE_DEBUG_HOOKS
         if constexpr (std::is_same<T, Bf16Traits>::value && D == 128) {
             if (a.dbg_dq != nullptr && a.causal) {   // timeline build (tools/timeline_bwd.py dq): bf16 D128 causal only
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dq_kernel<T, D, true, true>),
@@ -955,6 +956,7 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
                 tl_done = true;
             }
         }
+#endif
         if (tl_done) {
         } else if (a.causal)
             hipLaunchKernelGGL((fa_bwd_dq_kernel<T, D, true>), grid, block, DqCfg<D>::LDS, stream, p);
@@ -971,6 +973,7 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
         const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv * p.gsplit)), block(512);
         p.dbg = a.dbg;
         bool tl_done = false;
+#ifdef AULE_DEBUG_HOOKS
         if constexpr (std::is_same<T, Bf16Traits>::value && D == 128) {
             if (a.dbg != nullptr && a.causal) {   // timeline build (tools/timeline_bwd.py): bf16 D128 causal only
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkdv_kernel<T, D, true, true>),
@@ -979,6 +982,7 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
                 tl_done = true;
             }
         }
+#endif
         if (tl_done) {
         } else if (a.causal)
             hipLaunchKernelGGL((fa_bwd_dkdv_kernel<T, D, true>), grid, block, DkvCfg<D>::LDS, stream, p);

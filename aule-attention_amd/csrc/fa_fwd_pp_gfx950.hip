@@ -714,6 +714,7 @@ int set_attr_pp() {
 
 }  // namespace
 
+#ifdef AULE_DEBUG_HOOKS
 // Debug: run the bf16 D=128 kernel with s_memtime stamps (4 per tile per wave, workgroup 0):
 // [V-phase start, V-phase end, M-phase start (after barrier), M-phase end].
 int launch_fwd_pp_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream) {
@@ -745,6 +746,8 @@ int launch_fwd_pp_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_
     }
     return (int)hipGetLastError();
 }
+
+#endif  // AULE_DEBUG_HOOKS
 
 int launch_fwd_pp(const FwdArgs& a, hipStream_t stream) {
     if (a.dtype == kBF16) {

@@ -647,6 +647,7 @@ static bool raw_softmax_enabled() {
 
 }  // namespace
 
+#ifdef AULE_DEBUG_HOOKS
 // Debug: the bf16 D = 128 kernel with tagged s_memtime stamps of workgroup 0 (tools/timeline_ps.py).
 int launch_fwd_ps_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream) {
     if (a.dtype != kBF16 || a.D != 128) return -1;
@@ -674,6 +675,8 @@ int launch_fwd_ps_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_
     else go(&fa_fwd_ps_kernel<Bf16Traits, 128, false, true, true>);
     return (int)hipGetLastError();
 }
+
+#endif  // AULE_DEBUG_HOOKS
 
 // Shapes the persistent tile stream takes (everything else: fa_fwd_pp_gfx950.hip).
 bool fwd_ps_applicable(const FwdArgs& a) {

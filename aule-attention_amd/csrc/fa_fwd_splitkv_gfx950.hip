@@ -64,7 +64,9 @@ __global__ void __launch_bounds__(256) fa_fwd_splitkv_kernel(const SplitParams p
     const int unit = blockIdx.y / p.nrt, rt = blockIdx.y % p.nrt;
     const int b = unit / p.Hkv, hk = unit % p.Hkv;
     const int Sq = p.Sq;
-    const int Sk = PAGED ? p.context_lens[b] : p.Sk;   // paged: keys of this sequence
+    // paged: keys of this sequence, read on the device and bounded by what the block table can address (a stale or
+    // corrupt scheduler value must not index the table or the cache out of bounds)
+    const int Sk = PAGED ? min(max(p.context_lens[b], 0), p.max_blocks * p.block_size) : p.Sk;
     const int row = rt * 32 + l31;                 // packed row of this lane inside the unit
     const bool valid = row < g * Sq;
     const int head = hk * g + (valid ? row / Sq : 0), qi = valid ? row % Sq : 0;
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(256) fa_fwd_splitkv_kernel(const SplitParams p
     const int* const bt = PAGED ? p.block_tables + (size_t)b * p.max_blocks : nullptr;
     auto paged_row = [&](int kv) -> size_t {
         const int lb = kv / p.block_size, off = kv - lb * p.block_size;
-        const size_t phys = (size_t)bt[lb];
+        const size_t phys = (size_t)bt[min(lb, p.max_blocks - 1)];   // (tiles are rounded up: rows past Sk are masked, never out of the table)
         return ((phys * p.block_size + off) * p.Hkv + hk) * (size_t)RB;
     };
 

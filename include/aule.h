@@ -69,7 +69,9 @@ void aule_tensor_clear_all(void);                              /* src/lib.zig:39
 
 /* ---- handle-based forward: GQA (Hkv from K's shape), cross-attn, causal ---- */
 /* src/lib.zig:496-529 -> backend.zig:318-370 -> attention_gpu.zig:360-453.     */
-/* rot_cos/rot_sin handles must be 0 (fused RoPE: -3 + error text).             */
+/* rot_cos/rot_sin: both 0 (no rotation) or both handles of fp32 tensors shaped   */
+/* [1, 1, >= max(seq_q, seq_k), head_dim/2] (interleaved pairs, one table for all */
+/* heads); anything else is -3 + error text.                                      */
 /* window_size > 0: sliding window, key j visible to query i only if            */
 /* i - j < window_size, on top of the causal rule (the convention of the kernel */
 /* the reference runs on ROCm, python/aule/triton_flash_amd.py:179-183).        */
@@ -189,7 +191,8 @@ typedef struct aule_paged_desc {
     const void* k_cache;       /* [num_blocks, block_size, heads_kv, head_dim] */
     const void* v_cache;       /* same layout */
     const int32_t* block_tables;   /* [batch, max_blocks]: physical block of each logical block */
-    const int32_t* context_lens;   /* [batch]: keys per sequence (0 -> output row of zeros) */
+    const int32_t* context_lens;   /* [batch]: keys per sequence (0 -> output row of zeros); read on the device and clamped
+                                      there to [0, max_blocks * block_size], so a stale value cannot index out of the table */
     void* out;                 /* [batch, heads_q, head_dim] */
     void* workspace;           /* optional, as aule_attn_desc.workspace; size from aule_attention_paged_decode_workspace_size() */
     uint64_t workspace_bytes;

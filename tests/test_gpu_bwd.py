@@ -100,10 +100,10 @@ def _torch_ref(torch, q, k, v, causal, scale):
 
 def test_config3_gqa_torch_autograd_parity(torch_cuda):
     """BASELINE config #3: GQA 32q/8kv S=2048 D=128 bf16 causal fwd+bwd vs torch autograd
-    (plain fp32 math on the same bf16-quantised inputs)."""
+    (plain fp32 math on the same bf16-quantised inputs), at the batch bench.py times (B = 4)."""
     import aule
     torch = torch_cuda
-    B, Hq, Hkv, S, D = 1, 32, 8, 2048, 128
+    B, Hq, Hkv, S, D = 4, 32, 8, 2048, 128
     gen = torch.Generator(device="cuda").manual_seed(3)
     q, k, v, do = (torch.randn(B, h, S, D, device="cuda", dtype=torch.bfloat16, generator=gen)
                    for h in (Hq, Hkv, Hkv, Hq))
@@ -115,8 +115,15 @@ def test_config3_gqa_torch_autograd_parity(torch_cuda):
     ref.backward(do.float())
     assert_close(out.detach().float().cpu().numpy(), ref.detach().cpu().numpy(),
                  *fwd_tol("bf16", v.float().abs().max().item()), "C3 out")
+    achieved = {}
     for name, a, b in (("dq", q1.grad, q2.grad), ("dk", k1.grad, k2.grad), ("dv", v1.grad, v2.grad)):
         grad_close(a.float().cpu().numpy(), b.cpu().numpy(), "bf16", "C3 " + name)
+        achieved[name] = ((a.float() - b).abs().max() / b.abs().max()).item()
+    achieved["out"] = (out.detach().float() - ref.detach()).abs().max().item()
+    # the bar is 2e-2 of max|grad| (tests/util.py); what the kernels actually achieve goes on record (pytest -rP / -s)
+    print("C3 B=4 achieved: out max|err| %.3e; max|err| / max|grad|: dq %.3e dk %.3e dv %.3e"
+          % (achieved["out"], achieved["dq"], achieved["dk"], achieved["dv"]))
+    assert max(achieved["dq"], achieved["dk"], achieved["dv"]) < 1e-2   # half the documented bar: room to tighten it
 
 
 def test_sgd_step_lowers_loss(torch_cuda):

@@ -1,10 +1,9 @@
 """Parity of the NON-default forward kernels / softmax forms (selected by environment variables that the
 library reads once per process, hence one subprocess per variant):
 
-  AULE_HIP_FWD_KERNEL=iw        4-wave x 64-row in-wave pipelined kernel (bf16, D=128), fixed-reference fast pass + SAFE pass
-  AULE_HIP_FWD_KERNEL=iw1       the same schedule with 8 waves x 32 rows (VGPR-form MFMAs)
-  AULE_HIP_FWD_KERNEL=v1        first lock-step kernel
-  AULE_HIP_FWD_SOFTMAX=classic  ping-pong kernel with the online softmax only (no fixed-reference pass)
+  AULE_HIP_FWD_KERNEL=pp        every tiled problem on the ping-pong kernel (one workgroup per Q-block pair), the
+                                predecessor of the persistent tile stream and still the kernel behind window / short shapes
+  AULE_HIP_FWD_SOFTMAX=classic  online softmax only (no fixed-reference pass), on the tile stream and on the ping-pong kernel
 
 Each variant runs the same seeded cases against the fp64 oracle, including a large-logit case that the
 fixed-reference pass must hand over to the online form (its row sums leave the safe range).
@@ -28,15 +27,22 @@ import oracle
 from aule import _torch as at
 from util import fwd_tol, LSE_TOL
 res = []
-cases = [  # B, Hq, Hkv, Sq, Sk, causal, magnitude
-    (1, 2, 2, 64, 64, True, 1.0), (1, 2, 2, 300, 300, True, 1.0), (2, 4, 1, 1024, 1024, True, 1.0),
-    (1, 2, 2, 200, 333, False, 1.0), (1, 2, 2, 777, 130, False, 1.0), (1, 4, 2, 512, 512, True, 1.0),
-    (1, 2, 2, 512, 512, True, 6.0), (1, 2, 2, 512, 512, False, 12.0),
+cases = [  # B, Hq, Hkv, Sq, Sk, causal, magnitude, spike
+    (1, 2, 2, 64, 64, True, 1.0, 0), (1, 2, 2, 300, 300, True, 1.0, 0), (2, 4, 1, 1024, 1024, True, 1.0, 0),
+    (1, 2, 2, 200, 333, False, 1.0, 0), (1, 2, 2, 777, 130, False, 1.0, 0), (1, 4, 2, 512, 512, True, 1.0, 0),
+    (1, 2, 2, 512, 512, True, 6.0, 0), (1, 2, 2, 512, 512, False, 12.0, 0),
+    (2, 40, 8, 1280, 1280, True, 1.0, 0),    # 240 items with an unpaired middle block: every workgroup of the stream walks a list
+    # a key whose logit is ~160 (log2) above everything in the first tile, in every other head: the fixed-reference pass
+    # must fail its range verdict for those Q blocks in the middle of the part lists and the second, sparse stream
+    # (online softmax) must repair exactly them
+    (4, 16, 16, 1024, 1024, True, 1.0, 1), (1, 8, 8, 2048, 2048, False, 1.0, 1),
 ]
-for (B, Hq, Hkv, Sq, Sk, causal, mag) in cases:
+for (B, Hq, Hkv, Sq, Sk, causal, mag, spike) in cases:
     rng = np.random.RandomState(7)
     mk = lambda *s: torch.from_numpy((rng.randn(*s) * mag).astype(np.float32)).to(torch.bfloat16)
     q, k, v = mk(B, Hq, Sq, 128), mk(B, Hkv, Sk, 128), mk(B, Hkv, Sk, 128)
+    if spike:
+        k[:, ::2, Sk - 120, :] = (40.0 * q[:, ::2, Sq - 70, :].float()).to(torch.bfloat16)
     out, lse = at.fwd_raw(q.cuda(), k.cuda(), v.cuda(), causal, 1 / math.sqrt(128))
     torch.cuda.synchronize()
     ref, rl = oracle.fwd_f64(q.float().numpy(), k.float().numpy(), v.float().numpy(), causal)
@@ -44,15 +50,15 @@ for (B, Hq, Hkv, Sq, Sk, causal, mag) in cases:
     atol, rtol = fwd_tol("bf16", float(v.float().abs().max()))
     bad = int((np.abs(o - ref) > atol + rtol * np.abs(ref)).sum())
     lbad = int((np.abs(lse.cpu().numpy() - rl) > LSE_TOL["bf16"] * max(1.0, mag) + 1e-5 * np.abs(rl)).sum())
-    res.append({"case": [B, Hq, Hkv, Sq, Sk, int(causal), mag], "bad": bad, "lse_bad": lbad,
+    res.append({"case": [B, Hq, Hkv, Sq, Sk, int(causal), mag, spike], "bad": bad, "lse_bad": lbad,
                 "nan": int(np.isnan(o).sum()), "max_err": float(np.abs(o - ref).max())})
 print("RESULT " + json.dumps(res))
 '''
 
 
-@pytest.mark.parametrize("env", [{"AULE_HIP_FWD_KERNEL": "iw"}, {"AULE_HIP_FWD_KERNEL": "iw1"}, {"AULE_HIP_FWD_KERNEL": "v1"},
-                                 {"AULE_HIP_FWD_SOFTMAX": "classic"}],
-                         ids=["kernel-iw", "kernel-iw1", "kernel-v1", "softmax-classic"])
+@pytest.mark.parametrize("env", [{}, {"AULE_HIP_FWD_KERNEL": "pp"}, {"AULE_HIP_FWD_SOFTMAX": "classic"},
+                                 {"AULE_HIP_FWD_KERNEL": "pp", "AULE_HIP_FWD_SOFTMAX": "classic"}],
+                         ids=["default", "kernel-pp", "softmax-classic", "kernel-pp-softmax-classic"])
 def test_forward_variant_matches_oracle(env):
     e = dict(os.environ)
     e.update(env)

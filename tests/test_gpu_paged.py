@@ -92,6 +92,26 @@ def _dense_route(B, Hq, Hkv, Sk, D):
     return _capi.get_lib().aule_hip_debug_forward_route(ctypes.byref(d))
 
 
+def test_paged_context_len_beyond_the_block_table_is_clamped():
+    """A context length larger than max_blocks * block_size (a stale scheduler value) is clamped on the device to what
+    the table can address -- same result as the clamped length, no out-of-bounds table or cache read -- and the block
+    table / lengths may arrive as CPU tensors (they are moved to the query's device, not read through a host pointer)."""
+    import torch
+    import aule
+    torch.manual_seed(9)
+    B, Hq, Hkv, D, bs, nb = 2, 8, 2, 128, 16, 6
+    q = torch.randn(B, Hq, D, device="cuda", dtype=torch.float16)
+    kc = torch.randn(B * nb, bs, Hkv, D, device="cuda", dtype=torch.float16)
+    vc = torch.randn_like(kc)
+    bt = torch.arange(B * nb, dtype=torch.int32).reshape(B, nb)            # CPU on purpose
+    full = torch.tensor([nb * bs, nb * bs], dtype=torch.int32)
+    over = torch.tensor([nb * bs + 1000, 2 ** 30], dtype=torch.int32)
+    ref = aule.flash_attention_paged_amd(q, kc, vc, bt, full)
+    got = aule.flash_attention_paged_amd(q, kc, vc, bt, over)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+
+
 def test_paged_equals_contiguous_decode():
     """Identity block table + one context length = decode on contiguous K/V [B,Hkv,Sk,D].
 

@@ -9,6 +9,8 @@ base + {1 V-phase start, 2 staging done, 3 Q request / epilogue done, 4 softmax 
 import ctypes, math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "aule-attention_amd"))
+# the timeline hooks live in the debug library only (cd aule-attention_amd/csrc && make dbg)
+os.environ.setdefault("AULE_LIBRARY_PATH", os.path.join(ROOT, "build", "variants", "libaule_dbg.so"))
 import torch
 from aule import _capi
 
