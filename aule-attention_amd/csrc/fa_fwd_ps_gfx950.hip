@@ -21,7 +21,7 @@
 //     fragments), and on causal blocks six of the eight waves finish early and do it while they would idle;
 //   * no barrier beyond the two per tile step: the two groups stay one phase apart across seams.
 //
-// The fixed-reference softmax (bf16) keeps its per-block range verdict, but a failed block is no longer re-run on the
+// The fixed-reference softmax (bf16, and fp16 with a tighter verdict) keeps its per-block range verdict, but a failed block is no longer re-run on the
 // spot (that would stall the stream): verdicts are posted per part and, after the stream, the workgroup runs the
 // flagged parts again as a second, sparse stream with the online softmax.
 //
@@ -366,7 +366,12 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lse), lrs, hi == 0 ? (eq0w + l31) * 4 : 0x7ffffff0, 0, 0);
             }
             if constexpr (RAW) {   // range verdict of the fixed-reference pass (NaN fails it too)
-                const bool ok = (lt > 0x1p-100f) && (lt < 0x1p110f);
+                // bf16 weights have the fp32 exponent range: the row sum only has to stay finite.  fp16 weights overflow at
+                // 65504: a row sum below 2^15 proves that no single weight reached it (weights are positive), i.e. that no
+                // logit exceeded the first tile's maximum by 15 in log2 units; keys so far below it that their fp16 weight
+                // underflows carry < 2^-24 of the first tile's maximum weight.  (A row of > 2^15 near-equal logits fails
+                // the verdict without having overflowed and is merely recomputed with the online form.)
+                const bool ok = (lt > 0x1p-100f) && (lt < (T::kDType == 2 ? 0x1p110f : 0x1p15f));
                 if (__builtin_amdgcn_ballot_w64(!ok) != 0 && lane == 0) redo[cs] = redo[kMaxSlot] = 1;
             }
             ep_left = NR; ep_qoff = eqoff; ep_q0w = eq0w;
@@ -706,9 +711,15 @@ int launch_fwd_ps(const FwdArgs& a, hipStream_t stream) {
             if (a.D == 32) return launch_ps<Bf16Traits, 32, false>(a, stream);
         }
     } else if (a.dtype == kF16) {
-        if (a.D == 128) return launch_ps<F16Traits, 128, false>(a, stream);
-        if (a.D == 64) return launch_ps<F16Traits, 64, false>(a, stream);
-        if (a.D == 32) return launch_ps<F16Traits, 32, false>(a, stream);
+        if (raw_softmax_enabled()) {
+            if (a.D == 128) return launch_ps<F16Traits, 128, true>(a, stream);
+            if (a.D == 64) return launch_ps<F16Traits, 64, true>(a, stream);
+            if (a.D == 32) return launch_ps<F16Traits, 32, true>(a, stream);
+        } else {
+            if (a.D == 128) return launch_ps<F16Traits, 128, false>(a, stream);
+            if (a.D == 64) return launch_ps<F16Traits, 64, false>(a, stream);
+            if (a.D == 32) return launch_ps<F16Traits, 32, false>(a, stream);
+        }
     }
     return -1;
 }
@@ -716,7 +727,8 @@ int launch_fwd_ps(const FwdArgs& a, hipStream_t stream) {
 int configure_fwd_ps() {
     return set_attr_ps<Bf16Traits, 128, true>() | set_attr_ps<Bf16Traits, 64, true>() | set_attr_ps<Bf16Traits, 32, true>() |
            set_attr_ps<Bf16Traits, 128, false>() | set_attr_ps<Bf16Traits, 64, false>() | set_attr_ps<Bf16Traits, 32, false>() |
-           set_attr_ps<F16Traits, 128, false>() | set_attr_ps<F16Traits, 64, false>() | set_attr_ps<F16Traits, 32, false>();
+           set_attr_ps<F16Traits, 128, false>() | set_attr_ps<F16Traits, 64, false>() | set_attr_ps<F16Traits, 32, false>() |
+           set_attr_ps<F16Traits, 128, true>() | set_attr_ps<F16Traits, 64, true>() | set_attr_ps<F16Traits, 32, true>();
 }
 
 }  // namespace aule_hip

@@ -177,6 +177,29 @@ def test_online_softmax_rescale_is_exercised(torch_cuda, oracle_mod):
             assert_close(lse, ref_lse, LSE_TOL[dtype] * 4, 1e-5, "spike lse")
 
 
+def test_fp16_fixed_reference_verdict(torch_cuda, oracle_mod):
+    """fp16 runs the fixed-reference softmax with a verdict that must catch weights beyond 65504: (a) logits far above the
+    first tile's maximum -> the Q block is recomputed with the online form; (b) 33 024 equal logits per row -> row sums
+    beyond the 2^15 verdict bound without any overflow: recomputed, and exact either way."""
+    from aule import _torch as at
+    torch = torch_cuda
+    rng = np.random.RandomState(11)
+    q, k, v = (quantize(rng.randn(1, 2, 512, 128) * 6.0, "fp16") for _ in range(3))
+    out, lse = run_fwd(torch, q, k, v, "fp16", True, None)
+    ref, ref_lse = oracle_mod.fwd_f64(q, k, v, True, None)
+    assert_close(out, ref, *fwd_tol("fp16", np.abs(v).max()), "fp16 large logits")
+    assert_close(lse, ref_lse, LSE_TOL["fp16"] * 6, 1e-5, "fp16 large logits lse")
+    B, H, Sq, Sk, D = 16, 16, 512, 33024, 64
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    qz = torch.zeros(B, H, Sq, D, device="cuda", dtype=torch.float16)
+    kz, vz = (torch.randn(B, H, Sk, D, device="cuda", dtype=torch.float16, generator=gen) for _ in range(2))
+    o, l = at.fwd_raw(qz, kz, vz, False, 0.125)
+    torch.cuda.synchronize()
+    mean_v = vz.float().mean(dim=2, keepdim=True)            # uniform attention = the mean of V
+    assert (o.float() - mean_v).abs().max().item() < 1e-3
+    assert (l - math.log(Sk)).abs().max().item() < 1e-4
+
+
 # ---------------------------------------------------------------- full-size configs -----
 def _sample_rows(rng, total, n):
     return np.unique(np.concatenate([[0, total - 1], rng.randint(0, total, size=n)])).astype(np.int64)
