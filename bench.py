@@ -280,22 +280,37 @@ def main():
     }
 
     if dist is not None and (n_gpus > 1 or os.environ.get("AULE_BENCH_FORCE_GATHER")):
-        # the one collective of the sharded path: all-gather of O over xGMI (RCCL), timed separately
+        # the one exchange of the sharded path: every rank receives every rank's O over xGMI (RCCL), timed separately
+        # from `value` (kernel-only scaling): (a) one blocking all-gather behind the whole shard (round 1), (b) the shard
+        # in pieces, each piece's all-gather overlapping the next piece's kernels, (c) the same with direct peer sends
+        # (all links of the fully connected node at once) -- aule/dist.py, DESIGN.md "Multi-GPU"
+        from aule import dist as adist
         out = step().detach()
         gathered = torch.empty((n_gpus,) + tuple(out.shape), device=dev, dtype=out.dtype)
 
-        def step_gather():
+        def attn_nograd(a, b, c, causal=True, scale=None):
+            return aule.flash_attention(a.detach(), b.detach(), c.detach(), causal=causal, scale=scale)
+
+        def step_blocking():
             o = step().detach()
             dist.all_gather_into_tensor(gathered, o.contiguous())
 
-        for _ in range(2):
-            step_gather()
+        variants = {"blocking_all_gather": step_blocking}
+        if mode == "fwd" and B >= 2:
+            nch = min(4, B)
+            variants["chunked_all_gather"] = lambda: adist.attention_and_gather(q, k, v, causal=causal, attn_fn=attn_nograd,
+                                                                                  chunks=nch, transport="allgather")
+            variants["chunked_p2p"] = lambda: adist.attention_and_gather(q, k, v, causal=causal, attn_fn=attn_nograd,
+                                                                           chunks=nch, transport="p2p")
         gsteps = max(1, min(args.steps, 20))
-        gwall, _ = timed(step_gather, gsteps)
-        result["gather"] = {"ms_per_step": gwall * 1e3 / gsteps,
-                            "value": f_step * n_gpus * gsteps / gwall / 1e12,
-                            "bytes_per_rank": out.numel() * out.element_size(),
-                            "collective": "all_gather_into_tensor(O) via RCCL"}
+        result["gather"] = {"bytes_per_rank": out.numel() * out.element_size(), "steps": gsteps}
+        for name, fn in variants.items():
+            for _ in range(2):
+                fn()
+            gwall, _ = timed(fn, gsteps)
+            result["gather"][name] = {"ms_per_step": gwall * 1e3 / gsteps, "value": f_step * n_gpus * gsteps / gwall / 1e12,
+                                      "exposed_ms": gwall * 1e3 / gsteps - ms_per_step}
+        del gathered
 
     if rank == 0 and n_gpus == 1 and not args.no_extra and args.config == "c2":
         # the other half of the metric: fwd+bwd on config #3 (GQA 32q/8kv S=2048, B=4 as SURVEY 8d assumes), and config #5

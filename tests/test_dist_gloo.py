@@ -1,5 +1,5 @@
-"""World-size-2 CPU test (gloo) of the multi-GPU path: sharding + the single output
-all-gather reproduce the unsharded result exactly.  The per-shard compute function is
+"""World-size-2 (and 3) CPU tests (gloo) of the multi-GPU path: sharding + the chunked, overlapped output exchange -- as
+per-piece all-gathers or as direct peer sends -- reproduce the unsharded result exactly, for every chunk count.  The per-shard compute function is
 injected (the oracle, as the checker) because there is no GPU here; on the GPU box the
 same driver code runs with aule.flash_attention over RCCL (tests/test_gpu_dist.py)."""
 import os
@@ -40,30 +40,43 @@ def _worker(rank, world, port, case, q):
         o, _ = oracle.fwd_f64(a.numpy(), b.numpy(), c.numpy(), causal, scale)
         return torch.from_numpy(o)
 
-    full = adist.flash_attention_sharded(tq, tk, tv, causal=causal, attn_fn=attn)
     ref = attn(tq, tk, tv, causal=causal)
-    ok = bool(torch.equal(full, ref))
+    ok = True
+    equal_shards = len({e - s for s, e in adist.shard_plan(B, Hkv, world)[1]}) == 1
+    for transport in ("auto", "p2p") + (("allgather",) if equal_shards else ()):
+        for chunks in (1, 2, 3, 8):
+            full = adist.flash_attention_sharded(tq, tk, tv, causal=causal, attn_fn=attn, chunks=chunks, transport=transport)
+            ok = ok and bool(torch.equal(full, ref))    # chunked == unchunked == unsharded, bit for bit
+    if not equal_shards:
+        try:
+            adist.flash_attention_sharded(tq, tk, tv, causal=causal, attn_fn=attn, transport="allgather")
+            ok = False                                  # a ragged split must be refused by the all-gather transport
+        except ValueError:
+            pass
     shard = adist.flash_attention_sharded(tq, tk, tv, causal=causal, gather=False, attn_fn=attn)
     q.put((rank, ok, tuple(shard.shape)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", [
-    (4, 4, 2, 24, 24, 16, True),     # batch split 2+2
-    (3, 4, 2, 16, 20, 16, False),    # ragged batch split 2+1 (padded gather)
-    (1, 6, 2, 16, 16, 16, True),     # B < world: split (batch, kv-head) units, groups stay together
-    (1, 8, 1, 12, 12, 16, True),     # single unit: rank 1 gets nothing
+@pytest.mark.parametrize("case,world", [
+    ((4, 4, 2, 24, 24, 16, True), 2),     # batch split 2+2
+    ((8, 4, 2, 16, 16, 16, True), 2),     # batch split 4+4: up to four pieces per rank
+    ((3, 4, 2, 16, 20, 16, False), 2),    # ragged batch split 2+1: direct sends, no padding
+    ((1, 6, 2, 16, 16, 16, True), 2),     # B < world: split (batch, kv-head) units, groups stay together
+    ((1, 8, 1, 12, 12, 16, True), 2),     # single unit: rank 1 gets nothing
+    ((2, 12, 6, 16, 16, 16, True), 3),    # three ranks, unit split 4+4+4 with groups of two query heads
+    ((7, 2, 2, 16, 16, 16, False), 3),    # three ranks, ragged 3+2+2
 ])
-def test_sharded_equals_unsharded_world2(case):
+def test_sharded_equals_unsharded(case, world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(2)]
+    res = [q.get(timeout=180) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -79,3 +92,10 @@ def test_partition_properties():
             assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
             assert max(e - s for s, e in r) - min(e - s for s, e in r) <= 1
     assert adist.shard_plan(64, 32, 8)[0] == "batch" and adist.shard_plan(1, 8, 8)[0] == "unit"
+    for n in range(0, 12):
+        for c in (1, 2, 5, 20):
+            r = adist.chunk_ranges(n, c)
+            assert (not r and n == 0) or (r[0][0] == 0 and r[-1][1] == n and all(b > a for a, b in r) and len(r) <= max(1, c))
+    # config 4: B=64 H=32 S=8192 D=128 bf16 over 8 ranks -> 512 MiB per rank, 4 GiB in total
+    sizes, total = adist.gather_bytes(64, 32, 32, 8192, 128, 2, 8)
+    assert sizes == [512 << 20] * 8 and total == 4 << 30

@@ -24,13 +24,17 @@ def _run(cmd, extra_env=None):
 def test_bench_under_torchrun_one_rank():
     r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
               "--master-addr", "127.0.0.1", "--master-port", "29517", "bench.py", "--gpus", "1", "--steps", "3",
-              "--warmup", "1", "--batch", "1", "--no-cpu-baseline", "--no-extra"],
+              "--warmup", "1", "--batch", "2", "--condition-ms", "20", "--no-cpu-baseline", "--no-extra"],
              {"AULE_BENCH_FORCE_GATHER": "1"})
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["unit"] == "TFLOP/s"
-    assert "gather" in rec and rec["gather"]["ms_per_step"] > 0
+    # the output exchange, three ways (one blocking all-gather; pieces overlapped with the kernels, as all-gathers and as
+    # direct peer sends): each timed end to end
+    for name in ("blocking_all_gather", "chunked_all_gather", "chunked_p2p"):
+        assert rec["gather"][name]["ms_per_step"] > 0, name
+    assert rec["cold_start"]["value"] > 0 and rec["conditioning"]["steps"] > 0
     assert rec["roofline"]["bound"] == "mfma" and 0 < rec["roofline"]["frac"] < 1
 
 
@@ -47,8 +51,12 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 q = torch.randn(2, 8, 256, 128, device="cuda", dtype=torch.bfloat16)
 k = torch.randn(2, 2, 256, 128, device="cuda", dtype=torch.bfloat16)
 v = torch.randn(2, 2, 256, 128, device="cuda", dtype=torch.bfloat16)
-full = adist.flash_attention_sharded(q, k, v, causal=True)
 ref = aule.flash_attention(q, k, v, causal=True)
+for transport in ("auto", "allgather", "p2p"):
+    for chunks in (1, 2, 4):
+        full = adist.flash_attention_sharded(q, k, v, causal=True, chunks=chunks, transport=transport)
+        assert torch.equal(full, ref), (transport, chunks)
+full = adist.attention_and_gather(q, k, v, causal=True, chunks=2)
 assert torch.equal(full, ref)
 dist.destroy_process_group()
 print("OK")
