@@ -83,7 +83,7 @@ __device__ __forceinline__ void load_b_operand(const float* rowp, int hi, float 
 }
 
 template <int D, bool CAUSAL>
-__global__ void __launch_bounds__(256) fa_bwd_dq_f32_kernel(const BwdF32Params p) {
+__global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dq_f32_kernel(const BwdF32Params p) {
     constexpr int DB = D / 32;
     __shared__ __attribute__((aligned(16))) float Kt[D * 32];
     __shared__ __attribute__((aligned(16))) float Krm[kTile * D];
@@ -178,7 +178,7 @@ struct DkvF32Cfg {
 };
 
 template <int D, bool CAUSAL>
-__global__ void __launch_bounds__(256) fa_bwd_dkdv_f32_kernel(const BwdF32Params p) {
+__global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dkdv_f32_kernel(const BwdF32Params p) {
     constexpr int DB = D / 32, IMG = DkvF32Cfg<D>::IMG;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* const Qt = reinterpret_cast<float*>(smem_raw);

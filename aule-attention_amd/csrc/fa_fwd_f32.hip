@@ -11,7 +11,8 @@
 // Same lane-local structure as the 16-bit kernel (fa_fwd_gfx950.hip):
 //   S^T[kv][q] = K.Q^T (A = K from LDS, B = Q in registers), lane owns q = lane&31;
 //   O^T[d][q] = V^T.P^T with P's accumulator layout reused as the k-slot order.
-// workgroup = 4 waves x 32 query rows, KV tile = 32 rows, single-buffered LDS:
+// workgroup = 4 waves x 32 query rows, KV tile = 32 rows, single-buffered LDS with the next tile prefetched into
+// registers, at most 256 VGPRs so that two workgroups share a CU:
 //   Kt[d][32]  (transposed so that the A-operand ds_read_b32 is conflict-free)
 //   V [32][D]  row-major.
 #include "fa_device.h"
@@ -37,7 +38,7 @@ constexpr int kQB = 128;  // 4 waves x 32 rows
 constexpr int kKV = 32;
 
 template <int D, bool CAUSAL>
-__global__ void __launch_bounds__(256) fa_fwd_f32_kernel(const FwdF32Params p) {
+__global__ void __launch_bounds__(256, 2) fa_fwd_f32_kernel(const FwdF32Params p) {   // (<= 256 registers: two workgroups per CU hide each other's staging latency; D = 128 took 276 and ran alone)
     constexpr int DB = D / 32;
     constexpr int C4 = D / 4;               // 16-byte chunks per row
     constexpr int NCH = kKV * C4 / 256;     // chunks per thread per tile (D=128: 4, 64: 2, 32: 1)
@@ -86,9 +87,12 @@ __global__ void __launch_bounds__(256) fa_fwd_f32_kernel(const FwdF32Params p) {
     const int t_lo = W > 0 ? max(0, w.blk * kQB + coff - W + 1) / kKV : 0;   // tiles before the block's window: skipped
     const int wave_kv_lo = W > 0 ? q0w + coff - W + 1 : 0;                  // first key any row of this wave can see
 
-    for (int t = t_lo; t < nt; ++t) {
+    // Staging is software-pipelined: the next tile's K / V rows are requested into registers before this tile's MFMAs and
+    // written to LDS behind the barrier that retires this tile (the loads used to sit, latency exposed, at the top of
+    // every iteration of a single-buffered loop).
+    f32x4_t kx[NCH], vx[NCH];
+    auto issue_tile = [&](int t) __attribute__((always_inline)) {
         const int kv0 = t * kKV;
-        // ---- stage K (transposed) and V (row-major)
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int cidx = tid + 256 * i;
@@ -96,21 +100,35 @@ __global__ void __launch_bounds__(256) fa_fwd_f32_kernel(const FwdF32Params p) {
                 const int kv = cidx & 31, dc = cidx >> 5;
                 int r = kv0 + kv;
                 r = r < Sk ? r : Sk - 1;
-                const f32x4_t x = *reinterpret_cast<const f32x4_t*>(kg + (size_t)r * D + 4 * dc);
-                Kt[(4 * dc + 0) * 32 + kv] = x[0];
-                Kt[(4 * dc + 1) * 32 + kv] = x[1];
-                Kt[(4 * dc + 2) * 32 + kv] = x[2];
-                Kt[(4 * dc + 3) * 32 + kv] = x[3];
+                kx[i] = *reinterpret_cast<const f32x4_t*>(kg + (size_t)r * D + 4 * dc);
             }
             {   // V: coalesced rows
                 const int row = cidx / C4, cc = cidx % C4;
                 int r = kv0 + row;
                 r = r < Sk ? r : Sk - 1;
-                *reinterpret_cast<f32x4_t*>(&Vs[row * D + 4 * cc]) =
-                    *reinterpret_cast<const f32x4_t*>(vg + (size_t)r * D + 4 * cc);
+                vx[i] = *reinterpret_cast<const f32x4_t*>(vg + (size_t)r * D + 4 * cc);
             }
         }
+    };
+    auto write_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int cidx = tid + 256 * i;
+            const int kv = cidx & 31, dc = cidx >> 5;
+            Kt[(4 * dc + 0) * 32 + kv] = kx[i][0];
+            Kt[(4 * dc + 1) * 32 + kv] = kx[i][1];
+            Kt[(4 * dc + 2) * 32 + kv] = kx[i][2];
+            Kt[(4 * dc + 3) * 32 + kv] = kx[i][3];
+            const int row = cidx / C4, cc = cidx % C4;
+            *reinterpret_cast<f32x4_t*>(&Vs[row * D + 4 * cc]) = vx[i];
+        }
+    };
+    if (t_lo < nt) issue_tile(t_lo);
+    for (int t = t_lo; t < nt; ++t) {
+        const int kv0 = t * kKV;
+        write_tile();
         __syncthreads();
+        if (t + 1 < nt) issue_tile(t + 1);
 
         if (kv0 < wave_kv_hi && kv0 + kKV > wave_kv_lo) {
             f32x16_t s;

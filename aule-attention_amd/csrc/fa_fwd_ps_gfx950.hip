@@ -64,6 +64,19 @@ constexpr int kPSTLMax = 2048;
 #ifndef AULE_PS_VPRIO
 #define AULE_PS_VPRIO 0
 #endif
+// AULE_PS_YOUNG_PRIO=1: one static s_setprio 1 for the second-dispatched wave group, no per-phase flips (hardware guide, T5
+// static form: the younger half loses VALU arbitration to the older one on every segment)
+// Operand look-ahead (steps) of the two M-phase loops.  tools/timeline.py with one group idled: the M-phase takes the same
+// ~1640 cycles per 32 MFMAs with or without a partner -- it is bound by its own LDS operand latency.
+#ifndef AULE_PS_QK_AHEAD
+#define AULE_PS_QK_AHEAD 1
+#endif
+#ifndef AULE_PS_PV_AHEAD
+#define AULE_PS_PV_AHEAD 2
+#endif
+#ifndef AULE_PS_YOUNG_PRIO
+#define AULE_PS_YOUNG_PRIO 0
+#endif
 
 constexpr int kMaxItems = 64;            // per workgroup (the host sizes the grid accordingly)
 constexpr int kMaxSlot = 2 * kMaxItems;  // parts: two per item (the second one invalid for an unpaired block)
@@ -247,7 +260,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
 
         auto qk = [&](int buf) __attribute__((always_inline)) {  // S^T = K_tile . Q^T
             const char* kb = Ks + buf * KTILE + ka_base;
-            constexpr int kAhead = 1;
+            constexpr int kAhead = AULE_PS_QK_AHEAD;
             u32x4_t kf[KS][2];
             auto rd = [&](int ks) __attribute__((always_inline)) {
                 kf[ks][0] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32);
@@ -272,7 +285,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
         auto pv = [&](int buf) __attribute__((always_inline)) {  // O^T += V^T . P^T
             const char* vb = Vs + buf * VTILE + va_off;
             constexpr int NST = 4 * DB;
-            constexpr int kAhead = 2;
+            constexpr int kAhead = AULE_PS_PV_AHEAD;
             s16x4_t a0[NST], a1[NST];
             auto rd = [&](int st) __attribute__((always_inline)) {
                 const int sk = st / DB, d = st % DB;
@@ -472,16 +485,16 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
                 if (n_slot < nslot) issue_q(n_qoff, n_qb * kQBlock + wave * 32);
             }
             stamp(tlt + 3);
-            __builtin_amdgcn_s_setprio(AULE_PS_VPRIO);
+            if constexpr (!AULE_PS_YOUNG_PRIO) __builtin_amdgcn_s_setprio(AULE_PS_VPRIO);
             if constexpr (MODE >= 1) softmax(j * kKVTile, sm_tag);
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr (!AULE_PS_YOUNG_PRIO) __builtin_amdgcn_s_setprio(0);
             stamp(tlt + 4);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
             stamp(tlt + 5);
             // ---- M-phase
-            __builtin_amdgcn_s_setprio(AULE_PS_MPRIO);
+            if constexpr (!AULE_PS_YOUNG_PRIO) __builtin_amdgcn_s_setprio(AULE_PS_MPRIO);
             if constexpr (MODE >= 1) pv(P & 1);
             if constexpr (TL && MODE >= 1) { keep_live(o[0], o[DB - 1]); stamp(tlt + 6); }
             if constexpr (MODE == 2) {
@@ -505,7 +518,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
                 }
             }
             if constexpr (TL) { keep_live(s[0], s[1]); stamp(tlt + 7); }
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr (!AULE_PS_YOUNG_PRIO) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
@@ -514,6 +527,9 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
         // ---- prologue of the stream: tiles 0, 1, 2 of the first part (it has >= 4) and its Q, in one HBM round trip.
         //      Entry state of step 0: K_0 in LDS; group 0 holds (V_0, K_1), group 1 has written them and holds (V_1, K_2).
         stamp(0xe0);
+        if constexpr (AULE_PS_YOUNG_PRIO != 0) {
+            if (grp == 1) __builtin_amdgcn_s_setprio(1);   // (grp comes from readfirstlane: a scalar branch around one s_setprio)
+        }
 #pragma unroll
         for (int d = 0; d < DB; ++d)
 #pragma unroll
