@@ -21,6 +21,8 @@
 #include <cstring>
 #include <mutex>
 
+#include <dlfcn.h>
+
 #include "fa_kernels.h"
 
 // abi2: optional workspace / workspace_bytes appended to the forward and paged descriptors (96 -> 112, 104 -> 120)
@@ -164,6 +166,15 @@ extern "C" {
 int32_t aule_init(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_init) return 0;  // idempotent (src/lib.zig:60-63)
+    // AULE_BACKEND (src/backends/backend.zig:86-100): "hip" forces the backend this library IS -- a no-op; any value the
+    // reference does not know falls through to its auto-detection, i.e. to HIP here; "vulkan" and "cpu" name backends
+    // this build does not contain (no multi-backend dispatch, no CPU fallback): fail loudly instead of running something else.
+    if (const char* b = getenv("AULE_BACKEND")) {
+        if (strcmp(b, "vulkan") == 0 || strcmp(b, "cpu") == 0) {
+            set_error("Failed to initialize backend: AULE_BACKEND=%s, but this library contains the HIP (gfx950) backend only", b);
+            return -1;
+        }
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -654,12 +665,54 @@ static void drop_trivial_causal(int& causal, int& coff, int Sq, int window) {
     }
 }
 
+// roctx ranges around the launches (the reference has no tracing at all), so that
+// `rocprofv3 --marker-trace` shows "aule.forward" / "aule.backward" / "aule.paged_decode" / "aule.rope" next to the kernels.
+// Opt-in (AULE_ROCTX=1) and loaded lazily with dlopen: the library keeps its single link dependency (libamdhip64).
+struct RoctxRange {
+    using PushFn = int (*)(const char*);
+    using PopFn = int (*)();
+    static PushFn push_fn() {
+        static const PushFn fn = [] {
+            const char* e = getenv("AULE_ROCTX");
+            if (e == nullptr || e[0] != '1') return (PushFn) nullptr;
+            // rocprofv3 intercepts the rocprofiler-sdk flavour; libroctx64 is the legacy (roctracer) one
+            void* h = nullptr;
+            for (const char* name : {"librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so",
+                                     "/opt/rocm/lib/libroctx64.so"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (h != nullptr) break;
+            }
+            if (h == nullptr) return (PushFn) nullptr;
+            pop_slot() = reinterpret_cast<PopFn>(dlsym(h, "roctxRangePop"));
+            return reinterpret_cast<PushFn>(dlsym(h, "roctxRangePushA"));
+        }();
+        return fn;
+    }
+    static PopFn& pop_slot() {
+        static PopFn fn = nullptr;
+        return fn;
+    }
+    bool on = false;
+    explicit RoctxRange(const char* name) {
+        if (PushFn f = push_fn()) {
+            f(name);
+            on = pop_slot() != nullptr;
+        }
+    }
+    ~RoctxRange() {
+        if (on) pop_slot()();
+    }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 static float resolve_scale(float scale, uint32_t D) {
     if (scale == 0.0f || std::isnan(scale)) return 1.0f / std::sqrt((float)D);
     return scale;
 }
 
 int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
+    RoctxRange range("aule.forward");
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_init) {
         set_error("Library not initialized. Call aule_init() first.");
@@ -705,6 +758,7 @@ int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
 }
 
 int32_t aule_attention_paged_decode_ex(const aule_paged_desc* d) {
+    RoctxRange range("aule.paged_decode");
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_init) {
         set_error("Library not initialized. Call aule_init() first.");
@@ -756,6 +810,7 @@ int32_t aule_attention_paged_decode_ex(const aule_paged_desc* d) {
 }
 
 int32_t aule_rope_ex(const aule_rope_desc* d) {
+    RoctxRange range("aule.rope");
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_init) {
         set_error("Library not initialized. Call aule_init() first.");
@@ -815,6 +870,7 @@ uint64_t aule_attention_backward_workspace_size(const aule_attn_bwd_desc* d) {
 }
 
 int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
+    RoctxRange range("aule.backward");
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_init) {
         set_error("Library not initialized. Call aule_init() first.");
