@@ -23,16 +23,18 @@ def draw(rng):
     D = int(rng.choice([32, 64, 128]))
     Hkv = int(rng.choice([1, 1, 2, 3, 4, 8])); g = int(rng.choice([1, 1, 2, 4, 8, 5])); Hq = Hkv * g
     B = int(rng.choice([1, 1, 2, 3, 9]))
-    Sq = int(rng.choice([1, 1, 2, 3, 7, 16, 17, 31, 33, 64, 65, 100, 200, 256, 257, 300]))
+    Sq = int(rng.choice([1, 1, 2, 3, 7, 16, 17, 31, 33, 64, 65, 100, 200, 256, 257, 300, 512, 700, 1024, 1300]))   # (>= 512: several Q blocks -> the tile stream's seams)
     Sk = int(rng.choice([1, 5, 63, 64, 65, 130, 500, 1023, 1024, 1025, 2047, 2100, 3000, 4096, 5000, 9000]))
     causal = rng.choice(["none", "none", "top", "br", "br"])
     if causal == "br" and Sk < Sq: Sk = Sq + int(rng.choice([0, 1, 100, 1500, 4000]))
     W = int(rng.choice([-1, -1, -1, 1, 7, 64, 100, 1000]))
     scale = None if rng.rand() < 0.7 else float(rng.choice([0.3, -0.2, 0.05, 1.0]))
     # keep the fp64 judge (fwd + bwd ~ 8 B Hq Sq Sk D flops) within ~0.5 s
-    while 8.0 * B * Hq * Sq * Sk * D > 4e8:
+    while 8.0 * B * Hq * Sq * Sk * D > 6e8:
         if B > 1: B = 1
-        elif Sq > 64: Sq = Sq // 2
+        elif Hq > Hkv and g > 1: g = max(1, g // 2); Hq = Hkv * g
+        elif Hkv > 1: Hkv = 1; Hq = g
+        elif Sq > 64 and Sq * 4 > Sk: Sq = Sq // 2
         elif Hq > Hkv and g > 1: g = max(1, g // 2); Hq = Hkv * g
         else: Sk = max(Sq if causal == "br" else 1, Sk // 2)
     return dtype, B, Hq, Hkv, Sq, Sk, D, causal, W, scale
