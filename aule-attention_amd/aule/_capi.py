@@ -127,6 +127,20 @@ class RopeDesc(ctypes.Structure):
     ]
 
 
+class AttnRope(ctypes.Structure):
+    """struct aule_attn_rope (include/aule.h): the query rotation fused into the forward kernel."""
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("layout", ctypes.c_int32),
+        ("table_len", ctypes.c_uint32),
+        ("table_pitch", ctypes.c_uint32),
+        ("q_pos_offset", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
+        ("cos", ctypes.c_void_p),
+        ("sin", ctypes.c_void_p),
+    ]
+
+
 ROPE_HALF, ROPE_INTERLEAVED = 0, 1
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 
@@ -170,6 +184,8 @@ SIGNATURES = [
     ("aule_attention_backward_workspace_size", _U64, [ctypes.POINTER(AttnBwdDesc)]),
     ("aule_attention_paged_decode_ex", _I32, [ctypes.POINTER(PagedDesc)]),
     ("aule_rope_ex", _I32, [ctypes.POINTER(RopeDesc)]),
+    ("aule_attention_forward_rope_ex", _I32, [ctypes.POINTER(AttnDesc), ctypes.POINTER(AttnRope)]),
+    ("aule_attention_forward_rope_fusable", _I32, [ctypes.POINTER(AttnDesc), ctypes.POINTER(AttnRope)]),
     ("aule_attention_forward_workspace_size", ctypes.c_uint64, [ctypes.POINTER(AttnDesc)]),
     ("aule_attention_paged_decode_workspace_size", ctypes.c_uint64, [ctypes.POINTER(PagedDesc)]),
     ("aule_hip_build_info", ctypes.c_char_p, []),

@@ -67,9 +67,20 @@ def _workspace(nbytes, device):
     return torch.empty((nbytes,), device=device, dtype=torch.uint8) if nbytes > 0 else None
 
 
-def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1):
+def _attn_rope(cos, sin, q_pos):
+    r = _capi.AttnRope()
+    r.struct_size = ctypes.sizeof(_capi.AttnRope)
+    r.layout = _capi.ROPE_HALF
+    r.table_len, r.table_pitch, r.q_pos_offset = cos.shape[0], cos.stride(0), int(q_pos)
+    r.cos, r.sin = cos.data_ptr(), sin.data_ptr()
+    return r
+
+
+def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1, q_rope=None):
     """q [B,Hq,Sq,D], k/v [B,Hkv,Sk,D]: contiguous device tensors, D in SUPPORTED_HEAD_DIMS.
-    Returns (out, lse or None).  Asynchronous on the current stream."""
+    Returns (out, lse or None).  Asynchronous on the current stream.
+    q_rope = (cos, sin, q_pos): rotate Q inside the kernel (half-split pairs; K already rotated) -- only for shapes
+    rope_fusable() accepts, AuleError otherwise."""
     lib = _capi.get_lib()
     _same_device("flash attention forward", q, k, v)
     B, Hq, Sq, D = q.shape
@@ -92,8 +103,27 @@ def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1):
     ws = _workspace(lib.aule_attention_forward_workspace_size(ctypes.byref(d)), q.device)
     if ws is not None:
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-    _capi.check(lib.aule_attention_forward_ex(ctypes.byref(d)), "aule_attention_forward_ex")
+    if q_rope is not None:
+        r = _attn_rope(*q_rope)
+        _capi.check(lib.aule_attention_forward_rope_ex(ctypes.byref(d), ctypes.byref(r)), "aule_attention_forward_rope_ex")
+    else:
+        _capi.check(lib.aule_attention_forward_ex(ctypes.byref(d)), "aule_attention_forward_ex")
     return out, lse
+
+
+def rope_fusable(q, k, causal, window, cos, sin, q_pos):
+    """Would the forward kernel rotate Q itself for this problem (aule_attention_forward_rope_fusable)?  Host logic only."""
+    lib = _capi.get_lib()
+    if q.dtype not in _DTYPES or q.numel() == 0 or cos.stride(-1) != 1:
+        return False
+    d = _capi.AttnDesc()
+    d.struct_size = ctypes.sizeof(_capi.AttnDesc)
+    d.dtype = _DTYPES[q.dtype]
+    d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3]
+    d.causal = causal_code(causal)
+    d.window_size = int(window) if window is not None and window > 0 else -1
+    r = _attn_rope(cos, sin, q_pos)
+    return lib.aule_attention_forward_rope_fusable(ctypes.byref(d), ctypes.byref(r)) == 1
 
 
 def bwd_raw(q, k, v, out, dout, lse, causal, scale, window=-1):
@@ -283,6 +313,16 @@ def flash_attention_rope_hip(q, k, v, cos, sin, causal=True, scale=None, window=
     if max(Sq + q_pos, Sk) > cos.shape[0]:
         raise ValueError(f"RoPE table has {cos.shape[0]} rows, sequences need {max(Sq + q_pos, Sk)}")
     Dp = next(x for x in SUPPORTED_HEAD_DIMS if x >= D)
+    needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
+    if (not needs_grad and layout == "half" and Dp == D and os.environ.get("AULE_HIP_ROPE_FUSE", "1") != "0"
+            and rope_fusable(q, k, code, window, cos, sin, q_pos)):
+        # inference: K is rotated once per key, Q on its way into the attention kernel's registers (one read and one
+        # write of Q less; bit-identical to the two-pass form -- DESIGN.md 3.6).  The backward needs the rotated Q in
+        # memory, so training keeps the separate pass.
+        kr = rope_raw(k.contiguous(), cos, sin, layout, False, 0)
+        out, _ = fwd_raw(q.contiguous(), kr, v.contiguous(), code, float(scale), want_lse=False, window=window,
+                         q_rope=(cos, sin, q_pos))
+        return out if out.dtype == orig_dtype else out.to(orig_dtype)
     out = FlashAttentionRopeHipFunc.apply(q, k, v, cos, sin, code, float(scale), int(window), layout, q_pos, Dp)
     return out if out.dtype == orig_dtype else out.to(orig_dtype)
 

@@ -711,8 +711,32 @@ static float resolve_scale(float scale, uint32_t D) {
     return scale;
 }
 
-int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
-    RoctxRange range("aule.forward");
+// Descriptor -> launch arguments (shared by the plain and the fused-rotation entry points; no device work).
+static void fill_fwd_args(const aule_attn_desc* d, FwdArgs& a) {
+    a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->out; a.lse = d->lse;
+    a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv;
+    a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
+    a.scale = resolve_scale(d->scale, d->head_dim);
+    a.causal = d->causal != 0;
+    a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? (int)d->seq_k - (int)d->seq_q : 0;
+    a.dtype = d->dtype;
+    // W >= Sq + coff masks nothing (the last query sits at position Sq - 1 + coff)
+    a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
+    drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
+    a.ws = d->workspace; a.ws_bytes = d->workspace ? d->workspace_bytes : 0;
+}
+
+static bool fill_rope_args(const aule_attn_rope* r, uint32_t head_dim, FwdArgs& a) {
+    if (r == nullptr || r->struct_size != sizeof(aule_attn_rope) || r->layout != AULE_ROPE_HALF) return false;
+    if (r->table_len >= (1u << 30) || r->table_pitch >= (1u << 20) || r->q_pos_offset >= (1u << 30)) return false;
+    a.rope_cos = r->cos; a.rope_sin = r->sin;
+    a.rope_rows = (int)r->table_len;
+    a.rope_pitch = (int)(r->table_pitch ? r->table_pitch : head_dim / 2);
+    a.rope_pos = (int)r->q_pos_offset;
+    return true;
+}
+
+static int32_t forward_impl(const aule_attn_desc* d, const aule_attn_rope* rope) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_init) {
         set_error("Library not initialized. Call aule_init() first.");
@@ -738,23 +762,46 @@ int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
     rc = ensure_configured();
     if (rc) return rc;
     FwdArgs a;
-    a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->out; a.lse = d->lse;
-    a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv;
-    a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
-    a.scale = resolve_scale(d->scale, d->head_dim);
-    a.causal = d->causal != 0;
-    a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? (int)d->seq_k - (int)d->seq_q : 0;
-    a.dtype = d->dtype;
-    // W >= Sq + coff masks nothing (the last query sits at position Sq - 1 + coff)
-    a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
-    drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
-    a.ws = d->workspace; a.ws_bytes = d->workspace ? d->workspace_bytes : 0;
+    fill_fwd_args(d, a);
+    if (rope != nullptr) {
+        if (!fill_rope_args(rope, d->head_dim, a) || !aule_hip::fwd_rope_fusable(a)) {
+            set_error("Attention failed: the query rotation is not fused for this configuration "
+                      "(aule_attention_forward_rope_fusable() == 0): rotate Q with aule_rope_ex() and call aule_attention_forward_ex()");
+            return -3;
+        }
+    }
     rc = aule_hip::launch_fwd(a, (hipStream_t)d->stream);
     if (rc != 0) {
         set_error("Attention failed: %s", rc > 0 ? hipGetErrorString((hipError_t)rc) : "unsupported configuration");
         return -4;
     }
     return 0;
+}
+
+int32_t aule_attention_forward_ex(const aule_attn_desc* d) {
+    RoctxRange range("aule.forward");
+    return forward_impl(d, nullptr);
+}
+
+int32_t aule_attention_forward_rope_ex(const aule_attn_desc* d, const aule_attn_rope* rope) {
+    RoctxRange range("aule.forward_rope");
+    if (rope == nullptr) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        set_error("Attention failed: null rotation descriptor");
+        return -3;
+    }
+    return forward_impl(d, rope);
+}
+
+int32_t aule_attention_forward_rope_fusable(const aule_attn_desc* d, const aule_attn_rope* rope) {
+    if (d == nullptr || d->struct_size != sizeof(aule_attn_desc) || rope == nullptr) return 0;
+    if (d->dtype < 0 || d->dtype > 2 || d->heads_kv == 0 || d->heads_q % d->heads_kv != 0) return 0;
+    if (d->causal < 0 || d->causal > AULE_CAUSAL_BOTTOM_RIGHT || (d->causal == AULE_CAUSAL_BOTTOM_RIGHT && d->seq_k < d->seq_q)) return 0;
+    if ((uint64_t)d->batch * d->heads_q * d->seq_q == 0 || d->seq_k == 0) return 0;
+    if (d->batch >= (1u << 24) || d->heads_q >= (1u << 24) || d->seq_q >= (1u << 30) || d->seq_k >= (1u << 30)) return 0;
+    FwdArgs a;
+    fill_fwd_args(d, a);
+    return fill_rope_args(rope, d->head_dim, a) && aule_hip::fwd_rope_fusable(a) ? 1 : 0;
 }
 
 int32_t aule_attention_paged_decode_ex(const aule_paged_desc* d) {

@@ -94,6 +94,13 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// One rotary pair, x' = (x1 c - x2 s, x1 s + x2 c), with the contraction spelled out: rope_gfx950.hip and the forward
+// kernel's fused Q rotation must round identically.
+__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float si, float& y1, float& y2) {
+    y1 = __builtin_fmaf(x1, c, -(x2 * si));
+    y2 = __builtin_fmaf(x1, si, x2 * c);
+}
+
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 
 // value of the other 32-lane half (lane ^ 32)

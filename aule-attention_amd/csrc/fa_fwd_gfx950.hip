@@ -32,6 +32,7 @@ bool pp_split_applicable(const FwdArgs& a);
 int configure_fwd_pp();
 int launch_fwd_ps(const FwdArgs& a, hipStream_t stream);   // fa_fwd_ps_gfx950.hip (persistent tile stream)
 bool fwd_ps_applicable(const FwdArgs& a);
+bool fwd_ps_rope_fusable(const FwdArgs& a);
 int configure_fwd_ps();
 
 // AULE_HIP_FWD_KERNEL=pp keeps every tiled problem on the ping-pong kernel (A/B measurements against the stream)
@@ -86,6 +87,8 @@ int fwd_route(const FwdArgs& a) {
     return use_ps(a) ? 6 : 1;
 }
 
+bool fwd_rope_fusable(const FwdArgs& a) { return fwd_route(a) == 6 && fwd_ps_rope_fusable(a); }
+
 uint64_t fwd_workspace_bytes(FwdArgs a) {
     uint64_t bytes = 0;
     a.query_ws = &bytes;
@@ -102,6 +105,7 @@ uint64_t paged_workspace_bytes(PagedArgs a) {
 
 int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (a.query_ws != nullptr) *a.query_ws = 0;
+    if (a.rope_cos != nullptr && !fwd_rope_fusable(a)) return -1;   // only the stream kernel rotates Q itself
     const int sq = a.dtype == kF32 ? 0 : short_query_route(a);
     if (sq == 4) return launch_fwd_splitkv(a, stream);
     if (sq == 5) return launch_fwd_pp_split(a, stream);

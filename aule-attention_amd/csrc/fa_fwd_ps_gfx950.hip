@@ -51,6 +51,11 @@ struct FwdPSParams {
     int pair;     // item = Q blocks (nqb-1-i, i)
     int coff;     // causal position offset (query i sits at position i + coff)
     int nitems;   // nwork * B * Hq; workgroup g takes items g, g + gridDim.x, ...
+    // ROPE instances only: rotate Q on its way into the registers (half-split pairs; K arrives rotated).  Tables
+    // [rrows, rpitch] fp32, query i uses row i + rpos.
+    const float* rcos;
+    const float* rsin;
+    int rrows, rpitch, rpos;
     unsigned long long* dbg;   // timeline build only: [8 waves][kPSTLMax] tagged s_memtime stamps of workgroup 0
 };
 
@@ -85,7 +90,7 @@ __device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlan
 
 // D <= 64: the workgroup needs <= 75 KB of LDS, so two fit a CU if the kernel stays within 128 VGPRs (4 waves per SIMD);
 // the second workgroup fills the first one's barrier and seam bubbles (the predecessor's D = 64 instances do run that way).
-template <class T, int D, bool CAUSAL, bool RAWOK, bool TL = false>
+template <class T, int D, bool CAUSAL, bool RAWOK, bool TL = false, bool ROPE = false>
 __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const FwdPSParams p) {
     using C = Cfg<D>;
     using v8 = typename T::v8;
@@ -248,6 +253,46 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 qx[ks] = __builtin_amdgcn_raw_buffer_load_b128(qrs, qoffs + ks * 32, 0, 0);
+        };
+        // ROPE: the rotation of rope_gfx950.hip (same fp32 expression, same single rounding: the fragments come out bit-identical
+        // to a separate pass over Q), on the registers the Q request landed in.  Half-split pairs (d, d + D/2) are the
+        // fragments ks and ks + KS/2 of the same lane.  Table rows beyond the table read as 0 (descriptor bounds); they belong
+        // to rows >= Sq, whose Q is 0 already.  D = 128: two batches of 32 table registers (the accumulators are live).
+        auto rotate_q = [&](int q0) __attribute__((always_inline)) {
+            if constexpr (ROPE) {
+                const unsigned tbytes = (unsigned)p.rrows * (unsigned)p.rpitch * 4u;
+                const __amdgpu_buffer_rsrc_t crs = make_srd(p.rcos, tbytes), srs = make_srd(p.rsin, tbytes);
+                int lane_o = lane;
+                asm volatile("" : "+v"(lane_o));
+                const int toff = (q0 + (lane_o & 31) + p.rpos) * (p.rpitch * 4) + (lane_o >> 5) * 32;
+                constexpr int HK = KS / 2, BATCH = HK < 2 ? HK : 2;
+#pragma unroll
+                for (int k0 = 0; k0 < HK; k0 += BATCH) {
+                    u32x4_t tc[BATCH][2], ts[BATCH][2];
+#pragma unroll
+                    for (int b = 0; b < BATCH; ++b)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            tc[b][h] = __builtin_amdgcn_raw_buffer_load_b128(crs, toff + (k0 + b) * 64 + h * 16, 0, 0);
+                            ts[b][h] = __builtin_amdgcn_raw_buffer_load_b128(srs, toff + (k0 + b) * 64 + h * 16, 0, 0);
+                        }
+#pragma unroll
+                    for (int b = 0; b < BATCH; ++b)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned ua = qx[k0 + b][j], ub = qx[k0 + b + HK][j];
+                            const float c0 = __builtin_bit_cast(float, tc[b][j >> 1][(j & 1) * 2]);
+                            const float c1 = __builtin_bit_cast(float, tc[b][j >> 1][(j & 1) * 2 + 1]);
+                            const float s0 = __builtin_bit_cast(float, ts[b][j >> 1][(j & 1) * 2]);
+                            const float s1 = __builtin_bit_cast(float, ts[b][j >> 1][(j & 1) * 2 + 1]);
+                            float y1l, y2l, y1h, y2h;
+                            rope_pair(T::lo(ua), T::lo(ub), c0, s0, y1l, y2l);
+                            rope_pair(T::hi(ua), T::hi(ub), c1, s1, y1h, y2h);
+                            qx[k0 + b][j] = T::pack2(y1l, y1h);
+                            qx[k0 + b + HK][j] = T::pack2(y2l, y2h);
+                        }
+                }
+            }
         };
         auto take_q = [&]() __attribute__((always_inline)) {   // negative scale: flip the sign of Q once, in place
             if (flip != 0u) {
@@ -512,6 +557,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             if constexpr (MODE <= 1) {
                 if (j == nt - 1 && n_slot < nslot) {   // seam: S_0 of the next part, with its Q
                     __builtin_amdgcn_sched_barrier(0);
+                    rotate_q(n_qb * kQBlock + wave * 32);
                     take_q();
                     if constexpr (TL) { asm volatile("s_nop 0" : "+v"(qx[0]), "+v"(qx[KS - 1])); stamp(tlt + 6); }
                     qk((P + 1) & 1);
@@ -550,6 +596,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
         adv_k();                 // K_1 requested: the K cursor stands at tile 2, the V cursor at tile 1
         if (grp == 1) { adv_k(); adv_v(); }
         issue_q(qoff, q0w);
+        rotate_q(q0w);
         take_q();
         write_k(0);
 #pragma unroll
@@ -634,6 +681,7 @@ int launch_ps(const FwdArgs& a, hipStream_t stream) {
     p.coff = a.causal ? a.coff : 0;
     p.nitems = p.nwork * a.B * a.Hq;
     p.dbg = nullptr;
+    p.rcos = a.rope_cos; p.rsin = a.rope_sin; p.rrows = a.rope_rows; p.rpitch = a.rope_pitch; p.rpos = a.rope_pos;
     // one workgroup per CU (two for D <= 64); more only when a workgroup's list would not fit its part table
     const long long ncu = (long long)cu_count() * (D <= 64 ? 2 : 1);
     const long long rounds = (p.nitems + ncu * kMaxItems - 1) / (ncu * kMaxItems);
@@ -641,6 +689,16 @@ int launch_ps(const FwdArgs& a, hipStream_t stream) {
     if (G > p.nitems) G = p.nitems;
     const dim3 grid((unsigned)G), block(512);
     const size_t lds = Cfg<D>::LDS + kMaxSlot * 20 + 16;
+    if constexpr (RAWOK && D >= 64) {
+        if (a.rope_cos != nullptr) {
+            if (a.causal)
+                hipLaunchKernelGGL((fa_fwd_ps_kernel<T, D, true, true, false, true>), grid, block, lds, stream, p);
+            else
+                hipLaunchKernelGGL((fa_fwd_ps_kernel<T, D, false, true, false, true>), grid, block, lds, stream, p);
+            return (int)hipGetLastError();
+        }
+    }
+    if (a.rope_cos != nullptr) return -1;
     if (a.causal)
         hipLaunchKernelGGL((fa_fwd_ps_kernel<T, D, true, RAWOK>), grid, block, lds, stream, p);
     else
@@ -655,6 +713,12 @@ int set_attr_ps() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, false, RAWOK>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if constexpr (RAWOK && D >= 64) {
+        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, true, true, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, false, true, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
     return rc;
 }
 
@@ -713,6 +777,18 @@ bool fwd_ps_applicable(const FwdArgs& a) {
     if ((long long)a.B * a.Hq * a.Sq >= (1LL << 31) || (long long)a.B * a.Hkv * a.Sk >= (1LL << 31)) return false;
     if ((long long)a.Sq * a.D * 2 >= (1LL << 32) || (long long)a.Sk * a.D * 2 >= (1LL << 32)) return false;
     return true;
+}
+
+// Shapes whose Q rotation the stream kernel fuses (FwdArgs::rope_*): the fixed-reference instances of D = 64 / 128, tables
+// readable as 16-byte rows through a 32-bit buffer descriptor.
+bool fwd_ps_rope_fusable(const FwdArgs& a) {
+    if (!fwd_ps_applicable(a) || !raw_softmax_enabled() || (a.D != 64 && a.D != 128)) return false;
+    if (a.rope_cos == nullptr || a.rope_sin == nullptr || a.rope_pitch < a.D / 2 || (a.rope_pitch & 3) != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(a.rope_cos) | reinterpret_cast<uintptr_t>(a.rope_sin)) & 15) return false;
+    if (a.rope_pos < 0 || (long long)a.Sq + a.rope_pos > a.rope_rows) return false;
+    // rows of padding lanes (up to the end of the last 256-row block) index past the table: their offsets must not wrap
+    const long long last = ((long long)(a.Sq + kQBlock - 1) / kQBlock * kQBlock + a.rope_pos) * a.rope_pitch * 4;
+    return (long long)a.rope_rows * a.rope_pitch * 4 < (1LL << 32) && last < (1LL << 32);
 }
 
 int launch_fwd_ps(const FwdArgs& a, hipStream_t stream) {

@@ -35,6 +35,11 @@ struct FwdArgs {
     void* ws = nullptr;
     uint64_t ws_bytes = 0;
     uint64_t* query_ws = nullptr;   // dry run: the launcher stores the bytes it would need and launches nothing
+    // Fused query rotation (fwd_rope_fusable() shapes only): Q is rotated on its way into the kernel's registers with the
+    // half-split pairs of rope_gfx950.hip; K must arrive rotated.  Tables [rope_rows, rope_pitch] fp32, query i -> row i + rope_pos.
+    const float* rope_cos = nullptr;
+    const float* rope_sin = nullptr;
+    int rope_rows = 0, rope_pitch = 0, rope_pos = 0;
 };
 
 // The workspace of one launch: the caller's buffer, or hipMallocAsync / hipFreeAsync on the launch stream.
@@ -121,6 +126,8 @@ int launch_fwd(const FwdArgs& a, hipStream_t stream);
 // merge partials [npart][B*Hkv*nrt*32][D+2] fp32 (un-normalised O, m in log2 units, l) into O / LSE (fa_fwd_splitkv_gfx950.hip)
 int launch_splitkv_combine(const FwdArgs& a, float* part, int npart, int nrt, hipStream_t stream);
 int fwd_route(const FwdArgs& a);
+// launch_fwd honours FwdArgs::rope_* for these arguments (otherwise it refuses them: rotate Q with launch_rope first)
+bool fwd_rope_fusable(const FwdArgs& a);
 // bytes of workspace launch_fwd / launch_paged_decode would allocate for these arguments (0: single-launch path)
 uint64_t fwd_workspace_bytes(FwdArgs a);
 uint64_t paged_workspace_bytes(PagedArgs a);   // 0 fp32, 1 ping-pong, 2 in-wave, 3 v1, 4 split-KV, 5 tiled + packed rows + KV splits (host logic only)

@@ -72,8 +72,10 @@ __global__ void __launch_bounds__(256) rope_kernel(const RopeParams p) {
         for (int i = 0; i < V; ++i) {
             const float x1 = Conv<E>::ld(x.v[2 * i]), x2 = Conv<E>::ld(x.v[2 * i + 1]);
             const float si = p.sgn * sn.v[i];
-            y.v[2 * i] = Conv<E>::st(x1 * c.v[i] - x2 * si);
-            y.v[2 * i + 1] = Conv<E>::st(x1 * si + x2 * c.v[i]);
+            float y1, y2;
+            rope_pair(x1, x2, c.v[i], si, y1, y2);
+            y.v[2 * i] = Conv<E>::st(y1);
+            y.v[2 * i + 1] = Conv<E>::st(y2);
         }
         *reinterpret_cast<Pack<E, 2 * V>*>(xout + 2 * p0) = y;
     } else {
@@ -84,8 +86,10 @@ __global__ void __launch_bounds__(256) rope_kernel(const RopeParams p) {
         for (int i = 0; i < V; ++i) {
             const float x1 = Conv<E>::ld(a.v[i]), x2 = Conv<E>::ld(b.v[i]);
             const float si = p.sgn * sn.v[i];
-            ya.v[i] = Conv<E>::st(x1 * c.v[i] - x2 * si);
-            yb.v[i] = Conv<E>::st(x1 * si + x2 * c.v[i]);
+            float y1, y2;
+            rope_pair(x1, x2, c.v[i], si, y1, y2);
+            ya.v[i] = Conv<E>::st(y1);
+            yb.v[i] = Conv<E>::st(y2);
         }
         *reinterpret_cast<Pack<E, V>*>(xout + p0) = ya;
         *reinterpret_cast<Pack<E, V>*>(xout + p.half + p0) = yb;

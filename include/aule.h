@@ -231,6 +231,28 @@ typedef struct aule_rope_desc {
 } aule_rope_desc;
 int32_t aule_rope_ex(const aule_rope_desc* desc);
 
+/* Attention with the query rotation fused into the kernel (additive; inference path).  Replaces the Q half of       */
+/* python/aule/triton_flash.py:112-131 (the reference rotates Q in its forward prologue); K must arrive rotated --   */
+/* once per key by aule_rope_ex(), e.g. when it is appended to a KV cache -- because the tiled kernel re-reads every */
+/* K tile once per 256 query rows and would repeat the rotation each time.  Q is read un-rotated and */
+/* rotated in registers with exactly aule_rope_ex()'s arithmetic and rounding: the result is bit-identical to        */
+/* aule_rope_ex(Q) followed by aule_attention_forward_ex(), minus one read and one write of Q.  Taken only by the    */
+/* persistent forward kernel: fp16 / bf16, head_dim 64 or 128, AULE_ROPE_HALF, 16-byte aligned tables with           */
+/* table_pitch % 4 == 0, no sliding window -- ask aule_attention_forward_rope_fusable() (host logic only; 1 = yes)   */
+/* and fall back to the two calls otherwise; aule_attention_forward_rope_ex() returns -3 for other configurations.   */
+typedef struct aule_attn_rope {
+    uint32_t struct_size;      /* = sizeof(aule_attn_rope) */
+    int32_t layout;            /* AULE_ROPE_HALF */
+    uint32_t table_len;        /* rows of cos / sin; seq_q + q_pos_offset <= table_len */
+    uint32_t table_pitch;      /* floats per table row; 0 = head_dim/2 */
+    uint32_t q_pos_offset;     /* query i uses table row i + q_pos_offset (seq_k - seq_q for bottom-right causal) */
+    uint32_t reserved;
+    const float* cos;          /* [table_len, head_dim/2] fp32 */
+    const float* sin;
+} aule_attn_rope;
+int32_t aule_attention_forward_rope_ex(const aule_attn_desc* desc, const aule_attn_rope* rope);
+int32_t aule_attention_forward_rope_fusable(const aule_attn_desc* desc, const aule_attn_rope* rope);
+
 uint64_t aule_attention_backward_workspace_size(const aule_attn_bwd_desc* desc);
 
 /* Build/ABI identification: "aule-hip gfx950 <abi>" */

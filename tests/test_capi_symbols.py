@@ -161,3 +161,40 @@ def test_forward_routing_rule(monkeypatch):
     assert _route(1, 3, 2, 1, 8192, 128) == -3                       # heads not divisible
     # (AULE_HIP_FWD_SPLITKV=0 is read once per process into a static, so the off-switch is not testable here;
     #  tools/split_grid.py exercises it in a process of its own)
+
+
+def test_fused_query_rotation_rule(monkeypatch):
+    """aule_attention_forward_rope_fusable() (host logic): the persistent forward kernel rotates Q itself for fp16 / bf16,
+    head_dim 64 / 128, half-split pairs, 16-byte aligned tables of pitch % 4 == 0 that cover seq_q + q_pos_offset rows;
+    everything else is refused so that the caller rotates Q with aule_rope_ex()."""
+    monkeypatch.delenv("AULE_HIP_FWD_KERNEL", raising=False)
+    monkeypatch.delenv("AULE_HIP_FWD_SOFTMAX", raising=False)
+    lib = _capi.load()
+
+    def fusable(B=4, Hq=32, Hkv=32, Sq=2048, Sk=2048, D=128, dtype=2, causal=1, window=-1, rows=2048, pitch=0, pos=0,
+                layout=0, cos=0x1000, sin=0x2000, size=None):
+        d = _capi.AttnDesc()
+        d.struct_size = ctypes.sizeof(_capi.AttnDesc)
+        d.dtype = dtype
+        d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
+        d.causal, d.window_size = causal, window
+        r = _capi.AttnRope()
+        r.struct_size = ctypes.sizeof(_capi.AttnRope) if size is None else size
+        r.layout, r.table_len, r.table_pitch, r.q_pos_offset, r.cos, r.sin = layout, rows, pitch, pos, cos, sin
+        return lib.aule_attention_forward_rope_fusable(ctypes.byref(d), ctypes.byref(r))
+
+    assert ctypes.sizeof(_capi.AttnRope) == 40
+    assert fusable() == 1
+    assert fusable(D=64, dtype=1, causal=0) == 1
+    assert fusable(Sq=1024, Sk=4096, causal=2, rows=4096, pos=3072) == 1      # bottom-right: queries at Sk - Sq + i
+    assert fusable(D=32) == 0                                                  # no fused instance
+    assert fusable(dtype=0) == 0                                               # fp32 kernel
+    assert fusable(window=64) == 0                                             # ping-pong kernel
+    assert fusable(Sq=128, Sk=128) == 0                                        # fewer than four KV tiles: ping-pong kernel
+    assert fusable(Hq=8, Hkv=8, B=1, Sq=1, Sk=8192, causal=0, rows=8192) == 0  # short-query split paths
+    assert fusable(layout=1) == 0                                              # interleaved pairs: separate pass
+    assert fusable(rows=2047) == 0 and fusable(pos=1) == 0                     # table too short
+    assert fusable(pitch=66) == 0 and fusable(pitch=68) == 1                   # 16-byte rows
+    assert fusable(cos=0x1004) == 0 and fusable(sin=0) == 0                    # alignment, null
+    assert fusable(size=32) == 0
+    assert lib.aule_attention_forward_rope_fusable(None, None) == 0

@@ -195,3 +195,64 @@ def test_rope_rejections():
     q7 = torch.randn(1, 1, 8, 7, device="cuda")
     with pytest.raises(ValueError):
         aule.flash_attention_rope(q7, q7, q7, cos[:, :3], sin[:, :3])   # odd head_dim
+
+
+FUSED_CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, causal
+    ("bf16", 2, 8, 8, 1024, 1024, 128, True),        # two parts per workgroup list entry: prologue and seam rotations
+    ("bf16", 4, 32, 32, 2048, 2048, 128, True),      # the C2-like shape: several parts per workgroup
+    ("bf16", 1, 8, 2, 777, 1300, 128, False),        # ragged last block (rows >= Sq index past nothing: they read 0)
+    ("fp16", 2, 4, 4, 600, 600, 64, True),           # D = 64 instances (two workgroups per CU)
+    ("fp16", 1, 16, 4, 300, 2048, 128, "bottom-right"),   # queries at positions Sk - Sq + i
+    ("bf16", 1, 4, 4, 512, 512, 64, False),
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: "-".join(str(x) for x in c))
+def test_fused_query_rotation_is_the_separate_pass_bit_for_bit(case, oracle_mod, monkeypatch):
+    """aule_attention_forward_rope_ex (Q rotated in the forward kernel's registers, K by the pass) against
+    aule_rope_ex(Q) + aule_rope_ex(K) + aule_attention_forward_ex: the same arithmetic and rounding, so the outputs are
+    EQUAL; and both against the fp64 oracle chain.  The Python inference path takes the fused route by itself."""
+    import torch
+    from aule import _torch as at
+    dtype, B, Hq, Hkv, Sq, Sk, D, causal = case
+    rng = np.random.RandomState(23)
+    q, k, v = (quantize(rng.randn(*s).astype(np.float32), dtype) for s in ((B, Hq, Sq, D), (B, Hkv, Sk, D), (B, Hkv, Sk, D)))
+    cos, sin = oracle_mod.rope_tables(max(Sq, Sk) + 3, D)
+    qoff = Sk - Sq if causal == "bottom-right" else 0
+    tq, tk, tv, tc, ts = _dev(torch, q, dtype), _dev(torch, k, dtype), _dev(torch, v, dtype), _dev(torch, cos), _dev(torch, sin)
+    code = at.causal_code(causal)
+    assert at.rope_fusable(tq, tk, code, -1, tc, ts, qoff)
+    sc = 1.0 / math.sqrt(D)
+    kr = at.rope_raw(tk, tc, ts, "half", False, 0)
+    qr = at.rope_raw(tq, tc, ts, "half", False, qoff)
+    two_pass, _ = at.fwd_raw(qr, kr, tv, code, sc, want_lse=False)
+    fused, lse = at.fwd_raw(tq, kr, tv, code, sc, want_lse=True, q_rope=(tc, ts, qoff))
+    assert torch.equal(fused, two_pass)
+    with torch.no_grad():
+        auto = at.flash_attention_rope_hip(tq, tk, tv, tc, ts, causal=causal)
+    assert torch.equal(auto, two_pass)
+    monkeypatch.setenv("AULE_HIP_ROPE_FUSE", "0")
+    with torch.no_grad():
+        assert torch.equal(at.flash_attention_rope_hip(tq, tk, tv, tc, ts, causal=causal), two_pass)
+    if B * Hq * Sq * Sk <= 2 * 8 * 1024 * 1024:
+        qo = quantize(oracle_mod.rope_f64(q, cos, sin, "half", False, qoff), dtype)
+        ko = quantize(oracle_mod.rope_f64(k, cos, sin, "half"), dtype)
+        ref, ref_lse = oracle_mod.fwd_f64(qo, ko, v, causal, None, -1)
+        atol, rtol = fwd_tol(dtype, np.abs(v).max())
+        assert_close(fused.float().cpu().numpy(), ref, atol, rtol, "out")
+        assert_close(lse.cpu().numpy(), ref_lse, LSE_TOL[dtype], 0, "lse")
+
+
+def test_fused_query_rotation_rejections():
+    """Configurations the kernel does not rotate for are refused loudly (-3), never computed un-rotated."""
+    import torch
+    from aule import _capi, _torch as at
+    q = torch.randn(1, 4, 512, 32, device="cuda", dtype=torch.bfloat16)       # D = 32: no fused instance
+    cos = torch.ones(512, 16, device="cuda"); sin = torch.zeros(512, 16, device="cuda")
+    assert not at.rope_fusable(q, q, 1, -1, cos, sin, 0)
+    with pytest.raises(_capi.AuleError, match="not fused"):
+        at.fwd_raw(q, q, q, 1, 0.2, q_rope=(cos, sin, 0))
+    q = torch.randn(1, 4, 512, 128, device="cuda", dtype=torch.bfloat16)
+    cos = torch.ones(500, 64, device="cuda"); sin = torch.zeros(500, 64, device="cuda")   # table shorter than Sq
+    with pytest.raises(_capi.AuleError, match="not fused"):
+        at.fwd_raw(q, q, q, 1, 0.1, q_rope=(cos, sin, 0))
