@@ -281,10 +281,10 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const unsigned ua = qx[k0 + b][j], ub = qx[k0 + b + HK][j];
-                            const float c0 = __builtin_bit_cast(float, tc[b][j >> 1][(j & 1) * 2]);
-                            const float c1 = __builtin_bit_cast(float, tc[b][j >> 1][(j & 1) * 2 + 1]);
-                            const float s0 = __builtin_bit_cast(float, ts[b][j >> 1][(j & 1) * 2]);
-                            const float s1 = __builtin_bit_cast(float, ts[b][j >> 1][(j & 1) * 2 + 1]);
+                            // (whole-vector casts: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever the index)
+                            const f32x4_t cv = __builtin_bit_cast(f32x4_t, tc[b][j >> 1]), sv = __builtin_bit_cast(f32x4_t, ts[b][j >> 1]);
+                            const float c0 = cv[(j & 1) * 2], c1 = cv[(j & 1) * 2 + 1];
+                            const float s0 = sv[(j & 1) * 2], s1 = sv[(j & 1) * 2 + 1];
                             float y1l, y2l, y1h, y2h;
                             rope_pair(T::lo(ua), T::lo(ub), c0, s0, y1l, y2l);
                             rope_pair(T::hi(ua), T::hi(ub), c1, s1, y1h, y2h);
