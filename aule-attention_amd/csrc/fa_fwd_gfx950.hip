@@ -33,6 +33,8 @@ int configure_fwd_pp();
 int launch_fwd_ps(const FwdArgs& a, hipStream_t stream);   // fa_fwd_ps_gfx950.hip (persistent tile stream)
 bool fwd_ps_applicable(const FwdArgs& a);
 bool fwd_ps_rope_fusable(const FwdArgs& a);
+bool fwd_ps_split_applicable(const FwdArgs& a);            // small causal grids: pairs cut in two, partials + merge
+int launch_fwd_ps_split(const FwdArgs& a, hipStream_t stream);
 int configure_fwd_ps();
 
 // AULE_HIP_FWD_KERNEL=pp keeps every tiled problem on the ping-pong kernel (A/B measurements against the stream)
@@ -45,6 +47,7 @@ static int fwd_kernel_choice() {
     return v;
 }
 static bool use_ps(const FwdArgs& a) { return fwd_kernel_choice() == 0 && fwd_ps_applicable(a); }
+static bool use_ps_split(const FwdArgs& a) { return fwd_kernel_choice() == 0 && fwd_ps_split_applicable(a); }
 
 bool splitkv_applicable(const FwdArgs& a);                      // fa_fwd_splitkv_gfx950.hip
 int launch_fwd_splitkv(const FwdArgs& a, hipStream_t stream);
@@ -78,12 +81,13 @@ static int short_query_route(const FwdArgs& a) {
 }
 
 // Which kernel launch_fwd() picks for `a` (host logic only, no device work): 0 fp32, 1 ping-pong, 4 split-KV,
-// 5 ping-pong kernel with packed rows + KV splits, 6 persistent tile stream (2 and 3 were the removed in-wave and
-// lock-step kernels).  Lets the tests pin the path a shape exercises.
+// 5 ping-pong kernel with packed rows + KV splits, 6 persistent tile stream, 7 tile stream with every pair of causal Q
+// blocks cut in two (small grids; partials + merge) (2 and 3 were the removed in-wave and lock-step kernels).  Lets the tests pin the path a shape exercises.
 int fwd_route(const FwdArgs& a) {
     if (a.dtype == kF32) return 0;
     const int sq = short_query_route(a);
     if (sq) return sq;
+    if (use_ps_split(a)) return 7;
     return use_ps(a) ? 6 : 1;
 }
 
@@ -109,6 +113,7 @@ int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     const int sq = a.dtype == kF32 ? 0 : short_query_route(a);
     if (sq == 4) return launch_fwd_splitkv(a, stream);
     if (sq == 5) return launch_fwd_pp_split(a, stream);
+    if (sq == 0 && a.dtype != kF32 && use_ps_split(a)) return launch_fwd_ps_split(a, stream);
     if (a.query_ws != nullptr) return 0;   // single-launch paths need no workspace
     if (a.dtype == kF32) return launch_fwd_f32(a, stream);
     if (use_ps(a)) return launch_fwd_ps(a, stream);

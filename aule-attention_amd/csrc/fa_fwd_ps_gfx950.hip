@@ -56,6 +56,11 @@ struct FwdPSParams {
     const float* rcos;
     const float* rsin;
     int rrows, rpitch, rpos;
+    // SPLIT instances only (small causal grids, launch_ps_split): a pair of Q blocks is two work items; the far block's
+    // keys may be cut in two ranges, each leaving an fp32 partial in plane 0 / 1 of `part` ([2][B*Hq*Sq][D + 4]:
+    // un-normalised O, m in log2 units, l), merged by fa_fwd_ps_combine.
+    float* part;
+    int part_rows;
     unsigned long long* dbg;   // timeline build only: [8 waves][kPSTLMax] tagged s_memtime stamps of workgroup 0
 };
 
@@ -88,10 +93,33 @@ constexpr int kMaxSlot = 2 * kMaxItems;  // parts: two per item (the second one 
 
 __device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
+constexpr int kPartPad = 4;   // floats behind the D accumulators of a partial row: m, l, 2 unused (keeps rows 16-byte aligned)
+
+// KV tiles of Q block qb under the causal rule (query i at position i + coff).
+__host__ __device__ inline int ps_tiles(int qb, int Sk, int coff) {
+    int kv_hi = qb * kQBlock + kQBlock + coff;
+    kv_hi = kv_hi < Sk ? kv_hi : Sk;
+    kv_hi = kv_hi > 1 ? kv_hi : 1;
+    return (kv_hi + kKVTile - 1) / kKVTile;
+}
+// SPLIT plan of the pair (far, near) of Q blocks: piece 0 = tiles [0, a) of the far block, piece 1 = its tiles [a, nt) and
+// the whole near block -- half of the pair's tiles each.  The cut stays inside the keys EVERY row of the far block sees
+// (a * 64 <= its first position): piece 0 needs no mask, and every row of piece 1 sees the first key of its range, so both
+// ranges run the plain softmax (a finite maximum from their first tile on).  Returns a, or 0 when the far block is not
+// cut (pieces = the two blocks; ranges shorter than four tiles would starve the staging cursors).
+__host__ __device__ inline int ps_cut(int far, int near, int Sk, int coff) {
+    const int ntf = ps_tiles(far, Sk, coff), ntn = far != near ? ps_tiles(near, Sk, coff) : 0;
+    int a = (ntf + ntn + 1) / 2;
+    const int vis = (far * kQBlock + coff) / kKVTile;
+    a = a < vis ? a : vis;
+    return (a >= 4 && ntf - a >= 4) ? a : 0;
+}
+
 // D <= 64: the workgroup needs <= 75 KB of LDS, so two fit a CU if the kernel stays within 128 VGPRs (4 waves per SIMD);
 // the second workgroup fills the first one's barrier and seam bubbles (the predecessor's D = 64 instances do run that way).
-template <class T, int D, bool CAUSAL, bool RAWOK, bool TL = false, bool ROPE = false>
+template <class T, int D, bool CAUSAL, bool RAWOK, bool TL = false, bool ROPE = false, bool SPLIT = false>
 __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const FwdPSParams p) {
+    static_assert(!SPLIT || (CAUSAL && !TL && !ROPE), "SPLIT instances: causal, no timeline, no fused rotation");
     using C = Cfg<D>;
     using v8 = typename T::v8;
     using std::integral_constant;
@@ -129,16 +157,31 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
     const int nit = (p.nitems - (int)blockIdx.x + G - 1) / G;
     const int nslot = 2 * nit;
     if (tid < nslot) {
-        const WorkItem w = decode_work((int)blockIdx.x + (tid >> 1) * G, p.B, p.Hq, p.Hkv, p.nwork, false);
-        int qb = -1;
-        if (p.pair) {
-            const int far = p.nqb - 1 - w.blk;       // the larger block of the pair goes first
-            if ((tid & 1) == 0) qb = far;
-            else if (far != w.blk) qb = w.blk;
-        } else if ((tid & 1) == 0) {
-            qb = w.blk;
+        int qb = -1, range = 0;
+        if constexpr (SPLIT) {
+            // item = (pair, piece): .z = qb | partial plane + 1 << 24, .w = first tile | end tile << 16
+            const WorkItem w = decode_work((int)blockIdx.x + (tid >> 1) * G, p.B, p.Hq, p.Hkv, 2 * p.nwork, false);
+            const int near = w.blk >> 1, piece = w.blk & 1, far = p.nqb - 1 - near;
+            const int a = ps_cut(far, near, Sk, coff), ntf = ps_tiles(far, Sk, coff);
+            if (piece == 0) {
+                if ((tid & 1) == 0) { qb = far | (a ? 1 << 24 : 0); range = (a ? a : ntf) << 16; }
+            } else if ((tid & 1) == 0) {
+                if (a) { qb = far | (2 << 24); range = a | (ntf << 16); }
+            } else if (far != near) {
+                qb = near; range = ps_tiles(near, Sk, coff) << 16;
+            }
+            tab[tid] = int4{(w.b * p.Hq + w.h) * Sq, (w.b * p.Hkv + w.hk) * Sk, qb, range};
+        } else {
+            const WorkItem w = decode_work((int)blockIdx.x + (tid >> 1) * G, p.B, p.Hq, p.Hkv, p.nwork, false);
+            if (p.pair) {
+                const int far = p.nqb - 1 - w.blk;       // the larger block of the pair goes first
+                if ((tid & 1) == 0) qb = far;
+                else if (far != w.blk) qb = w.blk;
+            } else if ((tid & 1) == 0) {
+                qb = w.blk;
+            }
+            tab[tid] = int4{(w.b * p.Hq + w.h) * Sq, (w.b * p.Hkv + w.hk) * Sk, qb, 0};
         }
-        tab[tid] = int4{(w.b * p.Hq + w.h) * Sq, (w.b * p.Hkv + w.hk) * Sk, qb, 0};
         redo[tid] = 0;
     }
     if (tid == 0) redo[kMaxSlot] = 0;
@@ -154,6 +197,14 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
         const int kv_hi = CAUSAL ? max(1, min(Sk, qb * kQBlock + kQBlock + coff)) : Sk;
         return (kv_hi + kKVTile - 1) / kKVTile;
     };
+    // table entry -> Q block, first KV tile and tile count of the part, partial plane + 1 (0: the part's O is final)
+    auto e_qb = [&](const int4& e) __attribute__((always_inline)) { return SPLIT ? (rfl(e.z) & 0xffffff) : rfl(e.z); };
+    auto e_t0 = [&](const int4& e) __attribute__((always_inline)) { return SPLIT ? (rfl(e.w) & 0xffff) : 0; };
+    auto e_nt = [&](const int4& e) __attribute__((always_inline)) {
+        if constexpr (SPLIT) return (int)((unsigned)rfl(e.w) >> 16) - (rfl(e.w) & 0xffff);
+        else return nt_of(rfl(e.z));
+    };
+    auto e_pid = [&](const int4& e) __attribute__((always_inline)) { return SPLIT ? (rfl(e.z) >> 24) : 0; };
     auto head_srd = [&](const void* base, int rowoff, int rows) __attribute__((always_inline)) {
         return make_srd(reinterpret_cast<const char*>(base) + (size_t)(unsigned)rowoff * RB, (unsigned)rows * RB);
     };
@@ -192,11 +243,13 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
         if (cs >= nslot) return;
 
         // ---- staging cursors: the tile each of them requests next (slot, tile in the part, tiles of the part, head)
-        int ks_slot = cs, ks_t = 0, ks_nt, vs_slot = cs, vs_t = 0, vs_nt;
+        // (ks_t / vs_t count from the part's first tile: SPLIT parts start at tile ks_b / vs_b of their head)
+        int ks_slot = cs, ks_t = 0, ks_nt, ks_b, vs_slot = cs, vs_t = 0, vs_nt, vs_b;
         __amdgpu_buffer_rsrc_t krs, vrs;
         {
             const int4 e = tab[cs];
-            ks_nt = vs_nt = nt_of(rfl(e.z));
+            ks_nt = vs_nt = e_nt(e);
+            ks_b = vs_b = e_t0(e);
             krs = head_srd(p.k, rfl(e.y), Sk);
             vrs = head_srd(p.v, rfl(e.y), Sk);
         }
@@ -206,7 +259,8 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             ks_t = 0;
             if (ks_slot < nslot) {
                 const int4 e = tab[ks_slot];
-                ks_nt = nt_of(rfl(e.z));
+                ks_nt = e_nt(e);
+                ks_b = e_t0(e);
                 krs = head_srd(p.k, rfl(e.y), Sk);
             }
         };
@@ -216,7 +270,8 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             vs_t = 0;
             if (vs_slot < nslot) {
                 const int4 e = tab[vs_slot];
-                vs_nt = nt_of(rfl(e.z));
+                vs_nt = e_nt(e);
+                vs_b = e_t0(e);
                 vrs = head_srd(p.v, rfl(e.y), Sk);
             }
         };
@@ -224,13 +279,13 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
 #pragma unroll
             for (int i = 0; i < CH; ++i)
                 if (C::kFull || tid + 512 * i < C::NCHUNK)
-                    kst[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], ks_t * (kKVTile * RB), 0);
+                    kst[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], ((SPLIT ? ks_b : 0) + ks_t) * (kKVTile * RB), 0);
         };
         auto issue_v = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < CH; ++i)
                 if (C::kFull || tid + 512 * i < C::NCHUNK)
-                    vst[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], vs_t * (kKVTile * RB), 0);
+                    vst[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], ((SPLIT ? vs_b : 0) + vs_t) * (kKVTile * RB), 0);
         };
         bool have_k = true, have_v = true;   // kst / vst hold a requested tile that is not in LDS yet
 
@@ -265,7 +320,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
                 int lane_o = lane;
                 asm volatile("" : "+v"(lane_o));
                 const int toff = (q0 + (lane_o & 31) + p.rpos) * (p.rpitch * 4) + (lane_o >> 5) * 32;
-                constexpr int HK = KS / 2, BATCH = HK < 2 ? HK : 2;
+                constexpr int HK = KS / 2, BATCH = HK < 2 ? HK : 2;   // (all 16 table loads at once: 153 -> 172 us at the C2-like shape)
 #pragma unroll
                 for (int k0 = 0; k0 < HK; k0 += BATCH) {
                     u32x4_t tc[BATCH][2], ts[BATCH][2];
@@ -353,21 +408,27 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
 
         // ---- part scalars of the compute side
         int qoff, qb, nt, na, q0w, qposv, P0 = 0;
+        int tb = 0, pid = 0;                       // SPLIT: first KV tile of the part, partial plane + 1
         int n_slot, n_qoff = 0, n_qb = 0;          // the part after this one (n_slot == nslot: none)
         auto enter_part = [&](int slot) __attribute__((always_inline)) {
             const int4 e = tab[slot];
             qoff = rfl(e.x);
-            qb = rfl(e.z);
-            nt = nt_of(qb);
+            qb = e_qb(e);
+            nt = e_nt(e);
             q0w = qb * kQBlock + wave * 32;
             qposv = q0w + l31 + coff;
             const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32 + coff) : Sk;
             na = max(1, (wave_kv_hi + kKVTile - 1) / kKVTile);
+            if constexpr (SPLIT) {
+                tb = e_t0(e);
+                pid = e_pid(e);
+                na = max(1, min(na - tb, nt));     // the wave's active tiles INSIDE the part's range
+            }
             n_slot = next_valid(slot);
             if (n_slot < nslot) {
                 const int4 en = tab[n_slot];
                 n_qoff = rfl(en.x);
-                n_qb = rfl(en.z);
+                n_qb = e_qb(en);
             }
         };
 
@@ -434,6 +495,35 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             }
             ep_left = NR; ep_qoff = eqoff; ep_q0w = eq0w;
             stamp(0xd4);
+        };
+
+        // SPLIT: a part that covers only a range of its block's keys leaves the un-normalised accumulators, m and l as an
+        // fp32 partial row (16-byte stores straight from the accumulator layout: lane (q, hi) owns columns
+        // 32 d + 8 g + 4 hi .. + 3 of row q); fa_fwd_ps_combine merges the two planes.  Rows >= Sq fall outside the descriptor.
+        auto partial_store = [&](int eqoff, int eq0w, int plane) __attribute__((always_inline)) {
+            if constexpr (SPLIT) {
+                constexpr int PP = (D + kPartPad) * 4;   // bytes per partial row
+                int lane_o = lane;
+                asm volatile("" : "+v"(lane_o));
+                const int l31 = lane_o & 31, hi = lane_o >> 5;
+                const float lt = l + xhalf_fast(l);
+                float* const base = p.part + ((size_t)plane * (size_t)(unsigned)p.part_rows + (size_t)(unsigned)eqoff) * (D + kPartPad);
+                const __amdgpu_buffer_rsrc_t prs = make_srd(base, (unsigned)Sq * (unsigned)PP);
+                const int roff = (eq0w + l31) * PP;
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x4_t x = {o[d][4 * g4 + 0], o[d][4 * g4 + 1], o[d][4 * g4 + 2], o[d][4 * g4 + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x), prs, roff + (32 * d + 8 * g4 + 4 * hi) * 4, 0, 0);
+                    }
+                const u32x2_t ml = {__builtin_bit_cast(unsigned, m), __builtin_bit_cast(unsigned, lt)};
+                __builtin_amdgcn_raw_buffer_store_b64(ml, prs, hi == 0 ? roff + D * 4 : 0x7ffffff0, 0, 0);
+                if constexpr (RAW) {
+                    const bool ok = (lt > 0x1p-100f) && (lt < (T::kDType == 2 ? 0x1p110f : 0x1p15f));
+                    if (__builtin_amdgcn_ballot_w64(!ok) != 0 && lane == 0) redo[cs] = redo[kMaxSlot] = 1;
+                }
+            }
         };
 
         auto softmax = [&](int kv0, auto sm_tag) __attribute__((always_inline)) {
@@ -531,7 +621,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             }
             stamp(tlt + 3);
             if constexpr (!AULE_PS_YOUNG_PRIO) __builtin_amdgcn_s_setprio(AULE_PS_VPRIO);
-            if constexpr (MODE >= 1) softmax(j * kKVTile, sm_tag);
+            if constexpr (MODE >= 1) softmax(((SPLIT ? tb : 0) + j) * kKVTile, sm_tag);
             if constexpr (!AULE_PS_YOUNG_PRIO) __builtin_amdgcn_s_setprio(0);
             stamp(tlt + 4);
             __builtin_amdgcn_sched_barrier(0);
@@ -548,7 +638,8 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             }
             if constexpr (MODE == 1) {   // this wave's O of the part is final
                 __builtin_amdgcn_sched_barrier(0);
-                epilogue_pack(qoff, q0w);
+                if (SPLIT && pid != 0) partial_store(qoff, q0w, pid - 1);
+                else epilogue_pack(qoff, q0w);
 #pragma unroll
                 for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -587,10 +678,10 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
 #pragma unroll
         for (int i = 0; i < CH; ++i)
             if (C::kFull || tid + 512 * i < C::NCHUNK) {
-                kpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], 1 * (kKVTile * RB), 0);
+                kpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], ((SPLIT ? tb : 0) + 1) * (kKVTile * RB), 0);
                 if (grp == 1) {
-                    vpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], 1 * (kKVTile * RB), 0);
-                    kpre2[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], 2 * (kKVTile * RB), 0);
+                    vpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], ((SPLIT ? tb : 0) + 1) * (kKVTile * RB), 0);
+                    kpre2[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], ((SPLIT ? tb : 0) + 2) * (kKVTile * RB), 0);
                 }
             }
         adv_k();                 // K_1 requested: the K cursor stands at tile 2, the V cursor at tile 1
@@ -682,6 +773,7 @@ int launch_ps(const FwdArgs& a, hipStream_t stream) {
     p.nitems = p.nwork * a.B * a.Hq;
     p.dbg = nullptr;
     p.rcos = a.rope_cos; p.rsin = a.rope_sin; p.rrows = a.rope_rows; p.rpitch = a.rope_pitch; p.rpos = a.rope_pos;
+    p.part = nullptr; p.part_rows = 0;
     // one workgroup per CU (two for D <= 64); more only when a workgroup's list would not fit its part table
     const long long ncu = (long long)cu_count() * (D <= 64 ? 2 : 1);
     const long long rounds = (p.nitems + ncu * kMaxItems - 1) / (ncu * kMaxItems);
@@ -706,6 +798,87 @@ int launch_ps(const FwdArgs& a, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// Merge of the two partial planes of every far block the SPLIT plan cut (ps_cut() != 0): one thread per four columns of a
+// row, 1024 / D rows per 256-thread workgroup; blockIdx = (b * Hq + h, far block index, row group).  Blocks the plan
+// left whole were finished by the stream kernel: their workgroups exit.  Bound: HBM (2 x (D + 4) x 4 bytes read,
+// D x 2 + 4 written per row).
+template <class T, int D>
+__global__ void __launch_bounds__(256) fa_fwd_ps_combine(const FwdPSParams p) {
+    constexpr int TPR = D / 4, RPW = 256 / TPR, PP = D + kPartPad;
+    const int bh = (int)blockIdx.z, near = (int)blockIdx.y, far = p.nqb - 1 - near;
+    if (ps_cut(far, near, p.Sk, p.coff) == 0) return;
+    const int row = far * kQBlock + (int)blockIdx.x * RPW + (int)threadIdx.x / TPR;
+    if (row >= p.Sq) return;
+    const int c4 = ((int)threadIdx.x % TPR) * 4;
+    const size_t grow = (size_t)bh * p.Sq + row;
+    const float* r0 = p.part + grow * PP;
+    const float* r1 = p.part + ((size_t)p.part_rows + grow) * PP;
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(r0 + c4), b = *reinterpret_cast<const f32x4_t*>(r1 + c4);
+    const float m0 = r0[D], l0 = r0[D + 1], m1 = r1[D], l1 = r1[D + 1];
+    const float mx = fmaxf(m0, m1);
+    const float w0 = fast_exp2(m0 - mx), w1 = fast_exp2(m1 - mx);
+    const float lt = l0 * w0 + l1 * w1;
+    const float inv = 1.0f / lt;
+    u32x2_t u;
+    u[0] = T::pack2((a[0] * w0 + b[0] * w1) * inv, (a[1] * w0 + b[1] * w1) * inv);
+    u[1] = T::pack2((a[2] * w0 + b[2] * w1) * inv, (a[3] * w0 + b[3] * w1) * inv);
+    *reinterpret_cast<u32x2_t*>(static_cast<char*>(p.o) + (grow * D + c4) * 2) = u;
+    if (c4 == 0 && p.lse != nullptr) p.lse[grow] = (mx + fast_log2(lt)) * kLn2;
+}
+
+// Small causal grids: the paired launch has fewer items than the chip has workgroup slots, and a pair cannot be made
+// shorter by cutting its query rows (a workgroup's time is its KEY tiles: 128-row blocks would take as long).  So each
+// pair becomes two items of half the key tiles (ps_cut), the cut far blocks leave two fp32 partials, one more launch
+// merges them.  (measured: tools/ps_split_check.py.)
+struct PSSplitPlan {
+    bool ok;
+    int nqb, nwork, ncut;
+    long long nitems;
+    size_t bytes;
+};
+static PSSplitPlan ps_split_plan(const FwdArgs& a, int slots) {
+    PSSplitPlan s{};
+    s.nqb = (a.Sq + kQBlock - 1) / kQBlock;
+    s.nwork = (s.nqb + 1) / 2;
+    s.nitems = 2LL * s.nwork * a.B * a.Hq;
+    for (int near = 0; near < s.nwork; ++near) s.ncut += ps_cut(s.nqb - 1 - near, near, a.Sk, a.coff) != 0;
+    s.bytes = 2ull * a.B * a.Hq * a.Sq * (size_t)(a.D + kPartPad) * sizeof(float);
+    // worth it when the split items still fit the chip in one round and most pairs do get cut
+    s.ok = s.nitems <= slots && 2 * s.ncut >= s.nwork;
+    return s;
+}
+
+template <class T, int D, bool RAWOK>
+int launch_ps_split(const FwdArgs& a, hipStream_t stream) {
+    const int slots = cu_count() * (D <= 64 ? 2 : 1);
+    const PSSplitPlan s = ps_split_plan(a, slots);
+    if (a.query_ws != nullptr) {
+        *a.query_ws = s.bytes;
+        return 0;
+    }
+    ScopedWorkspace ws(s.bytes, a.ws, a.ws_bytes, stream);
+    if (ws.err != hipSuccess) return (int)ws.err;
+    FwdPSParams p{};
+    p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o; p.lse = a.lse;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
+    float c = a.scale * kLog2e;
+    p.negq = c < 0.f;
+    c = c < 0.f ? -c : c;
+    if (c == 0.f) c = 1e-30f;
+    p.c = c;
+    p.nqb = s.nqb; p.pair = 1; p.nwork = s.nwork; p.coff = a.coff;
+    p.nitems = (int)s.nitems;
+    p.part = static_cast<float*>(ws.ptr);
+    p.part_rows = a.B * a.Hq * a.Sq;
+    const size_t lds = Cfg<D>::LDS + kMaxSlot * 20 + 16;
+    hipLaunchKernelGGL((fa_fwd_ps_kernel<T, D, true, RAWOK, false, false, true>), dim3((unsigned)s.nitems), dim3(512), lds, stream, p);
+    int rc = (int)hipGetLastError();
+    if (rc != 0) return rc;
+    constexpr int RPW = 256 / (D / 4);
+    hipLaunchKernelGGL((fa_fwd_ps_combine<T, D>), dim3(kQBlock / RPW, (unsigned)s.nwork, (unsigned)(a.B * a.Hq)), dim3(256), 0, stream, p);
+    return (int)hipGetLastError();
+}
+
 template <class T, int D, bool RAWOK>
 int set_attr_ps() {
     const int lds = Cfg<D>::LDS + kMaxSlot * 20 + 16;
@@ -713,6 +886,9 @@ int set_attr_ps() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, false, RAWOK>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if constexpr (D >= 64)
+        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, true, RAWOK, false, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if constexpr (RAWOK && D >= 64) {
         rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, true, true, false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -789,6 +965,30 @@ bool fwd_ps_rope_fusable(const FwdArgs& a) {
     // rows of padding lanes (up to the end of the last 256-row block) index past the table: their offsets must not wrap
     const long long last = ((long long)(a.Sq + kQBlock - 1) / kQBlock * kQBlock + a.rope_pos) * a.rope_pitch * 4;
     return (long long)a.rope_rows * a.rope_pitch * 4 < (1LL << 32) && last < (1LL << 32);
+}
+
+// Small causal grids for the SPLIT instances (route 7).  AULE_HIP_FWD_PSSPLIT=0 turns the path off (A/B measurements).
+bool fwd_ps_split_applicable(const FwdArgs& a) {
+    static const int enabled = [] {
+        const char* e = getenv("AULE_HIP_FWD_PSSPLIT");
+        return (e != nullptr && e[0] == '0') ? 0 : 1;
+    }();
+    if (!enabled || !a.causal || (a.D != 64 && a.D != 128) || a.rope_cos != nullptr || !fwd_ps_applicable(a)) return false;
+    if ((long long)a.Sk >= 65535LL * kKVTile) return false;                               // tile indices are 16-bit in the table
+    if ((long long)a.Sq * (a.D + kPartPad) * 4 >= (1LL << 32)) return false;              // partial rows of a head: 32-bit offsets
+    return ps_split_plan(a, cu_count() * (a.D <= 64 ? 2 : 1)).ok;
+}
+
+int launch_fwd_ps_split(const FwdArgs& a, hipStream_t stream) {
+    const bool raw = raw_softmax_enabled();
+    if (a.dtype == kBF16) {
+        if (a.D == 128) return raw ? launch_ps_split<Bf16Traits, 128, true>(a, stream) : launch_ps_split<Bf16Traits, 128, false>(a, stream);
+        if (a.D == 64) return raw ? launch_ps_split<Bf16Traits, 64, true>(a, stream) : launch_ps_split<Bf16Traits, 64, false>(a, stream);
+    } else if (a.dtype == kF16) {
+        if (a.D == 128) return raw ? launch_ps_split<F16Traits, 128, true>(a, stream) : launch_ps_split<F16Traits, 128, false>(a, stream);
+        if (a.D == 64) return raw ? launch_ps_split<F16Traits, 64, true>(a, stream) : launch_ps_split<F16Traits, 64, false>(a, stream);
+    }
+    return -1;
 }
 
 int launch_fwd_ps(const FwdArgs& a, hipStream_t stream) {

@@ -122,7 +122,7 @@ def test_forward_routing_rule(monkeypatch):
     has at least four KV tiles and there is no window, else to its predecessor, the ping-pong kernel (1); fp32 to 0."""
     for var in ("AULE_HIP_FWD_KERNEL", "AULE_HIP_FWD_SPLITKV", "AULE_HIP_FWD_PPSPLIT"):
         monkeypatch.delenv(var, raising=False)
-    WAVE, TILED_SPLIT, PP, PS, F32 = 4, 5, 1, 6, 0
+    WAVE, TILED_SPLIT, PP, PS, F32, PS_SPLIT = 4, 5, 1, 6, 0, 7
     assert _route(1, 32, 1, 1, 16384, 64, dtype=1) == TILED_SPLIT    # C5b: 32 -> 17 us
     assert _route(1, 32, 1, 64, 16384, 64, dtype=1) == TILED_SPLIT   # C5c: 44 -> 28 us
     assert _route(8, 32, 8, 1, 2048, 128) == TILED_SPLIT             # 67 MB of K+V: below the streaming corner
@@ -158,6 +158,14 @@ def test_forward_routing_rule(monkeypatch):
     assert _route(1, 8, 8, 128, 128, 128, causal=1) == PP            # fewer than four KV tiles per Q block
     assert _route(2, 8, 8, 512, 192, 128) == PP
     assert _route(2, 8, 8, 512, 193, 128) == PS
+    # small causal grids: every pair of Q blocks cut in two when the doubled item count still fits one round of the chip
+    assert _route(1, 8, 8, 8192, 8192, 128, causal=1) == PS_SPLIT    # 128 paired items on 256 CUs
+    assert _route(1, 32, 8, 2048, 2048, 128, causal=1) == PS_SPLIT   # single-sequence prefill
+    assert _route(2, 8, 8, 8192, 8192, 128, causal=1) == PS          # 256 paired items: already one per CU
+    assert _route(1, 32, 32, 2048, 2048, 64, dtype=1, causal=1) == PS_SPLIT   # D = 64: two workgroups per CU
+    assert _route(1, 8, 8, 8192, 8192, 128) == PS                    # non-causal: nothing to pair
+    assert _route(1, 8, 8, 8192, 8192, 32, causal=1) == PS           # no D = 32 instances
+    assert _route(1, 8, 8, 300, 300, 128, causal=1) == PS            # one pair whose far block is too short to cut
     assert _route(1, 3, 2, 1, 8192, 128) == -3                       # heads not divisible
     # (AULE_HIP_FWD_SPLITKV=0 is read once per process into a static, so the off-switch is not testable here;
     #  tools/split_grid.py exercises it in a process of its own)
