@@ -190,6 +190,7 @@ SIGNATURES = [
     ("aule_attention_paged_decode_workspace_size", ctypes.c_uint64, [ctypes.POINTER(PagedDesc)]),
     ("aule_hip_build_info", ctypes.c_char_p, []),
     ("aule_hip_debug_forward_route", _I32, [ctypes.POINTER(AttnDesc)]),
+    ("aule_hip_debug_forward_split_plan", _I32, [ctypes.POINTER(AttnDesc), ctypes.POINTER(_I32), _I32]),
 ]
 
 _lib = None

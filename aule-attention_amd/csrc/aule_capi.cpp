@@ -1054,6 +1054,22 @@ int32_t aule_hip_debug_forward_route(const aule_attn_desc* d) {
     return aule_hip::fwd_route(a);
 }
 
+int32_t aule_hip_debug_forward_split_plan(const aule_attn_desc* d, int32_t* out, int32_t cap) {
+    if (d == nullptr || d->struct_size != sizeof(aule_attn_desc)) return -3;
+    if (d->causal < 0 || d->causal > AULE_CAUSAL_BOTTOM_RIGHT) return -3;
+    FwdArgs a;
+    a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv;
+    a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
+    if (a.Hkv <= 0 || a.Hq % a.Hkv != 0) return -3;
+    a.causal = d->causal != 0;
+    a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? a.Sk - a.Sq : 0;
+    a.dtype = d->dtype;
+    a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
+    drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
+    if (aule_hip::fwd_route(a) != 7) return 0;
+    return aule_hip::fwd_ps_split_plan_dump(a, out, cap);
+}
+
 #ifdef AULE_DEBUG_HOOKS
 /* Debug hook (debug library only): bf16 D=128 forward with per-phase s_memtime stamps of workgroup 0 written to
  * `stamps` (device pointer; 8 * 256 uint64 for the ping-pong kernel, 8 * 2048 with AULE_TL=ps for the tile stream).

@@ -56,11 +56,12 @@ struct FwdPSParams {
     const float* rcos;
     const float* rsin;
     int rrows, rpitch, rpos;
-    // SPLIT instances only (small causal grids, launch_ps_split): a pair of Q blocks is two work items; the far block's
-    // keys may be cut in two ranges, each leaving an fp32 partial in plane 0 / 1 of `part` ([2][B*Hq*Sq][D + 4]:
+    // SPLIT instances only (small causal grids, launch_ps_split): a pair of Q blocks is `npiece` work items; a block whose
+    // keys are cut into ranges leaves one fp32 partial per range in plane `piece` of `part` ([npiece][B*Hq*Sq][D + 4]:
     // un-normalised O, m in log2 units, l), merged by fa_fwd_ps_combine.
     float* part;
     int part_rows;
+    int npiece;
     unsigned long long* dbg;   // timeline build only: [8 waves][kPSTLMax] tagged s_memtime stamps of workgroup 0
 };
 
@@ -102,21 +103,76 @@ __host__ __device__ inline int ps_tiles(int qb, int Sk, int coff) {
     kv_hi = kv_hi > 1 ? kv_hi : 1;
     return (kv_hi + kKVTile - 1) / kKVTile;
 }
-// SPLIT plan of the pair (far, near) of Q blocks: piece 0 = tiles [0, a) of the far block, piece 1 = its tiles [a, nt) and
-// the whole near block -- half of the pair's tiles each.  The cut stays inside the keys EVERY row of the far block sees
-// (a * 64 <= its first position): piece 0 needs no mask, and every row of piece 1 sees the first key of its range, so both
-// ranges run the plain softmax (a finite maximum from their first tile on).  Returns a, or 0 when the far block is not
-// cut (pieces = the two blocks; ranges shorter than four tiles would starve the staging cursors).
-__host__ __device__ inline int ps_cut(int far, int near, int Sk, int coff) {
-    const int ntf = ps_tiles(far, Sk, coff), ntn = far != near ? ps_tiles(near, Sk, coff) : 0;
-    int a = (ntf + ntn + 1) / 2;
-    const int vis = (far * kQBlock + coff) / kKVTile;
-    a = a < vis ? a : vis;
-    return (a >= 4 && ntf - a >= 4) ? a : 0;
+// SPLIT plan of the pair (far, near) of Q blocks: the pair's key tiles, far block's first, are one sequence of
+// ntf + ntn tiles cut into n pieces of (nearly) equal length, piece j = [b[j], b[j + 1]) -- at most one range of each
+// block.  A cut inside a block stays within the keys EVERY row of the block sees whole (tile index <= first position
+// / 64): ranges before it need no mask, and every row of the range behind it sees that range's first key, so all ranges
+// run the plain softmax (a finite maximum from their first tile on).  Every range has at least four tiles (the staging
+// cursors run three tiles ahead); a cut with no admissible position collapses (b[j] = b[j - 1]: an empty piece).
+constexpr int kMaxPieces = 8;
+struct PSPair {
+    int ntf, ntn;
+    int b[kMaxPieces + 1];
+};
+__host__ __device__ inline PSPair ps_cuts(int far, int near, int Sk, int coff, int n) {
+    PSPair r;
+    r.ntf = ps_tiles(far, Sk, coff);
+    r.ntn = far != near ? ps_tiles(near, Sk, coff) : 0;
+    const int T = r.ntf + r.ntn;
+    int fhi = (far * kQBlock + coff) / kKVTile, nhi = (near * kQBlock + coff) / kKVTile;   // last admissible cut inside a block
+    fhi = fhi < r.ntf - 4 ? fhi : r.ntf - 4;
+    nhi = nhi < r.ntn - 4 ? nhi : r.ntn - 4;
+    r.b[0] = 0;
+    // (constant trip counts and indices: on the device the plan stays in registers)
+#pragma unroll
+    for (int j = 1; j <= kMaxPieces; ++j) {
+        if (j >= n) {
+            r.b[j] = T;
+            continue;
+        }
+        const int x = (int)(((long long)j * T + n / 2) / n), lo = r.b[j - 1] + 4;
+        int best = r.b[j - 1], bd = 1 << 30;
+        {   // inside the far block
+            const int l = lo > 4 ? lo : 4;
+            if (l <= fhi) {
+                const int c = x < l ? l : (x > fhi ? fhi : x), d = c > x ? c - x : x - c;
+                if (d < bd) { bd = d; best = c; }
+            }
+        }
+        if (r.ntn > 0 && r.ntf >= lo) {   // the block boundary
+            const int d = r.ntf > x ? r.ntf - x : x - r.ntf;
+            if (d < bd) { bd = d; best = r.ntf; }
+        }
+        if (r.ntn > 0) {   // inside the near block
+            int l = lo - r.ntf;
+            l = l > 4 ? l : 4;
+            if (l <= nhi) {
+                const int xn = x - r.ntf, cn = xn < l ? l : (xn > nhi ? nhi : xn), c = r.ntf + cn, d = c > x ? c - x : x - c;
+                if (d < bd) { bd = d; best = c; }
+            }
+        }
+        r.b[j] = best;
+    }
+    return r;
+}
+// Range [t0, t1) of the far (which = 0) / near (1) block inside piece j; t1 <= t0: the piece has no part of that block.
+__host__ __device__ inline void ps_range(const PSPair& r, int j, int which, int& t0, int& t1) {
+    int lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxPieces; ++i)
+        if (i == j) {
+            lo = r.b[i];
+            hi = r.b[i + 1];
+        }
+    if (which == 0) {
+        t0 = lo;
+        t1 = hi < r.ntf ? hi : r.ntf;
+    } else {
+        t0 = (lo > r.ntf ? lo : r.ntf) - r.ntf;
+        t1 = hi - r.ntf;
+    }
 }
 
-// D <= 64: the workgroup needs <= 75 KB of LDS, so two fit a CU if the kernel stays within 128 VGPRs (4 waves per SIMD);
-// the second workgroup fills the first one's barrier and seam bubbles (the predecessor's D = 64 instances do run that way).
 template <class T, int D, bool CAUSAL, bool RAWOK, bool TL = false, bool ROPE = false, bool SPLIT = false>
 __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const FwdPSParams p) {
     static_assert(!SPLIT || (CAUSAL && !TL && !ROPE), "SPLIT instances: causal, no timeline, no fused rotation");
@@ -159,16 +215,17 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
     if (tid < nslot) {
         int qb = -1, range = 0;
         if constexpr (SPLIT) {
-            // item = (pair, piece): .z = qb | partial plane + 1 << 24, .w = first tile | end tile << 16
-            const WorkItem w = decode_work((int)blockIdx.x + (tid >> 1) * G, p.B, p.Hq, p.Hkv, 2 * p.nwork, false);
-            const int near = w.blk >> 1, piece = w.blk & 1, far = p.nqb - 1 - near;
-            const int a = ps_cut(far, near, Sk, coff), ntf = ps_tiles(far, Sk, coff);
-            if (piece == 0) {
-                if ((tid & 1) == 0) { qb = far | (a ? 1 << 24 : 0); range = (a ? a : ntf) << 16; }
-            } else if ((tid & 1) == 0) {
-                if (a) { qb = far | (2 << 24); range = a | (ntf << 16); }
-            } else if (far != near) {
-                qb = near; range = ps_tiles(near, Sk, coff) << 16;
+            // item = (pair, piece): slot 0 its range of the far block, slot 1 of the near block.
+            // .z = qb | partial plane + 1 << 24 (0: the range is the whole block -- its O is final), .w = first tile | end tile << 16
+            const WorkItem w = decode_work((int)blockIdx.x + (tid >> 1) * G, p.B, p.Hq, p.Hkv, p.npiece * p.nwork, false);
+            const int near = w.blk / p.npiece, piece = w.blk % p.npiece, far = p.nqb - 1 - near;
+            const PSPair pr = ps_cuts(far, near, Sk, coff, p.npiece);
+            int t0, t1;
+            ps_range(pr, piece, tid & 1, t0, t1);
+            if (t1 > t0) {
+                const int whole = (tid & 1) ? pr.ntn : pr.ntf;
+                qb = ((tid & 1) ? near : far) | ((t0 == 0 && t1 == whole) ? 0 : (piece + 1) << 24);
+                range = t0 | (t1 << 16);
             }
             tab[tid] = int4{(w.b * p.Hq + w.h) * Sq, (w.b * p.Hkv + w.hk) * Sk, qb, range};
         } else {
@@ -773,7 +830,7 @@ int launch_ps(const FwdArgs& a, hipStream_t stream) {
     p.nitems = p.nwork * a.B * a.Hq;
     p.dbg = nullptr;
     p.rcos = a.rope_cos; p.rsin = a.rope_sin; p.rrows = a.rope_rows; p.rpitch = a.rope_pitch; p.rpos = a.rope_pos;
-    p.part = nullptr; p.part_rows = 0;
+    p.part = nullptr; p.part_rows = 0; p.npiece = 0;
     // one workgroup per CU (two for D <= 64); more only when a workgroup's list would not fit its part table
     const long long ncu = (long long)cu_count() * (D <= 64 ? 2 : 1);
     const long long rounds = (p.nitems + ncu * kMaxItems - 1) / (ncu * kMaxItems);
@@ -798,41 +855,59 @@ int launch_ps(const FwdArgs& a, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-// Merge of the two partial planes of every far block the SPLIT plan cut (ps_cut() != 0): one thread per four columns of a
-// row, 1024 / D rows per 256-thread workgroup; blockIdx = (b * Hq + h, far block index, row group).  Blocks the plan
-// left whole were finished by the stream kernel: their workgroups exit.  Bound: HBM (2 x (D + 4) x 4 bytes read,
-// D x 2 + 4 written per row).
+// Merge of the partial planes of every Q block the SPLIT plan cut into ranges: one thread per four columns of a row,
+// 1024 / D rows per 256-thread workgroup; blockIdx = (row group, Q block, b * Hq + h).  Blocks the plan left whole were
+// finished by the stream kernel: their workgroups exit.  Bound: HBM (ranges x (D + 4) x 4 bytes read, D x 2 + 4 written
+// per row).
 template <class T, int D>
 __global__ void __launch_bounds__(256) fa_fwd_ps_combine(const FwdPSParams p) {
     constexpr int TPR = D / 4, RPW = 256 / TPR, PP = D + kPartPad;
-    const int bh = (int)blockIdx.z, near = (int)blockIdx.y, far = p.nqb - 1 - near;
-    if (ps_cut(far, near, p.Sk, p.coff) == 0) return;
-    const int row = far * kQBlock + (int)blockIdx.x * RPW + (int)threadIdx.x / TPR;
+    const int bh = (int)blockIdx.z, qb = (int)blockIdx.y;
+    const int mirror = p.nqb - 1 - qb, near = qb < mirror ? qb : mirror, far = p.nqb - 1 - near;
+    const int which = (qb == far) ? 0 : 1;
+    const PSPair pr = ps_cuts(far, near, p.Sk, p.coff, p.npiece);
+    const int row = qb * kQBlock + (int)blockIdx.x * RPW + (int)threadIdx.x / TPR;
     if (row >= p.Sq) return;
     const int c4 = ((int)threadIdx.x % TPR) * 4;
     const size_t grow = (size_t)bh * p.Sq + row;
-    const float* r0 = p.part + grow * PP;
-    const float* r1 = p.part + ((size_t)p.part_rows + grow) * PP;
-    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(r0 + c4), b = *reinterpret_cast<const f32x4_t*>(r1 + c4);
-    const float m0 = r0[D], l0 = r0[D + 1], m1 = r1[D], l1 = r1[D + 1];
-    const float mx = fmaxf(m0, m1);
-    const float w0 = fast_exp2(m0 - mx), w1 = fast_exp2(m1 - mx);
-    const float lt = l0 * w0 + l1 * w1;
+    float mx = -INFINITY;
+    int nr = 0;
+    for (int j = 0; j < p.npiece; ++j) {
+        int t0, t1;
+        ps_range(pr, j, which, t0, t1);
+        if (t1 > t0) {
+            ++nr;
+            mx = fmaxf(mx, p.part[((size_t)j * p.part_rows + grow) * PP + D]);
+        }
+    }
+    if (nr < 2) return;   // one range = the whole block
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    float lt = 0.f;
+    for (int j = 0; j < p.npiece; ++j) {
+        int t0, t1;
+        ps_range(pr, j, which, t0, t1);
+        if (t1 > t0) {
+            const float* r = p.part + ((size_t)j * p.part_rows + grow) * PP;
+            const float w = fast_exp2(r[D] - mx);
+            acc += *reinterpret_cast<const f32x4_t*>(r + c4) * w;
+            lt += r[D + 1] * w;
+        }
+    }
     const float inv = 1.0f / lt;
     u32x2_t u;
-    u[0] = T::pack2((a[0] * w0 + b[0] * w1) * inv, (a[1] * w0 + b[1] * w1) * inv);
-    u[1] = T::pack2((a[2] * w0 + b[2] * w1) * inv, (a[3] * w0 + b[3] * w1) * inv);
+    u[0] = T::pack2(acc[0] * inv, acc[1] * inv);
+    u[1] = T::pack2(acc[2] * inv, acc[3] * inv);
     *reinterpret_cast<u32x2_t*>(static_cast<char*>(p.o) + (grow * D + c4) * 2) = u;
     if (c4 == 0 && p.lse != nullptr) p.lse[grow] = (mx + fast_log2(lt)) * kLn2;
 }
 
 // Small causal grids: the paired launch has fewer items than the chip has workgroup slots, and a pair cannot be made
 // shorter by cutting its query rows (a workgroup's time is its KEY tiles: 128-row blocks would take as long).  So each
-// pair becomes two items of half the key tiles (ps_cut), the cut far blocks leave two fp32 partials, one more launch
-// merges them.  (measured: tools/ps_split_check.py.)
+// pair becomes n items of 1/n of its key tiles (ps_cuts), a block cut into ranges leaves one fp32 partial per range, one
+// more launch merges them.  (measured: tools/ps_split_check.py.)
 struct PSSplitPlan {
     bool ok;
-    int nqb, nwork, ncut;
+    int nqb, nwork, n;
     long long nitems;
     size_t bytes;
 };
@@ -840,11 +915,25 @@ static PSSplitPlan ps_split_plan(const FwdArgs& a, int slots) {
     PSSplitPlan s{};
     s.nqb = (a.Sq + kQBlock - 1) / kQBlock;
     s.nwork = (s.nqb + 1) / 2;
-    s.nitems = 2LL * s.nwork * a.B * a.Hq;
-    for (int near = 0; near < s.nwork; ++near) s.ncut += ps_cut(s.nqb - 1 - near, near, a.Sk, a.coff) != 0;
-    s.bytes = 2ull * a.B * a.Hq * a.Sq * (size_t)(a.D + kPartPad) * sizeof(float);
-    // worth it when the split items still fit the chip in one round and most pairs do get cut
-    s.ok = s.nitems <= slots && 2 * s.ncut >= s.nwork;
+    const long long pairs = (long long)s.nwork * a.B * a.Hq;
+    // as many pieces as still fit the chip in one round, each at least eight tiles of the longest pair (the prologue
+    // of a piece costs about three tile steps, and every range costs a partial row per query)
+    const int T = ps_tiles(s.nqb - 1, a.Sk, a.coff) + (s.nqb > 1 ? ps_tiles(0, a.Sk, a.coff) : 0);
+    long long n = slots / (pairs > 0 ? pairs : 1);
+    n = n < kMaxPieces ? n : kMaxPieces;
+    n = n < T / 8 ? n : T / 8;
+    s.n = (int)n;
+    s.nitems = pairs * s.n;
+    s.bytes = (size_t)s.n * a.B * a.Hq * a.Sq * (size_t)(a.D + kPartPad) * sizeof(float);
+    if (s.n < 2) return s;
+    int ncut = 0;   // pairs that do get cut
+    for (int near = 0; near < s.nwork; ++near) {
+        const PSPair pr = ps_cuts(s.nqb - 1 - near, near, a.Sk, a.coff, s.n);
+        int pieces = 0;
+        for (int j = 0; j < s.n; ++j) pieces += pr.b[j + 1] > pr.b[j];
+        ncut += pieces >= 2;
+    }
+    s.ok = 2 * ncut >= s.nwork;
     return s;
 }
 
@@ -870,12 +959,13 @@ int launch_ps_split(const FwdArgs& a, hipStream_t stream) {
     p.nitems = (int)s.nitems;
     p.part = static_cast<float*>(ws.ptr);
     p.part_rows = a.B * a.Hq * a.Sq;
+    p.npiece = s.n;
     const size_t lds = Cfg<D>::LDS + kMaxSlot * 20 + 16;
     hipLaunchKernelGGL((fa_fwd_ps_kernel<T, D, true, RAWOK, false, false, true>), dim3((unsigned)s.nitems), dim3(512), lds, stream, p);
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
     constexpr int RPW = 256 / (D / 4);
-    hipLaunchKernelGGL((fa_fwd_ps_combine<T, D>), dim3(kQBlock / RPW, (unsigned)s.nwork, (unsigned)(a.B * a.Hq)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((fa_fwd_ps_combine<T, D>), dim3(kQBlock / RPW, (unsigned)s.nqb, (unsigned)(a.B * a.Hq)), dim3(256), 0, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -989,6 +1079,23 @@ int launch_fwd_ps_split(const FwdArgs& a, hipStream_t stream) {
         if (a.D == 64) return raw ? launch_ps_split<F16Traits, 64, true>(a, stream) : launch_ps_split<F16Traits, 64, false>(a, stream);
     }
     return -1;
+}
+
+// Host view of the SPLIT plan for the CPU tests (aule_hip_debug_forward_split_plan): out = {n, nwork, then per pair
+// ntf, ntn, b[0 .. kMaxPieces]}; returns the ints written, 0 when the shape does not take the path.
+int fwd_ps_split_plan_dump(const FwdArgs& a, int* out, int cap) {
+    if (!fwd_ps_split_applicable(a)) return 0;
+    const PSSplitPlan s = ps_split_plan(a, cu_count() * (a.D <= 64 ? 2 : 1));
+    const int per = 2 + kMaxPieces + 1, need = 2 + s.nwork * per;
+    if (out == nullptr || cap < need) return -need;
+    out[0] = s.n; out[1] = s.nwork;
+    for (int near = 0; near < s.nwork; ++near) {
+        const PSPair pr = ps_cuts(s.nqb - 1 - near, near, a.Sk, a.coff, s.n);
+        int* o = out + 2 + near * per;
+        o[0] = pr.ntf; o[1] = pr.ntn;
+        for (int j = 0; j <= kMaxPieces; ++j) o[2 + j] = pr.b[j];
+    }
+    return need;
 }
 
 int launch_fwd_ps(const FwdArgs& a, hipStream_t stream) {

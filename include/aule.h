@@ -258,8 +258,13 @@ uint64_t aule_attention_backward_workspace_size(const aule_attn_bwd_desc* desc);
 /* Build/ABI identification: "aule-hip gfx950 <abi>" */
 const char* aule_hip_build_info(void);
 /* Debug (not part of the drop-in ABI): forward kernel aule_attention_forward_ex would pick for `desc` --        */
-/* 0 fp32, 1 ping-pong, 2 in-wave, 3 lock-step, 4 split-KV; -3 bad descriptor.  Host logic only, no aule_init(). */
+/* 0 fp32, 1 ping-pong, 4 split-KV, 5 tiled split, 6 tile stream, 7 tile stream + causal split; -3 bad descriptor. */
+/* Host logic only, no aule_init().                                                                                  */
 int32_t aule_hip_debug_forward_route(const aule_attn_desc* desc);
+/* Debug: the causal-split plan of route 7 (small causal grids) as integers -- out = {pieces n, pairs, then per pair of   */
+/* Q blocks: tiles of the far block, of the near block, cut positions b[0..8]}; returns the ints written (negative: the */
+/* capacity needed), 0 when the shape does not take that route.  Host logic only.                                       */
+int32_t aule_hip_debug_forward_split_plan(const aule_attn_desc* desc, int32_t* out, int32_t cap);
 
 #ifdef __cplusplus
 }

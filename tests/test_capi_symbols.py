@@ -2,6 +2,7 @@
 include/aule.h declares, and behaves per the reference contract when NOT initialised
 (no compute calls are made here; the GPU tests do that)."""
 import ctypes
+import itertools
 import os
 import re
 
@@ -206,3 +207,60 @@ def test_fused_query_rotation_rule(monkeypatch):
     assert fusable(cos=0x1004) == 0 and fusable(sin=0) == 0                    # alignment, null
     assert fusable(size=32) == 0
     assert lib.aule_attention_forward_rope_fusable(None, None) == 0
+
+
+def test_causal_split_plan_invariants(monkeypatch):
+    """Route 7's plan (ps_cuts in fa_fwd_ps_gfx950.hip, through aule_hip_debug_forward_split_plan; host logic): for every pair
+    of Q blocks the pieces tile the pair's key tiles exactly; every range of a block has at least four tiles; a cut inside
+    a block lies within the keys every row of the block sees whole; the pieces fit the chip in one round and are balanced."""
+    monkeypatch.delenv("AULE_HIP_FWD_KERNEL", raising=False)
+    monkeypatch.delenv("AULE_HIP_FWD_PSSPLIT", raising=False)
+    lib = _capi.load()
+    seen, ns = 0, set()
+    for (B, Hq, Hkv, Sq, Sk, D, causal) in itertools.product((1, 2, 3), (4, 8, 32, 40), (1, 4), (300, 512, 777, 1024, 1792, 2048, 4096, 8192, 9000),
+                                                           (0, 1000, 4096, 20000), (64, 128), (1, 2)):
+        Sk = Sq if Sk == 0 else Sk
+        if (causal == 2 and Sk < Sq) or (causal == 1 and Sk != Sq and Sk < Sq):
+            continue
+        d = _capi.AttnDesc()
+        d.struct_size = ctypes.sizeof(_capi.AttnDesc)
+        d.dtype = 2
+        d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
+        d.causal, d.window_size = causal, -1
+        if lib.aule_hip_debug_forward_route(ctypes.byref(d)) != 7:
+            assert lib.aule_hip_debug_forward_split_plan(ctypes.byref(d), None, 0) == 0
+            continue
+        need = -lib.aule_hip_debug_forward_split_plan(ctypes.byref(d), None, 0)
+        buf = (ctypes.c_int32 * need)()
+        assert lib.aule_hip_debug_forward_split_plan(ctypes.byref(d), buf, need) == need
+        n, nwork = buf[0], buf[1]
+        coff = Sk - Sq if causal == 2 else 0
+        nqb = (Sq + 255) // 256
+        assert 2 <= n <= 8 and nwork == (nqb + 1) // 2
+        assert n * nwork * B * Hq <= 256 * (2 if D == 64 else 1)
+        cut_pairs, longest, total = 0, 0, 0
+        for near in range(nwork):
+            o = buf[2 + near * 11: 2 + (near + 1) * 11]
+            ntf, ntn, b = o[0], o[1], list(o[2:])
+            far = nqb - 1 - near
+            tiles = lambda qb: (max(1, min(Sk, qb * 256 + 256 + coff)) + 63) // 64
+            assert ntf == tiles(far) and ntn == (tiles(near) if far != near else 0)
+            T = ntf + ntn
+            assert b[0] == 0 and all(x == T for x in b[n:]) and all(b[j] <= b[j + 1] for j in range(8))
+            pieces = [(b[j], b[j + 1]) for j in range(n) if b[j + 1] > b[j]]
+            cut_pairs += len(pieces) >= 2
+            for lo, hi in pieces:
+                longest = max(longest, hi - lo)
+                for (blo, bhi, qb) in ((0, ntf, far), (ntf, T, near)):      # the piece's range of each block
+                    t0, t1 = max(lo, blo) - blo, min(hi, bhi) - blo
+                    if t1 <= t0:
+                        continue
+                    assert t1 - t0 >= 4, (B, Hq, Sq, Sk, D, causal, near, b)
+                    vis = (qb * 256 + coff) // 64                             # tiles every row of the block sees whole
+                    assert t0 == 0 or t0 <= vis, (B, Hq, Sq, Sk, D, causal, near, b)
+            total += T
+        assert 2 * cut_pairs >= nwork
+        assert longest <= -(-max(buf[2 + i * 11] + buf[3 + i * 11] for i in range(nwork)) // n) + 8   # balance: within 8 tiles of ideal
+        seen += 1
+        ns.add(n)
+    assert seen > 100 and {2, 4, 8} <= ns, (seen, ns)

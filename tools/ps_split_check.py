@@ -38,6 +38,8 @@ def timed(fn, n=30, cond_ms=250.0):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+if len(sys.argv) > 1:
+    SHAPES = [SHAPES[int(x)] for x in sys.argv[1:]]   # only these rows (profiling runs)
 print("AULE_HIP_FWD_PSSPLIT =", os.environ.get("AULE_HIP_FWD_PSSPLIT", "(unset: on)"), flush=True)
 for dtype, B, Hq, Hkv, S, D in SHAPES:
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
