@@ -62,6 +62,7 @@ struct FwdPSParams {
     float* part;
     int part_rows;
     int npiece;
+    unsigned magic;   // ps_magic(npiece)
     unsigned long long* dbg;   // timeline build only: [8 waves][kPSTLMax] tagged s_memtime stamps of workgroup 0
 };
 
@@ -110,11 +111,15 @@ __host__ __device__ inline int ps_tiles(int qb, int Sk, int coff) {
 // run the plain softmax (a finite maximum from their first tile on).  Every range has at least four tiles (the staging
 // cursors run three tiles ahead); a cut with no admissible position collapses (b[j] = b[j - 1]: an empty piece).
 constexpr int kMaxPieces = 8;
+constexpr int kSplitMinTiles = 16;   // shortest piece worth a workgroup of its own (ps_split_plan)
 struct PSPair {
     int ntf, ntn;
     int b[kMaxPieces + 1];
 };
-__host__ __device__ inline PSPair ps_cuts(int far, int near, int Sk, int coff, int n) {
+__host__ __device__ inline unsigned ps_magic(int n) { return (unsigned)((0x100000000ull + (unsigned)n - 1) / (unsigned)n); }
+// (magic = ps_magic(n), computed on the host: T / n as a multiply-high, exact for T < 2^29 -- a division would drag the
+// whole plan from the scalar unit into vector registers)
+__host__ __device__ inline PSPair ps_cuts(int far, int near, int Sk, int coff, int n, unsigned magic) {
     PSPair r;
     r.ntf = ps_tiles(far, Sk, coff);
     r.ntn = far != near ? ps_tiles(near, Sk, coff) : 0;
@@ -123,14 +128,15 @@ __host__ __device__ inline PSPair ps_cuts(int far, int near, int Sk, int coff, i
     fhi = fhi < r.ntf - 4 ? fhi : r.ntf - 4;
     nhi = nhi < r.ntn - 4 ? nhi : r.ntn - 4;
     r.b[0] = 0;
-    // (constant trip counts and indices: on the device the plan stays in registers)
+    const int q = (int)(((unsigned long long)(unsigned)T * magic) >> 32), rem = T - q * n;
+    // (constant trip counts and indices: on the device the plan stays in registers; one division)
 #pragma unroll
     for (int j = 1; j <= kMaxPieces; ++j) {
         if (j >= n) {
             r.b[j] = T;
             continue;
         }
-        const int x = (int)(((long long)j * T + n / 2) / n), lo = r.b[j - 1] + 4;
+        const int x = j * q + (j < rem ? j : rem), lo = r.b[j - 1] + 4;   // ideal cut: piece lengths differ by at most one
         int best = r.b[j - 1], bd = 1 << 30;
         {   // inside the far block
             const int l = lo > 4 ? lo : 4;
@@ -219,7 +225,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             // .z = qb | partial plane + 1 << 24 (0: the range is the whole block -- its O is final), .w = first tile | end tile << 16
             const WorkItem w = decode_work((int)blockIdx.x + (tid >> 1) * G, p.B, p.Hq, p.Hkv, p.npiece * p.nwork, false);
             const int near = w.blk / p.npiece, piece = w.blk % p.npiece, far = p.nqb - 1 - near;
-            const PSPair pr = ps_cuts(far, near, Sk, coff, p.npiece);
+            const PSPair pr = ps_cuts(far, near, Sk, coff, p.npiece, p.magic);
             int t0, t1;
             ps_range(pr, piece, tid & 1, t0, t1);
             if (t1 > t0) {
@@ -830,7 +836,7 @@ int launch_ps(const FwdArgs& a, hipStream_t stream) {
     p.nitems = p.nwork * a.B * a.Hq;
     p.dbg = nullptr;
     p.rcos = a.rope_cos; p.rsin = a.rope_sin; p.rrows = a.rope_rows; p.rpitch = a.rope_pitch; p.rpos = a.rope_pos;
-    p.part = nullptr; p.part_rows = 0; p.npiece = 0;
+    p.part = nullptr; p.part_rows = 0; p.npiece = 0; p.magic = 0;
     // one workgroup per CU (two for D <= 64); more only when a workgroup's list would not fit its part table
     const long long ncu = (long long)cu_count() * (D <= 64 ? 2 : 1);
     const long long rounds = (p.nitems + ncu * kMaxItems - 1) / (ncu * kMaxItems);
@@ -859,39 +865,50 @@ int launch_ps(const FwdArgs& a, hipStream_t stream) {
 // 1024 / D rows per 256-thread workgroup; blockIdx = (row group, Q block, b * Hq + h).  Blocks the plan left whole were
 // finished by the stream kernel: their workgroups exit.  Bound: HBM (ranges x (D + 4) x 4 bytes read, D x 2 + 4 written
 // per row).
-template <class T, int D>
+template <class T, int D, int N>
 __global__ void __launch_bounds__(256) fa_fwd_ps_combine(const FwdPSParams p) {
     constexpr int TPR = D / 4, RPW = 256 / TPR, PP = D + kPartPad;
     const int bh = (int)blockIdx.z, qb = (int)blockIdx.y;
     const int mirror = p.nqb - 1 - qb, near = qb < mirror ? qb : mirror, far = p.nqb - 1 - near;
     const int which = (qb == far) ? 0 : 1;
-    const PSPair pr = ps_cuts(far, near, p.Sk, p.coff, p.npiece);
+    const PSPair pr = ps_cuts(far, near, p.Sk, p.coff, p.npiece, p.magic);
     const int row = qb * kQBlock + (int)blockIdx.x * RPW + (int)threadIdx.x / TPR;
     if (row >= p.Sq) return;
     const int c4 = ((int)threadIdx.x % TPR) * 4;
     const size_t grow = (size_t)bh * p.Sq + row;
-    float mx = -INFINITY;
-    int nr = 0;
-    for (int j = 0; j < p.npiece; ++j) {
+    // which planes hold a range of this block (uniform over the workgroup: scalar code)
+    unsigned mask = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxPieces; ++j) {
         int t0, t1;
         ps_range(pr, j, which, t0, t1);
-        if (t1 > t0) {
-            ++nr;
-            mx = fmaxf(mx, p.part[((size_t)j * p.part_rows + grow) * PP + D]);
-        }
+        if (j < N && t1 > t0) mask |= 1u << j;
     }
-    if (nr < 2) return;   // one range = the whole block
+    if (__builtin_popcount(mask) < 2) return;   // one range = the whole block: the stream kernel finished it
+    // every plane's loads first (independent: one round trip), then the merge.  N = npiece is a template parameter and the
+    // loads are unconditional -- a plane without a range of this block reads the first plane that has one, with weight 0
+    // -- because per-plane branches around the loads make the compiler copy the whole register array at every merge point.
+    f32x4_t dj[N];
+    f32x2_t ml[N];
+    const float* const r0 = p.part + grow * PP;
+    const size_t plane = (size_t)p.part_rows * PP;
+    const int first = __builtin_ctz(mask);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float* r = r0 + (size_t)((mask >> j) & 1u ? j : first) * plane;
+        dj[j] = *reinterpret_cast<const f32x4_t*>(r + c4);
+        ml[j] = *reinterpret_cast<const f32x2_t*>(r + D);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < N; ++j) mx = fmaxf(mx, ml[j][0]);   // (a stand-in plane repeats a real one: the maximum is unchanged)
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     float lt = 0.f;
-    for (int j = 0; j < p.npiece; ++j) {
-        int t0, t1;
-        ps_range(pr, j, which, t0, t1);
-        if (t1 > t0) {
-            const float* r = p.part + ((size_t)j * p.part_rows + grow) * PP;
-            const float w = fast_exp2(r[D] - mx);
-            acc += *reinterpret_cast<const f32x4_t*>(r + c4) * w;
-            lt += r[D + 1] * w;
-        }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float w = (mask >> j) & 1u ? fast_exp2(ml[j][0] - mx) : 0.f;
+        acc += dj[j] * w;
+        lt += ml[j][1] * w;
     }
     const float inv = 1.0f / lt;
     u32x2_t u;
@@ -905,6 +922,17 @@ __global__ void __launch_bounds__(256) fa_fwd_ps_combine(const FwdPSParams p) {
 // shorter by cutting its query rows (a workgroup's time is its KEY tiles: 128-row blocks would take as long).  So each
 // pair becomes n items of 1/n of its key tiles (ps_cuts), a block cut into ranges leaves one fp32 partial per range, one
 // more launch merges them.  (measured: tools/ps_split_check.py.)
+// AULE_HIP_FWD_PSSPLIT=<n>: at most n pieces per pair; 0 (or 1) turns the path off (A/B measurements)
+static int ps_split_max_pieces() {
+    static const int v = [] {
+        const char* e = getenv("AULE_HIP_FWD_PSSPLIT");
+        if (e == nullptr || e[0] < '0' || e[0] > '9') return kMaxPieces;
+        const int n = atoi(e);
+        return n < kMaxPieces ? n : kMaxPieces;
+    }();
+    return v;
+}
+
 struct PSSplitPlan {
     bool ok;
     int nqb, nwork, n;
@@ -916,19 +944,22 @@ static PSSplitPlan ps_split_plan(const FwdArgs& a, int slots) {
     s.nqb = (a.Sq + kQBlock - 1) / kQBlock;
     s.nwork = (s.nqb + 1) / 2;
     const long long pairs = (long long)s.nwork * a.B * a.Hq;
-    // as many pieces as still fit the chip in one round, each at least eight tiles of the longest pair (the prologue
-    // of a piece costs about three tile steps, and every range costs a partial row per query)
+    // as many pieces as still fit the chip in one round (one workgroup per CU, also at D = 64: a second workgroup on a CU
+    // shares its matrix pipes), each at least kSplitMinTiles tiles of the longest pair.  Measured (tools/ps_split_prof.sh):
+    // pieces of 17+ tiles win (S4096 H8: 102 -> 71 us with 2 pieces, 59 us with 4), 9-10 tiles are a wash at D = 128
+    // (S1024 H32: 39.5 vs 40.1 us) and a loss at D = 64 (S2048 H32, 4 pieces: 57 -> 67 us): a piece costs a prologue,
+    // a partial row per query and its share of the merge launch.
     const int T = ps_tiles(s.nqb - 1, a.Sk, a.coff) + (s.nqb > 1 ? ps_tiles(0, a.Sk, a.coff) : 0);
     long long n = slots / (pairs > 0 ? pairs : 1);
-    n = n < kMaxPieces ? n : kMaxPieces;
-    n = n < T / 8 ? n : T / 8;
+    n = n < ps_split_max_pieces() ? n : ps_split_max_pieces();
+    n = n < T / kSplitMinTiles ? n : T / kSplitMinTiles;
     s.n = (int)n;
     s.nitems = pairs * s.n;
     s.bytes = (size_t)s.n * a.B * a.Hq * a.Sq * (size_t)(a.D + kPartPad) * sizeof(float);
     if (s.n < 2) return s;
     int ncut = 0;   // pairs that do get cut
     for (int near = 0; near < s.nwork; ++near) {
-        const PSPair pr = ps_cuts(s.nqb - 1 - near, near, a.Sk, a.coff, s.n);
+        const PSPair pr = ps_cuts(s.nqb - 1 - near, near, a.Sk, a.coff, s.n, ps_magic(s.n));
         int pieces = 0;
         for (int j = 0; j < s.n; ++j) pieces += pr.b[j + 1] > pr.b[j];
         ncut += pieces >= 2;
@@ -939,8 +970,7 @@ static PSSplitPlan ps_split_plan(const FwdArgs& a, int slots) {
 
 template <class T, int D, bool RAWOK>
 int launch_ps_split(const FwdArgs& a, hipStream_t stream) {
-    const int slots = cu_count() * (D <= 64 ? 2 : 1);
-    const PSSplitPlan s = ps_split_plan(a, slots);
+    const PSSplitPlan s = ps_split_plan(a, cu_count());
     if (a.query_ws != nullptr) {
         *a.query_ws = s.bytes;
         return 0;
@@ -960,12 +990,22 @@ int launch_ps_split(const FwdArgs& a, hipStream_t stream) {
     p.part = static_cast<float*>(ws.ptr);
     p.part_rows = a.B * a.Hq * a.Sq;
     p.npiece = s.n;
+    p.magic = ps_magic(s.n);
     const size_t lds = Cfg<D>::LDS + kMaxSlot * 20 + 16;
     hipLaunchKernelGGL((fa_fwd_ps_kernel<T, D, true, RAWOK, false, false, true>), dim3((unsigned)s.nitems), dim3(512), lds, stream, p);
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
     constexpr int RPW = 256 / (D / 4);
-    hipLaunchKernelGGL((fa_fwd_ps_combine<T, D>), dim3(kQBlock / RPW, (unsigned)s.nqb, (unsigned)(a.B * a.Hq)), dim3(256), 0, stream, p);
+    const dim3 cgrid(kQBlock / RPW, (unsigned)s.nqb, (unsigned)(a.B * a.Hq));
+    switch (s.n) {
+        case 2: hipLaunchKernelGGL((fa_fwd_ps_combine<T, D, 2>), cgrid, dim3(256), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((fa_fwd_ps_combine<T, D, 3>), cgrid, dim3(256), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((fa_fwd_ps_combine<T, D, 4>), cgrid, dim3(256), 0, stream, p); break;
+        case 5: hipLaunchKernelGGL((fa_fwd_ps_combine<T, D, 5>), cgrid, dim3(256), 0, stream, p); break;
+        case 6: hipLaunchKernelGGL((fa_fwd_ps_combine<T, D, 6>), cgrid, dim3(256), 0, stream, p); break;
+        case 7: hipLaunchKernelGGL((fa_fwd_ps_combine<T, D, 7>), cgrid, dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL((fa_fwd_ps_combine<T, D, 8>), cgrid, dim3(256), 0, stream, p); break;
+    }
     return (int)hipGetLastError();
 }
 
@@ -1057,16 +1097,12 @@ bool fwd_ps_rope_fusable(const FwdArgs& a) {
     return (long long)a.rope_rows * a.rope_pitch * 4 < (1LL << 32) && last < (1LL << 32);
 }
 
-// Small causal grids for the SPLIT instances (route 7).  AULE_HIP_FWD_PSSPLIT=0 turns the path off (A/B measurements).
+// Small causal grids for the SPLIT instances (route 7).
 bool fwd_ps_split_applicable(const FwdArgs& a) {
-    static const int enabled = [] {
-        const char* e = getenv("AULE_HIP_FWD_PSSPLIT");
-        return (e != nullptr && e[0] == '0') ? 0 : 1;
-    }();
-    if (!enabled || !a.causal || (a.D != 64 && a.D != 128) || a.rope_cos != nullptr || !fwd_ps_applicable(a)) return false;
+    if (ps_split_max_pieces() < 2 || !a.causal || (a.D != 64 && a.D != 128) || a.rope_cos != nullptr || !fwd_ps_applicable(a)) return false;
     if ((long long)a.Sk >= 65535LL * kKVTile) return false;                               // tile indices are 16-bit in the table
     if ((long long)a.Sq * (a.D + kPartPad) * 4 >= (1LL << 32)) return false;              // partial rows of a head: 32-bit offsets
-    return ps_split_plan(a, cu_count() * (a.D <= 64 ? 2 : 1)).ok;
+    return ps_split_plan(a, cu_count()).ok;
 }
 
 int launch_fwd_ps_split(const FwdArgs& a, hipStream_t stream) {
@@ -1085,12 +1121,12 @@ int launch_fwd_ps_split(const FwdArgs& a, hipStream_t stream) {
 // ntf, ntn, b[0 .. kMaxPieces]}; returns the ints written, 0 when the shape does not take the path.
 int fwd_ps_split_plan_dump(const FwdArgs& a, int* out, int cap) {
     if (!fwd_ps_split_applicable(a)) return 0;
-    const PSSplitPlan s = ps_split_plan(a, cu_count() * (a.D <= 64 ? 2 : 1));
+    const PSSplitPlan s = ps_split_plan(a, cu_count());
     const int per = 2 + kMaxPieces + 1, need = 2 + s.nwork * per;
     if (out == nullptr || cap < need) return -need;
     out[0] = s.n; out[1] = s.nwork;
     for (int near = 0; near < s.nwork; ++near) {
-        const PSPair pr = ps_cuts(s.nqb - 1 - near, near, a.Sk, a.coff, s.n);
+        const PSPair pr = ps_cuts(s.nqb - 1 - near, near, a.Sk, a.coff, s.n, ps_magic(s.n));
         int* o = out + 2 + near * per;
         o[0] = pr.ntf; o[1] = pr.ntn;
         for (int j = 0; j <= kMaxPieces; ++j) o[2 + j] = pr.b[j];

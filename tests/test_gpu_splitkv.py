@@ -87,10 +87,11 @@ def test_splitkv_feeds_the_backward(oracle_mod):
 CAUSAL_SPLIT_CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, causal, scale, spike
     ("bf16", 1, 4, 4, 2048, 2048, 128, True, None, 0),              # 8 Q blocks: 4 pairs, every far block cut
     ("bf16", 1, 8, 2, 1792, 1792, 128, True, None, 0),              # 7 Q blocks: the middle block is a pair of its own
-    ("bf16", 1, 2, 2, 1300, 1300, 128, True, None, 0),              # ragged last block (rows >= Sq never stored)
-    ("fp16", 2, 4, 4, 1536, 1536, 64, True, 0.2, 0),                # D = 64 instances (two workgroups per CU)
-    ("bf16", 1, 8, 8, 1024, 4096, 128, "bottom-right", None, 0),    # queries at positions Sk - Sq + i: long first ranges
-    ("fp16", 1, 4, 1, 1000, 3000, 128, "bottom-right", -0.1, 0),    # ragged Sq and Sk, negative scale
+    ("bf16", 1, 2, 2, 1900, 1900, 128, True, None, 0),              # ragged last block (rows >= Sq never stored)
+    ("fp16", 2, 4, 4, 2048, 2048, 64, True, 0.2, 0),                # D = 64 instances
+    ("bf16", 1, 8, 8, 1024, 4096, 128, "bottom-right", None, 0),    # queries at positions Sk - Sq + i: 7 pieces per pair
+    ("fp16", 1, 4, 1, 1000, 3000, 128, "bottom-right", -0.1, 0),    # ragged Sq and Sk, negative scale, 5 pieces
+    ("bf16", 1, 8, 8, 4096, 4096, 128, True, None, 0),              # 4 pieces: both blocks of the middle pairs are cut
     ("bf16", 1, 4, 4, 2048, 2048, 128, True, None, 40.0),           # a spiked key late in the far ranges: the fixed-reference
     ("fp16", 1, 4, 4, 2048, 2048, 128, True, None, 40.0),           #   verdict fails on partial parts -> re-run, same partial slot
 ]
