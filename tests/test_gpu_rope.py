@@ -202,7 +202,8 @@ FUSED_CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, causal
     ("bf16", 4, 32, 32, 2048, 2048, 128, True),      # the C2-like shape: several parts per workgroup
     ("bf16", 1, 8, 2, 777, 1300, 128, False),        # ragged last block (rows >= Sq index past nothing: they read 0)
     ("fp16", 2, 4, 4, 600, 600, 64, True),           # D = 64 instances (two workgroups per CU)
-    ("fp16", 1, 16, 4, 300, 2048, 128, "bottom-right"),   # queries at positions Sk - Sq + i
+    ("fp16", 16, 16, 4, 300, 2048, 128, "bottom-right"),  # queries at positions Sk - Sq + i (enough pairs of Q blocks that the
+                                                          # un-fused launch stays on the plain stream too: same kernel, same order)
     ("bf16", 1, 4, 4, 512, 512, 64, False),
 ]
 
