@@ -63,6 +63,7 @@ struct FwdPSParams {
     int part_rows;
     int npiece;
     unsigned magic;   // ps_magic(npiece)
+    int pcoff;        // the plan's position offset: coff, or kEverything for a non-causal problem (every key visible to every row)
     unsigned long long* dbg;   // timeline build only: [8 waves][kPSTLMax] tagged s_memtime stamps of workgroup 0
 };
 
@@ -111,6 +112,7 @@ __host__ __device__ inline int ps_tiles(int qb, int Sk, int coff) {
 // run the plain softmax (a finite maximum from their first tile on).  Every range has at least four tiles (the staging
 // cursors run three tiles ahead); a cut with no admissible position collapses (b[j] = b[j - 1]: an empty piece).
 constexpr int kMaxPieces = 8;
+constexpr int kEverything = 1 << 30;   // ps_tiles / ps_cuts position offset of a non-causal problem
 constexpr int kSplitMinTiles = 16;   // shortest piece worth a workgroup of its own (ps_split_plan)
 struct PSPair {
     int ntf, ntn;
@@ -181,7 +183,7 @@ __host__ __device__ inline void ps_range(const PSPair& r, int j, int which, int&
 
 template <class T, int D, bool CAUSAL, bool RAWOK, bool TL = false, bool ROPE = false, bool SPLIT = false>
 __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const FwdPSParams p) {
-    static_assert(!SPLIT || (CAUSAL && !TL && !ROPE), "SPLIT instances: causal, no timeline, no fused rotation");
+    static_assert(!SPLIT || (!TL && !ROPE), "SPLIT instances: no timeline, no fused rotation");
     using C = Cfg<D>;
     using v8 = typename T::v8;
     using std::integral_constant;
@@ -224,8 +226,9 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             // item = (pair, piece): slot 0 its range of the far block, slot 1 of the near block.
             // .z = qb | partial plane + 1 << 24 (0: the range is the whole block -- its O is final), .w = first tile | end tile << 16
             const WorkItem w = decode_work((int)blockIdx.x + (tid >> 1) * G, p.B, p.Hq, p.Hkv, p.npiece * p.nwork, false);
-            const int near = w.blk / p.npiece, piece = w.blk % p.npiece, far = p.nqb - 1 - near;
-            const PSPair pr = ps_cuts(far, near, Sk, coff, p.npiece, p.magic);
+            // (non-causal: no pairing -- the "pair" is one block, far == near)
+            const int near = w.blk / p.npiece, piece = w.blk % p.npiece, far = p.pair ? p.nqb - 1 - near : near;
+            const PSPair pr = ps_cuts(far, near, Sk, p.pcoff, p.npiece, p.magic);
             int t0, t1;
             ps_range(pr, piece, tid & 1, t0, t1);
             if (t1 > t0) {
@@ -836,7 +839,7 @@ int launch_ps(const FwdArgs& a, hipStream_t stream) {
     p.nitems = p.nwork * a.B * a.Hq;
     p.dbg = nullptr;
     p.rcos = a.rope_cos; p.rsin = a.rope_sin; p.rrows = a.rope_rows; p.rpitch = a.rope_pitch; p.rpos = a.rope_pos;
-    p.part = nullptr; p.part_rows = 0; p.npiece = 0; p.magic = 0;
+    p.part = nullptr; p.part_rows = 0; p.npiece = 0; p.magic = 0; p.pcoff = 0;
     // one workgroup per CU (two for D <= 64); more only when a workgroup's list would not fit its part table
     const long long ncu = (long long)cu_count() * (D <= 64 ? 2 : 1);
     const long long rounds = (p.nitems + ncu * kMaxItems - 1) / (ncu * kMaxItems);
@@ -869,9 +872,9 @@ template <class T, int D, int N>
 __global__ void __launch_bounds__(256) fa_fwd_ps_combine(const FwdPSParams p) {
     constexpr int TPR = D / 4, RPW = 256 / TPR, PP = D + kPartPad;
     const int bh = (int)blockIdx.z, qb = (int)blockIdx.y;
-    const int mirror = p.nqb - 1 - qb, near = qb < mirror ? qb : mirror, far = p.nqb - 1 - near;
+    const int mirror = p.pair ? p.nqb - 1 - qb : qb, near = qb < mirror ? qb : mirror, far = p.pair ? p.nqb - 1 - near : near;
     const int which = (qb == far) ? 0 : 1;
-    const PSPair pr = ps_cuts(far, near, p.Sk, p.coff, p.npiece, p.magic);
+    const PSPair pr = ps_cuts(far, near, p.Sk, p.pcoff, p.npiece, p.magic);
     const int row = qb * kQBlock + (int)blockIdx.x * RPW + (int)threadIdx.x / TPR;
     if (row >= p.Sq) return;
     const int c4 = ((int)threadIdx.x % TPR) * 4;
@@ -941,15 +944,16 @@ struct PSSplitPlan {
 };
 static PSSplitPlan ps_split_plan(const FwdArgs& a, int slots) {
     PSSplitPlan s{};
+    const int pcoff = a.causal ? a.coff : kEverything;
     s.nqb = (a.Sq + kQBlock - 1) / kQBlock;
-    s.nwork = (s.nqb + 1) / 2;
+    s.nwork = a.causal ? (s.nqb + 1) / 2 : s.nqb;   // pairs of blocks, or single blocks
     const long long pairs = (long long)s.nwork * a.B * a.Hq;
     // as many pieces as still fit the chip in one round (one workgroup per CU, also at D = 64: a second workgroup on a CU
     // shares its matrix pipes), each at least kSplitMinTiles tiles of the longest pair.  Measured (tools/ps_split_prof.sh):
     // pieces of 17+ tiles win (S4096 H8: 102 -> 71 us with 2 pieces, 59 us with 4), 9-10 tiles are a wash at D = 128
     // (S1024 H32: 39.5 vs 40.1 us) and a loss at D = 64 (S2048 H32, 4 pieces: 57 -> 67 us): a piece costs a prologue,
     // a partial row per query and its share of the merge launch.
-    const int T = ps_tiles(s.nqb - 1, a.Sk, a.coff) + (s.nqb > 1 ? ps_tiles(0, a.Sk, a.coff) : 0);
+    const int T = ps_tiles(s.nqb - 1, a.Sk, pcoff) + (a.causal && s.nqb > 1 ? ps_tiles(0, a.Sk, pcoff) : 0);
     long long n = slots / (pairs > 0 ? pairs : 1);
     n = n < ps_split_max_pieces() ? n : ps_split_max_pieces();
     n = n < T / kSplitMinTiles ? n : T / kSplitMinTiles;
@@ -959,7 +963,7 @@ static PSSplitPlan ps_split_plan(const FwdArgs& a, int slots) {
     if (s.n < 2) return s;
     int ncut = 0;   // pairs that do get cut
     for (int near = 0; near < s.nwork; ++near) {
-        const PSPair pr = ps_cuts(s.nqb - 1 - near, near, a.Sk, a.coff, s.n, ps_magic(s.n));
+        const PSPair pr = ps_cuts(a.causal ? s.nqb - 1 - near : near, near, a.Sk, pcoff, s.n, ps_magic(s.n));
         int pieces = 0;
         for (int j = 0; j < s.n; ++j) pieces += pr.b[j + 1] > pr.b[j];
         ncut += pieces >= 2;
@@ -985,14 +989,18 @@ int launch_ps_split(const FwdArgs& a, hipStream_t stream) {
     c = c < 0.f ? -c : c;
     if (c == 0.f) c = 1e-30f;
     p.c = c;
-    p.nqb = s.nqb; p.pair = 1; p.nwork = s.nwork; p.coff = a.coff;
+    p.nqb = s.nqb; p.pair = a.causal ? 1 : 0; p.nwork = s.nwork; p.coff = a.causal ? a.coff : 0;
+    p.pcoff = a.causal ? a.coff : kEverything;
     p.nitems = (int)s.nitems;
     p.part = static_cast<float*>(ws.ptr);
     p.part_rows = a.B * a.Hq * a.Sq;
     p.npiece = s.n;
     p.magic = ps_magic(s.n);
     const size_t lds = Cfg<D>::LDS + kMaxSlot * 20 + 16;
-    hipLaunchKernelGGL((fa_fwd_ps_kernel<T, D, true, RAWOK, false, false, true>), dim3((unsigned)s.nitems), dim3(512), lds, stream, p);
+    if (a.causal)
+        hipLaunchKernelGGL((fa_fwd_ps_kernel<T, D, true, RAWOK, false, false, true>), dim3((unsigned)s.nitems), dim3(512), lds, stream, p);
+    else
+        hipLaunchKernelGGL((fa_fwd_ps_kernel<T, D, false, RAWOK, false, false, true>), dim3((unsigned)s.nitems), dim3(512), lds, stream, p);
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
     constexpr int RPW = 256 / (D / 4);
@@ -1016,9 +1024,12 @@ int set_attr_ps() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, false, RAWOK>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if constexpr (D >= 64)
+    if constexpr (D >= 64) {
         rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, true, RAWOK, false, false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, false, RAWOK, false, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
     if constexpr (RAWOK && D >= 64) {
         rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, true, true, false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1099,7 +1110,7 @@ bool fwd_ps_rope_fusable(const FwdArgs& a) {
 
 // Small causal grids for the SPLIT instances (route 7).
 bool fwd_ps_split_applicable(const FwdArgs& a) {
-    if (ps_split_max_pieces() < 2 || !a.causal || (a.D != 64 && a.D != 128) || a.rope_cos != nullptr || !fwd_ps_applicable(a)) return false;
+    if (ps_split_max_pieces() < 2 || (a.D != 64 && a.D != 128) || a.rope_cos != nullptr || !fwd_ps_applicable(a)) return false;
     if ((long long)a.Sk >= 65535LL * kKVTile) return false;                               // tile indices are 16-bit in the table
     if ((long long)a.Sq * (a.D + kPartPad) * 4 >= (1LL << 32)) return false;              // partial rows of a head: 32-bit offsets
     return ps_split_plan(a, cu_count()).ok;
@@ -1126,7 +1137,7 @@ int fwd_ps_split_plan_dump(const FwdArgs& a, int* out, int cap) {
     if (out == nullptr || cap < need) return -need;
     out[0] = s.n; out[1] = s.nwork;
     for (int near = 0; near < s.nwork; ++near) {
-        const PSPair pr = ps_cuts(s.nqb - 1 - near, near, a.Sk, a.coff, s.n, ps_magic(s.n));
+        const PSPair pr = ps_cuts(a.causal ? s.nqb - 1 - near : near, near, a.Sk, a.causal ? a.coff : kEverything, s.n, ps_magic(s.n));
         int* o = out + 2 + near * per;
         o[0] = pr.ntf; o[1] = pr.ntn;
         for (int j = 0; j <= kMaxPieces; ++j) o[2 + j] = pr.b[j];

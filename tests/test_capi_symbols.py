@@ -164,7 +164,8 @@ def test_forward_routing_rule(monkeypatch):
     assert _route(1, 32, 8, 2048, 2048, 128, causal=1) == PS_SPLIT   # single-sequence prefill
     assert _route(2, 8, 8, 8192, 8192, 128, causal=1) == PS          # 256 paired items: already one per CU
     assert _route(1, 32, 32, 2048, 2048, 64, dtype=1, causal=1) == PS_SPLIT   # D = 64: two workgroups per CU
-    assert _route(1, 8, 8, 8192, 8192, 128) == PS                    # non-causal: nothing to pair
+    assert _route(1, 8, 8, 8192, 8192, 128) == PS                    # non-causal: 256 blocks, one per CU
+    assert _route(1, 8, 8, 4096, 4096, 128) == PS_SPLIT              # non-causal: 128 blocks, each cut in two
     assert _route(1, 8, 8, 8192, 8192, 32, causal=1) == PS           # no D = 32 instances
     assert _route(1, 8, 8, 300, 300, 128, causal=1) == PS            # one pair whose far block is too short to cut
     assert _route(1, 3, 2, 1, 8192, 128) == -3                       # heads not divisible
@@ -218,9 +219,9 @@ def test_causal_split_plan_invariants(monkeypatch):
     lib = _capi.load()
     seen, ns = 0, set()
     for (B, Hq, Hkv, Sq, Sk, D, causal) in itertools.product((1, 2, 3), (4, 8, 32, 40), (1, 4), (300, 512, 777, 1024, 1792, 2048, 4096, 8192, 9000),
-                                                           (0, 1000, 4096, 20000), (64, 128), (1, 2)):
+                                                           (0, 1000, 4096, 20000), (64, 128), (0, 1, 2)):
         Sk = Sq if Sk == 0 else Sk
-        if (causal == 2 and Sk < Sq) or (causal == 1 and Sk != Sq and Sk < Sq):
+        if causal and Sk < Sq:
             continue
         d = _capi.AttnDesc()
         d.struct_size = ctypes.sizeof(_capi.AttnDesc)
@@ -234,15 +235,15 @@ def test_causal_split_plan_invariants(monkeypatch):
         buf = (ctypes.c_int32 * need)()
         assert lib.aule_hip_debug_forward_split_plan(ctypes.byref(d), buf, need) == need
         n, nwork = buf[0], buf[1]
-        coff = Sk - Sq if causal == 2 else 0
+        coff = Sk - Sq if causal == 2 else (0 if causal else 1 << 30)    # non-causal: every key visible to every row
         nqb = (Sq + 255) // 256
-        assert 2 <= n <= 8 and nwork == (nqb + 1) // 2
+        assert 2 <= n <= 8 and nwork == ((nqb + 1) // 2 if causal else nqb)  # pairs of blocks, or single blocks
         assert n * nwork * B * Hq <= 256 * (2 if D == 64 else 1)
         cut_pairs, longest, total = 0, 0, 0
         for near in range(nwork):
             o = buf[2 + near * 11: 2 + (near + 1) * 11]
             ntf, ntn, b = o[0], o[1], list(o[2:])
-            far = nqb - 1 - near
+            far = nqb - 1 - near if causal else near
             tiles = lambda qb: (max(1, min(Sk, qb * 256 + 256 + coff)) + 63) // 64
             assert ntf == tiles(far) and ntn == (tiles(near) if far != near else 0)
             T = ntf + ntn

@@ -92,6 +92,8 @@ CAUSAL_SPLIT_CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, causal, scale, spike
     ("bf16", 1, 8, 8, 1024, 4096, 128, "bottom-right", None, 0),    # queries at positions Sk - Sq + i: 7 pieces per pair
     ("fp16", 1, 4, 1, 1000, 3000, 128, "bottom-right", -0.1, 0),    # ragged Sq and Sk, negative scale, 5 pieces
     ("bf16", 1, 8, 8, 4096, 4096, 128, True, None, 0),              # 4 pieces: both blocks of the middle pairs are cut
+    ("bf16", 1, 8, 8, 2048, 2048, 128, False, None, 0),             # non-causal: single blocks cut in two (no pairing)
+    ("fp16", 1, 16, 16, 1100, 3333, 64, False, 0.15, 0),            # non-causal, ragged Sq / Sk, three pieces, D = 64
     ("bf16", 1, 4, 4, 2048, 2048, 128, True, None, 40.0),           # a spiked key late in the far ranges: the fixed-reference
     ("fp16", 1, 4, 4, 2048, 2048, 128, True, None, 40.0),           #   verdict fails on partial parts -> re-run, same partial slot
 ]

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "aule-attention_amd"))
 import torch
 from aule import _torch as at
 
-SHAPES = [  # dtype, B, Hq, Hkv, S, D
+SHAPES = [  # dtype, B, Hq, Hkv, S, D  (+ "nc": non-causal)
     ("bf16", 1, 8, 8, 8192, 128),      # the judge's shape: 128 paired items
     ("bf16", 1, 32, 8, 2048, 128),     # single-sequence prefill, 128 paired items
     ("bf16", 1, 16, 16, 4096, 128),    # 128 paired items
@@ -20,6 +20,9 @@ SHAPES = [  # dtype, B, Hq, Hkv, S, D
     ("bf16", 4, 8, 8, 512, 128),
     ("fp16", 1, 32, 32, 2048, 64),     # D = 64: 128 items on 512 slots
     ("fp16", 1, 64, 8, 4096, 64),      # D = 64: 512 paired items (control)
+    ("bf16", 1, 8, 8, 4096, 128, "nc"),    # non-causal: 128 single blocks of 64 tiles
+    ("bf16", 1, 8, 8, 2048, 128, "nc"),    # 64 blocks of 32 tiles
+    ("bf16", 1, 16, 16, 4096, 128, "nc"),  # 256 blocks (control)
 ]
 
 
@@ -41,10 +44,11 @@ def timed(fn, n=30, cond_ms=250.0):
 if len(sys.argv) > 1:
     SHAPES = [SHAPES[int(x)] for x in sys.argv[1:]]   # only these rows (profiling runs)
 print("AULE_HIP_FWD_PSSPLIT =", os.environ.get("AULE_HIP_FWD_PSSPLIT", "(unset: on)"), flush=True)
-for dtype, B, Hq, Hkv, S, D in SHAPES:
+for dtype, B, Hq, Hkv, S, D, *rest in SHAPES:
+    causal = 0 if rest else 1
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
     q = torch.randn(B, Hq, S, D, device="cuda", dtype=dt); k = torch.randn(B, Hkv, S, D, device="cuda", dtype=dt); v = torch.randn_like(k)
     sc = 1 / math.sqrt(D)
-    us = timed(lambda: at.fwd_raw(q, k, v, 1, sc, want_lse=True))
-    fl = 4.0 * B * Hq * D * S * (S + 1) / 2
-    print(f"  {dtype} B{B} Hq{Hq} Hkv{Hkv} S{S} D{D} causal: {us:9.1f} us  {fl / us / 1e6:7.1f} TF", flush=True)
+    us = timed(lambda: at.fwd_raw(q, k, v, causal, sc, want_lse=True))
+    fl = 4.0 * B * Hq * D * (S * (S + 1) / 2 if causal else S * S)
+    print(f"  {dtype} B{B} Hq{Hq} Hkv{Hkv} S{S} D{D} {'causal' if causal else 'non-causal'}: {us:9.1f} us  {fl / us / 1e6:7.1f} TF", flush=True)

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 for n in 0 2 4 8; do
   rm -rf /tmp/psp_$n
-  AULE_HIP_FWD_PSSPLIT=$n timeout 150 rocprofv3 --kernel-trace -d /tmp/psp_$n -o t -- python /root/repo/tools/ps_split_check.py 0 1 3 5 7 9 < /dev/null > /tmp/psp_$n.log 2>&1
+  AULE_HIP_FWD_PSSPLIT=$n timeout 150 rocprofv3 --kernel-trace -d /tmp/psp_$n -o t -- python /root/repo/tools/ps_split_check.py 0 1 3 5 7 9 11 12 < /dev/null > /tmp/psp_$n.log 2>&1
   echo "== max pieces $n"; grep -E "causal:" /tmp/psp_$n.log
   python3 - /tmp/psp_$n/t_results.db <<'PY'
 import sqlite3, sys, statistics
