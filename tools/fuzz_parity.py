@@ -137,7 +137,61 @@ def run_rope(rng, i):
     return cfg, errs
 
 
+def run_split(rng, i):
+    """Small grids with long keys (route 7: pairs of causal Q blocks, or non-causal blocks, cut into pieces + merge) and, on
+    the same draw, the fused query rotation against the two-pass form.  Forward only (out + LSE vs the fp64 judge): the
+    shapes that reach this route cost the judge seconds each."""
+    dtype = rng.choice(["bf16", "fp16"])
+    D = int(rng.choice([64, 128])); Hkv = int(rng.choice([1, 2, 4])); g = int(rng.choice([1, 2, 4])); Hq = Hkv * g
+    Sq = int(rng.randint(1100, 3200)); causal = rng.choice(["none", "top", "br"])
+    Sk = Sq if causal == "top" and rng.rand() < 0.7 else int(Sq + rng.choice([0, 1, 63, 500, 2000]))
+    if causal == "none" and rng.rand() < 0.5: Sk = int(rng.randint(2048, 5000))
+    scale = None if rng.rand() < 0.7 else float(rng.choice([0.3, -0.2, 0.05]))
+    cz = {"none": False, "top": True, "br": "bottom-right"}[causal]
+    code = {"none": 0, "top": 1, "br": 2}[causal]
+    r = route(dtype, 1, Hq, Hkv, Sq, Sk, D, code, -1)
+    cfg = (dtype, 1, Hq, Hkv, Sq, Sk, D, causal, scale)
+    r2 = np.random.RandomState(9000 + i)
+    q, k, v = (quantize(r2.randn(*s).astype(np.float32), dtype) for s in ((1, Hq, Sq, D), (1, Hkv, Sk, D), (1, Hkv, Sk, D)))
+    sc = (1 / math.sqrt(D)) if scale is None else scale
+    dev = lambda a, d=dtype: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", torch_dtype(d))
+    tq, tk, tv = dev(q), dev(k), dev(v)
+    out, lse = at.fwd_raw(tq, tk, tv, cz, sc)
+    ref, rl = oracle.fwd_f64(q, k, v, cz, scale, -1)
+    errs = []
+    atol, rtol = fwd_tol(dtype, float(np.abs(v).max()))
+    o = out.float().cpu().numpy()
+    if not np.isfinite(o).all(): errs.append("out non-finite")
+    elif (np.abs(o - ref) > atol + rtol * np.abs(ref)).any(): errs.append(f"out err {np.abs(o-ref).max():.3e}")
+    if np.abs(lse.cpu().numpy() - rl).max() > LSE_TOL[dtype] + 1e-5 * np.abs(rl).max(): errs.append(f"lse err {np.abs(lse.cpu().numpy()-rl).max():.3e}")
+    # fused query rotation == rope(Q) pass + attention, bit for bit, whenever both launches take the plain tile stream
+    qoff = Sk - Sq if causal == "br" else 0
+    cos, sin = oracle.rope_tables(max(Sq + qoff, Sk) + 2, D)
+    tc, ts = dev(cos, "fp32"), dev(sin, "fp32")
+    if at.rope_fusable(tq, tk, code, -1, tc, ts, qoff):
+        fused = at.fwd_raw(tq, tk, tv, cz, sc, want_lse=False, q_rope=(tc, ts, qoff))[0]
+        qr = at.rope_raw(tq, tc, ts, "half", False, qoff)
+        two = at.fwd_raw(qr, tk, tv, cz, sc, want_lse=False)[0]
+        if r == 6:
+            if not torch.equal(fused, two): errs.append("fused rotation != two-pass (same kernel)")
+        elif (fused.float() - two.float()).abs().max().item() > 2 * atol + 0.02: errs.append("fused rotation far from two-pass")
+    return (r, cfg), errs
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "split":
+        n = int(sys.argv[2]) if len(sys.argv) > 2 else 40; seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+        rng = np.random.RandomState(seed); bad = 0; routes = {}
+        for i in range(n):
+            try:
+                (r, cfg), errs = run_split(rng, i)
+            except Exception as e:  # noqa: BLE001
+                (r, cfg), errs = (-9, ("?",)), [f"EXCEPTION {type(e).__name__}: {str(e)[:160]}"]
+            routes[r] = routes.get(r, 0) + 1
+            if errs:
+                bad += 1; print(f"FAIL split #{i} route={r} cfg={cfg}: {'; '.join(errs)}", flush=True)
+        print(f"split: {n} configurations, {bad} failing; forward routes exercised: {dict(sorted(routes.items()))}")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] in ("paged", "rope"):
         mode = sys.argv[1]; n = int(sys.argv[2]) if len(sys.argv) > 2 else 200; seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
         rng = np.random.RandomState(seed); bad = 0
