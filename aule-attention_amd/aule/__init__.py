@@ -155,9 +155,10 @@ def flash_attention_rope(q, k, v, cos, sin, causal=True, scale=None, window_size
     (triton_flash.py:561-603): half-split pairs, x_rot = x * cos + rotate_half(x) * sin, query i at table row i,
     key j at row j; cos / sin [seq_len, head_dim // 2] or [1, seq_len, head_dim // 2].
 
-    On MI355X the rotation is one HBM-streaming pass over Q and K (csrc/rope_gfx950.hip) ahead of the attention
-    kernels -- K is rotated once, not once per Q block -- and the backward returns the true gradients (rotated back),
-    which the reference's backward does not.  ROCm tensors; autograd-aware."""
+    On MI355X K is rotated by one HBM-streaming pass (csrc/rope_gfx950.hip) -- once per key, not once per Q block.  Q is
+    rotated by the same pass when gradients are needed (the backward kernels read the rotated Q, and return the true
+    gradients, rotated back -- the reference's backward does not) and inside the forward kernel, on its way into the
+    registers, otherwise (bit-identical, one read and one write of Q less: DESIGN.md 3.6).  ROCm tensors; autograd-aware."""
     try:
         import torch  # noqa: F401
     except ImportError as e:

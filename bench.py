@@ -357,6 +357,37 @@ def main():
         result["extra"].update({"c5_fwd_tflops": t5, "c5_fwd_frac_of_peak": t5 / PEAK_TFLOPS["fp16"], "c5_ms_per_step": ms5 / 20,
                                 "c5_workload": "MQA 32q/1kv B=1 S=16384 D=64 fp16 non-causal fwd (LSE stored)"})
 
+        del q5, k5, v5
+        # single-sequence prefill, the small-grid corner (128 paired items on 256 CUs: route 7, pairs of Q blocks cut in
+        # two + merge), and RoPE + attention the inference way (K by the pass, Q rotated inside the kernel, 3.6)
+        q6, k6, v6 = (torch.randn(1, 8, 8192, 128, device=dev, dtype=torch.bfloat16, generator=g3) for _ in range(3))
+
+        def step6():
+            with torch.no_grad():
+                aule.flash_attention(q6, k6, v6, causal=True)
+
+        condition(step6, args.condition_ms)
+        _, ms6 = timed(step6, 20)
+        result["extra"].update({"b1h8_s8192_fwd_tflops": fwd_flops(1, 8, 8192, 8192, 128, True) / (ms6 / 20 * 1e-3) / 1e12,
+                                "b1h8_s8192_ms_per_step": ms6 / 20,
+                                "b1h8_s8192_workload": "MHA 8 heads B=1 S=8192 D=128 bf16 causal fwd (small grid: stream kernel over 256 pieces + merge kernel)"})
+        del q6, k6, v6
+        B7, H7, S7, D7 = 4, 32, 2048, 128
+        q7, k7, v7 = (torch.randn(B7, H7, S7, D7, device=dev, dtype=torch.bfloat16, generator=g3) for _ in range(3))
+        cos7, sin7 = aule.precompute_rope_frequencies(S7, D7, device=dev)
+
+        def step7():
+            with torch.no_grad():
+                aule.flash_attention_rope(q7, k7, v7, cos7, sin7, causal=True)
+
+        condition(step7, args.condition_ms)
+        _, ms7 = timed(step7, 20)
+        result["extra"].update({"rope_attn_c2_tflops": fwd_flops(B7, H7, S7, S7, D7, True) / (ms7 / 20 * 1e-3) / 1e12,
+                                "rope_attn_c2_ms_per_step": ms7 / 20,
+                                "rope_attn_c2_workload": "RoPE + attention, B=4 H=32 S=2048 D=128 bf16 causal, inference: rope(K) pass + forward "
+                                                         "with Q rotated in registers (attention FLOPs only)"})
+        del q7, k7, v7
+
     if rank == 0:
         # the reference harness counts 4*B*H*S^2*D with NO causal discount (tests/benchmark_attention.zig:68-75):
         # for a causal shape that includes the masked half, so it is about twice `value`.  Printed for comparison with the
