@@ -20,6 +20,9 @@ SHAPES = [  # name, B, Hq, Hkv, Sq, Sk, D, dtype, causal
     ("route4-decode", 8, 32, 8, 1, 8192, 128, "bf16", False),
     ("route5-bottom-right", 2, 16, 4, 48, 4096, 128, "bf16", "bottom-right"),
     ("plain-causal", 1, 8, 8, 1024, 1024, 128, "bf16", True),
+    ("route7-causal-split", 1, 8, 8, 4096, 4096, 128, "bf16", True),      # stream kernel over pieces + merge kernel, caller workspace
+    ("route7-noncausal-split", 1, 8, 8, 2048, 2048, 128, "fp16", False),
+    ("route6-fused-rope", 4, 16, 16, 1024, 1024, 128, "bf16", True),      # the forward that rotates Q itself (tables captured too)
 ]
 
 
@@ -55,9 +58,15 @@ def test_forward_capture_replays_bit_identical(shape):
     _, B, Hq, Hkv, Sq, Sk, D, dtype, causal = shape
     q, k, v = _mk(torch, B, Hq, Hkv, Sq, Sk, D, dtype)
     sc = 1 / math.sqrt(D)
-    eager, eager_lse = at.fwd_raw(q, k, v, causal, sc)
+    rope = None
+    if shape[0].endswith("fused-rope"):
+        import aule
+        cos, sin = aule.precompute_rope_frequencies(Sk, D)
+        rope = (cos.contiguous(), sin.contiguous(), 0)
+        assert at.rope_fusable(q, k, 1, -1, rope[0], rope[1], 0)
+    eager, eager_lse = at.fwd_raw(q, k, v, causal, sc, q_rope=rope)
     torch.cuda.synchronize()
-    g, outs = _capture(torch, lambda: at.fwd_raw(q, k, v, causal, sc))
+    g, outs = _capture(torch, lambda: at.fwd_raw(q, k, v, causal, sc, q_rope=rope))
     for o, l in outs:
         o.zero_(); l.zero_()
     g.replay()
@@ -66,7 +75,7 @@ def test_forward_capture_replays_bit_identical(shape):
         assert torch.equal(o, eager) and torch.equal(l, eager_lse)
     # new inputs in the captured buffers: the replay computes on them (no stale pointers into a freed workspace)
     q.copy_(torch.randn_like(q))
-    want, _ = at.fwd_raw(q, k, v, causal, sc)
+    want, _ = at.fwd_raw(q, k, v, causal, sc, q_rope=rope)
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(outs[-1][0], want)
