@@ -91,6 +91,18 @@ constexpr int kPSTLMax = 2048;
 #define AULE_PS_YOUNG_PRIO 0
 #endif
 
+// AULE_PS_DMA=1: K / V tiles go from global memory straight into LDS (buffer_load ... lds, 1 KiB per wave instruction)
+// instead of through 16 staging registers and ds_write_b128 (D >= 64 instances; D = 32 keeps the register path).
+#ifndef AULE_PS_DMA
+#define AULE_PS_DMA 1
+#endif
+template <int D> constexpr bool ps_dma() { return AULE_PS_DMA != 0 && D >= 64; }
+// LDS of one workgroup without the part table: register path = Cfg<D>::LDS (2 padded K tiles, 2 V tiles, 8 slabs);
+// DMA path = 2 un-padded (swizzled) K tiles, 3 V tiles, 8 slabs.
+template <int D> constexpr int ps_tile_lds() {
+    return ps_dma<D>() ? 2 * kKVTile * Cfg<D>::RB + 3 * Cfg<D>::VTILE + 8 * Cfg<D>::QSLAB : Cfg<D>::LDS;
+}
+
 constexpr int kMaxItems = 64;            // per workgroup (the host sizes the grid accordingly)
 constexpr int kMaxSlot = 2 * kMaxItems;  // parts: two per item (the second one invalid for an unpaired block)
 
@@ -190,18 +202,22 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
     constexpr int RB = C::RB, RBP = C::RBP, CPR = C::CPR, KTILE = C::KTILE, VTILE = C::VTILE;
     constexpr int CH = C::CH, KS = C::KS, DB = C::DB;
 
+    constexpr bool DMA = ps_dma<D>();
+    constexpr int KT = DMA ? kKVTile * RB : KTILE;   // bytes of a K tile in LDS (DMA: rows un-padded, 16-byte chunks swizzled)
+    constexpr int NVB = DMA ? 3 : 2;                 // V tiles in LDS (DMA: one more -- a tile is requested two phases earlier)
+    constexpr int TLDS = ps_tile_lds<D>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Ks = smem;
-    char* const Vs = smem + 2 * KTILE;
+    char* const Vs = smem + 2 * KT;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = rfl(tid >> 6);
     const int grp = wave >> 2;  // 0: leads, 1: runs one phase behind
     const int l31 = lane & 31, hi = lane >> 5;
-    char* const Qs = smem + 2 * KTILE + 2 * VTILE + wave * C::QSLAB;
-    int4* const tab = reinterpret_cast<int4*>(smem + C::LDS);                     // [kMaxSlot] {q row offset, kv row offset, qb | -1, -}
-    int* const redo = reinterpret_cast<int*>(smem + C::LDS + kMaxSlot * 16);      // [kMaxSlot] range verdicts, [kMaxSlot] = any
+    char* const Qs = smem + 2 * KT + NVB * VTILE + wave * C::QSLAB;
+    int4* const tab = reinterpret_cast<int4*>(smem + TLDS);                     // [kMaxSlot] {q row offset, kv row offset, qb | -1, -}
+    int* const redo = reinterpret_cast<int*>(smem + TLDS + kMaxSlot * 16);      // [kMaxSlot] range verdicts, [kMaxSlot] = any
 
     const int Sq = p.Sq, Sk = p.Sk, coff = p.coff;
     const float c = p.c;
@@ -286,7 +302,28 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
         const int bidx = (tid >> 3) + 64 * i;
         v_g[i] = ((bidx / (D / 16)) * 4 + ((tid >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (tid & 1)) * 16;
     }
-    const int ka_base = l31 * RBP + hi * 16;
+    // DMA: a wave instruction writes 64 x 16 bytes at a wave-uniform LDS address + lane * 16, from per-lane global
+    // addresses.  K: piece j = rows of 1 KiB of the un-padded tile; position (row r, chunk c') holds global chunk
+    // c' ^ swz(r), swz(r) = (r * CPR / 16) & (CPR - 1) -- with that the 16 lanes ds_read_b128 serves per LDS cycle (rows
+    // {0-3, 12-15, 20-27} of one chunk index) hit 16 different 16-byte bank groups.  V: the register path's image is
+    // already lane-linear (thread t, chunk i at t * 16 + i * 8192).  Wave w of a group takes pieces 4 i + (w & 3).
+    constexpr int KP = DMA ? (kKVTile * RB) / 4096 : 1, VP = DMA ? VTILE / 4096 : 1;
+    int kdma_g[KP], vdma_g[VP];
+    if constexpr (DMA) {
+        constexpr int SH = CPR == 16 ? 0 : (CPR == 8 ? 1 : 2);
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {
+            const int q = (4 * i + (wave & 3)) * 64 + lane, r = q / CPR, cs = q % CPR;
+            kdma_g[i] = r * RB + (cs ^ ((r >> SH) & (CPR - 1))) * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            const int pc = 4 * i + (wave & 3), t = (pc & 7) * 64 + lane, bidx = (t >> 3) + 64 * (pc >> 3);
+            vdma_g[i] = ((bidx / (D / 16)) * 4 + ((t >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (t & 1)) * 16;
+        }
+    }
+    constexpr int SWSH = CPR == 16 ? 0 : (CPR == 8 ? 1 : 2);
+    const int ka_base = DMA ? l31 * RB + ((((l31 >> SWSH) & (CPR - 1)) ^ hi) * 16) : l31 * RBP + hi * 16;
     const int va_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
 
     u32x4_t kst[CH], vst[CH];
@@ -352,6 +389,38 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             for (int i = 0; i < CH; ++i)
                 if (C::kFull || tid + 512 * i < C::NCHUNK)
                     vst[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], ((SPLIT ? vs_b : 0) + vs_t) * (kKVTile * RB), 0);
+        };
+        auto dma_k = [&](int buf) __attribute__((always_inline)) {   // the K tile at the cursor -> Ks[buf] (this wave's pieces)
+#if defined(__HIP_DEVICE_COMPILE__)   // (the LDS address-space cast does not exist in the host pass)
+            using lds_ptr = __attribute__((address_space(3))) void*;
+#pragma unroll
+            for (int i = 0; i < KP; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_ptr)(Ks + buf * KT + (4 * i + (wave & 3)) * 1024), 16, kdma_g[i],
+                                                         ((SPLIT ? ks_b : 0) + ks_t) * (kKVTile * RB), 0, 0);
+#endif
+        };
+        auto dma_v = [&](int buf) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            using lds_ptr = __attribute__((address_space(3))) void*;
+#pragma unroll
+            for (int i = 0; i < VP; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_ptr)(Vs + buf * VTILE + (4 * i + (wave & 3)) * 1024), 16, vdma_g[i],
+                                                         ((SPLIT ? vs_b : 0) + vs_t) * (kKVTile * RB), 0, 0);
+#endif
+        };
+        // phase barriers.  DMA: raw s_barrier (a fence would drain the DMA queue at every barrier); a group waits for the
+        // pieces it requested at the start of its V-phase at the end of the M-phase that follows (one tile step of flight).
+        auto phase_barrier = [&](bool end_of_m) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DMA) {
+                if (end_of_m) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            } else {
+                __syncthreads();
+            }
+            __builtin_amdgcn_sched_barrier(0);
         };
         bool have_k = true, have_v = true;   // kst / vst hold a requested tile that is not in LDS yet
 
@@ -425,12 +494,18 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
         };
 
         auto qk = [&](int buf) __attribute__((always_inline)) {  // S^T = K_tile . Q^T
-            const char* kb = Ks + buf * KTILE + ka_base;
+            const char* kb = Ks + buf * KT + (DMA ? 0 : ka_base);
             constexpr int kAhead = AULE_PS_QK_AHEAD;
             u32x4_t kf[KS][2];
             auto rd = [&](int ks) __attribute__((always_inline)) {
-                kf[ks][0] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32);
-                kf[ks][1] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32 + 32 * RBP);
+                if constexpr (DMA) {   // swizzled chunk: (2 ks + hi) ^ swz(row) = one XOR on the byte offset
+                    const int a = ka_base ^ (ks * 32);
+                    kf[ks][0] = *reinterpret_cast<const u32x4_t*>(kb + a);
+                    kf[ks][1] = *reinterpret_cast<const u32x4_t*>(kb + a + 32 * RB);
+                } else {
+                    kf[ks][0] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32);
+                    kf[ks][1] = *reinterpret_cast<const u32x4_t*>(kb + ks * 32 + 32 * RBP);
+                }
             };
             f32x16_t z;
 #pragma unroll
@@ -673,12 +748,34 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             // ---- V-phase: staging.  Group d writes the tiles it requested one step ago (V of position P + d,
             //      K of position P + 1 + d) and requests the next ones (hazards: DESIGN.md "forward schedule";
             //      positions run through the seams, so nothing changes there).
-            if (have_v) write_v((P + grp) & 1);
-            if (have_k) write_k((P + 1 + grp) & 1);
-            have_v = vs_slot < nslot;
-            if (have_v) { issue_v(); adv_v(); }
-            have_k = ks_slot < nslot;
-            if (have_k) { issue_k(); adv_k(); }
+            if constexpr (DMA) {
+                // V cursor at tile P + 1, K cursor at tile P + 2 (every wave keeps both; group 0 requests V, group 1 K).
+                // V_{P+1} -> Vs[(P+1) % 3]: its last reader (PV of tile P - 2) finished two phases ago.  K_{P+2} -> Ks[P & 1]:
+                // its last reader (QK^T of tile P, group 1's M-phase(P - 1)) finished in the phase before this one.
+                have_v = vs_slot < nslot;
+                have_k = ks_slot < nslot;
+                if (grp == 0) {
+                    if (have_v) dma_v((P + 1) % 3);
+                } else {
+                    if (have_k) dma_k(P & 1);
+                }
+                if (have_v) adv_v();
+                if (have_k) adv_k();
+            } else {
+#ifndef AULE_PS_X_NOWRITE   // (timing experiments only, tools/ps_experiments.sh: results are garbage with either flag)
+                if (have_v) write_v((P + grp) & 1);
+                if (have_k) write_k((P + 1 + grp) & 1);
+#endif
+                have_v = vs_slot < nslot;
+                have_k = ks_slot < nslot;
+#ifdef AULE_PS_X_NOLOAD
+                if (have_v) adv_v();
+                if (have_k) adv_k();
+#else
+                if (have_v) { issue_v(); adv_v(); }
+                if (have_k) { issue_k(); adv_k(); }
+#endif
+            }
             if (ep_left > 0) drain_rows(kDrain);
             stamp(tlt + 2);
             if constexpr (MODE == 1) {
@@ -690,13 +787,11 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             if constexpr (MODE >= 1) softmax(((SPLIT ? tb : 0) + j) * kKVTile, sm_tag);
             if constexpr (!AULE_PS_YOUNG_PRIO) __builtin_amdgcn_s_setprio(0);
             stamp(tlt + 4);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
+            phase_barrier(false);
             stamp(tlt + 5);
             // ---- M-phase
             if constexpr (!AULE_PS_YOUNG_PRIO) __builtin_amdgcn_s_setprio(AULE_PS_MPRIO);
-            if constexpr (MODE >= 1) pv(P & 1);
+            if constexpr (MODE >= 1) pv(DMA ? P % 3 : (P & 1));
             if constexpr (TL && MODE >= 1) { keep_live(o[0], o[DB - 1]); stamp(tlt + 6); }
             if constexpr (MODE == 2) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -722,9 +817,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             }
             if constexpr (TL) { keep_live(s[0], s[1]); stamp(tlt + 7); }
             if constexpr (!AULE_PS_YOUNG_PRIO) __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
+            phase_barrier(true);
         };
 
         // ---- prologue of the stream: tiles 0, 1, 2 of the first part (it has >= 4) and its Q, in one HBM round trip.
@@ -738,43 +831,58 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
         enter_part(cs);
-        issue_k(); adv_k();      // K_0
-        issue_v(); adv_v();      // V_0
-        u32x4_t kpre1[CH], vpre1[CH], kpre2[CH];
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-            if (C::kFull || tid + 512 * i < C::NCHUNK) {
-                kpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], ((SPLIT ? tb : 0) + 1) * (kKVTile * RB), 0);
-                if (grp == 1) {
-                    vpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], ((SPLIT ? tb : 0) + 1) * (kKVTile * RB), 0);
-                    kpre2[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], ((SPLIT ? tb : 0) + 2) * (kKVTile * RB), 0);
+        if constexpr (DMA) {
+            // K_0 -> Ks[0], K_1 -> Ks[1] (group 1's waves), V_0 -> Vs[0] (group 0's): with Q, one HBM round trip.  Leaves
+            // the K cursor at tile 2 and the V cursor at tile 1, the state step 0 expects.
+            if (grp == 1) dma_k(0); else dma_v(0);
+            adv_k();
+            adv_v();
+            if (grp == 1) dma_k(1);
+            adv_k();
+            issue_q(qoff, q0w);
+            rotate_q(q0w);
+            take_q();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 starts one phase late
+        } else {
+            issue_k(); adv_k();      // K_0
+            issue_v(); adv_v();      // V_0
+            u32x4_t kpre1[CH], vpre1[CH], kpre2[CH];
+    #pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if (C::kFull || tid + 512 * i < C::NCHUNK) {
+                    kpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], ((SPLIT ? tb : 0) + 1) * (kKVTile * RB), 0);
+                    if (grp == 1) {
+                        vpre1[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, v_g[i], ((SPLIT ? tb : 0) + 1) * (kKVTile * RB), 0);
+                        kpre2[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, k_g[i], ((SPLIT ? tb : 0) + 2) * (kKVTile * RB), 0);
+                    }
+                }
+            adv_k();                 // K_1 requested: the K cursor stands at tile 2, the V cursor at tile 1
+            if (grp == 1) { adv_k(); adv_v(); }
+            issue_q(qoff, q0w);
+            rotate_q(q0w);
+            take_q();
+            write_k(0);
+    #pragma unroll
+            for (int i = 0; i < CH; ++i) kst[i] = kpre1[i];
+            if (grp == 1) {
+                write_v(0);
+                write_k(1);
+    #pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    vst[i] = vpre1[i];
+                    kst[i] = kpre2[i];
                 }
             }
-        adv_k();                 // K_1 requested: the K cursor stands at tile 2, the V cursor at tile 1
-        if (grp == 1) { adv_k(); adv_v(); }
-        issue_q(qoff, q0w);
-        rotate_q(q0w);
-        take_q();
-        write_k(0);
-#pragma unroll
-        for (int i = 0; i < CH; ++i) kst[i] = kpre1[i];
-        if (grp == 1) {
-            write_v(0);
-            write_k(1);
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                vst[i] = vpre1[i];
-                kst[i] = kpre2[i];
-            }
+            __syncthreads();
+            if (grp == 1) __syncthreads();  // group 1 starts one phase late
         }
-        __syncthreads();
-        if (grp == 1) __syncthreads();  // group 1 starts one phase late
         stamp(0xe1);
         qk(0);                          // pre-phase: S_0
         if constexpr (TL) { keep_live(s[0], s[1]); stamp(0xe2); }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
+        phase_barrier(false);
 
         // ---- the stream
         for (;;) {
@@ -797,7 +905,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
         }
         stamp(0xf0);
         while (ep_left > 0) drain_rows(ep_left < kDrain ? ep_left : kDrain);
-        if (grp == 0) __syncthreads();  // pairs with group 1's last phase barrier: all waves aligned again
+        if (grp == 0) phase_barrier(false);  // pairs with group 1's last phase barrier: all waves aligned again
         stamp(0xf1);
     };
 
@@ -846,7 +954,7 @@ int launch_ps(const FwdArgs& a, hipStream_t stream) {
     long long G = ncu * rounds;
     if (G > p.nitems) G = p.nitems;
     const dim3 grid((unsigned)G), block(512);
-    const size_t lds = Cfg<D>::LDS + kMaxSlot * 20 + 16;
+    const size_t lds = ps_tile_lds<D>() + kMaxSlot * 20 + 16;
     if constexpr (RAWOK && D >= 64) {
         if (a.rope_cos != nullptr) {
             if (a.causal)
@@ -996,7 +1104,7 @@ int launch_ps_split(const FwdArgs& a, hipStream_t stream) {
     p.part_rows = a.B * a.Hq * a.Sq;
     p.npiece = s.n;
     p.magic = ps_magic(s.n);
-    const size_t lds = Cfg<D>::LDS + kMaxSlot * 20 + 16;
+    const size_t lds = ps_tile_lds<D>() + kMaxSlot * 20 + 16;
     if (a.causal)
         hipLaunchKernelGGL((fa_fwd_ps_kernel<T, D, true, RAWOK, false, false, true>), dim3((unsigned)s.nitems), dim3(512), lds, stream, p);
     else
@@ -1019,7 +1127,7 @@ int launch_ps_split(const FwdArgs& a, hipStream_t stream) {
 
 template <class T, int D, bool RAWOK>
 int set_attr_ps() {
-    const int lds = Cfg<D>::LDS + kMaxSlot * 20 + 16;
+    const int lds = ps_tile_lds<D>() + kMaxSlot * 20 + 16;
     int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, true, RAWOK>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_fwd_ps_kernel<T, D, false, RAWOK>),
@@ -1068,7 +1176,7 @@ int launch_fwd_ps_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_
     long long G = ncu * rounds;
     if (G > p.nitems) G = p.nitems;
     const dim3 grid((unsigned)G), block(512);
-    const size_t lds = Cfg<128>::LDS + kMaxSlot * 20 + 16;
+    const size_t lds = ps_tile_lds<128>() + kMaxSlot * 20 + 16;
     auto go = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
