@@ -97,6 +97,13 @@ constexpr int kPSTLMax = 2048;
 #define AULE_PS_DMA 1
 #endif
 template <int D> constexpr bool ps_dma() { return AULE_PS_DMA != 0 && D >= 64; }
+// AULE_PS_DMA_SPREAD=1: a wave's DMA pieces of a step are issued one by one between the four exp blocks of the softmax
+// instead of back to back at the start of the V-phase (a piece costs 60-185 issue cycles next to other memory traffic,
+// 25-60 in a VALU-only gap: MI355X_MICROARCH "per-instruction cycle constants").  Measured same-box: 7 % SLOWER on every
+// D = 128 shape (C2 1007 -> 940 TF), D = 64 unchanged -- the burst at the start of the phase stays.
+#ifndef AULE_PS_DMA_SPREAD
+#define AULE_PS_DMA_SPREAD 0
+#endif
 // LDS of one workgroup without the part table: register path = Cfg<D>::LDS (2 padded K tiles, 2 V tiles, 8 slabs);
 // DMA path = 2 un-padded (swizzled) K tiles, 3 V tiles, 8 slabs.
 template <int D> constexpr int ps_tile_lds() {
@@ -308,20 +315,21 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
     // {0-3, 12-15, 20-27} of one chunk index) hit 16 different 16-byte bank groups.  V: the register path's image is
     // already lane-linear (thread t, chunk i at t * 16 + i * 8192).  Wave w of a group takes pieces 4 i + (w & 3).
     constexpr int KP = DMA ? (kKVTile * RB) / 4096 : 1, VP = DMA ? VTILE / 4096 : 1;
-    int kdma_g[KP], vdma_g[VP];
-    if constexpr (DMA) {
+    // (per-lane source offsets are recomputed where a piece is issued, from an opaque lane id: held in registers across the
+    // tile loop they get spilled, and the reload's vmcnt(0) would put every piece behind the previous one's HBM round trip)
+    auto kdma_off = [&](int i) __attribute__((always_inline)) {
         constexpr int SH = CPR == 16 ? 0 : (CPR == 8 ? 1 : 2);
-#pragma unroll
-        for (int i = 0; i < KP; ++i) {
-            const int q = (4 * i + (wave & 3)) * 64 + lane, r = q / CPR, cs = q % CPR;
-            kdma_g[i] = r * RB + (cs ^ ((r >> SH) & (CPR - 1))) * 16;
-        }
-#pragma unroll
-        for (int i = 0; i < VP; ++i) {
-            const int pc = 4 * i + (wave & 3), t = (pc & 7) * 64 + lane, bidx = (t >> 3) + 64 * (pc >> 3);
-            vdma_g[i] = ((bidx / (D / 16)) * 4 + ((t >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (t & 1)) * 16;
-        }
-    }
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int q = (4 * i + (wave & 3)) * 64 + lane_o, r = q / CPR, cs = q % CPR;
+        return r * RB + (cs ^ ((r >> SH) & (CPR - 1))) * 16;
+    };
+    auto vdma_off = [&](int i) __attribute__((always_inline)) {
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int pc = 4 * i + (wave & 3), t = (pc & 7) * 64 + lane_o, bidx = (t >> 3) + 64 * (pc >> 3);
+        return ((bidx / (D / 16)) * 4 + ((t >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (t & 1)) * 16;
+    };
     constexpr int SWSH = CPR == 16 ? 0 : (CPR == 8 ? 1 : 2);
     const int ka_base = DMA ? l31 * RB + ((((l31 >> SWSH) & (CPR - 1)) ^ hi) * 16) : l31 * RBP + hi * 16;
     const int va_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
@@ -395,8 +403,23 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             using lds_ptr = __attribute__((address_space(3))) void*;
 #pragma unroll
             for (int i = 0; i < KP; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_ptr)(Ks + buf * KT + (4 * i + (wave & 3)) * 1024), 16, kdma_g[i],
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_ptr)(Ks + buf * KT + (4 * i + (wave & 3)) * 1024), 16, kdma_off(i),
                                                          ((SPLIT ? ks_b : 0) + ks_t) * (kKVTile * RB), 0, 0);
+#endif
+        };
+        // one piece of this wave's share of the step's request (group 0: V tile, group 1: K tile), cursors not yet advanced
+        auto dma_piece = [&](int i, int P) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            using lds_ptr = __attribute__((address_space(3))) void*;
+            if (grp == 0) {
+                if (i < VP && vs_slot < nslot)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_ptr)(Vs + ((P + 1) % 3) * VTILE + (4 * i + (wave & 3)) * 1024), 16,
+                                                             vdma_off(i < VP ? i : 0), ((SPLIT ? vs_b : 0) + vs_t) * (kKVTile * RB), 0, 0);
+            } else {
+                if (i < KP && ks_slot < nslot)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_ptr)(Ks + (P & 1) * KT + (4 * i + (wave & 3)) * 1024), 16,
+                                                             kdma_off(i < KP ? i : 0), ((SPLIT ? ks_b : 0) + ks_t) * (kKVTile * RB), 0, 0);
+            }
 #endif
         };
         auto dma_v = [&](int buf) __attribute__((always_inline)) {
@@ -404,7 +427,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             using lds_ptr = __attribute__((address_space(3))) void*;
 #pragma unroll
             for (int i = 0; i < VP; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_ptr)(Vs + buf * VTILE + (4 * i + (wave & 3)) * 1024), 16, vdma_g[i],
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_ptr)(Vs + buf * VTILE + (4 * i + (wave & 3)) * 1024), 16, vdma_off(i),
                                                          ((SPLIT ? vs_b : 0) + vs_t) * (kKVTile * RB), 0, 0);
 #endif
         };
@@ -667,7 +690,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             }
         };
 
-        auto softmax = [&](int kv0, auto sm_tag) __attribute__((always_inline)) {
+        auto softmax = [&](int kv0, auto sm_tag, auto&& gap) __attribute__((always_inline)) {   // gap(i): filler before exp block i
             constexpr int SM = decltype(sm_tag)::value;   // 0 online (lazy rescale), 1 fixed reference, 2 first tile of a part
             const bool need_mask = (CAUSAL && (kv0 + kKVTile - 1 > q0w + coff)) || (kv0 + kKVTile > Sk);
             if (need_mask) {
@@ -721,10 +744,12 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+                for (int kk = 0; kk < 2; ++kk) {
+                    gap(2 * sb + kk);
                     pr[sb][kk] = softmax_oct<T>(s[sb][8 * kk], s[sb][8 * kk + 1], s[sb][8 * kk + 2], s[sb][8 * kk + 3],
                                                   s[sb][8 * kk + 4], s[sb][8 * kk + 5], s[sb][8 * kk + 6], s[sb][8 * kk + 7],
                                                   c, nm, a0, a1);
+                }
             l += a0 + a1;
             // pin the results of this phase HERE (register-only code is otherwise sunk past the barrier)
             asm volatile("" : "+v"(pr[0][0]), "+v"(pr[0][1]), "+v"(pr[1][0]), "+v"(pr[1][1]), "+v"(l), "+v"(m));
@@ -754,13 +779,15 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
                 // its last reader (QK^T of tile P, group 1's M-phase(P - 1)) finished in the phase before this one.
                 have_v = vs_slot < nslot;
                 have_k = ks_slot < nslot;
-                if (grp == 0) {
-                    if (have_v) dma_v((P + 1) % 3);
-                } else {
-                    if (have_k) dma_k(P & 1);
+                if constexpr (!(AULE_PS_DMA_SPREAD != 0 && MODE >= 1)) {
+                    if (grp == 0) {
+                        if (have_v) dma_v((P + 1) % 3);
+                    } else {
+                        if (have_k) dma_k(P & 1);
+                    }
+                    if (have_v) adv_v();
+                    if (have_k) adv_k();
                 }
-                if (have_v) adv_v();
-                if (have_k) adv_k();
             } else {
 #ifndef AULE_PS_X_NOWRITE   // (timing experiments only, tools/ps_experiments.sh: results are garbage with either flag)
                 if (have_v) write_v((P + grp) & 1);
@@ -784,7 +811,15 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             }
             stamp(tlt + 3);
             if constexpr (!AULE_PS_YOUNG_PRIO) __builtin_amdgcn_s_setprio(AULE_PS_VPRIO);
-            if constexpr (MODE >= 1) softmax(((SPLIT ? tb : 0) + j) * kKVTile, sm_tag);
+            if constexpr (MODE >= 1) {
+                if constexpr (DMA && AULE_PS_DMA_SPREAD != 0) {
+                    softmax(((SPLIT ? tb : 0) + j) * kKVTile, sm_tag, [&](int i) __attribute__((always_inline)) { dma_piece(i, P); });
+                    if (have_v) adv_v();
+                    if (have_k) adv_k();
+                } else {
+                    softmax(((SPLIT ? tb : 0) + j) * kKVTile, sm_tag, [](int) {});
+                }
+            }
             if constexpr (!AULE_PS_YOUNG_PRIO) __builtin_amdgcn_s_setprio(0);
             stamp(tlt + 4);
             phase_barrier(false);
