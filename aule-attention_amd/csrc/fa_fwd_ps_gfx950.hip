@@ -315,21 +315,24 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
     // {0-3, 12-15, 20-27} of one chunk index) hit 16 different 16-byte bank groups.  V: the register path's image is
     // already lane-linear (thread t, chunk i at t * 16 + i * 8192).  Wave w of a group takes pieces 4 i + (w & 3).
     constexpr int KP = DMA ? (kKVTile * RB) / 4096 : 1, VP = DMA ? VTILE / 4096 : 1;
-    // (per-lane source offsets are recomputed where a piece is issued, from an opaque lane id: held in registers across the
-    // tile loop they get spilled, and the reload's vmcnt(0) would put every piece behind the previous one's HBM round trip)
-    auto kdma_off = [&](int i) __attribute__((always_inline)) {
+    // Per-lane source offset of piece 0; piece i is 4096 bytes further on in both maps (16 more rows of K; V: the sub-tile
+    // index advances by 32), which goes into the instruction's scalar offset.  Recomputed once per step from an opaque
+    // lane id: held in a register across the tile loop it gets spilled, and the reload's vmcnt(0) would put the request
+    // behind the previous one's HBM round trip.
+    auto kdma_off0 = [&]() __attribute__((always_inline)) {
         constexpr int SH = CPR == 16 ? 0 : (CPR == 8 ? 1 : 2);
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
-        const int q = (4 * i + (wave & 3)) * 64 + lane_o, r = q / CPR, cs = q % CPR;
+        const int q = (wave & 3) * 64 + lane_o, r = q / CPR, cs = q % CPR;
         return r * RB + (cs ^ ((r >> SH) & (CPR - 1))) * 16;
     };
-    auto vdma_off = [&](int i) __attribute__((always_inline)) {
+    auto vdma_off0 = [&]() __attribute__((always_inline)) {
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
-        const int pc = 4 * i + (wave & 3), t = (pc & 7) * 64 + lane_o, bidx = (t >> 3) + 64 * (pc >> 3);
+        const int t = (wave & 3) * 64 + lane_o, bidx = t >> 3;
         return ((bidx / (D / 16)) * 4 + ((t >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (t & 1)) * 16;
     };
+    static_assert(!DMA || (4 * 64 / CPR) * RB == 4096, "a wave's next piece: 4096 bytes further in the K tile");
     constexpr int SWSH = CPR == 16 ? 0 : (CPR == 8 ? 1 : 2);
     const int ka_base = DMA ? l31 * RB + ((((l31 >> SWSH) & (CPR - 1)) ^ hi) * 16) : l31 * RBP + hi * 16;
     const int va_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
@@ -401,10 +404,11 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
         auto dma_k = [&](int buf) __attribute__((always_inline)) {   // the K tile at the cursor -> Ks[buf] (this wave's pieces)
 #if defined(__HIP_DEVICE_COMPILE__)   // (the LDS address-space cast does not exist in the host pass)
             using lds_ptr = __attribute__((address_space(3))) void*;
+            const int off0 = kdma_off0();
 #pragma unroll
             for (int i = 0; i < KP; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_ptr)(Ks + buf * KT + (4 * i + (wave & 3)) * 1024), 16, kdma_off(i),
-                                                         ((SPLIT ? ks_b : 0) + ks_t) * (kKVTile * RB), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_ptr)(Ks + buf * KT + (4 * i + (wave & 3)) * 1024), 16, off0,
+                                                         ((SPLIT ? ks_b : 0) + ks_t) * (kKVTile * RB) + i * 4096, 0, 0);
 #endif
         };
         // one piece of this wave's share of the step's request (group 0: V tile, group 1: K tile), cursors not yet advanced
@@ -414,21 +418,22 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
             if (grp == 0) {
                 if (i < VP && vs_slot < nslot)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_ptr)(Vs + ((P + 1) % 3) * VTILE + (4 * i + (wave & 3)) * 1024), 16,
-                                                             vdma_off(i < VP ? i : 0), ((SPLIT ? vs_b : 0) + vs_t) * (kKVTile * RB), 0, 0);
+                                                             vdma_off0(), ((SPLIT ? vs_b : 0) + vs_t) * (kKVTile * RB) + i * 4096, 0, 0);
             } else {
                 if (i < KP && ks_slot < nslot)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_ptr)(Ks + (P & 1) * KT + (4 * i + (wave & 3)) * 1024), 16,
-                                                             kdma_off(i < KP ? i : 0), ((SPLIT ? ks_b : 0) + ks_t) * (kKVTile * RB), 0, 0);
+                                                             kdma_off0(), ((SPLIT ? ks_b : 0) + ks_t) * (kKVTile * RB) + i * 4096, 0, 0);
             }
 #endif
         };
         auto dma_v = [&](int buf) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
             using lds_ptr = __attribute__((address_space(3))) void*;
+            const int off0 = vdma_off0();
 #pragma unroll
             for (int i = 0; i < VP; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_ptr)(Vs + buf * VTILE + (4 * i + (wave & 3)) * 1024), 16, vdma_off(i),
-                                                         ((SPLIT ? vs_b : 0) + vs_t) * (kKVTile * RB), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_ptr)(Vs + buf * VTILE + (4 * i + (wave & 3)) * 1024), 16, off0,
+                                                         ((SPLIT ? vs_b : 0) + vs_t) * (kKVTile * RB) + i * 4096, 0, 0);
 #endif
         };
         // phase barriers.  DMA: raw s_barrier (a fence would drain the DMA queue at every barrier); a group waits for the
