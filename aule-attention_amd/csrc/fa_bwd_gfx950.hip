@@ -234,13 +234,21 @@ __device__ __forceinline__ void store4(char* row_ptr, int d_elem, float a, float
 constexpr int kDqQBlock = 256;
 constexpr int kDqKV = 64;
 
+// AULE_DQ_DMA=1 (D >= 64): the dQ kernel's K / V images arrive by LDS-DMA (buffer_load ... lds) instead of through staging
+// registers and six ds_write_b128 per thread and tile -- as in the forward (fa_fwd_ps_gfx950.hip): un-padded row-major
+// images with the 16-byte chunks XOR-swizzled, the sub-tiled image as it was (it is lane-linear).
+#ifndef AULE_DQ_DMA
+#define AULE_DQ_DMA 1
+#endif
 template <int D>
 struct DqCfg {
     static constexpr int RB = D * 2, RBP = RB + 16, CPR = RB / 16;
-    static constexpr int RM = kDqKV * RBP, ST = kDqKV * RB, NCHUNK = kDqKV * CPR;
+    static constexpr bool kDMA = AULE_DQ_DMA != 0 && D >= 64;
+    static constexpr int RM = kDqKV * (kDMA ? RB : RBP), ST = kDqKV * RB, NCHUNK = kDqKV * CPR;
     static constexpr int CH = (NCHUNK + 511) / 512, KS = D / 16, DB = D / 32;
     static constexpr bool kFull = (NCHUNK % 512) == 0;
-    static constexpr int LDS = 4 * RM + 3 * ST;  // Krm x2, Vrm x2, Kst x3
+    static constexpr int NVRM = kDMA ? 3 : 2;        // V row-major images (DMA: group 0 requests its half two phases earlier)
+    static constexpr int LDS = (2 + NVRM) * RM + 3 * ST;  // Krm x2, Vrm x2 (DMA: x3), Kst x3
 };
 
 template <class T, int D, bool CAUSAL, bool TL = false>
@@ -262,9 +270,11 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
     using v8 = typename T::v8;
     constexpr int RB = Cfg::RB, RBP = Cfg::RBP, RM = Cfg::RM, ST = Cfg::ST, CH = Cfg::CH, KS = Cfg::KS, DB = Cfg::DB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool DMA = Cfg::kDMA;
+    constexpr int NVRM = Cfg::NVRM, CPR = Cfg::CPR;
     char* const Krm = smem;
     char* const Vrm = smem + 2 * RM;
-    char* const Kst = smem + 4 * RM;
+    char* const Kst = smem + (2 + NVRM) * RM;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -291,11 +301,52 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
         st_g[i] = row * RB + cc * 16;
         st_rm[i] = row * RBP + cc * 16;
     }
-    const int a_base = l31 * RBP + hi * 16;
+    constexpr int SWSH = CPR == 16 ? 0 : (CPR == 8 ? 1 : 2);
+    // DMA: row l31 of an un-padded image, chunk (2 ks + hi) ^ swz(row) = one XOR with 32 ks on this base (see sdp)
+    const int a_base = DMA ? l31 * RB + ((((l31 >> SWSH) & (CPR - 1)) ^ hi) * 16) : l31 * RBP + hi * 16;
     const int tr_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
 
     u32x4_t kst[CH], vst[CH];
     int t_lo = 0;  // first KV tile any row of the current Q block can see (sliding window; else 0)
+    // ---- DMA staging.  A wave instruction moves 64 x 16 bytes to a wave-uniform LDS address + lane * 16; wave w of a group
+    //      owns pieces 4 i + (w & 3) of a 16-piece (D = 64: 8-piece) image, 4096 source bytes apart in both maps, so one
+    //      per-lane offset per map + the scalar offset address them.  Row-major images: position (row r, chunk c') holds
+    //      global chunk c' ^ swz(r).  Per tile step (start of V-phase(j)):
+    //        group 0: Kst_{j+1} -> Kst[(j+1) % 3], lower half of Vrm_{j+2} -> Vrm[(j+2) % 3]
+    //        group 1: Krm_{j+2} -> Krm[j & 1],     upper half of Vrm_{j+2}
+    //      (every target's last reader finished at least one phase earlier; Vrm needs its third buffer for group 0's half);
+    //      a group waits for its requests at the end of the M-phase that follows, one barrier before their first reader.
+    constexpr int KP = DMA ? ST / 4096 : 1;   // pieces per wave and full image
+    const int rm_off0 = [&] {
+        const int q = (wave & 3) * 64 + lane, r = q / CPR, cs = q % CPR;
+        return r * RB + (cs ^ ((r >> SWSH) & (CPR - 1))) * 16;
+    }();
+    const int st_off0 = [&] {
+        const int t = (wave & 3) * 64 + lane, bidx = t >> 3;
+        return ((bidx / (D / 16)) * 4 + ((t >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (t & 1)) * 16;
+    }();
+    auto dma_img = [&](const __amdgpu_buffer_rsrc_t& rs, char* img, int off0, int t, int i0, int i1) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        using lds_ptr = __attribute__((address_space(3))) void*;
+#pragma unroll
+        for (int i = 0; i < KP; ++i)
+            if (i >= i0 && i < i1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(img + (4 * i + (wave & 3)) * 1024), 16, off0,
+                                                         (t_lo + t) * kDqKV * RB + i * 4096, 0, 0);
+#endif
+    };
+    auto phase_barrier = [&](bool end_of_m) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DMA) {
+            if (end_of_m) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            __syncthreads();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto issue_loads = [&](int t) {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
@@ -327,7 +378,24 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
         const int kv_hi = CAUSAL ? min(Sk, qb * kDqQBlock + kDqQBlock + coff) : Sk;
         t_lo = p.window > 0 ? min(max(0, qb * kDqQBlock + coff - p.window + 1) / kDqKV, (kv_hi + kDqKV - 1) / kDqKV - 1) : 0;
 
-        issue_loads(0);
+        const int nt_p = (kv_hi + kDqKV - 1) / kDqKV - t_lo;   // (= nt below)
+        if constexpr (DMA) {
+            // tiles 0 and 1 of the row-major images and tile 0 of the sub-tiled one, with Q / dO / O: one HBM round trip
+            if (grp == 0) {
+                dma_img(krs, Kst, st_off0, 0, 0, KP);
+                dma_img(vrs, Vrm, rm_off0, 0, 0, KP / 2);
+                if (nt_p > 1) dma_img(vrs, Vrm + RM, rm_off0, 1, 0, KP / 2);
+            } else {
+                dma_img(krs, Krm, rm_off0, 0, 0, KP);
+                dma_img(vrs, Vrm, rm_off0, 0, KP / 2, KP);
+                if (nt_p > 1) {
+                    dma_img(krs, Krm + RM, rm_off0, 1, 0, KP);
+                    dma_img(vrs, Vrm + RM, rm_off0, 1, KP / 2, KP);
+                }
+            }
+        } else {
+            issue_loads(0);
+        }
         v8 qf[KS], dof[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -370,18 +438,27 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
         auto sdp = [&](int t) {  // S^T = K_t.Q^T ; dP^T = V_t.dO^T
             int kro = (t & 1) * RM + a_base;
             asm volatile("" : "+v"(kro));
-            const char* krm = Krm + kro;
-            const char* vrm = Vrm + kro;
+            const char* krm = Krm + (DMA ? (t & 1) * RM : kro);
+            const char* vrm = Vrm + (DMA ? (t % 3) * RM : kro);
             f32x16_t z;
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
             constexpr int kAhead = AULE_DQ_SDP_AHEAD;
             u32x4_t ka[KS][2], va[KS][2];
             auto rd = [&](int ks) {
+                if constexpr (DMA) {
+                    const int a = a_base ^ (ks * 32);   // swizzled chunk of this lane's row (rows +32: same swizzle)
 #pragma unroll
-                for (int sb = 0; sb < 2; ++sb) {
-                    ka[ks][sb] = *reinterpret_cast<const u32x4_t*>(krm + sb * 32 * RBP + ks * 32);
-                    va[ks][sb] = *reinterpret_cast<const u32x4_t*>(vrm + sb * 32 * RBP + ks * 32);
+                    for (int sb = 0; sb < 2; ++sb) {
+                        ka[ks][sb] = *reinterpret_cast<const u32x4_t*>(krm + a + sb * 32 * RB);
+                        va[ks][sb] = *reinterpret_cast<const u32x4_t*>(vrm + a + sb * 32 * RB);
+                    }
+                } else {
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb) {
+                        ka[ks][sb] = *reinterpret_cast<const u32x4_t*>(krm + sb * 32 * RBP + ks * 32);
+                        va[ks][sb] = *reinterpret_cast<const u32x4_t*>(vrm + sb * 32 * RBP + ks * 32);
+                    }
                 }
             };
 #pragma unroll
@@ -405,7 +482,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
             }
         };
         auto dq_mm = [&](int t) {  // dQ^T += K_t^T . dS_t^T  (A = K^T by transpose read, B = dS in registers)
-            int kofs = 4 * RM + (t % 3) * ST + tr_off;
+            int kofs = (2 + NVRM) * RM + (t % 3) * ST + tr_off;
             asm volatile("" : "+v"(kofs));  // one base register + 16-bit immediates (else 32 hoisted addresses spill)
             const char* ktr = smem + kofs;
             constexpr int NST = 4 * DB, kAhead = AULE_DQ_MM_AHEAD;
@@ -480,32 +557,46 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
 
         // ---- prologue: tile 0 -> all images (all waves); group 0 holds tile 1 in registers, group 1 writes
         //      its share of tile 1 and holds tile 2.
-        write_tile(0);
-        if (nt > 1) issue_loads(1);
-        if (grp == 1) {
-            if (nt > 1) write_tile(1);
-            if (nt > 2) issue_loads(2);
+        if constexpr (DMA) {
+            phase_barrier(true);            // the part's first tiles (requested above) have landed
+            if (grp == 1) phase_barrier(false);
+        } else {
+            write_tile(0);
+            if (nt > 1) issue_loads(1);
+            if (grp == 1) {
+                if (nt > 1) write_tile(1);
+                if (nt > 2) issue_loads(2);
+            }
+            __syncthreads();
+            if (grp == 1) __syncthreads();  // group 1 starts one phase late
         }
-        __syncthreads();
-        if (grp == 1) __syncthreads();  // group 1 starts one phase late
         if (na > 0) sdp(0);             // pre-phase
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
+        phase_barrier(false);
 
         auto tile_step = [&](int j, auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
             // ---- V-phase(j): staging, then P/dS of tile j
             stamp();   // 0
-            if (j + 1 + grp < nt) write_tile(j + 1 + grp);
-            stamp();   // 1
-            if (j + 2 + grp < nt) issue_loads(j + 2 + grp);
+            if constexpr (DMA) {
+                if (grp == 0) {
+                    if (j + 1 < nt) dma_img(krs, Kst + ((j + 1) % 3) * ST, st_off0, j + 1, 0, KP);
+                    if (j + 2 < nt) dma_img(vrs, Vrm + ((j + 2) % 3) * RM, rm_off0, j + 2, 0, KP / 2);
+                } else {
+                    if (j + 2 < nt) {
+                        dma_img(krs, Krm + (j & 1) * RM, rm_off0, j + 2, 0, KP);
+                        dma_img(vrs, Vrm + ((j + 2) % 3) * RM, rm_off0, j + 2, KP / 2, KP);
+                    }
+                }
+                stamp();   // 1
+            } else {
+                if (j + 1 + grp < nt) write_tile(j + 1 + grp);
+                stamp();   // 1
+                if (j + 2 + grp < nt) issue_loads(j + 2 + grp);
+            }
             stamp();   // 2
             if constexpr (MODE >= 1) softmax((t_lo + j) * kDqKV);
             stamp();   // 3
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
+            phase_barrier(false);
             stamp();   // 4
             // ---- M-phase(j): dQ^T += K_j^T.dS_j^T ; S^T_{j+1}, dP^T_{j+1}
             __builtin_amdgcn_s_setprio(1);
@@ -519,9 +610,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
             if constexpr (TL) asm volatile("s_nop 0" : "+v"(s[1]), "+v"(dp[1]));
             stamp();   // 6
             __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
+            phase_barrier(true);
             stamp();   // 7
         };
         int j = 0;
@@ -539,7 +628,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
                     store4<T>(orow, 32 * d + 8 * g4 + 4 * hi, acc[d][4 * g4] * sc, acc[d][4 * g4 + 1] * sc,
                               acc[d][4 * g4 + 2] * sc, acc[d][4 * g4 + 3] * sc);
         }
-        if (grp == 0) __syncthreads();  // pairs with group 1's last phase barrier
+        if (grp == 0) phase_barrier(false);  // pairs with group 1's last phase barrier
     }
 }
 
