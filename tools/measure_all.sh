@@ -18,3 +18,10 @@ python tools/bwd_ab.py 2>&1 | grep -v amdgpu
 echo "--- decode / paged decode"
 python tools/bench_paged.py 2>&1 | tail -6
 python tools/bench_decode_ws.py 2>&1 | tail -6
+echo "--- RoPE + attention: fused query rotation vs two passes (tools/rope_ab.py)"
+python tools/rope_ab.py 2>&1 | grep -v amdgpu
+echo "--- small grids: route 7 on (default) / off (AULE_HIP_FWD_PSSPLIT=0) (tools/ps_split_check.py)"
+python tools/ps_split_check.py 2>&1 | grep -v amdgpu
+AULE_HIP_FWD_PSSPLIT=0 python tools/ps_split_check.py 2>&1 | grep -v amdgpu
+echo "--- fp32 kernels"
+python tools/f32_bench.py 2>&1 | grep -v amdgpu
