@@ -58,6 +58,20 @@ for dtype, B, Hq, g, Sq, Sk, D, causal, W in itertools.product(
     # the launch plans of the two-launch paths (dry runs: no device work, no allocation)
     ws = lib.aule_attention_forward_workspace_size(ctypes.byref(d))
     assert ws >= 0 and (ws == 0 or r in (4, 5, 7)), (r, ws)
+    # the causal-split plan (route 7) into a buffer of exactly the size it asks for, and into one that is too small
+    need = lib.aule_hip_debug_forward_split_plan(ctypes.byref(d), None, 0)
+    assert (need < 0) == (r == 7), (r, need)
+    if r == 7:
+        buf = (ctypes.c_int32 * (-need))()
+        assert lib.aule_hip_debug_forward_split_plan(ctypes.byref(d), buf, -need) == -need
+        assert lib.aule_hip_debug_forward_split_plan(ctypes.byref(d), buf, -need - 1) == need
+        assert ws == buf[0] * B * Hq * Sq * (D + 4) * 4, (ws, buf[0])
+    # the fused-rotation rule: host logic, the table pointers are never dereferenced
+    rp = _capi.AttnRope()
+    rp.struct_size = ctypes.sizeof(_capi.AttnRope)
+    rp.table_len, rp.table_pitch, rp.q_pos_offset, rp.cos, rp.sin = max(Sq, Sk) + 1, D // 2, (Sk - Sq if causal == 2 and Sk >= Sq else 0), 0x10000, 0x20000
+    f = lib.aule_attention_forward_rope_fusable(ctypes.byref(d), ctypes.byref(rp))
+    assert f in (0, 1) and (f == 0 or (dtype in (1, 2) and D in (64, 128) and (W == -1 or W >= Sq)))   # (a window >= Sq masks nothing)
     n += 1
 assert {0, 1, 4, 5, 6, 7} <= set(routes), routes
 b = _capi.AttnBwdDesc()
