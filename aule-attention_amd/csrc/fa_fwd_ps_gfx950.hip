@@ -92,7 +92,9 @@ constexpr int kPSTLMax = 2048;
 #endif
 
 // AULE_PS_DMA=1: K / V tiles go from global memory straight into LDS (buffer_load ... lds, 1 KiB per wave instruction)
-// instead of through 16 staging registers and ds_write_b128 (D >= 64 instances; D = 32 keeps the register path).
+// instead of through 16 staging registers and ds_write_b128 (D >= 64 instances; D = 32 keeps the register path).  A lane
+// whose source lies beyond the descriptor's range writes ZEROS into LDS (tools/probe_lds_dma.hip), exactly what the
+// register path's out-of-range loads deliver: the ragged last tile needs no clamping here either.
 #ifndef AULE_PS_DMA
 #define AULE_PS_DMA 1
 #endif
