@@ -104,7 +104,7 @@ def run_checks():
         ("bf16", 4, 32, 32, 4096, 4096, 128, False),
         ("bf16", 1, 8, 8, 1024, 512, 128, True),       # Sq > Sk, top-left
         ("bf16", 1, 8, 8, 512, 1024, 128, "bottom-right"),
-        ("bf16", 2, 8, 2, 1000, 3000, 128, "bottom-right"),
+        ("bf16", 2, 32, 8, 1000, 3000, 128, "bottom-right"),   # (128 pairs of long blocks: too many to cut -- stays on route 6)
         ("fp16", 2, 8, 8, 1024, 1024, 128, True),
         ("fp16", 1, 32, 1, 4096, 4096, 64, False),     # C5-like (MQA, D64)
         ("fp16", 8, 32, 32, 2048, 2048, 64, True),
@@ -123,6 +123,8 @@ def run_checks():
     ok &= check("fp16", 16, 16, 16, 512, 33024, 64, False, qzero=True)  # row sums 33024 > 2^15 without any overflow: verdict fails, still exact
     ok &= check("bf16", 2, 4, 4, 1024, 1024, 128, True, scale=-0.1)
     ok &= check("bf16", 2, 4, 4, 1024, 1024, 64, False, scale=0.3)
+    ok &= check("bf16", 2, 8, 2, 1000, 3000, 128, "bottom-right", want_route=7)   # few pairs, long keys: the split instances
+    ok &= check("bf16", 1, 8, 8, 4096, 4096, 128, False, want_route=7)
     # shapes that must stay on the predecessor (fewer than 4 tiles in the first part)
     ok &= check("bf16", 1, 2, 2, 64, 64, 128, True, want_route=1)
     ok &= check("bf16", 1, 2, 2, 777, 130, 128, False, want_route=1)
