@@ -104,7 +104,7 @@ def run_checks():
         ("bf16", 4, 32, 32, 4096, 4096, 128, False),
         ("bf16", 1, 8, 8, 1024, 512, 128, True),       # Sq > Sk, top-left
         ("bf16", 1, 8, 8, 512, 1024, 128, "bottom-right"),
-        ("bf16", 2, 32, 8, 1000, 3000, 128, "bottom-right"),   # (128 pairs of long blocks: too many to cut -- stays on route 6)
+        ("bf16", 4, 32, 8, 1000, 3000, 128, "bottom-right"),   # (256 pairs of blocks: one per CU -- stays on route 6)
         ("fp16", 2, 8, 8, 1024, 1024, 128, True),
         ("fp16", 1, 32, 1, 4096, 4096, 64, False),     # C5-like (MQA, D64)
         ("fp16", 8, 32, 32, 2048, 2048, 64, True),
