@@ -650,10 +650,16 @@ constexpr int kQT = 32;        // query rows per tile
 #endif
 constexpr int kDkvAhead = AULE_DKV_AHEAD;  // operand look-ahead of the dK/dV kernel's MFMA loops (steps)
 
+// AULE_DKV_DMA=1: the Q / dO tiles of the dK/dV kernel arrive by LDS-DMA (as in the forward and the dQ kernel): the
+// row-major images un-padded with the XOR chunk swizzle, the sub-tiled images as they were; one piece per wave and image.
+#ifndef AULE_DKV_DMA
+#define AULE_DKV_DMA 1
+#endif
 template <int D>
 struct DkvCfg {
     static constexpr int RB = D * 2, RBP = RB + 16, CPR = RB / 16;
-    static constexpr int RM = kQT * RBP;                 // row-major padded image
+    static constexpr bool kDMA = AULE_DKV_DMA != 0;
+    static constexpr int RM = kQT * (kDMA ? RB : RBP);   // row-major image (register staging: rows padded by 16 B)
     static constexpr int ST = kQT * RB;                  // sub-tiled image
     static constexpr int NCHUNK = kQT * CPR;             // <= 512: at most one chunk per thread and tensor
     static constexpr int KS = D / 16, DB = D / 32;
@@ -710,8 +716,17 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
     const int st_cc = (bidx % (D / 16)) * 2 + (tid & 1);
     const int st_g = st_row * RB + st_cc * 16;
     const int st_rm = st_row * RBP + st_cc * 16;
-    const int a_base = l31 * RBP + hi * 16;  // operand rows l31, chunk 2ks + hi (row-major padded images)
+    constexpr bool DMA = Cfg::kDMA;
+    constexpr int SWSH = CPR == 16 ? 0 : (CPR == 8 ? 1 : 2);
+    const int a_base = l31 * RBP + hi * 16;  // operand rows l31, chunk 2ks + hi (row-major padded images: the V slab, and Q / dO without DMA)
+    const int a_sw = l31 * RB + ((((l31 >> SWSH) & (CPR - 1)) ^ hi) * 16);   // DMA images: chunk (2 ks + hi) ^ swz(row) = a_sw ^ 32 ks
     const int tr_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
+    // DMA: wave w moves piece w (64 x 16 bytes, lane-linear in LDS) of each of the four images of a tile
+    constexpr int NPIECE = ST / 1024;   // pieces per image (D = 128: 8 -- one per wave)
+    const int rm_g = [&] {
+        const int q = wave * 64 + lane, r = q / CPR, cs = q % CPR;
+        return r * RB + (cs ^ ((r >> SWSH) & (CPR - 1))) * 16;
+    }();
 
     const int nparts = (CAUSAL && (nkb - 1 - w.blk) != w.blk) ? 2 : 1;
     for (int part = 0; part < nparts; ++part) {
@@ -754,7 +769,19 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
             const __amdgpu_buffer_rsrc_t qrs = make_srd_b(reinterpret_cast<const char*>(p.q) + qb * RB, (unsigned)Sq * RB);
             const __amdgpu_buffer_rsrc_t grs = make_srd_b(reinterpret_cast<const char*>(p.dout) + qb * RB, (unsigned)Sq * RB);
             const int q0 = qt * kQT;
-            if (stager) {
+            if constexpr (DMA) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                // tile `it` -> stage buffer it & 1 (its last readers finished before the barrier that ended iteration it - 2)
+                using lds_ptr = __attribute__((address_space(3))) void*;
+                if (wave < NPIECE) {
+                    char* base = stage0 + (it & 1) * STAGE + wave * 1024;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_ptr)(base), 16, rm_g, q0 * RB, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_ptr)(base + RM), 16, st_g, q0 * RB, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_ptr)(base + RM + ST), 16, rm_g, q0 * RB, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_ptr)(base + 2 * RM + ST), 16, st_g, q0 * RB, 0, 0);
+                }
+#endif
+            } else if (stager) {
                 qst = __builtin_amdgcn_raw_buffer_load_b128(qrs, st_g, q0 * RB, 0);
                 dst = __builtin_amdgcn_raw_buffer_load_b128(grs, st_g, q0 * RB, 0);
             }
@@ -769,7 +796,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
         };
         auto write_stage = [&](int buf) {
             char* base = stage0 + buf * STAGE;
-            if (stager) {
+            if (!DMA && stager) {
                 *reinterpret_cast<u32x4_t*>(base + st_rm) = qst;
                 *reinterpret_cast<u32x4_t*>(base + RM + tid * 16) = qst;
                 *reinterpret_cast<u32x4_t*>(base + RM + ST + st_rm) = dst;
@@ -788,6 +815,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
             issue_loads(0);
             write_stage(0);
         }
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
         for (int it = 0; it < nit; ++it) {
@@ -798,9 +826,9 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
             // the tile contributes to this wave's keys iff some query row q >= key row exists
             if ((!CAUSAL || q0 + coff + kQT - 1 >= n0w) && (W <= 0 || q0 + coff < n0w + 31 + W)) {
                 const char* base = stage0 + cur * STAGE;
-                const char* qrm = base + a_base;
+                const char* qrm = base + (DMA ? 0 : a_base);
                 const char* qtr = base + RM + tr_off;
-                const char* grm = base + RM + ST + a_base;
+                const char* grm = base + RM + ST + (DMA ? 0 : a_base);
                 const char* gtr = base + 2 * RM + ST + tr_off;
                 const char* vsl = Vslab + a_base;
                 const float* scal = reinterpret_cast<const float*>(base + 2 * RM + 2 * ST);
@@ -811,8 +839,9 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
                 {   // operands requested kDkvAhead k-steps early (hand-pipelined like the forward's M-phase loops)
                     u32x4_t qa[KS], da[KS], vb[KS];
                     auto rd = [&](int ks) __attribute__((always_inline)) {
-                        qa[ks] = *reinterpret_cast<const u32x4_t*>(qrm + ks * 32);
-                        da[ks] = *reinterpret_cast<const u32x4_t*>(grm + ks * 32);
+                        const int a = DMA ? (a_sw ^ (ks * 32)) : ks * 32;
+                        qa[ks] = *reinterpret_cast<const u32x4_t*>(qrm + a);
+                        da[ks] = *reinterpret_cast<const u32x4_t*>(grm + a);
                         vb[ks] = *reinterpret_cast<const u32x4_t*>(vsl + ks * 32);
                     };
 #pragma unroll
@@ -932,6 +961,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
             stamp();   // 3
             if (it + 1 < nit) write_stage(cur ^ 1);
             stamp();   // 4
+            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's images have landed
             __syncthreads();
             stamp();   // 5
         }
