@@ -727,6 +727,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dkdv_kernel(const BwdParams p) {
         const int q = wave * 64 + lane, r = q / CPR, cs = q % CPR;
         return r * RB + (cs ^ ((r >> SWSH) & (CPR - 1))) * 16;
     }();
+    (void)NPIECE; (void)rm_g;   // (used in the device pass only)
 
     const int nparts = (CAUSAL && (nkb - 1 - w.blk) != w.blk) ? 2 : 1;
     for (int part = 0; part < nparts; ++part) {

@@ -347,6 +347,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
     static_assert(!DMA || (4 * 64 / CPR) * RB == 4096, "a wave's next piece: 4096 bytes further in the K tile");
     // AULE_PS_DMA_HOIST=1: the offset of the one map a wave uses in the steady state (group 0: V, group 1: K) in a register
     const int dma_off_h = (AULE_PS_DMA_HOIST && DMA) ? (grp == 0 ? vdma_off0() : kdma_off0()) : 0;
+    (void)KP; (void)VP; (void)dma_off_h;   // (used in the device pass only)
     constexpr int SWSH = CPR == 16 ? 0 : (CPR == 8 ? 1 : 2);
     const int ka_base = DMA ? l31 * RB + ((((l31 >> SWSH) & (CPR - 1)) ^ hi) * 16) : l31 * RBP + hi * 16;
     const int va_off = hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
