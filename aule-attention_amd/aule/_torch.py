@@ -112,8 +112,9 @@ def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1, q_rope=None):
 
 
 def rope_fusable(q, k, causal, window, cos, sin, q_pos):
-    """Would the forward kernel rotate Q itself for this problem (aule_attention_forward_rope_fusable)?  Host logic only."""
-    lib = _capi.get_lib()
+    """Would the forward kernel rotate Q itself for this problem (aule_attention_forward_rope_fusable)?  Host logic only:
+    no device, no aule_init()."""
+    lib = _capi.load()
     if q.dtype not in _DTYPES or q.numel() == 0 or cos.stride(-1) != 1:
         return False
     d = _capi.AttnDesc()

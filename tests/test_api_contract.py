@@ -115,3 +115,23 @@ def test_rope_exports_match_reference_signatures():
     x = torch.zeros(1, 1, 8, 16)
     with pytest.raises(aule.AuleError):          # CPU tensors: no fallback
         aule.flash_attention_rope(x, x, x, cos, sin)
+
+
+def test_fused_rotation_rule_from_python():
+    """aule._torch.rope_fusable is host logic (shapes, dtypes, table geometry): it answers without a GPU, and the way
+    flash_attention_rope uses it -- fused only for inference, half-split pairs, un-padded head_dim -- is what DESIGN 3.6 says."""
+    import torch
+    from aule import _torch as at
+    q = torch.zeros(4, 32, 2048, 128, dtype=torch.bfloat16)
+    k = torch.zeros(4, 8, 2048, 128, dtype=torch.bfloat16)
+    cos, sin = aule.precompute_rope_frequencies(2048, 128, device="cpu")
+    cos, sin = cos.contiguous(), sin.contiguous()
+    assert at.rope_fusable(q, k, 1, -1, cos, sin, 0)
+    assert at.rope_fusable(q, k, 0, -1, cos, sin, 0)
+    assert not at.rope_fusable(q, k, 1, 128, cos, sin, 0)                    # sliding window: the ping-pong kernel
+    assert not at.rope_fusable(q.float(), k.float(), 1, -1, cos, sin, 0)     # fp32 kernel
+    assert not at.rope_fusable(q[..., :32].contiguous(), k[..., :32].contiguous(), 1, -1, cos[:, :16].contiguous(), sin[:, :16].contiguous(), 0)
+    assert not at.rope_fusable(q, k, 1, -1, cos[:1000], sin[:1000], 0)       # table shorter than the sequence
+    assert not at.rope_fusable(q, k, 1, -1, cos, sin, 1)                     # ... or than sequence + offset
+    assert not at.rope_fusable(q[:, :, :1], k, 0, -1, cos, sin, 0)           # one query row: a short-query route
+    assert not at.rope_fusable(q, k, 1, -1, cos.t().contiguous().t(), sin, 0)    # table rows not contiguous
