@@ -99,3 +99,53 @@ def test_partition_properties():
     # config 4: B=64 H=32 S=8192 D=128 bf16 over 8 ranks -> 512 MiB per rank, 4 GiB in total
     sizes, total = adist.gather_bytes(64, 32, 32, 8192, 128, 2, 8)
     assert sizes == [512 << 20] * 8 and total == 4 << 30
+
+
+def _worker_local(rank, world, port, q):
+    """attention_and_gather: every rank holds ONLY its own equal shard (what bench.py --gpus N does) and ends with the
+    concatenation of all shards' outputs, for both transports and several piece counts."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "aule-attention_amd"))
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from aule import dist as adist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    Bl, Hq, Hkv, S, D = 3, 4, 2, 20, 16
+
+    def shard(r):
+        rng = np.random.RandomState(100 + r)
+        return tuple(torch.from_numpy(rng.randn(*s).astype(np.float32)) for s in ((Bl, Hq, S, D), (Bl, Hkv, S, D), (Bl, Hkv, S, D)))
+
+    def attn(a, b, c, causal=True, scale=None):
+        o, _ = oracle.fwd_f64(a.numpy(), b.numpy(), c.numpy(), causal, scale)
+        return torch.from_numpy(o)
+
+    want = torch.cat([attn(*shard(r)) for r in range(world)], dim=0)
+    mine = shard(rank)
+    ok = True
+    for transport in ("allgather", "p2p"):
+        for chunks in (1, 2, 3, 7):
+            full = adist.attention_and_gather(*mine, causal=True, attn_fn=attn, chunks=chunks, transport=transport)
+            ok = ok and tuple(full.shape) == (world * Bl, Hq, S, D) and bool(torch.equal(full, want))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_local_shards_gathered(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_local, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
