@@ -36,18 +36,24 @@ bool fwd_ps_rope_fusable(const FwdArgs& a);
 bool fwd_ps_split_applicable(const FwdArgs& a);            // small causal grids: pairs cut in two, partials + merge
 int launch_fwd_ps_split(const FwdArgs& a, hipStream_t stream);
 int configure_fwd_ps();
+int launch_fwd_w4(const FwdArgs& a, hipStream_t stream);   // fa_fwd_w4_gfx950.hip (one wave per SIMD, 4 x 64 rows)
+bool fwd_w4_applicable(const FwdArgs& a);
+int configure_fwd_w4();
 
-// AULE_HIP_FWD_KERNEL=pp keeps every tiled problem on the ping-pong kernel (A/B measurements against the stream)
+// AULE_HIP_FWD_KERNEL=pp keeps every tiled problem on the ping-pong kernel, =ps on the two-waves-per-SIMD tile stream (A/B
+// measurements against the one-wave-per-SIMD kernel)
 static int fwd_kernel_choice() {
     static const int v = [] {
         const char* e = getenv("AULE_HIP_FWD_KERNEL");
         if (e != nullptr && e[0] == 'p' && e[1] == 'p') return 4;
+        if (e != nullptr && e[0] == 'p' && e[1] == 's') return 6;
         return 0;
     }();
     return v;
 }
-static bool use_ps(const FwdArgs& a) { return fwd_kernel_choice() == 0 && fwd_ps_applicable(a); }
-static bool use_ps_split(const FwdArgs& a) { return fwd_kernel_choice() == 0 && fwd_ps_split_applicable(a); }
+static bool use_ps(const FwdArgs& a) { return fwd_kernel_choice() != 4 && fwd_ps_applicable(a); }
+static bool use_ps_split(const FwdArgs& a) { return fwd_kernel_choice() != 4 && fwd_ps_split_applicable(a); }
+static bool use_w4(const FwdArgs& a) { return fwd_kernel_choice() == 0 && fwd_w4_applicable(a); }
 
 bool splitkv_applicable(const FwdArgs& a);                      // fa_fwd_splitkv_gfx950.hip
 int launch_fwd_splitkv(const FwdArgs& a, hipStream_t stream);
@@ -81,16 +87,19 @@ static int short_query_route(const FwdArgs& a) {
 }
 
 // Which kernel launch_fwd() picks for `a` (host logic only, no device work): 0 fp32, 1 ping-pong, 4 split-KV,
-// 5 ping-pong kernel with packed rows + KV splits, 6 persistent tile stream, 7 tile stream with every pair of causal Q
-// blocks cut in two (small grids; partials + merge) (2 and 3 were the removed in-wave and lock-step kernels).  Lets the tests pin the path a shape exercises.
+// 5 ping-pong kernel with packed rows + KV splits, 6 persistent tile stream (two waves per SIMD), 7 tile stream with every
+// pair of causal Q blocks cut in two (small grids; partials + merge), 8 persistent stream with one wave per SIMD (4 x 64 rows)
+// (2 and 3 were the removed in-wave and lock-step kernels).  Lets the tests pin the path a shape exercises.
 int fwd_route(const FwdArgs& a) {
     if (a.dtype == kF32) return 0;
     const int sq = short_query_route(a);
     if (sq) return sq;
     if (use_ps_split(a)) return 7;
+    if (use_w4(a)) return 8;
     return use_ps(a) ? 6 : 1;
 }
 
+// (arguments that carry rotation tables never take route 8: fwd_w4_applicable refuses them, so they land on the stream that fuses the rotation)
 bool fwd_rope_fusable(const FwdArgs& a) { return fwd_route(a) == 6 && fwd_ps_rope_fusable(a); }
 
 uint64_t fwd_workspace_bytes(FwdArgs a) {
@@ -116,6 +125,7 @@ int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (sq == 0 && a.dtype != kF32 && use_ps_split(a)) return launch_fwd_ps_split(a, stream);
     if (a.query_ws != nullptr) return 0;   // single-launch paths need no workspace
     if (a.dtype == kF32) return launch_fwd_f32(a, stream);
+    if (use_w4(a)) return launch_fwd_w4(a, stream);
     if (use_ps(a)) return launch_fwd_ps(a, stream);
     return launch_fwd_pp(a, stream);   // window, fewer than four KV tiles per Q block, AULE_HIP_FWD_KERNEL=pp
 }
@@ -125,6 +135,7 @@ int configure_fwd() {
     rc |= configure_fwd_f32();
     rc |= configure_fwd_pp();
     rc |= configure_fwd_ps();
+    rc |= configure_fwd_w4();
     return rc;
 }
 

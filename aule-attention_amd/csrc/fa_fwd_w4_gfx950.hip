@@ -1,0 +1,574 @@
+// fa_fwd_w4_gfx950.hip -- FlashAttention-2 forward (16-bit I/O), ONE WAVE PER SIMD: workgroup = 4 waves x 64 query rows.
+//
+// Replaces python/aule/triton_flash_amd.py:97-240 (_flash_attn_fwd_amd; the tile shapes it autotunes over: :58-95) at the
+// headline shapes.  The predecessors (fa_fwd_ps_gfx950.hip, fa_fwd_pp_gfx950.hip) put two 32-row waves on every SIMD: one
+// ds_read_b128 per QK^T MFMA, two transpose reads per PV MFMA, two barriers per tile, 57 cycles per MFMA measured.  Here
+//
+//   * a wave owns the whole 512-register file of its SIMD: O^T (128 registers), the Q fragments (64) and ONE K tile (64)
+//     live in accumulator registers, one V tile (64) in the top arch VGPRs, all named literally by the instruction
+//     streams of fa_fwd_w4_asm.inc (generated: tools/gen_w4.py, register map in its docstring); hipcc gets v0-v191 for the
+//     scores, the packed P, the softmax temporaries and addresses (amdgpu_num_vgpr(192));
+//   * a wave computes TWO 32-row blocks (A, B) against every K / V fragment it reads: 48 LDS reads per 64 MFMAs;
+//   * the softmax runs in the gaps of the wave's own MFMAs: a tile step is phase 1 [S_{j+1} = K_{j+1} Q^T | softmax of
+//     S_j[B] | V_j transpose reads | LDS-DMA requests] and phase 2 [O^T += V_j^T P_j^T | softmax of S_{j+1}[A] | K_{j+2}
+//     reads], 32 MFMAs each, every filler placed by the generator; ONE barrier per tile;
+//   * K / V tiles arrive by LDS-DMA into 2-deep rings (K three tiles ahead of the PV tile, V one), the images of the
+//     predecessor (K rows with XOR-swizzled 16-byte chunks, V in [kv/4][d/16][4][16] sub-tiles);
+//   * persistent grid, one workgroup per CU walking a list of 256-row Q blocks ("parts": the (n-1-i, i) causal pairs), the
+//     next part's first tiles and its Q requested while this part finishes.
+//
+// Softmax: fixed reference: m_ref = row maximum of tile 0, P = exp2(S c - m_ref) for every tile, a range
+// verdict on the row sums at the end of the part.  A part that fails it is run again after the stream with the EXACT
+// row maximum as reference (one extra QK^T-only pass over its tiles), so the fast path is the only softmax code.
+//
+// Covers: bf16 / fp16, D = 128 / 64, causal (top-left or shifted by coff >= 0) and non-causal, scale > 0, any Sq, every part
+// with at least 4 KV tiles, no window, no fused rotation -- everything else stays on the predecessors.
+#include <cstdlib>
+#include <type_traits>
+
+#include "fa_device.h"
+#include "fa_kernels.h"
+#include "fa_fwd_tile.h"
+
+namespace aule_hip {
+namespace {
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // (literal registers above the compiler's budget are "reserved": that is the point)
+#include "fa_fwd_w4_asm.inc"
+
+struct FwdW4Params {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* o;
+    float* lse;
+    int B, Hq, Hkv, Sq, Sk;
+    float c;      // scale * log2(e) > 0
+    int nqb;      // 256-row Q blocks
+    int nwork;    // work items per head: ceil(nqb/2) when pairing, else nqb
+    int pair;     // item = Q blocks (nqb-1-i, i)
+    int coff;     // causal position offset (query i sits at position i + coff)
+    int nitems;   // nwork * B * Hq; workgroup g takes items g, g + gridDim.x, ...
+    unsigned long long* dbg;   // timeline build only: [4 waves][kW4TLMax] tagged s_memtime stamps of workgroup 0
+};
+
+constexpr int kW4TLMax = 2048;
+constexpr int kW4MaxItems = 64;              // per workgroup (the host sizes the grid accordingly)
+constexpr int kW4MaxSlot = 2 * kW4MaxItems;  // parts: two per item (the second one invalid for an unpaired block)
+
+__device__ __forceinline__ int w4_rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+template <int N>
+__device__ __forceinline__ float w4_acc_read() {
+    float x = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "n"(N));
+#endif
+    return x;
+}
+
+// O^T block (QB, d) -> registers -> scaled, rounded, written transposed into the slab row of this lane: lane (q, hi) owns columns
+// 32 d + 8 g + 4 hi .. + 3 of row q in accumulator registers 4 g .. 4 g + 3 of block d
+template <class T, int DB, int BASE, int I = 0>
+__device__ __forceinline__ void w4_pack_block(char* dst, float inv) {
+    if constexpr (I < DB * 4) {
+        constexpr int d = I / 4, g4 = I % 4, N = BASE + d * 16 + 4 * g4;
+        u32x2_t u;
+        u[0] = T::pack2(w4_acc_read<N>() * inv, w4_acc_read<N + 1>() * inv);
+        u[1] = T::pack2(w4_acc_read<N + 2>() * inv, w4_acc_read<N + 3>() * inv);
+        *reinterpret_cast<u32x2_t*>(dst + (32 * d + 8 * g4) * 2) = u;
+        w4_pack_block<T, DB, BASE, I + 1>(dst, inv);
+    }
+}
+
+template <int D> constexpr int w4_lds_bytes() {
+    return 4 * 64 * 2 * D + 8 * 32 * (2 * D + 16) + kW4MaxSlot * 20 + 16;
+}
+
+template <class T, int D, bool CAUSAL, bool TL>
+__device__ __forceinline__ void w4_body(const FwdW4Params& p) {
+    using A = W4Asm<T, D>;
+    using std::integral_constant;
+    constexpr int RB = 2 * D, RBP = RB + 16, CPR = RB / 16, KS = D / 16, DB = D / 32;
+    constexpr int KT = 64 * RB, VT = KT, NP = KT / 4096;
+    constexpr int SLAB = 32 * RBP;   // one 32-row block of O, rows padded by 16 bytes
+    constexpr int OFF_V = 2 * KT, OFF_SLAB = OFF_V + 2 * VT, TLDS = OFF_SLAB + 8 * SLAB;
+    static_assert(A::NP == NP, "generator / kernel disagree on the tile geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = w4_rfl(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    int4* const tab = reinterpret_cast<int4*>(smem + TLDS);                       // [kW4MaxSlot] {q row offset, kv row offset, qb | -1, -}
+    int* const redo = reinterpret_cast<int*>(smem + TLDS + kW4MaxSlot * 16);      // [kW4MaxSlot] range verdicts, [kW4MaxSlot] = any
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#else
+    const unsigned lds0 = 0;
+#endif
+
+    const int Sq = p.Sq, Sk = p.Sk, coff = p.coff;
+    const float c = p.c;
+    int tl_n = 0;
+    auto stamp = [&](int tag) __attribute__((always_inline)) {   // timeline build: (tag << 56) | shader clock
+        if constexpr (TL) {
+            if (blockIdx.x == 0 && tl_n < kW4TLMax) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0) p.dbg[wave * kW4TLMax + tl_n] = (t & 0x00ffffffffffffffull) | ((unsigned long long)tag << 56);
+                ++tl_n;
+            }
+        }
+    };
+
+    // ---- part table: thread t describes part (t & 1) of this workgroup's item t >> 1
+    const int G = (int)gridDim.x;
+    const int nit = (p.nitems - (int)blockIdx.x + G - 1) / G;
+    const int nslot = 2 * nit;
+    if (tid < nslot) {
+        int qb = -1;
+        const WorkItem w = decode_work((int)blockIdx.x + (tid >> 1) * G, p.B, p.Hq, p.Hkv, p.nwork, false);
+        if (p.pair) {
+            const int far = p.nqb - 1 - w.blk;       // the larger block of the pair goes first
+            if ((tid & 1) == 0) qb = far;
+            else if (far != w.blk) qb = w.blk;
+        } else if ((tid & 1) == 0) {
+            qb = w.blk;
+        }
+        tab[tid] = int4{(w.b * p.Hq + w.h) * Sq, (w.b * p.Hkv + w.hk) * Sk, qb, 0};
+        redo[tid] = 0;
+    }
+    if (tid == 0) redo[kW4MaxSlot] = 0;
+    __syncthreads();
+
+    auto next_valid = [&](int slot) __attribute__((always_inline)) {
+        do {
+            ++slot;
+        } while (slot < nslot && w4_rfl(tab[slot].z) < 0);
+        return slot;
+    };
+    auto nt_of = [&](int qb) __attribute__((always_inline)) {
+        const int kv_hi = CAUSAL ? max(1, min(Sk, qb * kQBlock + kQBlock + coff)) : Sk;
+        return (kv_hi + kKVTile - 1) / kKVTile;
+    };
+    auto head_srd = [&](const void* base, int rowoff, int rows) __attribute__((always_inline)) {
+        return make_srd(reinterpret_cast<const char*>(base) + (size_t)(unsigned)rowoff * RB, (unsigned)rows * RB);
+    };
+
+    // ---- lane constants: LDS addresses of the operand reads, per-lane source offsets of the DMA pieces
+    constexpr int SWSH = CPR == 16 ? 0 : 1;
+    unsigned ka[KS];   // K fragment (ks, h = 0) of ring slot 0: chunk (2 ks + hi) ^ swz(row) of row l31; h = 1: + 32 rows
+    {
+        const unsigned ka_base = (unsigned)(l31 * RB + ((((l31 >> SWSH) & (CPR - 1)) ^ hi) * 16));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) ka[ks] = lds0 + (ka_base ^ (unsigned)(ks * 32));
+    }
+    const unsigned va = lds0 + OFF_V + (unsigned)(hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8);
+    // per-lane source offset of this wave's piece 0 of a K / V tile; piece i: + 4096 bytes in both maps (16 more rows of K; V: 32
+    // sub-tiles further), which goes into the request's scalar offset
+    unsigned kvo, vvo;
+    {
+        const int q = wave * 64 + lane, r = q / CPR, cs = q % CPR;
+        kvo = (unsigned)(r * RB + (cs ^ ((r >> SWSH) & (CPR - 1))) * 16);
+        const int bidx = q >> 3;
+        vvo = (unsigned)(((bidx / (D / 16)) * 4 + ((q >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (q & 1)) * 16);
+    }
+    A::set_consts();
+    const unsigned wave1k = (unsigned)wave * 1024u;
+    const unsigned oob = (unsigned)Sk * RB;   // a scalar offset at which every lane of a request is out of range (LDS gets zeros)
+
+    auto step_end = [&]() __attribute__((always_inline)) {   // every request of this step landed, every LDS read returned; one barrier per tile
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    auto run_stream = [&](auto redo_tag) __attribute__((always_inline)) {
+        constexpr bool REDO = decltype(redo_tag)::value != 0;
+        int cs = next_valid(-1);
+        if (cs >= nslot) return;
+
+        // ---- part scalars.  A part spans nte = nt rounded up to even ring positions (an odd part ends with one idle
+        //      step), so tile j of EVERY part sits in ring slot j & 1 and parities are compile-time.
+        int qoff, kvoff, qb, nt, nte, na, jm, r0;
+        int n_slot, n_qoff = 0, n_kvoff = 0, n_qb = 0;
+        bool pre = false;           // the next part's K_0, K_1, V_0 and Q ride along with this part's last steps
+        // request cursors: what step j asks for (K tile j + 3, V tile j + 1); soff == oob: nothing
+        __amdgpu_buffer_rsrc_t ksrd, vsrd;
+        unsigned ksoff, vsoff;
+        auto enter_part = [&](int slot) __attribute__((always_inline)) {
+            const int4 e = tab[slot];
+            qoff = w4_rfl(e.x);
+            kvoff = w4_rfl(e.y);
+            qb = w4_rfl(e.z);
+            nt = nt_of(qb);
+            nte = (nt + 1) & ~1;
+            r0 = qb * kQBlock + wave * 64;
+            const int vis = CAUSAL ? min(Sk, r0 + 64 + coff) : Sk;   // keys the wave's last row sees
+            na = min(nt, max(1, (vis + kKVTile - 1) / kKVTile));
+            const int min_thr = CAUSAL ? min(r0 + coff, Sk - 1) : Sk - 1;   // keys EVERY row of the wave sees: 0 .. min_thr
+            jm = (min_thr + 1) >> 6;                                        // first tile that needs the mask
+            n_slot = next_valid(slot);
+            pre = !REDO && n_slot < nslot;
+            if (n_slot < nslot) {
+                const int4 en = tab[n_slot];
+                n_qoff = w4_rfl(en.x);
+                n_kvoff = w4_rfl(en.y);
+                n_qb = w4_rfl(en.z);
+            }
+            ksrd = head_srd(p.k, kvoff, Sk);
+            vsrd = head_srd(p.v, kvoff, Sk);
+            ksoff = 3u * KT;        // (every part has at least four tiles)
+            vsoff = (unsigned)VT;
+            A::zero_sums();
+        };
+        // last visible key (minus 4 hi) of the lane's row in block QB, relative to tile j (recomputed where a mask is needed:
+        // a handful of tiles per part)
+        auto thr_of = [&](int qbsel, int j) __attribute__((always_inline)) {
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int row = r0 + 32 * qbsel + (lane_o & 31) + coff;
+            return (CAUSAL ? min(row, Sk - 1) : Sk - 1) - (lane_o >> 5) * 4 - 64 * j;
+        };
+        // after step j's requests: the cursors of step j + 1 (K tile j + 4: this part's, or tile 0 / 1 of the next part --
+        // its prologue reads those two before it requests more; V tile j + 2, or the next part's V_0)
+        auto advance = [&](int j) __attribute__((always_inline)) {
+            if (__builtin_expect(j + 4 < nt, 1)) {   // (one compare in the steady state: this sits between the two phases of a plain step)
+                ksoff += KT;
+                vsoff += VT;
+                return;
+            }
+            const int tk = j + 4, tv = j + 2;
+            if (pre && tk == nte) { ksrd = head_srd(p.k, n_kvoff, Sk); ksoff = 0; }
+            else if (pre && tk == nte + 1) ksoff = KT;
+            else ksoff = oob;
+            if (tv < nt) vsoff += VT;
+            else if (pre && tv == nte) { vsrd = head_srd(p.v, n_kvoff, Sk); vsoff = 0; }
+            else vsoff = oob;
+        };
+        auto issue_q = [&](int q_off, int q_b) __attribute__((always_inline)) {   // rows >= Sq read as 0
+            const __amdgpu_buffer_rsrc_t qrs = head_srd(p.q, q_off, Sq);
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const unsigned vo = (unsigned)((q_b * kQBlock + wave * 64 + (lane_o & 31)) * RB + (lane_o >> 5) * 16);
+            A::load_q(qrs, vo, vo + 32 * RB);
+        };
+        // - m_ref of block BLK from the scores of tile 0 (lane-local 32 values + the other half's)
+        auto neg_ref = [&](auto blk_tag, bool masked, int thr) __attribute__((always_inline)) {
+            constexpr int BLK = decltype(blk_tag)::value;
+            float mx = masked ? A::template rowmax<BLK, 1>(thr) : A::template rowmax<BLK, 0>(thr);
+            mx = fmaxf(mx, xhalf_fast(mx));
+            return -(mx * c);
+        };
+        // the requests of a step as separate statements (everywhere but the plain step, which carries them in its gaps).  An
+        // out-of-range request would write ZEROS into its ring slot -- harmless in a plain step, whose slots are free by
+        // construction, but at a part's last step the K slot already holds the next part's K_0: skipped here.
+        auto requests = [&](auto par_tag, int j) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_tag)::value;
+            if (ksoff != oob) A::dma_tile(lds0 + (PAR ^ 1) * KT + wave1k, ksrd, ksoff, kvo);
+            if (vsoff != oob) A::dma_tile(lds0 + OFF_V + (PAR ^ 1) * VT + wave1k, vsrd, vsoff, vvo);
+            advance(j);
+        };
+
+        // ---- tile step j (PAR = j & 1: ring slots and the S[B] / P[A] copies in use)
+        // plain: nothing masked, not the first, not the last tile of the wave
+        constexpr unsigned HP = (NP / 2 > 0 ? NP / 2 : 1) * 4096u;   // bytes of the pieces one statement requests
+        auto plain = [&](auto par_tag, int j) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_tag)::value;
+            stamp(0x10 + PAR);
+            const unsigned kl = lds0 + (PAR ^ 1) * KT + wave1k, vl = lds0 + OFF_V + (PAR ^ 1) * VT + wave1k;
+            A::template p1<0, PAR, 1, 1, 1, 1>(c, va, 0, kl, ksrd, ksoff, ksoff + 4096u, kvo);
+            A::template p1<1, PAR, 1, 1, 1, 1>(c, va, 0, kl, ksrd, ksoff + HP, ksoff + HP + 4096u, kvo);
+            A::template p1<2, PAR, 1, 1, 1, 1>(c, va, 0, vl, vsrd, vsoff, vsoff + 4096u, vvo);
+            A::template p1<3, PAR, 1, 1, 1, 1>(c, va, 0, vl, vsrd, vsoff + HP, vsoff + HP + 4096u, vvo);
+            advance(j);
+            A::template p2<0, PAR, 1, 1, 1>(c, ka[0], ka[KS / 4 - 1], 0);
+            A::template p2<1, PAR, 1, 1, 1>(c, ka[KS / 4], ka[2 * (KS / 4) - 1], 0);
+            A::template p2<2, PAR, 1, 1, 1>(c, ka[2 * (KS / 4)], ka[3 * (KS / 4) - 1], 0);
+            A::template p2<3, PAR, 1, 1, 1>(c, ka[3 * (KS / 4)], ka[KS - 1], 0);
+            step_end();
+        };
+        // QK: S of tile j + 1 is computed (not the wave's last tile).  SM: 1 plain, 2 masked (both softmax halves).  PV: 1, or 2 for tile 0.
+        auto step = [&](auto par_tag, auto qk_tag, auto sm_tag, auto pv_tag, int j) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_tag)::value, QK = decltype(qk_tag)::value, SM = decltype(sm_tag)::value, PV = decltype(pv_tag)::value;
+            stamp(0x20 + PAR + 2 * QK + 4 * SM);
+            requests(par_tag, j);
+            const int tB = SM == 2 ? thr_of(1, j) : 0;
+            A::template p1<0, PAR, QK, SM, 1, 0>(c, va, tB, 0, ksrd, 0, 0, 0);
+            A::template p1<1, PAR, QK, SM, 1, 0>(c, va, tB, 0, ksrd, 0, 0, 0);
+            A::template p1<2, PAR, QK, SM, 1, 0>(c, va, tB, 0, ksrd, 0, 0, 0);
+            A::template p1<3, PAR, QK, SM, 1, 0>(c, va, tB, 0, ksrd, 0, 0, 0);
+            constexpr int SMA = QK ? SM : 0;
+            const int tA = SMA == 2 ? thr_of(0, j + 1) : 0;
+            A::template p2<0, PAR, PV, SMA, 1>(c, ka[0], ka[KS / 4 - 1], tA);
+            A::template p2<1, PAR, PV, SMA, 1>(c, ka[KS / 4], ka[2 * (KS / 4) - 1], tA);
+            A::template p2<2, PAR, PV, SMA, 1>(c, ka[2 * (KS / 4)], ka[3 * (KS / 4) - 1], tA);
+            A::template p2<3, PAR, PV, SMA, 1>(c, ka[3 * (KS / 4)], ka[KS - 1], tA);
+            step_end();
+        };
+        auto idle = [&](int j) __attribute__((always_inline)) {   // a tile this wave does not see (or the padding step of an odd part)
+            stamp(0x08);
+            if (j & 1) requests(integral_constant<int, 1>{}, j);
+            else requests(integral_constant<int, 0>{}, j);
+            step_end();
+        };
+        // part prologue = "step -1" (K_0, K_1, V_0 of the part in the ring, Q requested): S_0, the references, P_0[A]; leaves K_1
+        // in the fragment registers and K_2 requested
+        auto prologue = [&]() __attribute__((always_inline)) {
+            stamp(0x30);
+            A::template kread_all<0>(ka);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Q fragments
+            A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
+            A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
+            A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
+            A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
+            asm volatile("s_barrier" ::: "memory");            // every wave holds K_0: its ring slot takes K_2
+            A::dma_tile(lds0 + wave1k, ksrd, (unsigned)(2 * KT), kvo);
+            const int tA = thr_of(0, 0);
+            if constexpr (!REDO) {
+                A::template set_ref<0>(neg_ref(integral_constant<int, 0>{}, jm == 0, tA));
+                A::template set_ref<1>(neg_ref(integral_constant<int, 1>{}, jm == 0, thr_of(1, 0)));
+            }
+            if (jm == 0) {
+                A::template p2<0, 1, 0, 2, 1>(c, ka[0], ka[KS / 4 - 1], tA);
+                A::template p2<1, 1, 0, 2, 1>(c, ka[KS / 4], ka[2 * (KS / 4) - 1], tA);
+                A::template p2<2, 1, 0, 2, 1>(c, ka[2 * (KS / 4)], ka[3 * (KS / 4) - 1], tA);
+                A::template p2<3, 1, 0, 2, 1>(c, ka[3 * (KS / 4)], ka[KS - 1], tA);
+            } else {
+                A::template p2<0, 1, 0, 1, 1>(c, ka[0], ka[KS / 4 - 1], tA);
+                A::template p2<1, 1, 0, 1, 1>(c, ka[KS / 4], ka[2 * (KS / 4) - 1], tA);
+                A::template p2<2, 1, 0, 1, 1>(c, ka[2 * (KS / 4)], ka[3 * (KS / 4) - 1], tA);
+                A::template p2<3, 1, 0, 1, 1>(c, ka[3 * (KS / 4)], ka[KS - 1], tA);
+            }
+            step_end();
+        };
+
+        // ---- epilogue of a part: O = O^T / l, rounded, transposed through the wave's two LDS slabs, whole-row stores; LSE;
+        //      range verdict of the fixed reference
+        auto epilogue = [&]() __attribute__((always_inline)) {
+            stamp(0x40);
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the last PV MFMAs -> v_accvgpr_read
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int l31o = lane_o & 31, hio = lane_o >> 5;
+            char* const slab = smem + OFF_SLAB + wave * 2 * SLAB;
+            const __amdgpu_buffer_rsrc_t lrs = make_srd(p.lse + (size_t)(unsigned)qoff, p.lse != nullptr ? (unsigned)Sq * 4u : 0u);
+            bool bad = false;
+            auto half = [&](auto qb_tag) __attribute__((always_inline)) {
+                constexpr int QB = decltype(qb_tag)::value;
+                float lt, nm;
+                A::template get_sums<QB>(lt, nm);
+                lt += xhalf_fast(lt);
+                const float inv = __builtin_amdgcn_rcpf(lt);
+                w4_pack_block<T, DB, QB * DB * 16>(slab + QB * SLAB + l31o * RBP + 8 * hio, inv);
+                const float lse = (fast_log2(lt) - nm) * kLn2;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lse), lrs, hio == 0 ? (r0 + 32 * QB + l31o) * 4 : 0x7ffffff0, 0, 0);
+                if constexpr (!REDO) bad = bad || !((lt > 0x1p-100f) && (lt < (T::kDType == 2 ? 0x1p110f : 0x1p15f)));
+            };
+            half(integral_constant<int, 0>{});
+            half(integral_constant<int, 1>{});
+            if constexpr (!REDO) {
+                if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) redo[cs] = redo[kW4MaxSlot] = 1;
+            }
+            const __amdgpu_buffer_rsrc_t ors = head_srd(p.o, qoff, Sq);   // rows >= Sq are dropped by the bounds check
+#pragma unroll
+            for (int i0 = 0; i0 < CPR; i0 += 2) {
+                u32x4_t x[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int idx = (i0 + i) * 64 + lane_o, row = idx / CPR, cc = idx % CPR;
+                    x[i] = *reinterpret_cast<const u32x4_t*>(slab + (row >> 5) * SLAB + (row & 31) * RBP + cc * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int idx = (i0 + i) * 64 + lane_o, row = idx / CPR, cc = idx % CPR;
+                    __builtin_amdgcn_raw_buffer_store_b128(x[i], ors, (r0 + row) * RB + cc * 16, 0, 0);
+                }
+            }
+            stamp(0x41);
+        };
+
+        // REDO only: the exact row maxima of the part, one QK^T-only pass over its tiles through ring slot 0
+        auto max_pass = [&]() __attribute__((always_inline)) {
+            float mA = -INFINITY, mB = -INFINITY;   // in units of c
+            issue_q(qoff, qb);
+            for (int j = 0; j < nt; ++j) {
+                __syncthreads();
+                A::dma_tile(lds0 + wave1k, ksrd, (unsigned)j * KT, kvo);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (j < na) {
+                    A::template kread_all<0>(ka);
+                    A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
+                    A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
+                    A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
+                    A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
+                    mA = fmaxf(mA, -neg_ref(integral_constant<int, 0>{}, true, thr_of(0, j)));
+                    mB = fmaxf(mB, -neg_ref(integral_constant<int, 1>{}, true, thr_of(1, j)));
+                }
+            }
+            A::template set_ref<0>(-mA);
+            A::template set_ref<1>(-mB);
+            __syncthreads();
+        };
+
+        // ---- the stream
+        bool cold = true;
+        enter_part(cs);
+        for (;;) {
+            if (REDO || cold) {   // nothing of this part is in flight
+                if constexpr (REDO) max_pass();
+                else issue_q(qoff, qb);
+                A::dma_tile(lds0 + wave1k, ksrd, 0u, kvo);
+                A::dma_tile(lds0 + KT + wave1k, ksrd, (unsigned)KT, kvo);
+                A::dma_tile(lds0 + OFF_V + wave1k, vsrd, 0u, vvo);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                cold = false;
+            }
+            prologue();
+            using I0 = integral_constant<int, 0>;
+            using I1 = integral_constant<int, 1>;
+            using I2 = integral_constant<int, 2>;
+            int j = 1;
+            if (na == 1) {
+                step(I0{}, I0{}, I2{}, I2{}, 0);                      // the only tile: masked, O starts at 0
+            } else {
+                if (jm <= 1) step(I0{}, I1{}, I2{}, I2{}, 0);         // tile 0 (O starts at 0), S_1
+                else step(I0{}, I1{}, I1{}, I2{}, 0);
+                for (;;) {   // j odd at the top
+                    if (j + 1 >= na) { step(I1{}, I0{}, I2{}, I1{}, j); break; }
+                    if (j + 1 < jm) plain(I1{}, j);
+                    else step(I1{}, I1{}, I2{}, I1{}, j);
+                    ++j;
+                    if (j + 1 >= na) { step(I0{}, I0{}, I2{}, I1{}, j); break; }
+                    if (j + 1 < jm) plain(I0{}, j);
+                    else step(I0{}, I1{}, I2{}, I1{}, j);
+                    ++j;
+                }
+                ++j;
+            }
+            for (; j < nte; ++j) idle(j);
+            if (pre) issue_q(n_qoff, n_qb);   // (the Q registers are free since the wave's last QK^T)
+            epilogue();
+            if (n_slot >= nslot) break;
+            cs = n_slot;
+            enter_part(cs);
+            if constexpr (REDO) __syncthreads();
+        }
+        stamp(0x50);
+    };
+
+    run_stream(std::integral_constant<int, 0>{});
+    __syncthreads();   // every verdict posted, every LDS tile buffer idle
+    if (w4_rfl(redo[kW4MaxSlot]) != 0) {
+        __syncthreads();
+        if (tid < nslot && redo[tid] == 0) tab[tid].z = -1;   // second, sparse stream: only the flagged parts
+        __syncthreads();
+        run_stream(std::integral_constant<int, 1>{});
+    }
+}
+
+// The kernels: hipcc's VGPR budget is the generator's NV (an attribute wants a literal: one wrapper per head size).
+template <class T, bool CAUSAL, bool TL>
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(52))) fa_fwd_w4_kernel_d128(const FwdW4Params p) {
+    static_assert(W4Asm<T, 128>::NV == 52, "amdgpu_num_vgpr of the D = 128 kernel must be the generator's NV");
+    w4_body<T, 128, CAUSAL, TL>(p);
+}
+template <class T, bool CAUSAL, bool TL>
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(84))) fa_fwd_w4_kernel_d64(const FwdW4Params p) {
+    static_assert(W4Asm<T, 64>::NV == 84, "amdgpu_num_vgpr of the D = 64 kernel must be the generator's NV");
+    w4_body<T, 64, CAUSAL, TL>(p);
+}
+template <class T, int D, bool CAUSAL, bool TL>
+constexpr auto w4_kernel() {
+    if constexpr (D == 128) return &fa_fwd_w4_kernel_d128<T, CAUSAL, TL>;
+    else return &fa_fwd_w4_kernel_d64<T, CAUSAL, TL>;
+}
+
+#pragma clang diagnostic pop
+
+// CU count of the current device, queried once per device id (the launch path asks on every call)
+static int w4_cu_count() {
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] > 0) return cached[dev];
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    cached[dev] = n;
+    return n;
+}
+
+template <class T, int D, bool TL = false>
+int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nullptr) {
+    FwdW4Params p;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o; p.lse = a.lse;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
+    p.c = a.scale * kLog2e;
+    p.nqb = (a.Sq + kQBlock - 1) / kQBlock;
+    p.pair = a.causal ? 1 : 0;
+    p.nwork = p.pair ? (p.nqb + 1) / 2 : p.nqb;
+    p.coff = a.causal ? a.coff : 0;
+    p.nitems = p.nwork * a.B * a.Hq;
+    p.dbg = dbg;
+    // one workgroup per CU; more only when a workgroup's list would not fit its part table
+    const long long ncu = w4_cu_count();
+    const long long rounds = (p.nitems + ncu * kW4MaxItems - 1) / (ncu * kW4MaxItems);
+    long long G = ncu * rounds;
+    if (G > p.nitems) G = p.nitems;
+    const dim3 grid((unsigned)G), block(256);
+    const size_t lds = w4_lds_bytes<D>();
+    if (a.causal)
+        hipLaunchKernelGGL((w4_kernel<T, D, true, TL>()), grid, block, lds, stream, p);
+    else
+        hipLaunchKernelGGL((w4_kernel<T, D, false, TL>()), grid, block, lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+template <class T, int D>
+int set_attr_w4() {
+    const int lds = w4_lds_bytes<D>();
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(w4_kernel<T, D, true, false>()),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(w4_kernel<T, D, false, false>()),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return rc;
+}
+
+}  // namespace
+
+// Shapes the one-wave-per-SIMD forward takes (everything else: fa_fwd_ps_gfx950.hip / fa_fwd_pp_gfx950.hip).
+bool fwd_w4_applicable(const FwdArgs& a) {
+    if (a.dtype != kBF16 && a.dtype != kF16) return false;
+    if (a.D != 128) return false;
+    if (a.window > 0 || a.rope_cos != nullptr) return false;
+    if (!(a.scale > 0.f) || !(a.scale < 3.0e38f)) return false;
+    if (a.causal && a.coff < 0) return false;
+    // every part needs >= 4 KV tiles (its prologue consumes tiles 0 and 1 and requests tile 2 before the first plain step):
+    // the shortest part is the first Q block
+    const long long first = a.causal ? ((long long)kQBlock + a.coff < a.Sk ? (long long)kQBlock + a.coff : a.Sk) : a.Sk;
+    if (first <= 3 * kKVTile) return false;
+    // row offsets are 32-bit in the part table, byte offsets inside one head 32-bit in the buffer descriptors
+    if ((long long)a.B * a.Hq * a.Sq >= (1LL << 31) || (long long)a.B * a.Hkv * a.Sk >= (1LL << 31)) return false;
+    if ((long long)a.Sq * a.D * 2 >= (1LL << 31) || (long long)a.Sk * a.D * 2 >= (1LL << 31)) return false;
+    return true;
+}
+
+int launch_fwd_w4(const FwdArgs& a, hipStream_t stream) {
+    if (a.dtype == kBF16 && a.D == 128) return launch_w4<Bf16Traits, 128>(a, stream);
+    if (a.dtype == kF16 && a.D == 128) return launch_w4<F16Traits, 128>(a, stream);
+    return -1;
+}
+
+#ifdef AULE_DEBUG_HOOKS
+// Debug: the bf16 D = 128 kernel with tagged s_memtime stamps of workgroup 0 (tools/timeline_w4.py).
+int launch_fwd_w4_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream) {
+    if (a.dtype != kBF16 || a.D != 128 || !fwd_w4_applicable(a)) return -1;
+    const int lds = w4_lds_bytes<128>();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(w4_kernel<Bf16Traits, 128, true, true>()), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(w4_kernel<Bf16Traits, 128, false, true>()), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return launch_w4<Bf16Traits, 128, true>(a, stream, dbg);
+}
+#endif
+
+int configure_fwd_w4() { return set_attr_w4<Bf16Traits, 128>() | set_attr_w4<F16Traits, 128>(); }
+
+}  // namespace aule_hip

@@ -1,0 +1,433 @@
+#!/usr/bin/env python3
+"""Writes aule-attention_amd/csrc/fa_fwd_w4_asm.inc: the hand-placed instruction streams of the 4-wave x 64-row forward
+(fa_fwd_w4_gfx950.hip).  Run it after editing; the output is committed (the build does not need Python).
+
+One wave per SIMD owns the whole 512-register file, and the tile loop names EVERY register it uses literally.  The kernel is
+compiled with amdgpu_num_vgpr(NV): hipcc allocates v0 .. v(NV-1) only (addresses, loop scalars, the epilogue's temporaries) and
+must never touch an accumulator register -- csrc/Makefile audits the .s for that (no scratch, no v_accvgpr_* outside the
+streams).  Map for D = 128 (D = 64: the same order, half the sizes):
+
+    accumulator file                                         arch VGPRs
+    a[0:127]    O^T, block (qb, d) at a[(qb DB + d) 16 ..]   v[0:NV)      hipcc
+    a[128:191]  Q fragments (qb, ks) at a[128 + (qb KS + ks) 4 ..]     then x0-x3 (softmax temporaries), lA0 lA1 lB0 lB1 (row sums),
+    a[192:255]  K fragments of ONE tile, (ks, h) at          nmA nmB (- reference), -inf,
+                a[192 + (2 ks + h) 4 ..]                     S[A] = xa0 xa1 (2 x 16), S[B] half 0 = yb0 (16), S[B] half 1 = yb1[2] (2 x 16, by tile
+                                                             parity), P[A] = pA[2][4] (by parity, 4 registers each), P[B] = pB[4],
+                                                             V^T fragments of ONE tile (sk, d) at VB0 + (sk DB + d) 4 ..
+
+(qb = 32-row half of the wave's 64 rows: block A / B; h = 32-key half of the 64-key tile; ks = 16-wide slice of D; sk = 16-key slice.)
+
+A tile step j (PAR = j & 1) is two phases of 4 statements; a statement is n MFMAs (n = KS in phase 1, 2 DB in phase 2) with its
+fillers PLACED in the MFMA gaps (a gap hides ~5 single-issue instructions next to a 32-cycle MFMA):
+
+    phase 1, statement Q:  S_{j+1} += K_{j+1} Q^T   |  softmax of 8 scores of S_j[B] -> P_j[B][Q]  |  2 DB transpose reads of V_j
+                           (| LDS-DMA pieces of the tiles the stream requests this step)
+    phase 2, statement Q:  O^T += V_j^T P_j^T       |  softmax of 8 scores of S_{j+1}[A] -> P_{j+1}[A][Q] |  KS / 2 reads of K_{j+2}
+
+S[B] half 0 is single-buffered (its old tile is consumed in statements 0-1 of phase 1, the new one is born in statements 2-3);
+half 1 is consumed while its successor is being accumulated, hence the parity copies.  The part prologue is "step -1" (PAR = 1).
+
+Hazards the strings take care of themselves (inline asm is invisible to hipcc's hazard recogniser):
+  * v_exp_f32 result -> next VALU reader: at least one instruction between (trans forwarding);
+  * MFMA result -> VALU reader: every S block is read at least 8 MFMAs after its last MFMA; bare MFMA statements end with
+    s_nop padding;
+  * s_add m0 -> buffer_load ... lds: one instruction between;
+  * a descriptor fresh from v_readfirstlane -> VMEM: statements that open with a VMEM instruction open with s_nop 4;
+  * LDS reads are complete (s_waitcnt lgkmcnt(0)) at the end of the last statement of phase 1 / in the kernel's step_end.
+"""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "aule-attention_amd", "csrc", "fa_fwd_w4_asm.inc")
+
+
+class Cfg:
+    def __init__(self, D, dt):
+        self.D, self.dt = D, dt
+        self.RB = 2 * D
+        self.KS, self.DB = D // 16, D // 32
+        self.KT = 64 * self.RB          # bytes of a K tile in LDS
+        self.VT = 64 * self.RB
+        self.QB0 = 32 * self.DB
+        self.KB0 = self.QB0 + 8 * self.KS
+        self.NP = self.KT // 4096       # LDS-DMA pieces per wave and tile
+        self.mfma = "v_mfma_f32_32x32x16_bf16" if dt == "bf16" else "v_mfma_f32_32x32x16_f16"
+        self.cvt = "v_cvt_pk_bf16_f32" if dt == "bf16" else "v_cvt_pk_f16_f32"
+        # arch VGPR map, top down
+        self.VB0 = 256 - 16 * self.DB                  # V fragments
+        self.PB = self.VB0 - 16                        # pB[4]
+        self.PA = self.PB - 32                         # pA[2][4]
+        self.YB1 = self.PA - 32                        # yb1[2]
+        self.YB0 = self.YB1 - 16
+        self.XA = self.YB0 - 32                        # xa0, xa1
+        self.NINF = self.XA - 1
+        self.NM = self.NINF - 3                        # nmA, nmB (+ one unused: keeps the tuples above 4-aligned)
+        self.L = self.NM - 4                           # lA0 lA1 lB0 lB1
+        self.X = self.L - 4                            # x0..x3
+        self.NV = self.X                               # hipcc's budget
+        assert self.NV % 4 == 0 and self.XA % 4 == 0, (self.NV, self.XA)
+
+    def O(self, qb, d):
+        b = (qb * self.DB + d) * 16
+        return f"a[{b}:{b + 15}]"
+
+    def Q(self, qb, ks):
+        b = self.QB0 + (qb * self.KS + ks) * 4
+        return f"a[{b}:{b + 3}]"
+
+    def K(self, ks, h):
+        b = self.KB0 + (2 * ks + h) * 4
+        return f"a[{b}:{b + 3}]"
+
+    def V(self, sk, d):
+        b = self.VB0 + (sk * self.DB + d) * 4
+        return f"v[{b}:{b + 3}]"
+
+    def Vhalf(self, sk, d, i):
+        b = self.VB0 + (sk * self.DB + d) * 4 + 2 * i
+        return f"v[{b}:{b + 1}]"
+
+    # S blocks: base register of (block, half, parity)
+    def sA(self, h):
+        return self.XA + 16 * h
+
+    def sB(self, h, par):
+        return self.YB0 if h == 0 else self.YB1 + 16 * par
+
+    def pA(self, par, sk):
+        return self.PA + 16 * par + 4 * sk
+
+    def pB(self, sk):
+        return self.PB + 4 * sk
+
+    def l(self, qb, i):
+        return self.L + 2 * qb + i
+
+    def nm(self, qb):
+        return self.NM + qb
+
+
+def tup(b, n):
+    return f"v[{b}:{b + n - 1}]"
+
+
+def kk(h, r):
+    """key index (minus 4 hi) inside the 64-key tile of accumulator register r of 32-key half h"""
+    return 32 * h + (r & 3) + 8 * (r >> 2)
+
+
+def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked):
+    """VALU of 8 scores (registers sbase + e0 .. + 7 of 32-key half blk_h) -> packed P at pbase..+3, row sums of block qb."""
+    ops = []
+    nm, l0, l1 = f"v{c.nm(qb)}", f"v{c.l(qb, 0)}", f"v{c.l(qb, 1)}"
+    for p in range(4):
+        xa, xb = f"v{c.X + (2 * p) % 4}", f"v{c.X + (2 * p + 1) % 4}"
+        sa, sb = f"v{sbase + e0 + 2 * p}", f"v{sbase + e0 + 2 * p + 1}"
+        ops.append(f"v_fma_f32 {xa}, {sa}, %[c], {nm}")
+        ops.append(f"v_fma_f32 {xb}, {sb}, %[c], {nm}")
+        if masked:
+            ops.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + 2 * p)}, %[thr]")
+            ops.append(f"v_cndmask_b32 {xa}, v{c.NINF}, {xa}, vcc")
+            ops.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + 2 * p + 1)}, %[thr]")
+            ops.append(f"v_cndmask_b32 {xb}, v{c.NINF}, {xb}, vcc")
+        ops.append(f"v_exp_f32 {xa}, {xa}")
+        ops.append(f"v_exp_f32 {xb}, {xb}")
+        ops.append(f"v_add_f32 {l0}, {l0}, {xa}")
+        ops.append(f"v_add_f32 {l1}, {l1}, {xb}")
+        ops.append(f"{c.cvt} v{pbase + p}, {xa}, {xb}")
+    return ops
+
+
+def place(mfmas, lds, valu, dma, lds_per_gap, dma_first_gap):
+    """Interleave: after MFMA g come that gap's fillers.  LDS reads go to the earliest gaps (lds_per_gap each), DMA pieces
+    (s_add m0 / one VALU / buffer_load) to gaps >= dma_first_gap, VALU fills every gap up to an even share.  Without
+    MFMAs the fillers are emitted in order."""
+    n = len(mfmas)
+    out = []
+    if n == 0:
+        out += lds
+        v = list(valu)
+        for piece in dma:
+            out.append(piece[0])
+            out.append(v.pop(0) if v else "s_nop 0")
+            out.append(piece[1])
+        out += v
+        return out
+    total = len(lds) + len(valu) + 2 * len(dma)
+    lds, valu, dma = list(lds), list(valu), list(dma)
+    for g in range(n):
+        out.append(mfmas[g])
+        quota = (g + 1) * total // n - g * total // n
+        if g == n - 1:
+            quota = 1 << 30
+        k = 0
+        for _ in range(lds_per_gap):
+            if lds and k < quota:
+                out.append(lds.pop(0)); k += 1
+        if dma and g >= dma_first_gap and len(valu) >= 1 and k + 3 <= max(quota, 3):
+            piece = dma.pop(0)
+            out.append(piece[0]); out.append(valu.pop(0)); out.append(piece[1]); k += 3
+        while valu and k < quota:
+            out.append(valu.pop(0)); k += 1
+    assert not lds and not valu and not dma, (len(lds), len(valu), len(dma))
+    return out
+
+
+def emit_asm(lines, outs, ins, clobbers, indent="            "):
+    body = "\n".join(f'{indent}    "{l}\\n\\t"' for l in lines)
+    cl = ", ".join(f'"{x}"' for x in clobbers)
+    return f"{indent}asm volatile(\n{body}\n{indent}    : {', '.join(outs)}\n{indent}    : {', '.join(ins)}\n{indent}    : {cl});\n"
+
+
+def vregs(b, n):
+    return [f"v{b + i}" for i in range(n)]
+
+
+def aregs(b, n):
+    return [f"a{b + i}" for i in range(n)]
+
+
+def gen_p1(c, Q, par, qk, sm, vr, dma):
+    """phase-1 statement of step PAR.  qk: MFMAs of S_{j+1}.  sm: 0 none, 1 plain, 2 masked (S_j[B]).  vr: V_j reads.  dma: embedded pieces."""
+    qb, KS, DB = Q >> 1, c.KS, c.DB
+    mf, clob = [], ["memory"]
+    if qk:
+        acc = [c.sA(0), c.sA(1)] if qb == 0 else [c.sB(0, par ^ 1), c.sB(1, par ^ 1)]
+        for t in range(KS // 2):
+            ks = (Q & 1) * (KS // 2) + t
+            for h in range(2):
+                a = tup(acc[h], 16)
+                mf.append(f"{c.mfma} {a}, {c.K(ks, h)}, {c.Q(qb, ks)}, {'0' if ks == 0 else a}")
+        clob += vregs(acc[0], 16) + vregs(acc[1], 16)
+    lds = []
+    if vr:
+        sk = Q
+        for d in range(DB):
+            for i in range(2):
+                off = par * c.VT + ((4 * sk) * (c.D // 16) + 2 * d) * 128 + i * 2 * (c.D // 16) * 128
+                lds.append(f"ds_read_b64_tr_b16 {c.Vhalf(sk, d, i)}, %[va] offset:{off}")
+        clob += vregs(c.VB0 + Q * DB * 4, DB * 4)
+    valu = []
+    if sm:
+        h = Q >> 1
+        valu = softmax_ops(c, c.sB(h, par), h, 8 * (Q & 1), c.pB(Q), 1, sm == 2)
+        clob += vregs(c.X, 4) + vregs(c.pB(Q), 4) + vregs(c.l(1, 0), 2)
+        if sm == 2:
+            clob.append("vcc")
+    pieces = []
+    if dma:
+        for t in range(max(1, c.NP // 2)):
+            pieces.append((f"s_add_u32 m0, %[lds], {((Q & 1) * max(1, c.NP // 2) + t) * 4096}",
+                           f"buffer_load_dwordx4 %[vo], %[srd], %[so{t}] offen lds"))
+        clob += ["m0", "scc"]
+    lines = place(mf, lds, valu, pieces, 2, 4 if len(mf) >= 8 else 2)
+    if vr and Q == 3:
+        lines.append("s_waitcnt lgkmcnt(0)")
+    if qk and not sm:
+        lines += ["s_nop 7", "s_nop 7"]      # bare MFMAs: results are read by whatever comes next
+    ins = []
+    if sm:
+        ins.append('[c] "s"(c)')
+        if sm == 2:
+            ins.append('[thr] "v"(thr)')
+    if vr:
+        ins.append('[va] "v"(va)')
+    if dma:
+        ins += ['[lds] "s"(dlds)', '[srd] "s"(dsrd)', '[so0] "s"(dso0)', '[so1] "s"(dso1)', '[vo] "v"(dvo)']
+    return emit_asm(lines, [], ins, clob)
+
+
+def gen_p2(c, Q, par, pv, sm, kr):
+    """phase-2 statement of step PAR.  pv: 0 none, 1 accumulate, 2 first tile of a part (C = 0 for sk = 0).  sm: softmax of S_{j+1}[A]
+    -> pA[PAR ^ 1][Q].  kr: reads of K_{j+2} (ring slot PAR)."""
+    qb, KS, DB = Q >> 1, c.KS, c.DB
+    mf, clob = [], ["memory"]
+    if pv:
+        for t in range(2):
+            sk = 2 * (Q & 1) + t
+            pf = tup(c.pA(par, sk), 4) if qb == 0 else tup(c.pB(sk), 4)
+            for d in range(DB):
+                o = c.O(qb, d)
+                mf.append(f"{c.mfma} {o}, {c.V(sk, d)}, {pf}, {'0' if (pv == 2 and sk == 0) else o}")
+        for d in range(DB):
+            clob += aregs((qb * DB + d) * 16, 16)
+    lds = []
+    if kr:
+        n = KS // 4
+        for t in range(n):
+            ks = Q * n + t
+            for h in range(2):
+                lds.append(f"ds_read_b128 {c.K(ks, h)}, %[ka{t}] offset:{par * c.KT + h * 32 * c.RB}")
+            clob += aregs(c.KB0 + 2 * ks * 4, 8)
+    valu = []
+    if sm:
+        h = Q >> 1
+        valu = softmax_ops(c, c.sA(h), h, 8 * (Q & 1), c.pA(par ^ 1, Q), 0, sm == 2)
+        clob += vregs(c.X, 4) + vregs(c.pA(par ^ 1, Q), 4) + vregs(c.l(0, 0), 2)
+        if sm == 2:
+            clob.append("vcc")
+    lines = place(mf, lds, valu, [], 1, 0)
+    ins = []
+    if sm:
+        ins.append('[c] "s"(c)')
+        if sm == 2:
+            ins.append('[thr] "v"(thr)')
+    if kr:
+        ins += [f'[ka{t}] "v"(ka{t})' for t in range(KS // 4)]
+    return emit_asm(lines, [], ins, clob)
+
+
+def p1_variants():
+    v = []
+    for Q in range(4):
+        for par in range(2):
+            v.append((Q, par, 1, 1, 1, 1))      # plain step (requests embedded)
+            v.append((Q, par, 1, 2, 1, 0))      # masked step
+            v.append((Q, par, 0, 2, 1, 0))      # the wave's last tile of a part
+        v.append((Q, 0, 1, 1, 1, 0))            # first step of a part, nothing masked
+        v.append((Q, 1, 1, 0, 0, 0))            # bare QK^T of tile 0 ("step -1": part prologue, exact-maximum pass)
+    return sorted(set(v))
+
+
+def p2_variants():
+    v = []
+    for Q in range(4):
+        for par in range(2):
+            v.append((Q, par, 1, 1, 1))         # plain step
+            v.append((Q, par, 1, 2, 1))         # masked step
+            v.append((Q, par, 1, 0, 1))         # last tile
+        v += [(Q, 0, 2, 1, 1), (Q, 0, 2, 2, 1), (Q, 0, 2, 0, 1)]   # first step of a part (O starts at 0)
+        v += [(Q, 1, 0, 1, 1), (Q, 1, 0, 2, 1)]                    # part prologue: P_0[A] next to the reads of K_1 (ring slot 1)
+    return sorted(set(v))
+
+
+def gen_struct(c):
+    name = f"W4Asm<{'Bf16Traits' if c.dt == 'bf16' else 'F16Traits'}, {c.D}>"
+    s = f"template <> struct {name} {{\n"
+    s += f"    static constexpr int KB0 = {c.KB0}, QB0 = {c.QB0}, NP = {c.NP}, NV = {c.NV};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n"
+    # ---- phase 1
+    s += ("    template <int Q, int PAR, int QK, int SM, int VR, int DMA>\n"
+          "    static __device__ __forceinline__ void p1(float c, unsigned va, int thr, unsigned dlds, __amdgpu_buffer_rsrc_t dsrd, unsigned dso0,\n"
+          "                                              unsigned dso1, unsigned dvo) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n"
+          "        (void)c; (void)va; (void)thr; (void)dlds; (void)dsrd; (void)dso0; (void)dso1; (void)dvo;\n")
+    first = True
+    for (Q, par, qk, sm, vr, dma) in p1_variants():
+        s += f"        {'if' if first else 'else if'} constexpr (Q == {Q} && PAR == {par} && QK == {qk} && SM == {sm} && VR == {vr} && DMA == {dma}) {{\n"
+        s += gen_p1(c, Q, par, qk, sm, vr, dma)
+        s += "        }\n"
+        first = False
+    s += "        else static_assert(Q < 0, \"fa_fwd_w4_asm.inc: phase-1 variant not generated\");\n"
+    s += "#endif\n    }\n"
+    # ---- phase 2
+    s += ("    template <int Q, int PAR, int PV, int SM, int KR>\n"
+          "    static __device__ __forceinline__ void p2(float c, unsigned ka0, unsigned ka1, int thr) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n"
+          "        (void)c; (void)ka0; (void)ka1; (void)thr;\n")
+    first = True
+    for (Q, par, pv, sm, kr) in p2_variants():
+        s += f"        {'if' if first else 'else if'} constexpr (Q == {Q} && PAR == {par} && PV == {pv} && SM == {sm} && KR == {kr}) {{\n"
+        s += gen_p2(c, Q, par, pv, sm, kr)
+        s += "        }\n"
+        first = False
+    s += "        else static_assert(Q < 0, \"fa_fwd_w4_asm.inc: phase-2 variant not generated\");\n"
+    s += "#endif\n    }\n"
+    # ---- all K fragments of the tile in ring slot PAR: part prologue
+    s += "    template <int PAR>\n    static __device__ __forceinline__ void kread_all(const unsigned* ka) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+    for par in range(2):
+        lines = []
+        for ks in range(c.KS):
+            for h in range(2):
+                lines.append(f"ds_read_b128 {c.K(ks, h)}, %[ka{ks}] offset:{par * c.KT + h * 32 * c.RB}")
+        lines.append("s_waitcnt lgkmcnt(0)")
+        ins = [f'[ka{ks}] "v"(ka[{ks}])' for ks in range(c.KS)]
+        s += f"        {'if' if par == 0 else 'else if'} constexpr (PAR == {par}) {{\n"
+        s += emit_asm(lines, [], ins, ["memory"] + aregs(c.KB0, 8 * c.KS))
+        s += "        }\n"
+    s += "#endif\n    }\n"
+    # ---- Q fragments: rows (q0 + 32 qb + l31), 16 bytes at 32 ks + 16 hi; vo = row offset + 16 hi of block A, block B 32 rows on
+    lines = ["s_nop 4"]
+    for qb in range(2):
+        for ks in range(c.KS):
+            lines.append(f"buffer_load_dwordx4 {c.Q(qb, ks)}, %[vo{qb}], %[srd], 0 offen offset:{32 * ks}")
+    s += "    static __device__ __forceinline__ void load_q(__amdgpu_buffer_rsrc_t srd, unsigned vo0, unsigned vo1) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+    s += emit_asm(lines, [], ['[srd] "s"(srd)', '[vo0] "v"(vo0)', '[vo1] "v"(vo1)'], ["memory"] + aregs(c.QB0, 8 * c.KS), indent="        ")
+    s += "#endif\n    }\n"
+    # ---- LDS-DMA of this wave's pieces of one tile (everywhere but the plain step)
+    lines = ["s_nop 4"]
+    for i in range(c.NP):
+        lines.append(f"s_add_u32 m0, %[lds], {i * 4096}")
+        lines.append(f"s_add_u32 %[t], %[soff], {i * 4096}")
+        lines.append("buffer_load_dwordx4 %[vo], %[srd], %[t] offen lds")
+    s += "    static __device__ __forceinline__ void dma_tile(unsigned dlds, __amdgpu_buffer_rsrc_t dsrd, unsigned dsoff, unsigned dvo) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+    s += "        unsigned t;\n"
+    s += emit_asm(lines, ['[t] "=&s"(t)'], ['[lds] "s"(dlds)', '[srd] "s"(dsrd)', '[soff] "s"(dsoff)', '[vo] "v"(dvo)'], ["memory", "m0", "scc"], indent="        ")
+    s += "#endif\n    }\n"
+    # ---- row maximum of tile 0: BLK 0 = S[A] (xa0, xa1), 1 = S[B] written by the bare QK^T (yb0, yb1[0]); lane-local 32 values
+    s += "    template <int BLK, int MASKED>\n    static __device__ __forceinline__ float rowmax(int thr) {\n        float mx = 0.f;\n#if defined(__HIP_DEVICE_COMPILE__)\n        (void)thr;\n"
+    first = True
+    for blk in range(2):
+        for masked in range(2):
+            b = [c.sA(0), c.sA(1)] if blk == 0 else [c.sB(0, 0), c.sB(1, 0)]
+            lines = []
+            regs = []
+            for h in range(2):
+                for r in range(16):
+                    regs.append((b[h] + r, kk(h, r)))
+            if masked:
+                # masked values go through two temporaries
+                lines.append(f"v_mov_b32 %[mx], v{c.NINF}")
+                for i in range(0, 32, 2):
+                    (ra, ka_), (rb, kb_) = regs[i], regs[i + 1]
+                    lines.append(f"v_cmp_le_i32 vcc, {ka_}, %[thr]")
+                    lines.append(f"v_cndmask_b32 v{c.X}, v{c.NINF}, v{ra}, vcc")
+                    lines.append(f"v_cmp_le_i32 vcc, {kb_}, %[thr]")
+                    lines.append(f"v_cndmask_b32 v{c.X + 1}, v{c.NINF}, v{rb}, vcc")
+                    lines.append(f"v_max3_f32 %[mx], %[mx], v{c.X}, v{c.X + 1}")
+            else:
+                lines.append(f"v_max3_f32 %[mx], v{regs[0][0]}, v{regs[1][0]}, v{regs[2][0]}")
+                for i in range(3, 31, 2):
+                    lines.append(f"v_max3_f32 %[mx], %[mx], v{regs[i][0]}, v{regs[i + 1][0]}")
+                lines.append(f"v_max_f32 %[mx], %[mx], v{regs[31][0]}")
+            s += f"        {'if' if first else 'else if'} constexpr (BLK == {blk} && MASKED == {masked}) {{\n"
+            s += emit_asm(lines, ['[mx] "=&v"(mx)'], ['[thr] "v"(thr)'] if masked else [], ["memory"] + (["vcc"] + vregs(c.X, 2) if masked else []))
+            s += "        }\n"
+            first = False
+    s += "#endif\n        return mx;\n    }\n"
+    # ---- scalars that live in literal registers
+    s += ("    static __device__ __forceinline__ void set_consts() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+          f"        asm volatile(\"v_mov_b32 v{c.NINF}, 0xff800000\" ::: \"v{c.NINF}\");\n#endif\n    }}\n")
+    s += ("    // start of a part: row sums 0\n"
+          "    static __device__ __forceinline__ void zero_sums() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+          f"        asm volatile(\"v_mov_b32 v{c.L}, 0\\n\\tv_mov_b32 v{c.L + 1}, 0\\n\\tv_mov_b32 v{c.L + 2}, 0\\n\\tv_mov_b32 v{c.L + 3}, 0\" ::: "
+          + ", ".join(f'"v{c.L + i}"' for i in range(4)) + ");\n#endif\n    }\n")
+    s += ("    // - reference of block QB (0 = A, 1 = B)\n"
+          "    template <int QB>\n    static __device__ __forceinline__ void set_ref(float nm) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+          f"        if constexpr (QB == 0) asm volatile(\"v_mov_b32 v{c.nm(0)}, %0\" :: \"v\"(nm) : \"v{c.nm(0)}\");\n"
+          f"        else asm volatile(\"v_mov_b32 v{c.nm(1)}, %0\" :: \"v\"(nm) : \"v{c.nm(1)}\");\n#endif\n    }}\n")
+    s += ("    // end of a part: row sum (both chains) and - reference of block QB\n"
+          "    template <int QB>\n    static __device__ __forceinline__ void get_sums(float& l, float& nm) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+          f"        if constexpr (QB == 0) asm volatile(\"v_add_f32 %0, v{c.l(0, 0)}, v{c.l(0, 1)}\\n\\tv_mov_b32 %1, v{c.nm(0)}\" : \"=&v\"(l), \"=v\"(nm));\n"
+          f"        else asm volatile(\"v_add_f32 %0, v{c.l(1, 0)}, v{c.l(1, 1)}\\n\\tv_mov_b32 %1, v{c.nm(1)}\" : \"=&v\"(l), \"=v\"(nm));\n#endif\n    }}\n")
+    s += "};\n\n"
+    return s
+
+
+def main():
+    hdr = ("// fa_fwd_w4_asm.inc -- GENERATED by tools/gen_w4.py (do not edit; edit the generator and re-run it).\n"
+           "// Hand-placed instruction streams of the 4-wave x 64-row forward: see the generator's docstring for the register map,\n"
+           "// the statement anatomy and the hazards the strings handle.  Included by fa_fwd_w4_gfx950.hip inside namespace aule_hip::{anonymous}.\n\n"
+           "template <class T, int D> struct W4Asm;\n\n")
+    body = ""
+    for D in (128, 64):
+        for dt in ("bf16", "f16"):
+            body += gen_struct(Cfg(D, dt))
+    with open(OUT, "w") as f:
+        f.write(hdr + body)
+    c = Cfg(128, "bf16")
+    print(f"wrote {OUT}: {len((hdr + body).splitlines())} lines; D128 map: NV={c.NV} X={c.X} L={c.L} NM={c.NM} NINF={c.NINF} XA={c.XA} YB0={c.YB0} "
+          f"YB1={c.YB1} PA={c.PA} PB={c.PB} VB0={c.VB0}")
+
+
+if __name__ == "__main__":
+    main()
