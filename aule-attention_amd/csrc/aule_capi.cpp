@@ -151,6 +151,7 @@ namespace aule_hip {
 #ifdef AULE_DEBUG_HOOKS
 int launch_fwd_pp_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
 int launch_fwd_ps_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
+int launch_fwd_w4_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
 #endif
 int configure_fwd();
 int configure_bwd();
@@ -1085,9 +1086,12 @@ int32_t aule_hip_debug_forward_timeline(const aule_attn_desc* d, unsigned long l
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
     a.dtype = d->dtype;
-    if (const char* e = getenv("AULE_TL"))
+    if (const char* e = getenv("AULE_TL")) {
         if (e[0] == 'p' && e[1] == 's')  // persistent tile stream: 8 waves x 2048 tagged stamps (tools/timeline_ps.py)
             return aule_hip::launch_fwd_ps_timeline(a, stamps, (hipStream_t)d->stream);
+        if (e[0] == 'w' && e[1] == '4')  // one wave per SIMD: 4 waves x 2048 tagged stamps (tools/timeline_w4.py)
+            return aule_hip::launch_fwd_w4_timeline(a, stamps, (hipStream_t)d->stream);
+    }
     return aule_hip::launch_fwd_pp_timeline(a, stamps, (hipStream_t)d->stream);
 }
 #endif  // AULE_DEBUG_HOOKS

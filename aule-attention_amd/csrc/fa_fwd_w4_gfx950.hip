@@ -280,11 +280,13 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             A::template p1<1, PAR, 1, 1, 1, 1>(c, va, 0, kl, ksrd, ksoff + HP, ksoff + HP + 4096u, kvo);
             A::template p1<2, PAR, 1, 1, 1, 1>(c, va, 0, vl, vsrd, vsoff, vsoff + 4096u, vvo);
             A::template p1<3, PAR, 1, 1, 1, 1>(c, va, 0, vl, vsrd, vsoff + HP, vsoff + HP + 4096u, vvo);
+            stamp(0x18);
             advance(j);
             A::template p2<0, PAR, 1, 1, 1>(c, ka[0], ka[KS / 4 - 1], 0);
             A::template p2<1, PAR, 1, 1, 1>(c, ka[KS / 4], ka[2 * (KS / 4) - 1], 0);
             A::template p2<2, PAR, 1, 1, 1>(c, ka[2 * (KS / 4)], ka[3 * (KS / 4) - 1], 0);
             A::template p2<3, PAR, 1, 1, 1>(c, ka[3 * (KS / 4)], ka[KS - 1], 0);
+            stamp(0x19);
             step_end();
         };
         // QK: S of tile j + 1 is computed (not the wave's last tile).  SM: 1 plain, 2 masked (both softmax halves).  PV: 1, or 2 for tile 0.
@@ -297,12 +299,14 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             A::template p1<1, PAR, QK, SM, 1, 0>(c, va, tB, 0, ksrd, 0, 0, 0);
             A::template p1<2, PAR, QK, SM, 1, 0>(c, va, tB, 0, ksrd, 0, 0, 0);
             A::template p1<3, PAR, QK, SM, 1, 0>(c, va, tB, 0, ksrd, 0, 0, 0);
+            stamp(0x18);
             constexpr int SMA = QK ? SM : 0;
             const int tA = SMA == 2 ? thr_of(0, j + 1) : 0;
             A::template p2<0, PAR, PV, SMA, 1>(c, ka[0], ka[KS / 4 - 1], tA);
             A::template p2<1, PAR, PV, SMA, 1>(c, ka[KS / 4], ka[2 * (KS / 4) - 1], tA);
             A::template p2<2, PAR, PV, SMA, 1>(c, ka[2 * (KS / 4)], ka[3 * (KS / 4) - 1], tA);
             A::template p2<3, PAR, PV, SMA, 1>(c, ka[3 * (KS / 4)], ka[KS - 1], tA);
+            stamp(0x19);
             step_end();
         };
         auto idle = [&](int j) __attribute__((always_inline)) {   // a tile this wave does not see (or the padding step of an odd part)
@@ -321,7 +325,9 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
             A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
             A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
+            stamp(0x31);
             asm volatile("s_barrier" ::: "memory");            // every wave holds K_0: its ring slot takes K_2
+            stamp(0x32);
             A::dma_tile(lds0 + wave1k, ksrd, (unsigned)(2 * KT), kvo);
             const int tA = thr_of(0, 0);
             if constexpr (!REDO) {
@@ -339,6 +345,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 A::template p2<2, 1, 0, 1, 1>(c, ka[2 * (KS / 4)], ka[3 * (KS / 4) - 1], tA);
                 A::template p2<3, 1, 0, 1, 1>(c, ka[3 * (KS / 4)], ka[KS - 1], tA);
             }
+            stamp(0x33);
             step_end();
         };
 
@@ -369,6 +376,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             if constexpr (!REDO) {
                 if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) redo[cs] = redo[kW4MaxSlot] = 1;
             }
+            stamp(0x42);
             const __amdgpu_buffer_rsrc_t ors = head_srd(p.o, qoff, Sq);   // rows >= Sq are dropped by the bounds check
 #pragma unroll
             for (int i0 = 0; i0 < CPR; i0 += 2) {
