@@ -1050,6 +1050,7 @@ int32_t aule_hip_debug_forward_route(const aule_attn_desc* d) {
     a.causal = d->causal != 0;
     a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? a.Sk - a.Sq : 0;
     a.dtype = d->dtype;
+    a.scale = resolve_scale(d->scale, d->head_dim);   // (the sign of the scale picks the kernel: negative scales stay off route 8)
     a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
     drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
     return aule_hip::fwd_route(a);

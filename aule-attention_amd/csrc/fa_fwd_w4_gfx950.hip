@@ -12,8 +12,11 @@
 //   * the softmax runs in the gaps of the wave's own MFMAs: a tile step is phase 1 [S_{j+1} = K_{j+1} Q^T | softmax of
 //     S_j[B] | V_j transpose reads | LDS-DMA requests] and phase 2 [O^T += V_j^T P_j^T | softmax of S_{j+1}[A] | K_{j+2}
 //     reads], 32 MFMAs each, every filler placed by the generator; ONE barrier per tile;
-//   * K / V tiles arrive by LDS-DMA into 2-deep rings (K three tiles ahead of the PV tile, V one), the images of the
-//     predecessor (K rows with XOR-swizzled 16-byte chunks, V in [kv/4][d/16][4][16] sub-tiles);
+//   * K / V tiles arrive by LDS-DMA into 3-deep rings, requested TWO tile steps before their first reader (K four tiles ahead
+//     of the PV tile, V two): under load a request takes ~1.1 us to land, longer than one step -- the first build (2-deep rings,
+//     vmcnt(0) at every step) waited ~500 of its 3100 cycles per step there (profiles/r3_w4_v1_timeline_*.txt).  A step waits
+//     only for the PREVIOUS step's requests (s_waitcnt vmcnt(8)).  Images as in the predecessor (K rows with XOR-swizzled
+//     16-byte chunks, V in [kv/4][d/16][4][16] sub-tiles);
 //   * persistent grid, one workgroup per CU walking a list of 256-row Q blocks ("parts": the (n-1-i, i) causal pairs), the
 //     next part's first tiles and its Q requested while this part finishes.
 //
@@ -35,7 +38,10 @@ namespace {
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"   // (literal registers above the compiler's budget are "reserved": that is the point)
-#include "fa_fwd_w4_asm.inc"
+#ifndef W4_ASM_INC
+#define W4_ASM_INC "fa_fwd_w4_asm.inc"
+#endif
+#include W4_ASM_INC   // (tools/w4_experiments.sh builds timing variants from differently generated streams)
 
 struct FwdW4Params {
     const void* q;
@@ -53,7 +59,9 @@ struct FwdW4Params {
     unsigned long long* dbg;   // timeline build only: [4 waves][kW4TLMax] tagged s_memtime stamps of workgroup 0
 };
 
-constexpr int kW4TLMax = 2048;
+constexpr int kW4TLMax = 2048;    // stamps per wave in the debug buffer
+constexpr int kW4TLLds = 512;     // ... kept in LDS while the kernel runs (a global store per stamp would count in vmcnt and
+                                  // make the step's counted wait cover one of its own requests)
 constexpr int kW4MaxItems = 64;              // per workgroup (the host sizes the grid accordingly)
 constexpr int kW4MaxSlot = 2 * kW4MaxItems;  // parts: two per item (the second one invalid for an unpaired block)
 
@@ -82,8 +90,8 @@ __device__ __forceinline__ void w4_pack_block(char* dst, float inv) {
     }
 }
 
-template <int D> constexpr int w4_lds_bytes() {
-    return 4 * 64 * 2 * D + 8 * 32 * (2 * D + 16) + kW4MaxSlot * 20 + 16;
+template <int D> constexpr int w4_lds_bytes() {   // 3 K + 3 V ring slots, one 32-row slab per wave, the part table
+    return 6 * 64 * 2 * D + 4 * 32 * (2 * D + 16) + kW4MaxSlot * 20 + 16;
 }
 
 template <class T, int D, bool CAUSAL, bool TL>
@@ -93,7 +101,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     constexpr int RB = 2 * D, RBP = RB + 16, CPR = RB / 16, KS = D / 16, DB = D / 32;
     constexpr int KT = 64 * RB, VT = KT, NP = KT / 4096;
     constexpr int SLAB = 32 * RBP;   // one 32-row block of O, rows padded by 16 bytes
-    constexpr int OFF_V = 2 * KT, OFF_SLAB = OFF_V + 2 * VT, TLDS = OFF_SLAB + 8 * SLAB;
+    constexpr int OFF_V = 3 * KT, OFF_SLAB = OFF_V + 3 * VT, TLDS = OFF_SLAB + 4 * SLAB;
     static_assert(A::NP == NP, "generator / kernel disagree on the tile geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -109,18 +117,45 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     const unsigned lds0 = 0;
 #endif
 
-    const int Sq = p.Sq, Sk = p.Sk, coff = p.coff;
+    // The tile loop keeps ~50 scalars live; the kernel arguments are NOT among them: everything outside the plain step reads them
+    // through an opaque pointer (a fresh s_load from the kernarg segment instead of a register held for the whole kernel --
+    // with them resident hipcc spilled scalars into vector lanes, then vectors to scratch, and every reload's vmcnt(0) drained
+    // the LDS-DMA queue in the middle of the loop).
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) FwdW4Params* KernargPtr;   // (constant address space: scalar loads)
+#else
+    typedef const FwdW4Params* KernargPtr;
+#endif
+    auto P = [&]() __attribute__((always_inline)) -> KernargPtr {
+        // (the parameter block is the kernel's only explicit argument: offset 0 of the kernarg segment.  Taking &p instead would
+        // make clang copy the block to scratch.)
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned long long a = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+        const unsigned long long a = 0;
+#endif
+        unsigned lo = (unsigned)a, hi = (unsigned)(a >> 32);
+        asm volatile("" : "+s"(lo), "+s"(hi));   // (not hoistable; its results count as divergent, hence the readfirstlanes)
+        lo = (unsigned)w4_rfl((int)lo);
+        hi = (unsigned)w4_rfl((int)hi);
+        return (KernargPtr)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    };
+    const int Sk = p.Sk, coff = p.coff;
     const float c = p.c;
     int tl_n = 0;
+    unsigned long long* const tl_lds = reinterpret_cast<unsigned long long*>(smem + TLDS + kW4MaxSlot * 20 + 16);   // TL only
     auto stamp = [&](int tag) __attribute__((always_inline)) {   // timeline build: (tag << 56) | shader clock
         if constexpr (TL) {
-            if (blockIdx.x == 0 && tl_n < kW4TLMax) {
+            if (blockIdx.x == 0 && tl_n < kW4TLLds) {
                 const unsigned long long t = __builtin_amdgcn_s_memtime();
-                if (lane == 0) p.dbg[wave * kW4TLMax + tl_n] = (t & 0x00ffffffffffffffull) | ((unsigned long long)tag << 56);
+                if (lane == 0) tl_lds[wave * kW4TLLds + tl_n] = (t & 0x00ffffffffffffffull) | ((unsigned long long)tag << 56);
                 ++tl_n;
             }
         }
     };
+    if constexpr (TL) {
+        for (int i = tid; i < 4 * kW4TLLds; i += 256) tl_lds[i] = 0;
+    }
 
     // ---- part table: thread t describes part (t & 1) of this workgroup's item t >> 1
     const int G = (int)gridDim.x;
@@ -136,7 +171,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         } else if ((tid & 1) == 0) {
             qb = w.blk;
         }
-        tab[tid] = int4{(w.b * p.Hq + w.h) * Sq, (w.b * p.Hkv + w.hk) * Sk, qb, 0};
+        tab[tid] = int4{(w.b * p.Hq + w.h) * p.Sq, (w.b * p.Hkv + w.hk) * Sk, qb, 0};
         redo[tid] = 0;
     }
     if (tid == 0) redo[kW4MaxSlot] = 0;
@@ -152,18 +187,22 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         const int kv_hi = CAUSAL ? max(1, min(Sk, qb * kQBlock + kQBlock + coff)) : Sk;
         return (kv_hi + kKVTile - 1) / kKVTile;
     };
+    // (every piece of a descriptor goes through readfirstlane where it is built: hipcc moves uniform arithmetic to the vector
+    // unit now and then -- the timeline build does -- and the requests want their descriptors in scalar registers)
     auto head_srd = [&](const void* base, int rowoff, int rows) __attribute__((always_inline)) {
-        return make_srd(reinterpret_cast<const char*>(base) + (size_t)(unsigned)rowoff * RB, (unsigned)rows * RB);
+        const unsigned long long a = (unsigned long long)(uintptr_t)base + (unsigned long long)(unsigned)rowoff * RB;
+        const unsigned lo = (unsigned)w4_rfl((int)(unsigned)a), hi = (unsigned)w4_rfl((int)(unsigned)(a >> 32));
+        return make_srd(reinterpret_cast<const void*>((uintptr_t)(((unsigned long long)hi << 32) | lo)), (unsigned)w4_rfl(rows * RB));
     };
+    auto sq_of = [&]() __attribute__((always_inline)) { return P()->Sq; };
 
     // ---- lane constants: LDS addresses of the operand reads, per-lane source offsets of the DMA pieces
     constexpr int SWSH = CPR == 16 ? 0 : 1;
-    unsigned ka[KS];   // K fragment (ks, h = 0) of ring slot 0: chunk (2 ks + hi) ^ swz(row) of row l31; h = 1: + 32 rows
-    {
-        const unsigned ka_base = (unsigned)(l31 * RB + ((((l31 >> SWSH) & (CPR - 1)) ^ hi) * 16));
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) ka[ks] = lds0 + (ka_base ^ (unsigned)(ks * 32));
-    }
+    // K fragment (ks, h = 0) of ring slot 0: chunk (2 ks + hi) ^ swz(row) of row l31 = ka0 ^ 32 ks (the swizzle bits, the hi bit and
+    // the row offset occupy disjoint bit ranges; slot offsets are multiples of the tile size); h = 1: + 32 rows.  ONE register:
+    // the eight addresses of a tile are rebuilt where they are used (one v_xor each, what adding the slot offset cost anyway).
+    const unsigned ka0 = lds0 + (unsigned)(l31 * RB + ((((l31 >> SWSH) & (CPR - 1)) ^ hi) * 16));
+    auto kaddr = [&](unsigned base, int ks) __attribute__((always_inline)) { return base ^ (unsigned)(ks * 32); };
     const unsigned va = lds0 + OFF_V + (unsigned)(hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8);
     // per-lane source offset of this wave's piece 0 of a K / V tile; piece i: + 4096 bytes in both maps (16 more rows of K; V: 32
     // sub-tiles further), which goes into the request's scalar offset
@@ -178,8 +217,15 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     const unsigned wave1k = (unsigned)wave * 1024u;
     const unsigned oob = (unsigned)Sk * RB;   // a scalar offset at which every lane of a request is out of range (LDS gets zeros)
 
-    auto step_end = [&]() __attribute__((always_inline)) {   // every request of this step landed, every LDS read returned; one barrier per tile
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // end of a tile step: the requests of the PREVIOUS step have landed (everything but this step's NREQ pieces), every LDS read
+    // of this wave has returned; one barrier per tile
+    auto step_end = [&](auto nreq_tag) __attribute__((always_inline)) {
+        constexpr int NREQ = decltype(nreq_tag)::value;
+        static_assert(NREQ == 0 || NREQ == NP || NREQ == 2 * NP, "pieces a step may have in flight");
+        if constexpr (NREQ == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if constexpr (NREQ == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if constexpr (NREQ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
     auto run_stream = [&](auto redo_tag) __attribute__((always_inline)) {
@@ -187,38 +233,58 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         int cs = next_valid(-1);
         if (cs >= nslot) return;
 
-        // ---- part scalars.  A part spans nte = nt rounded up to even ring positions (an odd part ends with one idle
-        //      step), so tile j of EVERY part sits in ring slot j & 1 and parities are compile-time.
-        int qoff, kvoff, qb, nt, nte, na, jm, r0;
-        int n_slot, n_qoff = 0, n_kvoff = 0, n_qb = 0;
-        bool pre = false;           // the next part's K_0, K_1, V_0 and Q ride along with this part's last steps
-        // request cursors: what step j asks for (K tile j + 3, V tile j + 1); soff == oob: nothing
-        __amdgpu_buffer_rsrc_t ksrd, vsrd;
+        // ---- part scalars
+        int qoff, kvoff, qb, nt, na, jm, r0;
+        int n_slot;
+        bool pre = false;           // the next part's K_0..K_2, V_0, V_1 and Q ride along with this part's last steps
+        // ring phase: stream position mod 3.  At step j (phase rp) V_j sits in slot rp, K_{j+2} in slot rp + 2, the step requests
+        // K_{j+4} into slot rp + 1 and V_{j+2} into slot rp + 2 (all mod 3); positions run on through the parts.
+        int rp = 0;
+        auto slot = [&](int d) __attribute__((always_inline)) { const int x = rp + d; return x >= 3 ? x - 3 : x; };
+        // request cursors: what step j asks for (K tile j + 4, V tile j + 2); soff == oob: nothing
+        // (the heads' base addresses are carried as two dwords and made into descriptors WHERE THEY ARE USED, through
+        // readfirstlane: a descriptor held in a variable across the loop is what hipcc moves to vector registers when scalar
+        // pressure rises -- the timeline build did -- and the requests want scalar operands)
+        unsigned klo = 0, khi = 0, vlo = 0, vhi = 0;
         unsigned ksoff, vsoff;
-        auto enter_part = [&](int slot) __attribute__((always_inline)) {
-            const int4 e = tab[slot];
+        auto srd_of = [&](unsigned lo, unsigned hi) __attribute__((always_inline)) {
+            const unsigned l = (unsigned)w4_rfl((int)lo), h = (unsigned)w4_rfl((int)hi);
+            return make_srd(reinterpret_cast<const void*>((uintptr_t)(((unsigned long long)h << 32) | l)), (unsigned)w4_rfl((int)oob));
+        };
+        auto head_lohi = [&](const void* base, int rowoff, unsigned& lo, unsigned& hi) __attribute__((always_inline)) {
+            const unsigned long long a = (unsigned long long)(uintptr_t)base + (unsigned long long)(unsigned)rowoff * RB;
+            lo = (unsigned)a;
+            hi = (unsigned)(a >> 32);
+        };
+        // (K_3 of the next part is NOT prefetched: its ring slot is the one K_0 sits in until the next part's prologue has read it;
+        // every part requests its own K_3 at its step 0)
+        auto set_k = [&](int t) __attribute__((always_inline)) {   // tile t of this part, or tile t - nt < 3 of the next one
+            head_lohi(P()->k, kvoff, klo, khi);
+            ksoff = oob;
+            if (t < nt) ksoff = (unsigned)t * KT;
+            else if (pre && t - nt < 3) { head_lohi(P()->k, w4_rfl(tab[n_slot].y), klo, khi); ksoff = (unsigned)(t - nt) * KT; }
+        };
+        auto set_v = [&](int t) __attribute__((always_inline)) {   // ... or tile t - nt < 2 of the next one
+            head_lohi(P()->v, kvoff, vlo, vhi);
+            vsoff = oob;
+            if (t < nt) vsoff = (unsigned)t * VT;
+            else if (pre && t - nt < 2) { head_lohi(P()->v, w4_rfl(tab[n_slot].y), vlo, vhi); vsoff = (unsigned)(t - nt) * VT; }
+        };
+        auto enter_part = [&](int sl) __attribute__((always_inline)) {
+            const int4 e = tab[sl];
             qoff = w4_rfl(e.x);
             kvoff = w4_rfl(e.y);
             qb = w4_rfl(e.z);
             nt = nt_of(qb);
-            nte = (nt + 1) & ~1;
             r0 = qb * kQBlock + wave * 64;
             const int vis = CAUSAL ? min(Sk, r0 + 64 + coff) : Sk;   // keys the wave's last row sees
             na = min(nt, max(1, (vis + kKVTile - 1) / kKVTile));
             const int min_thr = CAUSAL ? min(r0 + coff, Sk - 1) : Sk - 1;   // keys EVERY row of the wave sees: 0 .. min_thr
             jm = (min_thr + 1) >> 6;                                        // first tile that needs the mask
-            n_slot = next_valid(slot);
+            n_slot = next_valid(sl);
             pre = !REDO && n_slot < nslot;
-            if (n_slot < nslot) {
-                const int4 en = tab[n_slot];
-                n_qoff = w4_rfl(en.x);
-                n_kvoff = w4_rfl(en.y);
-                n_qb = w4_rfl(en.z);
-            }
-            ksrd = head_srd(p.k, kvoff, Sk);
-            vsrd = head_srd(p.v, kvoff, Sk);
-            ksoff = 3u * KT;        // (every part has at least four tiles)
-            vsoff = (unsigned)VT;
+            set_k(4);
+            set_v(2);
             A::zero_sums();
         };
         // last visible key (minus 4 hi) of the lane's row in block QB, relative to tile j (recomputed where a mask is needed:
@@ -229,24 +295,19 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             const int row = r0 + 32 * qbsel + (lane_o & 31) + coff;
             return (CAUSAL ? min(row, Sk - 1) : Sk - 1) - (lane_o >> 5) * 4 - 64 * j;
         };
-        // after step j's requests: the cursors of step j + 1 (K tile j + 4: this part's, or tile 0 / 1 of the next part --
-        // its prologue reads those two before it requests more; V tile j + 2, or the next part's V_0)
+        // after step j: the ring moves on, the cursors of step j + 1 (K tile j + 5, V tile j + 3)
         auto advance = [&](int j) __attribute__((always_inline)) {
-            if (__builtin_expect(j + 4 < nt, 1)) {   // (one compare in the steady state: this sits between the two phases of a plain step)
+            rp = slot(1);
+            if (__builtin_expect(j + 5 < nt, 1)) {   // (one compare in the steady state)
                 ksoff += KT;
                 vsoff += VT;
                 return;
             }
-            const int tk = j + 4, tv = j + 2;
-            if (pre && tk == nte) { ksrd = head_srd(p.k, n_kvoff, Sk); ksoff = 0; }
-            else if (pre && tk == nte + 1) ksoff = KT;
-            else ksoff = oob;
-            if (tv < nt) vsoff += VT;
-            else if (pre && tv == nte) { vsrd = head_srd(p.v, n_kvoff, Sk); vsoff = 0; }
-            else vsoff = oob;
+            set_k(j + 5);
+            set_v(j + 3);
         };
         auto issue_q = [&](int q_off, int q_b) __attribute__((always_inline)) {   // rows >= Sq read as 0
-            const __amdgpu_buffer_rsrc_t qrs = head_srd(p.q, q_off, Sq);
+            const __amdgpu_buffer_rsrc_t qrs = head_srd(P()->q, q_off, sq_of());
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const unsigned vo = (unsigned)((q_b * kQBlock + wave * 64 + (lane_o & 31)) * RB + (lane_o >> 5) * 16);
@@ -259,106 +320,138 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             mx = fmaxf(mx, xhalf_fast(mx));
             return -(mx * c);
         };
-        // the requests of a step as separate statements (everywhere but the plain step, which carries them in its gaps).  An
-        // out-of-range request would write ZEROS into its ring slot -- harmless in a plain step, whose slots are free by
-        // construction, but at a part's last step the K slot already holds the next part's K_0: skipped here.
-        auto requests = [&](auto par_tag, int j) __attribute__((always_inline)) {
-            constexpr int PAR = decltype(par_tag)::value;
-            if (ksoff != oob) A::dma_tile(lds0 + (PAR ^ 1) * KT + wave1k, ksrd, ksoff, kvo);
-            if (vsoff != oob) A::dma_tile(lds0 + OFF_V + (PAR ^ 1) * VT + wave1k, vsrd, vsoff, vvo);
-            advance(j);
-        };
+        // (readfirstlane: hipcc sometimes moves the ring arithmetic to the vector unit; the requests want scalar registers)
+        auto k_lds = [&]() __attribute__((always_inline)) { return (unsigned)w4_rfl((int)(lds0 + (unsigned)slot(1) * KT + wave1k)); };
+        auto v_lds = [&]() __attribute__((always_inline)) { return (unsigned)w4_rfl((int)(lds0 + OFF_V + (unsigned)slot(2) * VT + wave1k)); };
+        auto ring_lds = [&](unsigned base, int d) __attribute__((always_inline)) { return (unsigned)w4_rfl((int)(lds0 + base + (unsigned)slot(d) * KT + wave1k)); };
 
-        // ---- tile step j (PAR = j & 1: ring slots and the S[B] / P[A] copies in use)
-        // plain: nothing masked, not the first, not the last tile of the wave
-        constexpr unsigned HP = (NP / 2 > 0 ? NP / 2 : 1) * 4096u;   // bytes of the pieces one statement requests
+        // ---- tile step j (PAR = j & 1: the S[B] / P[A] register copies in use)
+        // plain: nothing masked, not the first, not the last tile of the wave; the requests ride in the gaps (K pieces in phase 1,
+        // V pieces in phase 2: an out-of-range request writes zeros into a ring slot that is free by construction)
         auto plain = [&](auto par_tag, int j) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_tag)::value;
             stamp(0x10 + PAR);
-            const unsigned kl = lds0 + (PAR ^ 1) * KT + wave1k, vl = lds0 + OFF_V + (PAR ^ 1) * VT + wave1k;
-            A::template p1<0, PAR, 1, 1, 1, 1>(c, va, 0, kl, ksrd, ksoff, ksoff + 4096u, kvo);
-            A::template p1<1, PAR, 1, 1, 1, 1>(c, va, 0, kl, ksrd, ksoff + HP, ksoff + HP + 4096u, kvo);
-            A::template p1<2, PAR, 1, 1, 1, 1>(c, va, 0, vl, vsrd, vsoff, vsoff + 4096u, vvo);
-            A::template p1<3, PAR, 1, 1, 1, 1>(c, va, 0, vl, vsrd, vsoff + HP, vsoff + HP + 4096u, vvo);
+            const unsigned kl = k_lds(), vl = v_lds();
+            const __amdgpu_buffer_rsrc_t ksrd = srd_of(klo, khi), vsrd = srd_of(vlo, vhi);
+            const unsigned vap = va + (unsigned)rp * VT, kb = ka0 + (unsigned)slot(2) * KT;
+            A::template p1<0, PAR, 1, 1, 1, 1>(c, vap, 0, kl, ksrd, ksoff, kvo);
+            A::template p1<1, PAR, 1, 1, 1, 1>(c, vap, 0, kl, ksrd, ksoff + 4096u, kvo);
+            A::template p1<2, PAR, 1, 1, 1, 1>(c, vap, 0, kl, ksrd, ksoff + (NP == 4 ? 8192u : 4096u), kvo);
+            A::template p1<3, PAR, 1, 1, 1, 1>(c, vap, 0, kl, ksrd, ksoff + 12288u, kvo);
+#ifndef W4_TL_SEAM
             stamp(0x18);
-            advance(j);
-            A::template p2<0, PAR, 1, 1, 1>(c, ka[0], ka[KS / 4 - 1], 0);
-            A::template p2<1, PAR, 1, 1, 1>(c, ka[KS / 4], ka[2 * (KS / 4) - 1], 0);
-            A::template p2<2, PAR, 1, 1, 1>(c, ka[2 * (KS / 4)], ka[3 * (KS / 4) - 1], 0);
-            A::template p2<3, PAR, 1, 1, 1>(c, ka[3 * (KS / 4)], ka[KS - 1], 0);
+#endif
+            A::template p2<0, PAR, 1, 1, 1, 1>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), 0, vl, vsrd, vsoff, vvo);
+            A::template p2<1, PAR, 1, 1, 1, 1>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), 0, vl, vsrd, vsoff + 4096u, vvo);
+            A::template p2<2, PAR, 1, 1, 1, 1>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), 0, vl, vsrd, vsoff + (NP == 4 ? 8192u : 4096u), vvo);
+            A::template p2<3, PAR, 1, 1, 1, 1>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), 0, vl, vsrd, vsoff + 12288u, vvo);
             stamp(0x19);
-            step_end();
+            advance(j);
+            step_end(integral_constant<int, 2 * NP>{});
+        };
+        // the requests of a step as separate statements (everywhere but the plain step); returns the pieces now in flight.  An
+        // out-of-range request is skipped: at a part's last steps its ring slot may already hold a tile of the next part.
+        auto requests = [&]() __attribute__((always_inline)) {
+            int n = 0;
+            if (ksoff != oob) { A::dma_tile(k_lds(), srd_of(klo, khi), (unsigned)w4_rfl((int)ksoff), kvo); n += NP; }
+            if (vsoff != oob) { A::dma_tile(v_lds(), srd_of(vlo, vhi), (unsigned)w4_rfl((int)vsoff), vvo); n += NP; }
+            return n;
+        };
+        // (a part's last step does not wait for requests at all when the next part follows: what is in flight then are the next
+        // head's K_2, V_0, V_1 -- first touches of that head, ~2x the latency of the tiles in the middle of a head; the wave's
+        // epilogue gives them time, the next prologue's vmcnt(0) and closing barrier make them visible before step 0 reads them)
+        auto end_n = [&](int n, int j) __attribute__((always_inline)) {
+            if (pre && j == nt - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (n == 2 * NP) step_end(integral_constant<int, 2 * NP>{});
+            else if (n == NP) step_end(integral_constant<int, NP>{});
+            else step_end(integral_constant<int, 0>{});
         };
         // QK: S of tile j + 1 is computed (not the wave's last tile).  SM: 1 plain, 2 masked (both softmax halves).  PV: 1, or 2 for tile 0.
         auto step = [&](auto par_tag, auto qk_tag, auto sm_tag, auto pv_tag, int j) __attribute__((always_inline)) {
+            const __amdgpu_buffer_rsrc_t ksrd = make_srd(nullptr, 0);   // (unused operand of the statements without requests)
             constexpr int PAR = decltype(par_tag)::value, QK = decltype(qk_tag)::value, SM = decltype(sm_tag)::value, PV = decltype(pv_tag)::value;
             stamp(0x20 + PAR + 2 * QK + 4 * SM);
-            requests(par_tag, j);
+            if constexpr (PV == 2)   // tile 0: K_3 goes where K_0 was (the prologue's last barrier freed the slot); it is older than this
+                                     // step's own requests, so the step's closing wait covers it
+                A::dma_tile(ring_lds(0, 0), head_srd(P()->k, kvoff, Sk), 3u * KT, kvo);
+            const int n = requests();
+            const unsigned vap = va + (unsigned)rp * VT, kb = ka0 + (unsigned)slot(2) * KT;
             const int tB = SM == 2 ? thr_of(1, j) : 0;
-            A::template p1<0, PAR, QK, SM, 1, 0>(c, va, tB, 0, ksrd, 0, 0, 0);
-            A::template p1<1, PAR, QK, SM, 1, 0>(c, va, tB, 0, ksrd, 0, 0, 0);
-            A::template p1<2, PAR, QK, SM, 1, 0>(c, va, tB, 0, ksrd, 0, 0, 0);
-            A::template p1<3, PAR, QK, SM, 1, 0>(c, va, tB, 0, ksrd, 0, 0, 0);
+            A::template p1<0, PAR, QK, SM, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
+            A::template p1<1, PAR, QK, SM, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
+            A::template p1<2, PAR, QK, SM, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
+            A::template p1<3, PAR, QK, SM, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
             stamp(0x18);
             constexpr int SMA = QK ? SM : 0;
             const int tA = SMA == 2 ? thr_of(0, j + 1) : 0;
-            A::template p2<0, PAR, PV, SMA, 1>(c, ka[0], ka[KS / 4 - 1], tA);
-            A::template p2<1, PAR, PV, SMA, 1>(c, ka[KS / 4], ka[2 * (KS / 4) - 1], tA);
-            A::template p2<2, PAR, PV, SMA, 1>(c, ka[2 * (KS / 4)], ka[3 * (KS / 4) - 1], tA);
-            A::template p2<3, PAR, PV, SMA, 1>(c, ka[3 * (KS / 4)], ka[KS - 1], tA);
+            A::template p2<0, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0);
+            A::template p2<1, PAR, PV, SMA, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0);
+            A::template p2<2, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), tA, 0, ksrd, 0, 0);
+            A::template p2<3, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0);
             stamp(0x19);
-            step_end();
+            advance(j);
+#ifdef W4_TL_SEAM
+            stamp(0x1a);
+#endif
+            end_n(n, j);
+#ifdef W4_TL_SEAM
+            stamp(0x1b);
+#endif
         };
-        auto idle = [&](int j) __attribute__((always_inline)) {   // a tile this wave does not see (or the padding step of an odd part)
+        auto idle = [&](int j) __attribute__((always_inline)) {   // a tile this wave does not see
             stamp(0x08);
-            if (j & 1) requests(integral_constant<int, 1>{}, j);
-            else requests(integral_constant<int, 0>{}, j);
-            step_end();
+            const int n = requests();
+            advance(j);
+            end_n(n, j);
         };
-        // part prologue = "step -1" (K_0, K_1, V_0 of the part in the ring, Q requested): S_0, the references, P_0[A]; leaves K_1
-        // in the fragment registers and K_2 requested
+        // part prologue = "step -1" (K_0, K_1 of the part in the ring, Q requested): S_0, the references, P_0[A]; leaves K_1 in
+        // the fragment registers
         auto prologue = [&]() __attribute__((always_inline)) {
             stamp(0x30);
-            A::template kread_all<0>(ka);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Q fragments
-            A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
-            A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
-            A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
-            A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
+            const __amdgpu_buffer_rsrc_t ksrd = make_srd(nullptr, 0);   // (unused operand)
+            unsigned kap[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kap[ks] = kaddr(ka0 + (unsigned)rp * KT, ks);
+            A::kread_all(kap);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Q fragments (and, after a part, the epilogue's stores)
+            A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+            A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+            A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+            A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
             stamp(0x31);
-            asm volatile("s_barrier" ::: "memory");            // every wave holds K_0: its ring slot takes K_2
-            stamp(0x32);
-            A::dma_tile(lds0 + wave1k, ksrd, (unsigned)(2 * KT), kvo);
             const int tA = thr_of(0, 0);
             if constexpr (!REDO) {
                 A::template set_ref<0>(neg_ref(integral_constant<int, 0>{}, jm == 0, tA));
                 A::template set_ref<1>(neg_ref(integral_constant<int, 1>{}, jm == 0, thr_of(1, 0)));
             }
+            const unsigned kb = ka0 + (unsigned)slot(1) * KT;   // K_1
             if (jm == 0) {
-                A::template p2<0, 1, 0, 2, 1>(c, ka[0], ka[KS / 4 - 1], tA);
-                A::template p2<1, 1, 0, 2, 1>(c, ka[KS / 4], ka[2 * (KS / 4) - 1], tA);
-                A::template p2<2, 1, 0, 2, 1>(c, ka[2 * (KS / 4)], ka[3 * (KS / 4) - 1], tA);
-                A::template p2<3, 1, 0, 2, 1>(c, ka[3 * (KS / 4)], ka[KS - 1], tA);
+                A::template p2<0, 1, 0, 2, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0);
+                A::template p2<1, 1, 0, 2, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0);
+                A::template p2<2, 1, 0, 2, 1, 0>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), tA, 0, ksrd, 0, 0);
+                A::template p2<3, 1, 0, 2, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0);
             } else {
-                A::template p2<0, 1, 0, 1, 1>(c, ka[0], ka[KS / 4 - 1], tA);
-                A::template p2<1, 1, 0, 1, 1>(c, ka[KS / 4], ka[2 * (KS / 4) - 1], tA);
-                A::template p2<2, 1, 0, 1, 1>(c, ka[2 * (KS / 4)], ka[3 * (KS / 4) - 1], tA);
-                A::template p2<3, 1, 0, 1, 1>(c, ka[3 * (KS / 4)], ka[KS - 1], tA);
+                A::template p2<0, 1, 0, 1, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0);
+                A::template p2<1, 1, 0, 1, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0);
+                A::template p2<2, 1, 0, 1, 1, 0>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), tA, 0, ksrd, 0, 0);
+                A::template p2<3, 1, 0, 1, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0);
             }
             stamp(0x33);
-            step_end();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave holds K_0 and K_1: step 0 requests K_3 and K_4 into their slots
         };
 
-        // ---- epilogue of a part: O = O^T / l, rounded, transposed through the wave's two LDS slabs, whole-row stores; LSE;
-        //      range verdict of the fixed reference
+        // ---- epilogue of a part: O = O^T / l, rounded, transposed through the wave's LDS slab (block A, then block B), whole-row
+        //      stores; LSE; range verdict of the fixed reference
         auto epilogue = [&]() __attribute__((always_inline)) {
             stamp(0x40);
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the last PV MFMAs -> v_accvgpr_read
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const int l31o = lane_o & 31, hio = lane_o >> 5;
-            char* const slab = smem + OFF_SLAB + wave * 2 * SLAB;
-            const __amdgpu_buffer_rsrc_t lrs = make_srd(p.lse + (size_t)(unsigned)qoff, p.lse != nullptr ? (unsigned)Sq * 4u : 0u);
+            char* const slab = smem + OFF_SLAB + wave * SLAB;
+            float* const lsep = P()->lse;
+            const __amdgpu_buffer_rsrc_t lrs = make_srd(lsep + (size_t)(unsigned)qoff, lsep != nullptr ? (unsigned)sq_of() * 4u : 0u);
+            const __amdgpu_buffer_rsrc_t ors = head_srd(P()->o, qoff, sq_of());   // rows >= Sq are dropped by the bounds check
             bool bad = false;
             auto half = [&](auto qb_tag) __attribute__((always_inline)) {
                 constexpr int QB = decltype(qb_tag)::value;
@@ -366,49 +459,55 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 A::template get_sums<QB>(lt, nm);
                 lt += xhalf_fast(lt);
                 const float inv = __builtin_amdgcn_rcpf(lt);
-                w4_pack_block<T, DB, QB * DB * 16>(slab + QB * SLAB + l31o * RBP + 8 * hio, inv);
+                w4_pack_block<T, DB, QB * DB * 16>(slab + l31o * RBP + 8 * hio, inv);
                 const float lse = (fast_log2(lt) - nm) * kLn2;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lse), lrs, hio == 0 ? (r0 + 32 * QB + l31o) * 4 : 0x7ffffff0, 0, 0);
+#ifndef W4_X_NOVERDICT   // (timing experiments with garbage arithmetic: no second stream)
                 if constexpr (!REDO) bad = bad || !((lt > 0x1p-100f) && (lt < (T::kDType == 2 ? 0x1p110f : 0x1p15f)));
+#endif
+                // (the wave's own LDS accesses are ordered: no barrier between the slab's writes, reads and next writes)
+#pragma unroll
+                for (int i0 = 0; i0 < CPR / 2; i0 += 2) {
+                    u32x4_t x[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int idx = (i0 + i) * 64 + lane_o, row = idx / CPR, cc = idx % CPR;
+                        x[i] = *reinterpret_cast<const u32x4_t*>(slab + row * RBP + cc * 16);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int idx = (i0 + i) * 64 + lane_o, row = idx / CPR, cc = idx % CPR;
+                        __builtin_amdgcn_raw_buffer_store_b128(x[i], ors, (r0 + 32 * QB + row) * RB + cc * 16, 0, 0);
+                    }
+                }
             };
             half(integral_constant<int, 0>{});
+            stamp(0x42);
             half(integral_constant<int, 1>{});
             if constexpr (!REDO) {
                 if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) redo[cs] = redo[kW4MaxSlot] = 1;
-            }
-            stamp(0x42);
-            const __amdgpu_buffer_rsrc_t ors = head_srd(p.o, qoff, Sq);   // rows >= Sq are dropped by the bounds check
-#pragma unroll
-            for (int i0 = 0; i0 < CPR; i0 += 2) {
-                u32x4_t x[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int idx = (i0 + i) * 64 + lane_o, row = idx / CPR, cc = idx % CPR;
-                    x[i] = *reinterpret_cast<const u32x4_t*>(slab + (row >> 5) * SLAB + (row & 31) * RBP + cc * 16);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int idx = (i0 + i) * 64 + lane_o, row = idx / CPR, cc = idx % CPR;
-                    __builtin_amdgcn_raw_buffer_store_b128(x[i], ors, (r0 + row) * RB + cc * 16, 0, 0);
-                }
             }
             stamp(0x41);
         };
 
         // REDO only: the exact row maxima of the part, one QK^T-only pass over its tiles through ring slot 0
         auto max_pass = [&]() __attribute__((always_inline)) {
+            const __amdgpu_buffer_rsrc_t ksrd = make_srd(nullptr, 0);   // (unused operand)
             float mA = -INFINITY, mB = -INFINITY;   // in units of c
             issue_q(qoff, qb);
             for (int j = 0; j < nt; ++j) {
                 __syncthreads();
-                A::dma_tile(lds0 + wave1k, ksrd, (unsigned)j * KT, kvo);
+                A::dma_tile(lds0 + wave1k, head_srd(P()->k, kvoff, Sk), (unsigned)j * KT, kvo);
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 if (j < na) {
-                    A::template kread_all<0>(ka);
-                    A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
-                    A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
-                    A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
-                    A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0, 0);
+                    unsigned kap[KS];
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) kap[ks] = kaddr(ka0, ks);
+                    A::kread_all(kap);
+                    A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+                    A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+                    A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+                    A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
                     mA = fmaxf(mA, -neg_ref(integral_constant<int, 0>{}, true, thr_of(0, j)));
                     mB = fmaxf(mB, -neg_ref(integral_constant<int, 1>{}, true, thr_of(1, j)));
                 }
@@ -422,12 +521,15 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         bool cold = true;
         enter_part(cs);
         for (;;) {
-            if (REDO || cold) {   // nothing of this part is in flight
+            if (REDO || cold) {   // nothing of this part is in flight: K_0, K_1, K_2, V_0, V_1
                 if constexpr (REDO) max_pass();
                 else issue_q(qoff, qb);
-                A::dma_tile(lds0 + wave1k, ksrd, 0u, kvo);
-                A::dma_tile(lds0 + KT + wave1k, ksrd, (unsigned)KT, kvo);
-                A::dma_tile(lds0 + OFF_V + wave1k, vsrd, 0u, vvo);
+                const __amdgpu_buffer_rsrc_t k0 = head_srd(P()->k, kvoff, Sk), v0 = head_srd(P()->v, kvoff, Sk);
+                A::dma_tile(ring_lds(0, 0), k0, 0u, kvo);
+                A::dma_tile(ring_lds(0, 1), k0, (unsigned)KT, kvo);
+                A::dma_tile(ring_lds(0, 2), k0, 2u * KT, kvo);
+                A::dma_tile(ring_lds(OFF_V, 0), v0, 0u, vvo);
+                A::dma_tile(ring_lds(OFF_V, 1), v0, (unsigned)VT, vvo);
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 cold = false;
             }
@@ -453,8 +555,8 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 }
                 ++j;
             }
-            for (; j < nte; ++j) idle(j);
-            if (pre) issue_q(n_qoff, n_qb);   // (the Q registers are free since the wave's last QK^T)
+            for (; j < nt; ++j) idle(j);
+            if (pre) issue_q(w4_rfl(tab[n_slot].x), w4_rfl(tab[n_slot].z));   // (the Q registers are free since the wave's last QK^T)
             epilogue();
             if (n_slot >= nslot) break;
             cs = n_slot;
@@ -471,6 +573,11 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         if (tid < nslot && redo[tid] == 0) tab[tid].z = -1;   // second, sparse stream: only the flagged parts
         __syncthreads();
         run_stream(std::integral_constant<int, 1>{});
+    }
+    if constexpr (TL) {
+        __syncthreads();
+        if (blockIdx.x == 0)
+            for (int i = tid; i < 4 * kW4TLLds; i += 256) p.dbg[(i / kW4TLLds) * kW4TLMax + (i % kW4TLLds)] = tl_lds[i];
     }
 }
 
@@ -523,7 +630,7 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
     long long G = ncu * rounds;
     if (G > p.nitems) G = p.nitems;
     const dim3 grid((unsigned)G), block(256);
-    const size_t lds = w4_lds_bytes<D>();
+    const size_t lds = w4_lds_bytes<D>() + (TL ? 4 * kW4TLLds * 8 : 0);
     if (a.causal)
         hipLaunchKernelGGL((w4_kernel<T, D, true, TL>()), grid, block, lds, stream, p);
     else
@@ -570,7 +677,7 @@ int launch_fwd_w4(const FwdArgs& a, hipStream_t stream) {
 // Debug: the bf16 D = 128 kernel with tagged s_memtime stamps of workgroup 0 (tools/timeline_w4.py).
 int launch_fwd_w4_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream) {
     if (a.dtype != kBF16 || a.D != 128 || !fwd_w4_applicable(a)) return -1;
-    const int lds = w4_lds_bytes<128>();
+    const int lds = w4_lds_bytes<128>() + 4 * kW4TLLds * 8;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(w4_kernel<Bf16Traits, 128, true, true>()), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(w4_kernel<Bf16Traits, 128, false, true>()), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     return launch_w4<Bf16Traits, 128, true>(a, stream, dbg);

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Audit of the compiled one-wave-per-SIMD forward (fa_fwd_w4_gfx950.hip): the instruction streams of fa_fwd_w4_asm.inc name
+their registers literally, so hipcc must keep out of them.  Compiles the file to assembly and checks, per kernel:
+  * no scratch (private_segment_fixed_size 0, vgpr_spill_count 0): a spill reload's vmcnt(0) would drain the LDS-DMA queue, and
+    a spill INTO an accumulator register would corrupt O / Q / K silently;
+  * no v_accvgpr_* and no scratch_* instruction outside the ;;#ASMSTART / ;;#ASMEND brackets;
+  * hipcc's own VGPRs stay below the generator's budget NV (amdgpu_num_vgpr);
+  * the plain tile step (the statements that carry an LDS-DMA piece) is free of v_readlane / v_writelane (SGPR spills) and of
+    compiler-made s_waitcnt vmcnt.
+    python tools/audit_w4.py [--keep DIR]      exit code 0 = clean
+"""
+import os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "aule-attention_amd", "csrc", "fa_fwd_w4_gfx950.hip")
+
+
+def compile_to_asm(outdir):
+    out = os.path.join(outdir, "w4.s")
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-inline-asm", "-S", "--cuda-device-only", "-o", out, SRC]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out
+
+
+def kernels(text):
+    """name -> list of lines of the kernel's code"""
+    res = {}
+    cur = None
+    for l in text.split("\n"):
+        m = re.match(r"^(_ZN8aule_hip\S*fa_fwd_w4_kernel\S*):", l)
+        if m:
+            cur = m.group(1)
+            res[cur] = []
+            continue
+        if cur is not None:
+            res[cur].append(l)
+            if "s_endpgm" in l:
+                cur = None
+    return res
+
+
+def audit(path, verbose=True):
+    text = open(path).read()
+    problems = []
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n((?:\s+\.\S+:.*\n)+)", text):
+        body = m.group(2)
+        def field(k):
+            mm = re.search(r"\." + k + r":\s+(\d+)", body)
+            return int(mm.group(1)) if mm else None
+        meta[m.group(1)] = {k: field(k) for k in ("private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count", "vgpr_count", "agpr_count")}
+    ks = kernels(text)
+    if not ks:
+        problems.append("no fa_fwd_w4 kernel found in the assembly")
+    for name, lines in ks.items():
+        md = meta.get(name, {})
+        d = 128 if "d128" in name else 64
+        nv = 52 if d == 128 else 84
+        if md.get("private_segment_fixed_size") != 0 or md.get("vgpr_spill_count") != 0:
+            problems.append(f"{name}: scratch {md.get('private_segment_fixed_size')} bytes, {md.get('vgpr_spill_count')} VGPR spills")
+        # split into asm blocks and the compiler code between them
+        blocks, between, cur, inasm = [], [[]], [], False
+        for l in lines:
+            t = l.strip()
+            if t.startswith(";;#ASMSTART"):
+                inasm, cur = True, []
+                continue
+            if t.startswith(";;#ASMEND"):
+                inasm = False
+                blocks.append(cur)
+                between.append([])
+                continue
+            if inasm:
+                cur.append(t)
+            elif t and not t.startswith(";") and not t.startswith("."):
+                between[-1].append(t)
+        for seg in between:
+            for t in seg:
+                if "v_accvgpr" in t or t.startswith("scratch_"):
+                    problems.append(f"{name}: compiler-made `{t}`")
+                for r in re.findall(r"\bv(\d+)\b", t) + [x for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", t) for x in (a, b)]:
+                    if int(r) >= nv:
+                        problems.append(f"{name}: compiler instruction touches v{r} >= NV {nv}: `{t}`")
+        # plain tile steps: eight consecutive statements that each carry MFMAs and one LDS-DMA piece, then the wait + barrier
+        is_plain = [any("offen lds" in b for b in blk) and any("v_mfma" in b for b in blk) for blk in blocks]
+        plain_outside, nsteps = [], 0
+        k = 0
+        while k + 8 < len(blocks):
+            if all(is_plain[k:k + 8]) and any("s_barrier" in b for b in blocks[k + 8]):
+                nsteps += 1
+                for i in range(k + 1, k + 9):
+                    plain_outside += between[i]
+                k += 9
+            else:
+                k += 1
+        if nsteps == 0:
+            problems.append(f"{name}: no plain tile step recognised")
+        bad = [t for t in plain_outside if t.startswith("v_readlane") or t.startswith("v_writelane") or (t.startswith("s_waitcnt") and "vmcnt" in t)]
+        if bad:
+            problems.append(f"{name}: plain tile steps contain {len(bad)} of v_readlane / v_writelane / s_waitcnt vmcnt, e.g. `{bad[0]}`")
+        if verbose:
+            nsalu = sum(1 for t in plain_outside if t.startswith("s_"))
+            nvalu = sum(1 for t in plain_outside if t.startswith("v_"))
+            print(f"{name[:90]}: {md}  {nsteps} plain step bodies, compiler code per body: {nsalu / max(nsteps, 1):.0f} SALU, {nvalu / max(nsteps, 1):.0f} VALU")
+    return problems
+
+
+if __name__ == "__main__":
+    keep = None
+    if len(sys.argv) > 2 and sys.argv[1] == "--keep":
+        keep = sys.argv[2]
+        os.makedirs(keep, exist_ok=True)
+    with tempfile.TemporaryDirectory() as td:
+        path = compile_to_asm(keep or td)
+        probs = audit(path)
+    for pr in probs[:40]:
+        print("PROBLEM:", pr)
+    print("clean" if not probs else f"{len(probs)} problem(s)")
+    sys.exit(0 if not probs else 1)

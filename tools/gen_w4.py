@@ -24,7 +24,8 @@ fillers PLACED in the MFMA gaps (a gap hides ~5 single-issue instructions next t
                            (| LDS-DMA pieces of the tiles the stream requests this step)
     phase 2, statement Q:  O^T += V_j^T P_j^T       |  softmax of 8 scores of S_{j+1}[A] -> P_{j+1}[A][Q] |  KS / 2 reads of K_{j+2}
 
-S[B] half 0 is single-buffered (its old tile is consumed in statements 0-1 of phase 1, the new one is born in statements 2-3);
+The K and V tiles sit in 3-deep LDS rings; the ring slot of a read is in its address register (the kernel adds slot x tile bytes),
+so PAR only selects register copies.  S[B] half 0 is single-buffered (its old tile is consumed in statements 0-1 of phase 1, the new one is born in statements 2-3);
 half 1 is consumed while its successor is being accumulated, hence the parity copies.  The part prologue is "step -1" (PAR = 1).
 
 Hazards the strings take care of themselves (inline asm is invisible to hipcc's hazard recogniser):
@@ -38,7 +39,15 @@ Hazards the strings take care of themselves (inline asm is invisible to hipcc's 
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "aule-attention_amd", "csrc", "fa_fwd_w4_asm.inc")
+OUT = os.environ.get("W4_OUT", os.path.join(ROOT, "aule-attention_amd", "csrc", "fa_fwd_w4_asm.inc"))
+# Timing experiments only (tools/w4_experiments.sh; results are garbage): W4_X = comma list of
+#   noexp   v_exp_f32 -> v_mov_b32          nolds   no operand reads in the tile steps (stale fragments)
+#   nodma   no LDS-DMA pieces in the plain step     novalu  no softmax arithmetic at all      nocvt  no packing
+XFLAGS = set(filter(None, os.environ.get("W4_X", "").split(",")))
+# how x = c s - m_ref is computed (hardware finding, profiles/r3_w4_filler_costs.txt: 8-byte VOP3 instructions cost the in-order
+# wave several times what 4-byte VOP1 / VOP2 ones do next to the MFMAs)
+SCALE_FORM = os.environ.get("W4_SCALE", "fma")
+CREG = "v" if "cvgpr" in XFLAGS else "s"    # register class of the scale operand (experiment)
 
 
 class Cfg:
@@ -117,31 +126,55 @@ def kk(h, r):
 
 
 def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked):
-    """VALU of 8 scores (registers sbase + e0 .. + 7 of 32-key half blk_h) -> packed P at pbase..+3, row sums of block qb."""
+    """VALU of 8 scores (registers sbase + e0 .. + 7 of 32-key half blk_h) -> packed P at pbase..+3, row sums of block qb.
+    Two pairs are in flight at a time (x0 x1 | x2 x3): every consumer sits at least four instructions behind its producer
+    (dependent VALU issue stalls the in-order wave, and with it the next MFMA; v_exp needs one instruction of distance anyway)."""
     ops = []
     nm, l0, l1 = f"v{c.nm(qb)}", f"v{c.l(qb, 0)}", f"v{c.l(qb, 1)}"
-    for p in range(4):
-        xa, xb = f"v{c.X + (2 * p) % 4}", f"v{c.X + (2 * p + 1) % 4}"
-        sa, sb = f"v{sbase + e0 + 2 * p}", f"v{sbase + e0 + 2 * p + 1}"
-        ops.append(f"v_fma_f32 {xa}, {sa}, %[c], {nm}")
-        ops.append(f"v_fma_f32 {xb}, {sb}, %[c], {nm}")
+    for p0 in (0, 2):
+        x = {p0: (f"v{c.X}", f"v{c.X + 1}"), p0 + 1: (f"v{c.X + 2}", f"v{c.X + 3}")}
+        sc = {p: (f"v{sbase + e0 + 2 * p}", f"v{sbase + e0 + 2 * p + 1}") for p in (p0, p0 + 1)}
+        for p in (p0, p0 + 1):
+            for i in range(2):
+                if SCALE_FORM == "fma":          # one VOP3 (8 bytes)
+                    ops.append(f"v_fma_f32 {x[p][i]}, {sc[p][i]}, %[c], {nm}")
+                elif SCALE_FORM == "fmac":       # two 4-byte instructions: x = - m_ref ; x += c s
+                    ops.append(f"v_mov_b32 {x[p][i]}, {nm}")
+                    ops.append(f"v_fmac_f32 {x[p][i]}, %[c], {sc[p][i]}")
+                elif SCALE_FORM == "mulsub":
+                    ops.append(f"v_mul_f32 {x[p][i]}, %[c], {sc[p][i]}")
+                    ops.append(f"v_add_f32 {x[p][i]}, {nm}, {x[p][i]}")
         if masked:
-            ops.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + 2 * p)}, %[thr]")
-            ops.append(f"v_cndmask_b32 {xa}, v{c.NINF}, {xa}, vcc")
-            ops.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + 2 * p + 1)}, %[thr]")
-            ops.append(f"v_cndmask_b32 {xb}, v{c.NINF}, {xb}, vcc")
-        ops.append(f"v_exp_f32 {xa}, {xa}")
-        ops.append(f"v_exp_f32 {xb}, {xb}")
-        ops.append(f"v_add_f32 {l0}, {l0}, {xa}")
-        ops.append(f"v_add_f32 {l1}, {l1}, {xb}")
-        ops.append(f"{c.cvt} v{pbase + p}, {xa}, {xb}")
+            for p in (p0, p0 + 1):
+                for i in range(2):
+                    ops.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + 2 * p + i)}, %[thr]")
+                    ops.append(f"v_cndmask_b32 {x[p][i]}, v{c.NINF}, {x[p][i]}, vcc")
+        for p in (p0, p0 + 1):
+            ops.append(f"v_exp_f32 {x[p][0]}, {x[p][0]}")
+            ops.append(f"v_exp_f32 {x[p][1]}, {x[p][1]}")
+        for p in (p0, p0 + 1):
+            ops.append(f"v_add_f32 {l0}, {l0}, {x[p][0]}")
+            ops.append(f"v_add_f32 {l1}, {l1}, {x[p][1]}")
+            ops.append(f"{c.cvt} v{pbase + p}, {x[p][0]}, {x[p][1]}")
+    if "noexp" in XFLAGS:
+        ops = [o.replace("v_exp_f32", "v_mov_b32") for o in ops]
+    if "dropexp" in XFLAGS:
+        ops = [o for o in ops if "v_exp_f32" not in o]
+    if "dropfma" in XFLAGS:
+        ops = [o for o in ops if "v_fma_f32" not in o]
+    if "dropadd" in XFLAGS:
+        ops = [o for o in ops if "v_add_f32" not in o]
+    if "nocvt" in XFLAGS:
+        ops = [o for o in ops if "v_cvt_pk" not in o]
+    if "novalu" in XFLAGS:
+        ops = []
     return ops
 
 
-def place(mfmas, lds, valu, dma, lds_per_gap, dma_first_gap):
-    """Interleave: after MFMA g come that gap's fillers.  LDS reads go to the earliest gaps (lds_per_gap each), DMA pieces
-    (s_add m0 / one VALU / buffer_load) to gaps >= dma_first_gap, VALU fills every gap up to an even share.  Without
-    MFMAs the fillers are emitted in order."""
+def place(mfmas, lds, valu, dma, lds_per_gap, dma_gap):
+    """Interleave: after MFMA g come that gap's fillers, in program order.  LDS reads go to the earliest gaps (lds_per_gap each);
+    the DMA piece (s_add m0 / one VALU / buffer_load ... lds -- a ~40-cycle issue by itself) gets gap dma_gap nearly to itself;
+    the VALU fill the other gaps to an even share.  Without MFMAs the fillers are emitted in order."""
     n = len(mfmas)
     out = []
     if n == 0:
@@ -153,27 +186,53 @@ def place(mfmas, lds, valu, dma, lds_per_gap, dma_first_gap):
             out.append(piece[1])
         out += v
         return out
-    total = len(lds) + len(valu) + 2 * len(dma)
-    lds, valu, dma = list(lds), list(valu), list(dma)
+    assert len(dma) <= 1
+    lds, valu = list(lds), list(valu)
+    if dma and not valu:
+        valu = ["s_nop 0"]      # (the instruction between the M0 write and the request)
+    nl = [0] * n
+    rest = len(lds)
+    for g in range(n):
+        if dma and g == dma_gap:
+            continue
+        nl[g] = min(lds_per_gap, rest)
+        rest -= nl[g]
+    assert rest == 0
+    normal = [g for g in range(n) if not (dma and g == dma_gap)]
+    nv = [0] * n
+    left = len(valu) - (1 if dma else 0)
+    total = left + sum(nl)
+    for i, g in enumerate(normal):      # even share of (LDS + VALU) over the normal gaps, the remainder to the late ones
+        share = total * (i + 1) // len(normal) - total * i // len(normal)
+        nv[g] = max(0, share - nl[g])
+    # rounding: hand what is left over to (or take the excess from) the late gaps
+    diff = left - sum(nv)
+    g = len(normal) - 1
+    assert diff >= 0 or sum(nv) >= -diff, (diff, nv)
+    while diff != 0:
+        if diff > 0:
+            nv[normal[g]] += 1; diff -= 1
+        elif nv[normal[g]] > 0:
+            nv[normal[g]] -= 1; diff += 1
+        g = g - 1 if g > 0 else len(normal) - 1
+    if dma:
+        nv[dma_gap] = 1
     for g in range(n):
         out.append(mfmas[g])
-        quota = (g + 1) * total // n - g * total // n
-        if g == n - 1:
-            quota = 1 << 30
-        k = 0
-        for _ in range(lds_per_gap):
-            if lds and k < quota:
-                out.append(lds.pop(0)); k += 1
-        if dma and g >= dma_first_gap and len(valu) >= 1 and k + 3 <= max(quota, 3):
-            piece = dma.pop(0)
-            out.append(piece[0]); out.append(valu.pop(0)); out.append(piece[1]); k += 3
-        while valu and k < quota:
-            out.append(valu.pop(0)); k += 1
-    assert not lds and not valu and not dma, (len(lds), len(valu), len(dma))
+        for _ in range(nl[g]):
+            out.append(lds.pop(0))
+        if dma and g == dma_gap:
+            out.append(dma[0][0]); out.append(valu.pop(0)); out.append(dma[0][1])
+        else:
+            for _ in range(nv[g]):
+                out.append(valu.pop(0))
+    assert not lds and not valu, (len(lds), len(valu))
     return out
 
 
 def emit_asm(lines, outs, ins, clobbers, indent="            "):
+    if not lines:
+        lines = ["s_nop 0"]
     body = "\n".join(f'{indent}    "{l}\\n\\t"' for l in lines)
     cl = ", ".join(f'"{x}"' for x in clobbers)
     return f"{indent}asm volatile(\n{body}\n{indent}    : {', '.join(outs)}\n{indent}    : {', '.join(ins)}\n{indent}    : {cl});\n"
@@ -187,8 +246,18 @@ def aregs(b, n):
     return [f"a{b + i}" for i in range(n)]
 
 
+def dma_piece(c, Q):
+    """LDS-DMA piece a statement carries (K in phase 1, V in phase 2): piece Q of 4, or piece Q / 2 in statements 0 and 2 of 2."""
+    if c.NP == 4:
+        return Q
+    if c.NP == 2 and Q in (0, 2):
+        return Q // 2
+    return None
+
+
 def gen_p1(c, Q, par, qk, sm, vr, dma):
-    """phase-1 statement of step PAR.  qk: MFMAs of S_{j+1}.  sm: 0 none, 1 plain, 2 masked (S_j[B]).  vr: V_j reads.  dma: embedded pieces."""
+    """phase-1 statement of step PAR.  qk: MFMAs of S_{j+1}.  sm: 0 none, 1 plain, 2 masked (S_j[B]).  vr: V_j reads (ring slot in the
+    address register).  dma: this statement's piece of the K tile the step requests."""
     qb, KS, DB = Q >> 1, c.KS, c.DB
     mf, clob = [], ["memory"]
     if qk:
@@ -204,7 +273,7 @@ def gen_p1(c, Q, par, qk, sm, vr, dma):
         sk = Q
         for d in range(DB):
             for i in range(2):
-                off = par * c.VT + ((4 * sk) * (c.D // 16) + 2 * d) * 128 + i * 2 * (c.D // 16) * 128
+                off = ((4 * sk) * (c.D // 16) + 2 * d) * 128 + i * 2 * (c.D // 16) * 128
                 lds.append(f"ds_read_b64_tr_b16 {c.Vhalf(sk, d, i)}, %[va] offset:{off}")
         clob += vregs(c.VB0 + Q * DB * 4, DB * 4)
     valu = []
@@ -215,31 +284,33 @@ def gen_p1(c, Q, par, qk, sm, vr, dma):
         if sm == 2:
             clob.append("vcc")
     pieces = []
-    if dma:
-        for t in range(max(1, c.NP // 2)):
-            pieces.append((f"s_add_u32 m0, %[lds], {((Q & 1) * max(1, c.NP // 2) + t) * 4096}",
-                           f"buffer_load_dwordx4 %[vo], %[srd], %[so{t}] offen lds"))
+    if dma and dma_piece(c, Q) is not None:
+        pieces.append((f"s_add_u32 m0, %[lds], {dma_piece(c, Q) * 4096}", "buffer_load_dwordx4 %[vo], %[srd], %[so] offen lds"))
         clob += ["m0", "scc"]
-    lines = place(mf, lds, valu, pieces, 2, 4 if len(mf) >= 8 else 2)
+    if "nolds" in XFLAGS:
+        lds = []
+    if "nodma" in XFLAGS:
+        pieces = []
+    lines = place(mf, lds, valu, pieces, 2, len(mf) - 3 if len(mf) >= 8 else len(mf) - 1)
     if vr and Q == 3:
         lines.append("s_waitcnt lgkmcnt(0)")
     if qk and not sm:
         lines += ["s_nop 7", "s_nop 7"]      # bare MFMAs: results are read by whatever comes next
     ins = []
     if sm:
-        ins.append('[c] "s"(c)')
+        ins.append(f'[c] "{CREG}"(c)')
         if sm == 2:
             ins.append('[thr] "v"(thr)')
     if vr:
         ins.append('[va] "v"(va)')
-    if dma:
-        ins += ['[lds] "s"(dlds)', '[srd] "s"(dsrd)', '[so0] "s"(dso0)', '[so1] "s"(dso1)', '[vo] "v"(dvo)']
+    if pieces:
+        ins += ['[lds] "s"(dlds)', '[srd] "s"(dsrd)', '[so] "s"(dso)', '[vo] "v"(dvo)']
     return emit_asm(lines, [], ins, clob)
 
 
-def gen_p2(c, Q, par, pv, sm, kr):
+def gen_p2(c, Q, par, pv, sm, kr, dma):
     """phase-2 statement of step PAR.  pv: 0 none, 1 accumulate, 2 first tile of a part (C = 0 for sk = 0).  sm: softmax of S_{j+1}[A]
-    -> pA[PAR ^ 1][Q].  kr: reads of K_{j+2} (ring slot PAR)."""
+    -> pA[PAR ^ 1][Q].  kr: reads of K_{j+2} (ring slot in the address registers).  dma: this statement's piece of the V tile."""
     qb, KS, DB = Q >> 1, c.KS, c.DB
     mf, clob = [], ["memory"]
     if pv:
@@ -257,7 +328,7 @@ def gen_p2(c, Q, par, pv, sm, kr):
         for t in range(n):
             ks = Q * n + t
             for h in range(2):
-                lds.append(f"ds_read_b128 {c.K(ks, h)}, %[ka{t}] offset:{par * c.KT + h * 32 * c.RB}")
+                lds.append(f"ds_read_b128 {c.K(ks, h)}, %[ka{t}] offset:{h * 32 * c.RB}")
             clob += aregs(c.KB0 + 2 * ks * 4, 8)
     valu = []
     if sm:
@@ -266,14 +337,24 @@ def gen_p2(c, Q, par, pv, sm, kr):
         clob += vregs(c.X, 4) + vregs(c.pA(par ^ 1, Q), 4) + vregs(c.l(0, 0), 2)
         if sm == 2:
             clob.append("vcc")
-    lines = place(mf, lds, valu, [], 1, 0)
+    pieces = []
+    if dma and dma_piece(c, Q) is not None:
+        pieces.append((f"s_add_u32 m0, %[lds], {dma_piece(c, Q) * 4096}", "buffer_load_dwordx4 %[vo], %[srd], %[so] offen lds"))
+        clob += ["m0", "scc"]
+    if "nolds" in XFLAGS:
+        lds = []
+    if "nodma" in XFLAGS:
+        pieces = []
+    lines = place(mf, lds, valu, pieces, 1, len(mf) - 3 if len(mf) >= 8 else len(mf) - 1)
     ins = []
     if sm:
-        ins.append('[c] "s"(c)')
+        ins.append(f'[c] "{CREG}"(c)')
         if sm == 2:
             ins.append('[thr] "v"(thr)')
     if kr:
         ins += [f'[ka{t}] "v"(ka{t})' for t in range(KS // 4)]
+    if pieces:
+        ins += ['[lds] "s"(dlds)', '[srd] "s"(dsrd)', '[so] "s"(dso)', '[vo] "v"(dvo)']
     return emit_asm(lines, [], ins, clob)
 
 
@@ -281,7 +362,7 @@ def p1_variants():
     v = []
     for Q in range(4):
         for par in range(2):
-            v.append((Q, par, 1, 1, 1, 1))      # plain step (requests embedded)
+            v.append((Q, par, 1, 1, 1, 1))      # plain step (K request embedded)
             v.append((Q, par, 1, 2, 1, 0))      # masked step
             v.append((Q, par, 0, 2, 1, 0))      # the wave's last tile of a part
         v.append((Q, 0, 1, 1, 1, 0))            # first step of a part, nothing masked
@@ -293,11 +374,11 @@ def p2_variants():
     v = []
     for Q in range(4):
         for par in range(2):
-            v.append((Q, par, 1, 1, 1))         # plain step
-            v.append((Q, par, 1, 2, 1))         # masked step
-            v.append((Q, par, 1, 0, 1))         # last tile
-        v += [(Q, 0, 2, 1, 1), (Q, 0, 2, 2, 1), (Q, 0, 2, 0, 1)]   # first step of a part (O starts at 0)
-        v += [(Q, 1, 0, 1, 1), (Q, 1, 0, 2, 1)]                    # part prologue: P_0[A] next to the reads of K_1 (ring slot 1)
+            v.append((Q, par, 1, 1, 1, 1))      # plain step (V request embedded)
+            v.append((Q, par, 1, 2, 1, 0))      # masked step
+            v.append((Q, par, 1, 0, 1, 0))      # last tile
+        v += [(Q, 0, 2, 1, 1, 0), (Q, 0, 2, 2, 1, 0), (Q, 0, 2, 0, 1, 0)]   # first step of a part (O starts at 0)
+        v += [(Q, 1, 0, 1, 1, 0), (Q, 1, 0, 2, 1, 0)]                       # part prologue: P_0[A] next to the reads of K_1
     return sorted(set(v))
 
 
@@ -307,10 +388,10 @@ def gen_struct(c):
     s += f"    static constexpr int KB0 = {c.KB0}, QB0 = {c.QB0}, NP = {c.NP}, NV = {c.NV};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n"
     # ---- phase 1
     s += ("    template <int Q, int PAR, int QK, int SM, int VR, int DMA>\n"
-          "    static __device__ __forceinline__ void p1(float c, unsigned va, int thr, unsigned dlds, __amdgpu_buffer_rsrc_t dsrd, unsigned dso0,\n"
-          "                                              unsigned dso1, unsigned dvo) {\n"
+          "    static __device__ __forceinline__ void p1(float c, unsigned va, int thr, unsigned dlds, __amdgpu_buffer_rsrc_t dsrd, unsigned dso,\n"
+          "                                              unsigned dvo) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
-          "        (void)c; (void)va; (void)thr; (void)dlds; (void)dsrd; (void)dso0; (void)dso1; (void)dvo;\n")
+          "        (void)c; (void)va; (void)thr; (void)dlds; (void)dsrd; (void)dso; (void)dvo;\n")
     first = True
     for (Q, par, qk, sm, vr, dma) in p1_variants():
         s += f"        {'if' if first else 'else if'} constexpr (Q == {Q} && PAR == {par} && QK == {qk} && SM == {sm} && VR == {vr} && DMA == {dma}) {{\n"
@@ -320,30 +401,28 @@ def gen_struct(c):
     s += "        else static_assert(Q < 0, \"fa_fwd_w4_asm.inc: phase-1 variant not generated\");\n"
     s += "#endif\n    }\n"
     # ---- phase 2
-    s += ("    template <int Q, int PAR, int PV, int SM, int KR>\n"
-          "    static __device__ __forceinline__ void p2(float c, unsigned ka0, unsigned ka1, int thr) {\n"
+    s += ("    template <int Q, int PAR, int PV, int SM, int KR, int DMA>\n"
+          "    static __device__ __forceinline__ void p2(float c, unsigned ka0, unsigned ka1, int thr, unsigned dlds, __amdgpu_buffer_rsrc_t dsrd,\n"
+          "                                              unsigned dso, unsigned dvo) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
-          "        (void)c; (void)ka0; (void)ka1; (void)thr;\n")
+          "        (void)c; (void)ka0; (void)ka1; (void)thr; (void)dlds; (void)dsrd; (void)dso; (void)dvo;\n")
     first = True
-    for (Q, par, pv, sm, kr) in p2_variants():
-        s += f"        {'if' if first else 'else if'} constexpr (Q == {Q} && PAR == {par} && PV == {pv} && SM == {sm} && KR == {kr}) {{\n"
-        s += gen_p2(c, Q, par, pv, sm, kr)
+    for (Q, par, pv, sm, kr, dma) in p2_variants():
+        s += f"        {'if' if first else 'else if'} constexpr (Q == {Q} && PAR == {par} && PV == {pv} && SM == {sm} && KR == {kr} && DMA == {dma}) {{\n"
+        s += gen_p2(c, Q, par, pv, sm, kr, dma)
         s += "        }\n"
         first = False
     s += "        else static_assert(Q < 0, \"fa_fwd_w4_asm.inc: phase-2 variant not generated\");\n"
     s += "#endif\n    }\n"
-    # ---- all K fragments of the tile in ring slot PAR: part prologue
-    s += "    template <int PAR>\n    static __device__ __forceinline__ void kread_all(const unsigned* ka) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
-    for par in range(2):
-        lines = []
-        for ks in range(c.KS):
-            for h in range(2):
-                lines.append(f"ds_read_b128 {c.K(ks, h)}, %[ka{ks}] offset:{par * c.KT + h * 32 * c.RB}")
-        lines.append("s_waitcnt lgkmcnt(0)")
-        ins = [f'[ka{ks}] "v"(ka[{ks}])' for ks in range(c.KS)]
-        s += f"        {'if' if par == 0 else 'else if'} constexpr (PAR == {par}) {{\n"
-        s += emit_asm(lines, [], ins, ["memory"] + aregs(c.KB0, 8 * c.KS))
-        s += "        }\n"
+    # ---- all K fragments of one tile (ring slot in the address registers): part prologue
+    lines = []
+    for ks in range(c.KS):
+        for h in range(2):
+            lines.append(f"ds_read_b128 {c.K(ks, h)}, %[ka{ks}] offset:{h * 32 * c.RB}")
+    lines.append("s_waitcnt lgkmcnt(0)")
+    ins = [f'[ka{ks}] "v"(ka[{ks}])' for ks in range(c.KS)]
+    s += "    static __device__ __forceinline__ void kread_all(const unsigned* ka) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+    s += emit_asm(lines, [], ins, ["memory"] + aregs(c.KB0, 8 * c.KS), indent="        ")
     s += "#endif\n    }\n"
     # ---- Q fragments: rows (q0 + 32 qb + l31), 16 bytes at 32 ks + 16 hi; vo = row offset + 16 hi of block A, block B 32 rows on
     lines = ["s_nop 4"]
@@ -361,6 +440,8 @@ def gen_struct(c):
         lines.append("buffer_load_dwordx4 %[vo], %[srd], %[t] offen lds")
     s += "    static __device__ __forceinline__ void dma_tile(unsigned dlds, __amdgpu_buffer_rsrc_t dsrd, unsigned dsoff, unsigned dvo) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
     s += "        unsigned t;\n"
+    s += "        // (readfirstlane: hipcc sometimes moves uniform arithmetic to the vector unit; the request wants scalar registers)\n"
+    s += "        dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n        dsoff = (unsigned)__builtin_amdgcn_readfirstlane((int)dsoff);\n"
     s += emit_asm(lines, ['[t] "=&s"(t)'], ['[lds] "s"(dlds)', '[srd] "s"(dsrd)', '[soff] "s"(dsoff)', '[vo] "v"(dvo)'], ["memory", "m0", "scc"], indent="        ")
     s += "#endif\n    }\n"
     # ---- row maximum of tile 0: BLK 0 = S[A] (xa0, xa1), 1 = S[B] written by the bare QK^T (yb0, yb1[0]); lane-local 32 values

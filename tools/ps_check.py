@@ -21,7 +21,7 @@ DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
 UNIT = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}
 
 
-def route(dtype, B, Hq, Hkv, Sq, Sk, D, causal):
+def route(dtype, B, Hq, Hkv, Sq, Sk, D, causal, scale=1.0):
     lib = _capi.get_lib()
     lib.aule_hip_debug_forward_route.restype = ctypes.c_int32
     lib.aule_hip_debug_forward_route.argtypes = [ctypes.POINTER(_capi.AttnDesc)]
@@ -29,7 +29,7 @@ def route(dtype, B, Hq, Hkv, Sq, Sk, D, causal):
     d.struct_size = ctypes.sizeof(_capi.AttnDesc)
     d.dtype = {"fp16": 1, "bf16": 2}[dtype]
     d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
-    d.scale = 1.0
+    d.scale = scale
     d.causal = at.causal_code(causal)
     d.window_size = -1
     return lib.aule_hip_debug_forward_route(ctypes.byref(d))
@@ -57,7 +57,7 @@ def check(dtype, B, Hq, Hkv, Sq, Sk, D, causal, mag=1.0, scale=None, want_route=
         q.zero_()   # every logit equal: uniform attention, row sums = number of visible keys
     sc = 1 / math.sqrt(D) if scale is None else scale
     cz = at.causal_code(causal)
-    r = route(dtype, B, Hq, Hkv, Sq, Sk, D, causal)
+    r = route(dtype, B, Hq, Hkv, Sq, Sk, D, causal, sc)
     out, lse = at.fwd_raw(q, k, v, causal, sc)
     out2, _ = at.fwd_raw(q, k, v, causal, sc, want_lse=False)
     torch.cuda.synchronize()

@@ -77,10 +77,14 @@ for w in waves:
             kind = "plain" if tag < 0x20 else f"gen{tag:#x}"
             j = i + 1
             p1 = p2 = None
-            while j < len(r) and r[j][0] in (0x18, 0x19):
+            extra = []
+            while j < len(r) and r[j][0] in (0x18, 0x19, 0x1a, 0x1b):
                 if r[j][0] == 0x18: p1 = r[j][1]
-                else: p2 = r[j][1]
+                elif r[j][0] == 0x19: p2 = r[j][1]
+                else: extra.append(r[j])
                 j += 1
+            if extra and os.environ.get("ALL"):
+                print(f"      {kind} at +{tm - t0}: p1 {p1 - tm} p2 {p2 - p1} " + " ".join(f"{a:#x}:+{b - p2}" for a, b in extra) + f" next +{(r[j][1] if j < len(r) else 0) - p2}")
             end = r[j][1] if j < len(r) else tm
             if p1 is not None and p2 is not None:
                 a = acc.setdefault(kind, [0, 0, 0, 0])
