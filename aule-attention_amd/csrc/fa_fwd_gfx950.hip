@@ -53,7 +53,16 @@ static int fwd_kernel_choice() {
 }
 static bool use_ps(const FwdArgs& a) { return fwd_kernel_choice() != 4 && fwd_ps_applicable(a); }
 static bool use_ps_split(const FwdArgs& a) { return fwd_kernel_choice() != 4 && fwd_ps_split_applicable(a); }
-static bool use_w4(const FwdArgs& a) { return fwd_kernel_choice() == 0 && fwd_w4_applicable(a); }
+// AULE_HIP_FWD_SOFTMAX=classic asks for the online softmax throughout: the one-wave-per-SIMD kernel has no online form (its
+// fall-back is a second pass with the exact row maximum), so such runs stay on the two-waves-per-SIMD kernels
+static bool softmax_classic() {
+    static const int v = [] {
+        const char* e = getenv("AULE_HIP_FWD_SOFTMAX");
+        return (e != nullptr && e[0] == 'c') ? 1 : 0;
+    }();
+    return v == 1;
+}
+static bool use_w4(const FwdArgs& a) { return fwd_kernel_choice() == 0 && !softmax_classic() && fwd_w4_applicable(a); }
 
 bool splitkv_applicable(const FwdArgs& a);                      // fa_fwd_splitkv_gfx950.hip
 int launch_fwd_splitkv(const FwdArgs& a, hipStream_t stream);
@@ -99,8 +108,15 @@ int fwd_route(const FwdArgs& a) {
     return use_ps(a) ? 6 : 1;
 }
 
-// (arguments that carry rotation tables never take route 8: fwd_w4_applicable refuses them, so they land on the stream that fuses the rotation)
-bool fwd_rope_fusable(const FwdArgs& a) { return fwd_route(a) == 6 && fwd_ps_rope_fusable(a); }
+// The query rotation is fused by the two-waves-per-SIMD stream only.  A problem the one-wave-per-SIMD kernel would take WITHOUT
+// the tables is answered "not fusable": rotating Q in a pass of its own and running that kernel is faster than fusing on the
+// predecessor (C2: 10 us for the pass against ~35 us between the kernels), and the callers fall back to exactly that.
+bool fwd_rope_fusable(const FwdArgs& a) {
+    FwdArgs plain = a;
+    plain.rope_cos = plain.rope_sin = nullptr;
+    if (use_w4(plain)) return false;
+    return fwd_route(a) == 6 && fwd_ps_rope_fusable(a);
+}
 
 uint64_t fwd_workspace_bytes(FwdArgs a) {
     uint64_t bytes = 0;

@@ -99,7 +99,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     using A = W4Asm<T, D>;
     using std::integral_constant;
     constexpr int RB = 2 * D, RBP = RB + 16, CPR = RB / 16, KS = D / 16, DB = D / 32;
-    constexpr int KT = 64 * RB, VT = KT, NP = KT / 4096;
+    constexpr int KT = 64 * RB, VT = KT, NP = KT / 4096, NQ = 2 * KS;   // NQ: buffer loads of a wave's Q fragments
     constexpr int SLAB = 32 * RBP;   // one 32-row block of O, rows padded by 16 bytes
     constexpr int OFF_V = 3 * KT, OFF_SLAB = OFF_V + 3 * VT, TLDS = OFF_SLAB + 4 * SLAB;
     static_assert(A::NP == NP, "generator / kernel disagree on the tile geometry");
@@ -221,11 +221,19 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     // of this wave has returned; one barrier per tile
     auto step_end = [&](auto nreq_tag) __attribute__((always_inline)) {
         constexpr int NREQ = decltype(nreq_tag)::value;
-        static_assert(NREQ == 0 || NREQ == NP || NREQ == 2 * NP, "pieces a step may have in flight");
-        if constexpr (NREQ == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if constexpr (NREQ == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if constexpr (NREQ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        static_assert(NREQ % 2 == 0 && NREQ <= 24, "vector-memory operations a step may leave in flight");
+#define W4_STEP_END(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+        if constexpr (NREQ == 0) W4_STEP_END(0);
+        else if constexpr (NREQ == 2) W4_STEP_END(2);
+        else if constexpr (NREQ == 4) W4_STEP_END(4);
+        else if constexpr (NREQ == 8) W4_STEP_END(8);
+        else if constexpr (NREQ == 10) W4_STEP_END(10);
+        else if constexpr (NREQ == 12) W4_STEP_END(12);
+        else if constexpr (NREQ == 16) W4_STEP_END(16);
+        else if constexpr (NREQ == 18) W4_STEP_END(18);
+        else if constexpr (NREQ == 20) W4_STEP_END(20);
+        else W4_STEP_END(24);
+#undef W4_STEP_END
     };
 
     auto run_stream = [&](auto redo_tag) __attribute__((always_inline)) {
@@ -364,6 +372,9 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             if (pre && j == nt - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else if (n == 2 * NP) step_end(integral_constant<int, 2 * NP>{});
             else if (n == NP) step_end(integral_constant<int, NP>{});
+            else if (n == 2 * NP + NQ) step_end(integral_constant<int, 2 * NP + NQ>{});
+            else if (n == NP + NQ) step_end(integral_constant<int, NP + NQ>{});
+            else if (n == NQ) step_end(integral_constant<int, NQ>{});
             else step_end(integral_constant<int, 0>{});
         };
         // QK: S of tile j + 1 is computed (not the wave's last tile).  SM: 1 plain, 2 masked (both softmax halves).  PV: 1, or 2 for tile 0.
@@ -400,7 +411,14 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         };
         auto idle = [&](int j) __attribute__((always_inline)) {   // a tile this wave does not see
             stamp(0x08);
-            const int n = requests();
+            // the wave's Q registers are free (its last QK^T is behind it): the next part's Q rows now, not at the seam, where the
+            // four waves' 64 row-strided loads (one 16-byte chunk per lane and row: ~64 cache lines per instruction) queue up
+            // behind each other for ~3000 cycles -- the waves that see the whole block are then alone on that path
+            int n = requests();
+            if (pre && j == na) {   // (behind the step's requests, and counted: the step's closing wait does not cover them)
+                issue_q(w4_rfl(tab[n_slot].x), w4_rfl(tab[n_slot].z));
+                n += NQ;
+            }
             advance(j);
             end_n(n, j);
         };
@@ -556,7 +574,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 ++j;
             }
             for (; j < nt; ++j) idle(j);
-            if (pre) issue_q(w4_rfl(tab[n_slot].x), w4_rfl(tab[n_slot].z));   // (the Q registers are free since the wave's last QK^T)
+            if (pre && na == nt) issue_q(w4_rfl(tab[n_slot].x), w4_rfl(tab[n_slot].z));   // (waves with idle steps asked in their first one)
             epilogue();
             if (n_slot >= nslot) break;
             cs = n_slot;

@@ -119,11 +119,12 @@ def test_forward_routing_rule(monkeypatch):
     """The dispatcher is host logic (no device needed).  Non-causal 16-bit problems that the plain tiled launch would
     run badly go to one of two kernels by a MEASURED rule (tools/ppsplit_grid.py, tools/ppsplit_decode.py):
     5 = tiled kernel with packed rows + KV splits (most shapes), 4 = wave-per-chunk split-KV kernel (>= 32 units,
-    <= 16 packed rows, K+V >= 100 MB); everything else 16-bit goes to the persistent tile stream (6) when every Q block
-    has at least four KV tiles and there is no window, else to its predecessor, the ping-pong kernel (1); fp32 to 0."""
+    <= 16 packed rows, K+V >= 100 MB); everything else 16-bit goes to a persistent tile stream when every Q block has at
+    least four KV tiles and there is no window -- the one-wave-per-SIMD kernel (8) at D = 128 with a positive scale, the
+    two-waves-per-SIMD stream (6) otherwise -- else to the ping-pong kernel (1); fp32 to 0."""
     for var in ("AULE_HIP_FWD_KERNEL", "AULE_HIP_FWD_SPLITKV", "AULE_HIP_FWD_PPSPLIT"):
         monkeypatch.delenv(var, raising=False)
-    WAVE, TILED_SPLIT, PP, PS, F32, PS_SPLIT = 4, 5, 1, 6, 0, 7
+    WAVE, TILED_SPLIT, PP, PS, F32, PS_SPLIT, W4 = 4, 5, 1, 6, 0, 7, 8
     assert _route(1, 32, 1, 1, 16384, 64, dtype=1) == TILED_SPLIT    # C5b: 32 -> 17 us
     assert _route(1, 32, 1, 64, 16384, 64, dtype=1) == TILED_SPLIT   # C5c: 44 -> 28 us
     assert _route(8, 32, 8, 1, 2048, 128) == TILED_SPLIT             # 67 MB of K+V: below the streaming corner
@@ -137,37 +138,38 @@ def test_forward_routing_rule(monkeypatch):
     assert _route(16, 32, 8, 1, 8192, 128) == TILED_SPLIT            # large-batch decode: 376 -> 117 us
     assert _route(64, 32, 8, 1, 8192, 128) == TILED_SPLIT            # 1506 -> 461 us
     assert _route(1, 8, 8, 300, 8192, 128) == TILED_SPLIT            # Sq > 64, 16 tiled workgroups: 162 -> 34 us
-    assert _route(8, 32, 32, 1, 2048, 128) == PS                     # MHA decode: nothing to pack, chip already full
-    assert _route(16, 32, 32, 1, 8192, 128) == PS
-    assert _route(1, 32, 32, 2048, 2048, 128) == PS                  # 256 full Q blocks
-    assert _route(4, 32, 32, 4096, 4096, 128) == PS                  # C2 shape, non-causal
-    assert _route(1, 32, 8, 1, 8192, 128, causal=1) == PS            # causal
+    assert _route(8, 32, 32, 1, 2048, 128) == W4                     # MHA decode: nothing to pack, chip already full
+    assert _route(16, 32, 32, 1, 8192, 128) == W4
+    assert _route(1, 32, 32, 2048, 2048, 128) == W4                  # 256 full Q blocks
+    assert _route(4, 32, 32, 4096, 4096, 128) == W4                  # C2 shape, non-causal
+    assert _route(1, 32, 8, 1, 8192, 128, causal=1) == W4            # causal
     # bottom-right aligned causal (additive mode): one query sees every key -> the non-causal problem; short chunks
     # (Sq <= 256, no window) take the tiled kernel's SPLIT instances with a mask; the rest stays on the plain kernel
     assert _route(1, 32, 8, 1, 8192, 128, causal=2) == TILED_SPLIT   # = non-causal, 8 units
     assert _route(8, 32, 8, 1, 8192, 128, causal=2) == WAVE          # = non-causal, the streaming corner
     assert _route(8, 32, 8, 64, 8192, 128, causal=2) == TILED_SPLIT  # 210 -> 94 us
     assert _route(1, 32, 8, 8, 32768, 128, causal=2) == TILED_SPLIT  # 641 -> 44 us
-    assert _route(4, 32, 8, 1024, 4096, 128, causal=2) == PS         # Sq > 256
+    assert _route(4, 32, 8, 1024, 4096, 128, causal=2) == W4         # Sq > 256
     assert _route(8, 32, 8, 64, 8192, 128, causal=2, window=16) == PP
-    assert _route(8, 32, 8, 64, 8192, 128, causal=1) == PS           # top-left: sees the first Sq keys only
+    assert _route(8, 32, 8, 64, 8192, 128, causal=1) == W4           # top-left: sees the first Sq keys only
     assert _route(1, 32, 8, 1, 8192, 128, causal=2, window=128) == PP   # a window from the end needs the mask
     assert _route(1, 32, 8, 8, 8192, 128, window=4) == PP            # window
     assert _route(1, 32, 8, 8, 8192, 128, window=64) == TILED_SPLIT  # W >= Sq masks nothing: dropped
     assert _route(1, 32, 8, 1, 8192, 128, dtype=0) == F32
-    assert _route(4, 32, 32, 4096, 4096, 128, causal=1) == PS        # the headline shape
+    assert _route(4, 32, 32, 4096, 4096, 128, causal=1) == W4        # the headline shape
     assert _route(1, 8, 8, 128, 128, 128, causal=1) == PP            # fewer than four KV tiles per Q block
     assert _route(2, 8, 8, 512, 192, 128) == PP
-    assert _route(2, 8, 8, 512, 193, 128) == PS
+    assert _route(2, 8, 8, 512, 193, 128) == W4
     # small causal grids: every pair of Q blocks cut in two when the doubled item count still fits one round of the chip
     assert _route(1, 8, 8, 8192, 8192, 128, causal=1) == PS_SPLIT    # 128 paired items on 256 CUs
     assert _route(1, 32, 8, 2048, 2048, 128, causal=1) == PS_SPLIT   # single-sequence prefill
-    assert _route(2, 8, 8, 8192, 8192, 128, causal=1) == PS          # 256 paired items: already one per CU
+    assert _route(2, 8, 8, 8192, 8192, 128, causal=1) == W4          # 256 paired items: already one per CU
     assert _route(1, 32, 32, 2048, 2048, 64, dtype=1, causal=1) == PS_SPLIT   # D = 64: two workgroups per CU
-    assert _route(1, 8, 8, 8192, 8192, 128) == PS                    # non-causal: 256 blocks, one per CU
+    assert _route(1, 8, 8, 8192, 8192, 128) == W4                    # non-causal: 256 blocks, one per CU
     assert _route(1, 8, 8, 4096, 4096, 128) == PS_SPLIT              # non-causal: 128 blocks, each cut in two
     assert _route(1, 8, 8, 8192, 8192, 32, causal=1) == PS           # no D = 32 instances
-    assert _route(1, 8, 8, 300, 300, 128, causal=1) == PS            # one pair whose far block is too short to cut
+    assert _route(8, 32, 32, 2048, 2048, 64, dtype=1, causal=1) == PS         # D = 64 stays on the two-waves-per-SIMD stream
+    assert _route(1, 8, 8, 300, 300, 128, causal=1) == W4            # one pair whose far block is too short to cut
     assert _route(1, 3, 2, 1, 8192, 128) == -3                       # heads not divisible
     # (AULE_HIP_FWD_SPLITKV=0 is read once per process into a static, so the off-switch is not testable here;
     #  tools/split_grid.py exercises it in a process of its own)

@@ -34,7 +34,7 @@ def test_bench_under_torchrun_one_rank():
     # direct peer sends): each timed end to end
     for name in ("blocking_all_gather", "chunked_all_gather", "chunked_p2p"):
         assert rec["gather"][name]["ms_per_step"] > 0, name
-    assert rec["cold_start"]["value"] > 0 and rec["conditioning"]["steps"] > 0
+    assert rec["steady_state"]["value"] > 0 and rec["steady_state"]["conditioning_steps"] > 0 and rec["world_size"] == 1
     assert rec["roofline"]["bound"] == "mfma" and 0 < rec["roofline"]["frac"] < 1
 
 

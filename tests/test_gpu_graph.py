@@ -22,7 +22,10 @@ SHAPES = [  # name, B, Hq, Hkv, Sq, Sk, D, dtype, causal
     ("plain-causal", 1, 8, 8, 1024, 1024, 128, "bf16", True),
     ("route7-causal-split", 1, 8, 8, 4096, 4096, 128, "bf16", True),      # stream kernel over pieces + merge kernel, caller workspace
     ("route7-noncausal-split", 1, 8, 8, 2048, 2048, 128, "fp16", False),
-    ("route6-fused-rope", 4, 16, 16, 1024, 1024, 128, "bf16", True),      # the forward that rotates Q itself (tables captured too)
+    ("route8-one-wave-per-simd", 4, 16, 16, 1024, 1024, 128, "bf16", True),   # the D = 128 default: several parts per workgroup
+    ("route6-fused-rope", 4, 16, 16, 1024, 1024, 64, "bf16", True),       # the forward that rotates Q itself (tables captured too;
+                                                                          # D = 64: at D = 128 the library prefers a rotation pass +
+                                                                          # the one-wave-per-SIMD kernel)
 ]
 
 

@@ -12,6 +12,7 @@ the rot_cos / rot_sin handles of aule_attention_forward_gpu (interleaved pairs, 
     on relative position only (shifting every position by the same offset leaves the output unchanged).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -222,13 +223,17 @@ def test_fused_query_rotation_is_the_separate_pass_bit_for_bit(case, oracle_mod,
     qoff = Sk - Sq if causal == "bottom-right" else 0
     tq, tk, tv, tc, ts = _dev(torch, q, dtype), _dev(torch, k, dtype), _dev(torch, v, dtype), _dev(torch, cos), _dev(torch, sin)
     code = at.causal_code(causal)
-    assert at.rope_fusable(tq, tk, code, -1, tc, ts, qoff)
+    # D = 128 problems of this kind run on the one-wave-per-SIMD kernel, which does not rotate Q itself: the library answers
+    # "not fusable" there (a rotation pass + that kernel beats fusing on its predecessor) and every route below is the two passes
+    fus = at.rope_fusable(tq, tk, code, -1, tc, ts, qoff)
+    assert fus == (D != 128 or os.environ.get("AULE_HIP_FWD_KERNEL", "") == "ps")
     sc = 1.0 / math.sqrt(D)
     kr = at.rope_raw(tk, tc, ts, "half", False, 0)
     qr = at.rope_raw(tq, tc, ts, "half", False, qoff)
-    two_pass, _ = at.fwd_raw(qr, kr, tv, code, sc, want_lse=False)
-    fused, lse = at.fwd_raw(tq, kr, tv, code, sc, want_lse=True, q_rope=(tc, ts, qoff))
-    assert torch.equal(fused, two_pass)
+    two_pass, lse = at.fwd_raw(qr, kr, tv, code, sc, want_lse=True)
+    if fus:
+        fused, lse = at.fwd_raw(tq, kr, tv, code, sc, want_lse=True, q_rope=(tc, ts, qoff))
+        assert torch.equal(fused, two_pass)
     with torch.no_grad():
         auto = at.flash_attention_rope_hip(tq, tk, tv, tc, ts, causal=causal)
     assert torch.equal(auto, two_pass)
@@ -240,7 +245,7 @@ def test_fused_query_rotation_is_the_separate_pass_bit_for_bit(case, oracle_mod,
         ko = quantize(oracle_mod.rope_f64(k, cos, sin, "half"), dtype)
         ref, ref_lse = oracle_mod.fwd_f64(qo, ko, v, causal, None, -1)
         atol, rtol = fwd_tol(dtype, np.abs(v).max())
-        assert_close(fused.float().cpu().numpy(), ref, atol, rtol, "out")
+        assert_close(two_pass.float().cpu().numpy(), ref, atol, rtol, "out")
         assert_close(lse.cpu().numpy(), ref_lse, LSE_TOL[dtype], 0, "lse")
 
 

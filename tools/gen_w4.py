@@ -391,7 +391,9 @@ def gen_struct(c):
           "    static __device__ __forceinline__ void p1(float c, unsigned va, int thr, unsigned dlds, __amdgpu_buffer_rsrc_t dsrd, unsigned dso,\n"
           "                                              unsigned dvo) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
-          "        (void)c; (void)va; (void)thr; (void)dlds; (void)dsrd; (void)dso; (void)dvo;\n")
+          "        (void)c; (void)va; (void)thr; (void)dlds; (void)dsrd; (void)dso; (void)dvo;\n"
+          "        if constexpr (DMA != 0) {   // (readfirstlane: hipcc sometimes moves uniform arithmetic to the vector unit; the request wants scalars)\n"
+          "            dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n            dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n        }\n")
     first = True
     for (Q, par, qk, sm, vr, dma) in p1_variants():
         s += f"        {'if' if first else 'else if'} constexpr (Q == {Q} && PAR == {par} && QK == {qk} && SM == {sm} && VR == {vr} && DMA == {dma}) {{\n"
@@ -405,7 +407,9 @@ def gen_struct(c):
           "    static __device__ __forceinline__ void p2(float c, unsigned ka0, unsigned ka1, int thr, unsigned dlds, __amdgpu_buffer_rsrc_t dsrd,\n"
           "                                              unsigned dso, unsigned dvo) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
-          "        (void)c; (void)ka0; (void)ka1; (void)thr; (void)dlds; (void)dsrd; (void)dso; (void)dvo;\n")
+          "        (void)c; (void)ka0; (void)ka1; (void)thr; (void)dlds; (void)dsrd; (void)dso; (void)dvo;\n"
+          "        if constexpr (DMA != 0) {\n"
+          "            dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n            dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n        }\n")
     first = True
     for (Q, par, pv, sm, kr, dma) in p2_variants():
         s += f"        {'if' if first else 'else if'} constexpr (Q == {Q} && PAR == {par} && PV == {pv} && SM == {sm} && KR == {kr} && DMA == {dma}) {{\n"
