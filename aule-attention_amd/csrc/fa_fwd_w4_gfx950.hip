@@ -217,23 +217,25 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     const unsigned wave1k = (unsigned)wave * 1024u;
     const unsigned oob = (unsigned)Sk * RB;   // a scalar offset at which every lane of a request is out of range (LDS gets zeros)
 
-    // end of a tile step: the requests of the PREVIOUS step have landed (everything but this step's NREQ pieces), every LDS read
-    // of this wave has returned; one barrier per tile
-    auto step_end = [&](auto nreq_tag) __attribute__((always_inline)) {
+    // The tile barrier of step j: the wave's LDS reads of step j - 1 have returned (so a request of step j may overwrite their
+    // ring slots once every wave is here), and the tiles requested at step j - 2 have landed (everything but the NREQ pieces
+    // step j - 1 asked for) -- every wave waits for its own pieces, the barrier makes them everybody's.  Generic and idle steps
+    // run it first thing; the plain step carries it behind its second MFMA (fa_fwd_w4_asm.inc, phase-1 statement 0).
+    auto step_begin = [&](auto nreq_tag) __attribute__((always_inline)) {
         constexpr int NREQ = decltype(nreq_tag)::value;
         static_assert(NREQ % 2 == 0 && NREQ <= 24, "vector-memory operations a step may leave in flight");
-#define W4_STEP_END(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
-        if constexpr (NREQ == 0) W4_STEP_END(0);
-        else if constexpr (NREQ == 2) W4_STEP_END(2);
-        else if constexpr (NREQ == 4) W4_STEP_END(4);
-        else if constexpr (NREQ == 8) W4_STEP_END(8);
-        else if constexpr (NREQ == 10) W4_STEP_END(10);
-        else if constexpr (NREQ == 12) W4_STEP_END(12);
-        else if constexpr (NREQ == 16) W4_STEP_END(16);
-        else if constexpr (NREQ == 18) W4_STEP_END(18);
-        else if constexpr (NREQ == 20) W4_STEP_END(20);
-        else W4_STEP_END(24);
-#undef W4_STEP_END
+#define W4_STEP_BEGIN(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+        if constexpr (NREQ == 0) W4_STEP_BEGIN(0);
+        else if constexpr (NREQ == 2) W4_STEP_BEGIN(2);
+        else if constexpr (NREQ == 4) W4_STEP_BEGIN(4);
+        else if constexpr (NREQ == 8) W4_STEP_BEGIN(8);
+        else if constexpr (NREQ == 10) W4_STEP_BEGIN(10);
+        else if constexpr (NREQ == 12) W4_STEP_BEGIN(12);
+        else if constexpr (NREQ == 16) W4_STEP_BEGIN(16);
+        else if constexpr (NREQ == 18) W4_STEP_BEGIN(18);
+        else if constexpr (NREQ == 20) W4_STEP_BEGIN(20);
+        else W4_STEP_BEGIN(24);
+#undef W4_STEP_BEGIN
     };
 
     auto run_stream = [&](auto redo_tag) __attribute__((always_inline)) {
@@ -242,12 +244,13 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         if (cs >= nslot) return;
 
         // ---- part scalars
-        int qoff, kvoff, qb, nt, na, jm, r0;
+        int qoff, kvoff, qb, nt, nt3, na, jm, r0;   // nt3: nt rounded up to a multiple of 3 (idle steps pad the part: every part starts at ring phase 0)
         int n_slot;
         bool pre = false;           // the next part's K_0..K_2, V_0, V_1 and Q ride along with this part's last steps
         // ring phase: stream position mod 3.  At step j (phase rp) V_j sits in slot rp, K_{j+2} in slot rp + 2, the step requests
         // K_{j+4} into slot rp + 1 and V_{j+2} into slot rp + 2 (all mod 3); positions run on through the parts.
         int rp = 0;
+        int nprev = 0;   // pieces the previous step requested (the only vector-memory operations the next tile barrier leaves in flight)
         auto slot = [&](int d) __attribute__((always_inline)) { const int x = rp + d; return x >= 3 ? x - 3 : x; };
         // request cursors: what step j asks for (K tile j + 4, V tile j + 2); soff == oob: nothing
         // (the heads' base addresses are carried as two dwords and made into descriptors WHERE THEY ARE USED, through
@@ -266,17 +269,17 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         };
         // (K_3 of the next part is NOT prefetched: its ring slot is the one K_0 sits in until the next part's prologue has read it;
         // every part requests its own K_3 at its step 0)
-        auto set_k = [&](int t) __attribute__((always_inline)) {   // tile t of this part, or tile t - nt < 3 of the next one
+        auto set_k = [&](int t) __attribute__((always_inline)) {   // tile t of this part, or tile t - nt3 < 3 of the next one
             head_lohi(P()->k, kvoff, klo, khi);
             ksoff = oob;
             if (t < nt) ksoff = (unsigned)t * KT;
-            else if (pre && t - nt < 3) { head_lohi(P()->k, w4_rfl(tab[n_slot].y), klo, khi); ksoff = (unsigned)(t - nt) * KT; }
+            else if (pre && t >= nt3 && t - nt3 < 3) { head_lohi(P()->k, w4_rfl(tab[n_slot].y), klo, khi); ksoff = (unsigned)(t - nt3) * KT; }
         };
-        auto set_v = [&](int t) __attribute__((always_inline)) {   // ... or tile t - nt < 2 of the next one
+        auto set_v = [&](int t) __attribute__((always_inline)) {   // ... or tile t - nt3 < 2 of the next one
             head_lohi(P()->v, kvoff, vlo, vhi);
             vsoff = oob;
             if (t < nt) vsoff = (unsigned)t * VT;
-            else if (pre && t - nt < 2) { head_lohi(P()->v, w4_rfl(tab[n_slot].y), vlo, vhi); vsoff = (unsigned)(t - nt) * VT; }
+            else if (pre && t >= nt3 && t - nt3 < 2) { head_lohi(P()->v, w4_rfl(tab[n_slot].y), vlo, vhi); vsoff = (unsigned)(t - nt3) * VT; }
         };
         auto enter_part = [&](int sl) __attribute__((always_inline)) {
             const int4 e = tab[sl];
@@ -284,6 +287,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             kvoff = w4_rfl(e.y);
             qb = w4_rfl(e.z);
             nt = nt_of(qb);
+            nt3 = (nt + 2) / 3 * 3;
             r0 = qb * kQBlock + wave * 64;
             const int vis = CAUSAL ? min(Sk, r0 + 64 + coff) : Sk;   // keys the wave's last row sees
             na = min(nt, max(1, (vis + kKVTile - 1) / kKVTile));
@@ -336,26 +340,59 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         // ---- tile step j (PAR = j & 1: the S[B] / P[A] register copies in use)
         // plain: nothing masked, not the first, not the last tile of the wave; the requests ride in the gaps (K pieces in phase 1,
         // V pieces in phase 2: an out-of-range request writes zeros into a ring slot that is free by construction)
-        auto plain = [&](auto par_tag, int j) __attribute__((always_inline)) {
-            constexpr int PAR = decltype(par_tag)::value;
+        // (ring slots as immediates: SL = stream position mod 3.  Six bodies -- slot x parity -- so that between two MFMA
+        // statements of a plain step hipcc has nothing to compute but the requests' scalar offsets: the first build with run-time
+        // slots spent ~55 scalar instructions and half a dozen branches between two steps, with the matrix pipe idle)
+        auto plain = [&](auto sl_tag, auto par_tag) __attribute__((always_inline)) {
+            constexpr int SL = decltype(sl_tag)::value, PAR = decltype(par_tag)::value;
             stamp(0x10 + PAR);
-            const unsigned kl = k_lds(), vl = v_lds();
+            const unsigned kl = lds0 + ((SL + 1) % 3) * KT + wave1k, vl = lds0 + OFF_V + ((SL + 2) % 3) * VT + wave1k;
             const __amdgpu_buffer_rsrc_t ksrd = srd_of(klo, khi), vsrd = srd_of(vlo, vhi);
-            const unsigned vap = va + (unsigned)rp * VT, kb = ka0 + (unsigned)slot(2) * KT;
-            A::template p1<0, PAR, 1, 1, 1, 1>(c, vap, 0, kl, ksrd, ksoff, kvo);
-            A::template p1<1, PAR, 1, 1, 1, 1>(c, vap, 0, kl, ksrd, ksoff + 4096u, kvo);
-            A::template p1<2, PAR, 1, 1, 1, 1>(c, vap, 0, kl, ksrd, ksoff + (NP == 4 ? 8192u : 4096u), kvo);
-            A::template p1<3, PAR, 1, 1, 1, 1>(c, vap, 0, kl, ksrd, ksoff + 12288u, kvo);
-#ifndef W4_TL_SEAM
+            A::template p1<0, PAR, 1, 1, 1, 1, SL>(c, va, 0, kl, ksrd, ksoff, kvo);
+            A::template p1<1, PAR, 1, 1, 1, 1, SL>(c, va, 0, kl, ksrd, ksoff + 4096u, kvo);
+            A::template p1<2, PAR, 1, 1, 1, 1, SL>(c, va, 0, kl, ksrd, ksoff + (NP == 4 ? 8192u : 4096u), kvo);
+            A::template p1<3, PAR, 1, 1, 1, 1, SL>(c, va, 0, kl, ksrd, ksoff + 12288u, kvo);
             stamp(0x18);
-#endif
-            A::template p2<0, PAR, 1, 1, 1, 1>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), 0, vl, vsrd, vsoff, vvo);
-            A::template p2<1, PAR, 1, 1, 1, 1>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), 0, vl, vsrd, vsoff + 4096u, vvo);
-            A::template p2<2, PAR, 1, 1, 1, 1>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), 0, vl, vsrd, vsoff + (NP == 4 ? 8192u : 4096u), vvo);
-            A::template p2<3, PAR, 1, 1, 1, 1>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), 0, vl, vsrd, vsoff + 12288u, vvo);
+            constexpr int KSL = (SL + 2) % 3;
+            A::template p2<0, PAR, 1, 1, 1, 1, KSL>(c, kaddr(ka0, 0), kaddr(ka0, KS / 4 - 1), 0, vl, vsrd, vsoff, vvo);
+            A::template p2<1, PAR, 1, 1, 1, 1, KSL>(c, kaddr(ka0, KS / 4), kaddr(ka0, 2 * (KS / 4) - 1), 0, vl, vsrd, vsoff + 4096u, vvo);
+            A::template p2<2, PAR, 1, 1, 1, 1, KSL>(c, kaddr(ka0, 2 * (KS / 4)), kaddr(ka0, 3 * (KS / 4) - 1), 0, vl, vsrd, vsoff + (NP == 4 ? 8192u : 4096u), vvo);
+            A::template p2<3, PAR, 1, 1, 1, 1, KSL>(c, kaddr(ka0, 3 * (KS / 4)), kaddr(ka0, KS - 1), 0, vl, vsrd, vsoff + 12288u, vvo);
             stamp(0x19);
-            advance(j);
-            step_end(integral_constant<int, 2 * NP>{});
+        };
+        // the request cursors of step j + 1, after plain step j (the ring phase is the body's business)
+        auto cursors = [&](int j) __attribute__((always_inline)) {
+            if (__builtin_expect(j + 5 < nt, 1)) {
+                ksoff += KT;
+                vsoff += VT;
+            } else {
+                set_k(j + 5);
+                set_v(j + 3);
+            }
+        };
+        // a run of plain steps [j, jend), j = 1 (mod 6) at entry.  Every part starts at ring phase 0 (parts are padded to a
+        // multiple of three positions), so step j of ANY part uses ring slot j mod 3 and parity j mod 2: the six bodies follow
+        // each other in a fixed order and the loop between them is one compare and one branch -- a run-time choice among the
+        // six came out of hipcc's structurizer as ~10 flag tests per step.
+        auto plain_run = [&](int& j, int jend) __attribute__((always_inline)) {
+            using I0 = integral_constant<int, 0>;
+            using I1 = integral_constant<int, 1>;
+            using I2 = integral_constant<int, 2>;
+            for (;;) {
+                if (j >= jend) break;
+                plain(I1{}, I1{}); cursors(j); ++j; rp = 2;
+                if (j >= jend) break;
+                plain(I2{}, I0{}); cursors(j); ++j; rp = 0;
+                if (j >= jend) break;
+                plain(I0{}, I1{}); cursors(j); ++j; rp = 1;
+                if (j >= jend) break;
+                plain(I1{}, I0{}); cursors(j); ++j; rp = 2;
+                if (j >= jend) break;
+                plain(I2{}, I1{}); cursors(j); ++j; rp = 0;
+                if (j >= jend) break;
+                plain(I0{}, I0{}); cursors(j); ++j; rp = 1;
+            }
+            nprev = 2 * NP;
         };
         // the requests of a step as separate statements (everywhere but the plain step); returns the pieces now in flight.  An
         // out-of-range request is skipped: at a part's last steps its ring slot may already hold a tile of the next part.
@@ -365,35 +402,34 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             if (vsoff != oob) { A::dma_tile(v_lds(), srd_of(vlo, vhi), (unsigned)w4_rfl((int)vsoff), vvo); n += NP; }
             return n;
         };
-        // (a part's last step does not wait for requests at all when the next part follows: what is in flight then are the next
-        // head's K_2, V_0, V_1 -- first touches of that head, ~2x the latency of the tiles in the middle of a head; the wave's
-        // epilogue gives them time, the next prologue's vmcnt(0) and closing barrier make them visible before step 0 reads them)
-        auto end_n = [&](int n, int j) __attribute__((always_inline)) {
-            if (pre && j == nt - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else if (n == 2 * NP) step_end(integral_constant<int, 2 * NP>{});
-            else if (n == NP) step_end(integral_constant<int, NP>{});
-            else if (n == 2 * NP + NQ) step_end(integral_constant<int, 2 * NP + NQ>{});
-            else if (n == NP + NQ) step_end(integral_constant<int, NP + NQ>{});
-            else if (n == NQ) step_end(integral_constant<int, NQ>{});
-            else step_end(integral_constant<int, 0>{});
+        auto begin_n = [&]() __attribute__((always_inline)) {
+            if (nprev == 2 * NP) step_begin(integral_constant<int, 2 * NP>{});
+            else if (nprev == NP) step_begin(integral_constant<int, NP>{});
+            else if (nprev == 2 * NP + NQ) step_begin(integral_constant<int, 2 * NP + NQ>{});
+            else if (nprev == NP + NQ) step_begin(integral_constant<int, NP + NQ>{});
+            else if (nprev == NQ) step_begin(integral_constant<int, NQ>{});
+            else step_begin(integral_constant<int, 0>{});
         };
-        // QK: S of tile j + 1 is computed (not the wave's last tile).  SM: 1 plain, 2 masked (both softmax halves).  PV: 1, or 2 for tile 0.
-        auto step = [&](auto par_tag, auto qk_tag, auto sm_tag, auto pv_tag, int j) __attribute__((always_inline)) {
+        // generic step.  QK: S of tile j + 1 is computed (not the wave's last tile).  SMB / SMA: softmax of S_j[B] / S_{j+1}[A]: 1 plain,
+        // 2 masked (SMA 0: none, with QK 0).  PV: 1, or 2 for tile 0 (O starts at 0).
+        auto step = [&](auto par_tag, auto qk_tag, auto smb_tag, auto sma_tag, auto pv_tag, int j) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_tag)::value, QK = decltype(qk_tag)::value, SMB = decltype(smb_tag)::value;
+            constexpr int SMA = decltype(sma_tag)::value, PV = decltype(pv_tag)::value;
+            static_assert((QK == 0) == (SMA == 0), "the softmax of S_{j+1}[A] rides with its QK^T");
             const __amdgpu_buffer_rsrc_t ksrd = make_srd(nullptr, 0);   // (unused operand of the statements without requests)
-            constexpr int PAR = decltype(par_tag)::value, QK = decltype(qk_tag)::value, SM = decltype(sm_tag)::value, PV = decltype(pv_tag)::value;
-            stamp(0x20 + PAR + 2 * QK + 4 * SM);
-            if constexpr (PV == 2)   // tile 0: K_3 goes where K_0 was (the prologue's last barrier freed the slot); it is older than this
-                                     // step's own requests, so the step's closing wait covers it
+            stamp(0x20 + PAR + 2 * QK + 4 * SMB);
+            begin_n();
+            if constexpr (PV == 2)   // tile 0: K_3 goes where K_0 was (this step's tile barrier freed the slot); it is older than this
+                                     // step's own requests, so the NEXT tile barrier covers it
                 A::dma_tile(ring_lds(0, 0), head_srd(P()->k, kvoff, Sk), 3u * KT, kvo);
             const int n = requests();
             const unsigned vap = va + (unsigned)rp * VT, kb = ka0 + (unsigned)slot(2) * KT;
-            const int tB = SM == 2 ? thr_of(1, j) : 0;
-            A::template p1<0, PAR, QK, SM, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
-            A::template p1<1, PAR, QK, SM, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
-            A::template p1<2, PAR, QK, SM, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
-            A::template p1<3, PAR, QK, SM, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
+            const int tB = SMB == 2 ? thr_of(1, j) : 0;
+            A::template p1<0, PAR, QK, SMB, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
+            A::template p1<1, PAR, QK, SMB, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
+            A::template p1<2, PAR, QK, SMB, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
+            A::template p1<3, PAR, QK, SMB, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
             stamp(0x18);
-            constexpr int SMA = QK ? SM : 0;
             const int tA = SMA == 2 ? thr_of(0, j + 1) : 0;
             A::template p2<0, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0);
             A::template p2<1, PAR, PV, SMA, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0);
@@ -401,26 +437,36 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             A::template p2<3, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0);
             stamp(0x19);
             advance(j);
-#ifdef W4_TL_SEAM
-            stamp(0x1a);
-#endif
-            end_n(n, j);
-#ifdef W4_TL_SEAM
-            stamp(0x1b);
-#endif
+            nprev = n;
         };
-        auto idle = [&](int j) __attribute__((always_inline)) {   // a tile this wave does not see
+        // ... picked at run time: the wave's last tile is always run masked (harmless where nothing is)
+        auto step_rt = [&](auto par_tag, auto pv_tag, int j) __attribute__((always_inline)) {
+            using I0 = integral_constant<int, 0>;
+            using I1 = integral_constant<int, 1>;
+            using I2 = integral_constant<int, 2>;
+            if (j + 1 >= na) step(par_tag, I0{}, I2{}, I0{}, pv_tag, j);
+            else if (j >= jm) step(par_tag, I1{}, I2{}, I2{}, pv_tag, j);
+            else if (j + 1 >= jm) step(par_tag, I1{}, I1{}, I2{}, pv_tag, j);
+            else step(par_tag, I1{}, I1{}, I1{}, pv_tag, j);
+        };
+        auto idle = [&](int j) __attribute__((always_inline)) {   // a tile this wave does not see, or a padding position of the part
             stamp(0x08);
+            // (a padding position has no readers: its barrier only keeps requests from overtaking the last tile's LDS reads.  It
+            // does NOT wait for tiles -- what is in flight there are the next head's first tiles, first touches with ~2x the usual
+            // latency -- the next prologue's vmcnt(0) + barrier make them visible before anything reads them.)
+            if (j >= nt) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else begin_n();
+            int n = requests();
             // the wave's Q registers are free (its last QK^T is behind it): the next part's Q rows now, not at the seam, where the
             // four waves' 64 row-strided loads (one 16-byte chunk per lane and row: ~64 cache lines per instruction) queue up
-            // behind each other for ~3000 cycles -- the waves that see the whole block are then alone on that path
-            int n = requests();
-            if (pre && j == na) {   // (behind the step's requests, and counted: the step's closing wait does not cover them)
+            // behind each other for ~3000 cycles -- the waves that see the whole block are then alone on that path.  (Behind the
+            // step's requests, and counted: the next tile barrier does not wait for them.)
+            if (pre && j == na) {
                 issue_q(w4_rfl(tab[n_slot].x), w4_rfl(tab[n_slot].z));
                 n += NQ;
             }
             advance(j);
-            end_n(n, j);
+            nprev = n;
         };
         // part prologue = "step -1" (K_0, K_1 of the part in the ring, Q requested): S_0, the references, P_0[A]; leaves K_1 in
         // the fragment registers
@@ -430,8 +476,10 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             unsigned kap[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) kap[ks] = kaddr(ka0 + (unsigned)rp * KT, ks);
+            // every wave's pieces of this part's first tiles (requested by the previous part's last steps, which no longer wait
+            // for them) and the Q fragments; the epilogue's stores ride along
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             A::kread_all(kap);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Q fragments (and, after a part, the epilogue's stores)
             A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
             A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
             A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
@@ -455,7 +503,8 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 A::template p2<3, 1, 0, 1, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0);
             }
             stamp(0x33);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave holds K_0 and K_1: step 0 requests K_3 and K_4 into their slots
+            nprev = 0;   // (the vmcnt(0) above left nothing in flight; step 0's tile barrier follows: every wave holds K_0 and K_1 then,
+                         // and step 0 requests K_3 and K_4 into their slots)
         };
 
         // ---- epilogue of a part: O = O^T / l, rounded, transposed through the wave's LDS slab (block A, then block B), whole-row
@@ -555,25 +604,23 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             using I0 = integral_constant<int, 0>;
             using I1 = integral_constant<int, 1>;
             using I2 = integral_constant<int, 2>;
+            // plain steps: the previous step left exactly 2 NP pieces in flight (the constant their in-stream barrier waits
+            // with), tile j + 1 needs no mask and is not the wave's last; everything else runs the generic body.  (A plain step
+            // requests unconditionally -- an out-of-range request writes zeros into its ring slot -- which is harmless up to the
+            // wave's last-but-one tile: the slots that hold tiles of the NEXT part by then are not the ones it targets.)
+            const int jend = min(jm, na) - 1;
+            step_rt(I0{}, I2{}, 0);   // tile 0 (O starts at 0)
             int j = 1;
-            if (na == 1) {
-                step(I0{}, I0{}, I2{}, I2{}, 0);                      // the only tile: masked, O starts at 0
-            } else {
-                if (jm <= 1) step(I0{}, I1{}, I2{}, I2{}, 0);         // tile 0 (O starts at 0), S_1
-                else step(I0{}, I1{}, I1{}, I2{}, 0);
-                for (;;) {   // j odd at the top
-                    if (j + 1 >= na) { step(I1{}, I0{}, I2{}, I1{}, j); break; }
-                    if (j + 1 < jm) plain(I1{}, j);
-                    else step(I1{}, I1{}, I2{}, I1{}, j);
-                    ++j;
-                    if (j + 1 >= na) { step(I0{}, I0{}, I2{}, I1{}, j); break; }
-                    if (j + 1 < jm) plain(I0{}, j);
-                    else step(I0{}, I1{}, I2{}, I1{}, j);
-                    ++j;
+            while (j < na) {
+                if (j < jend && nprev == 2 * NP && j % 6 == 1) {
+                    plain_run(j, jend);
+                    continue;
                 }
+                if (j & 1) step_rt(I1{}, I1{}, j);
+                else step_rt(I0{}, I1{}, j);
                 ++j;
             }
-            for (; j < nt; ++j) idle(j);
+            for (; j < nt3; ++j) idle(j);   // (tiles the wave does not see, and the padding of the part to a multiple of three positions)
             if (pre && na == nt) issue_q(w4_rfl(tab[n_slot].x), w4_rfl(tab[n_slot].z));   // (waves with idle steps asked in their first one)
             epilogue();
             if (n_slot >= nslot) break;

@@ -171,7 +171,7 @@ def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked):
     return ops
 
 
-def place(mfmas, lds, valu, dma, lds_per_gap, dma_gap):
+def place(mfmas, lds, valu, dma, lds_per_gap, dma_gap, lds_first_gap=0, after_gap=None):
     """Interleave: after MFMA g come that gap's fillers, in program order.  LDS reads go to the earliest gaps (lds_per_gap each);
     the DMA piece (s_add m0 / one VALU / buffer_load ... lds -- a ~40-cycle issue by itself) gets gap dma_gap nearly to itself;
     the VALU fill the other gaps to an even share.  Without MFMAs the fillers are emitted in order."""
@@ -192,7 +192,7 @@ def place(mfmas, lds, valu, dma, lds_per_gap, dma_gap):
         valu = ["s_nop 0"]      # (the instruction between the M0 write and the request)
     nl = [0] * n
     rest = len(lds)
-    for g in range(n):
+    for g in range(lds_first_gap, n):
         if dma and g == dma_gap:
             continue
         nl[g] = min(lds_per_gap, rest)
@@ -226,6 +226,8 @@ def place(mfmas, lds, valu, dma, lds_per_gap, dma_gap):
         else:
             for _ in range(nv[g]):
                 out.append(valu.pop(0))
+        if after_gap is not None and g == after_gap[0]:
+            out += after_gap[1]
     assert not lds and not valu, (len(lds), len(valu))
     return out
 
@@ -255,7 +257,7 @@ def dma_piece(c, Q):
     return None
 
 
-def gen_p1(c, Q, par, qk, sm, vr, dma):
+def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
     """phase-1 statement of step PAR.  qk: MFMAs of S_{j+1}.  sm: 0 none, 1 plain, 2 masked (S_j[B]).  vr: V_j reads (ring slot in the
     address register).  dma: this statement's piece of the K tile the step requests."""
     qb, KS, DB = Q >> 1, c.KS, c.DB
@@ -273,7 +275,8 @@ def gen_p1(c, Q, par, qk, sm, vr, dma):
         sk = Q
         for d in range(DB):
             for i in range(2):
-                off = ((4 * sk) * (c.D // 16) + 2 * d) * 128 + i * 2 * (c.D // 16) * 128
+                off = sl * c.VT + ((4 * sk) * (c.D // 16) + 2 * d) * 128 + i * 2 * (c.D // 16) * 128
+                assert off < 65536
                 lds.append(f"ds_read_b64_tr_b16 {c.Vhalf(sk, d, i)}, %[va] offset:{off}")
         clob += vregs(c.VB0 + Q * DB * 4, DB * 4)
     valu = []
@@ -291,7 +294,15 @@ def gen_p1(c, Q, par, qk, sm, vr, dma):
         lds = []
     if "nodma" in XFLAGS:
         pieces = []
-    lines = place(mf, lds, valu, pieces, 2, len(mf) - 3 if len(mf) >= 8 else len(mf) - 1)
+    if dma and Q == 0:
+        # the plain step's tile barrier: the K fragments this statement's MFMAs read were requested from LDS in the previous
+        # step's phase 2 (lgkmcnt(0) first); the first two MFMAs and their softmax fillers need nothing the barrier guards, so the
+        # wait for the tiles requested two steps ago (everything but the previous step's 2 NP pieces) and the barrier sit
+        # behind them -- the matrix pipe keeps running while the workgroup meets.  V reads and requests come after it.
+        lines = ["s_waitcnt lgkmcnt(0)"] + place(mf, lds, valu, pieces, 2, len(mf) - 2 if len(mf) >= 8 else len(mf) - 1, 2 if len(mf) >= 8 else 1,
+                                               (1 if len(mf) >= 8 else 0, [f"s_waitcnt vmcnt({2 * c.NP})", "s_barrier"]))
+    else:
+        lines = place(mf, lds, valu, pieces, 2, len(mf) - 3 if len(mf) >= 8 else len(mf) - 1)
     if vr and Q == 3:
         lines.append("s_waitcnt lgkmcnt(0)")
     if qk and not sm:
@@ -308,7 +319,7 @@ def gen_p1(c, Q, par, qk, sm, vr, dma):
     return emit_asm(lines, [], ins, clob)
 
 
-def gen_p2(c, Q, par, pv, sm, kr, dma):
+def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
     """phase-2 statement of step PAR.  pv: 0 none, 1 accumulate, 2 first tile of a part (C = 0 for sk = 0).  sm: softmax of S_{j+1}[A]
     -> pA[PAR ^ 1][Q].  kr: reads of K_{j+2} (ring slot in the address registers).  dma: this statement's piece of the V tile."""
     qb, KS, DB = Q >> 1, c.KS, c.DB
@@ -328,7 +339,7 @@ def gen_p2(c, Q, par, pv, sm, kr, dma):
         for t in range(n):
             ks = Q * n + t
             for h in range(2):
-                lds.append(f"ds_read_b128 {c.K(ks, h)}, %[ka{t}] offset:{h * 32 * c.RB}")
+                lds.append(f"ds_read_b128 {c.K(ks, h)}, %[ka{t}] offset:{sl * c.KT + h * 32 * c.RB}")
             clob += aregs(c.KB0 + 2 * ks * 4, 8)
     valu = []
     if sm:
@@ -362,11 +373,12 @@ def p1_variants():
     v = []
     for Q in range(4):
         for par in range(2):
-            v.append((Q, par, 1, 1, 1, 1))      # plain step (K request embedded)
-            v.append((Q, par, 1, 2, 1, 0))      # masked step
-            v.append((Q, par, 0, 2, 1, 0))      # the wave's last tile of a part
-        v.append((Q, 0, 1, 1, 1, 0))            # first step of a part, nothing masked
-        v.append((Q, 1, 1, 0, 0, 0))            # bare QK^T of tile 0 ("step -1": part prologue, exact-maximum pass)
+            for sl in range(3):
+                v.append((Q, par, 1, 1, 1, 1, sl))  # plain step (K request embedded; V_j in ring slot sl)
+            for qk in (0, 1):
+                for sm in (1, 2):
+                    v.append((Q, par, qk, sm, 1, 0, 0))     # generic steps: ring slot in the address register, requests apart
+        v.append((Q, 1, 1, 0, 0, 0, 0))             # bare QK^T of tile 0 ("step -1": part prologue, exact-maximum pass)
     return sorted(set(v))
 
 
@@ -374,11 +386,12 @@ def p2_variants():
     v = []
     for Q in range(4):
         for par in range(2):
-            v.append((Q, par, 1, 1, 1, 1))      # plain step (V request embedded)
-            v.append((Q, par, 1, 2, 1, 0))      # masked step
-            v.append((Q, par, 1, 0, 1, 0))      # last tile
-        v += [(Q, 0, 2, 1, 1, 0), (Q, 0, 2, 2, 1, 0), (Q, 0, 2, 0, 1, 0)]   # first step of a part (O starts at 0)
-        v += [(Q, 1, 0, 1, 1, 0), (Q, 1, 0, 2, 1, 0)]                       # part prologue: P_0[A] next to the reads of K_1
+            for sl in range(3):
+                v.append((Q, par, 1, 1, 1, 1, sl))  # plain step (V request embedded; K_{j+2} in ring slot sl)
+            for sm in (0, 1, 2):
+                v.append((Q, par, 1, sm, 1, 0, 0))  # generic steps
+        v += [(Q, 0, 2, 0, 1, 0, 0), (Q, 0, 2, 1, 1, 0, 0), (Q, 0, 2, 2, 1, 0, 0)]   # first step of a part (O starts at 0)
+        v += [(Q, 1, 0, 1, 1, 0, 0), (Q, 1, 0, 2, 1, 0, 0)]                          # part prologue: P_0[A] next to the reads of K_1
     return sorted(set(v))
 
 
@@ -387,7 +400,8 @@ def gen_struct(c):
     s = f"template <> struct {name} {{\n"
     s += f"    static constexpr int KB0 = {c.KB0}, QB0 = {c.QB0}, NP = {c.NP}, NV = {c.NV};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n"
     # ---- phase 1
-    s += ("    template <int Q, int PAR, int QK, int SM, int VR, int DMA>\n"
+    s += ("    // SL: ring slot of the tile the statement reads, as an immediate (plain steps); 0 where the address register carries it\n"
+          "    template <int Q, int PAR, int QK, int SM, int VR, int DMA, int SL = 0>\n"
           "    static __device__ __forceinline__ void p1(float c, unsigned va, int thr, unsigned dlds, __amdgpu_buffer_rsrc_t dsrd, unsigned dso,\n"
           "                                              unsigned dvo) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
@@ -395,15 +409,15 @@ def gen_struct(c):
           "        if constexpr (DMA != 0) {   // (readfirstlane: hipcc sometimes moves uniform arithmetic to the vector unit; the request wants scalars)\n"
           "            dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n            dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n        }\n")
     first = True
-    for (Q, par, qk, sm, vr, dma) in p1_variants():
-        s += f"        {'if' if first else 'else if'} constexpr (Q == {Q} && PAR == {par} && QK == {qk} && SM == {sm} && VR == {vr} && DMA == {dma}) {{\n"
-        s += gen_p1(c, Q, par, qk, sm, vr, dma)
+    for (Q, par, qk, sm, vr, dma, sl) in p1_variants():
+        s += f"        {'if' if first else 'else if'} constexpr (Q == {Q} && PAR == {par} && QK == {qk} && SM == {sm} && VR == {vr} && DMA == {dma} && SL == {sl}) {{\n"
+        s += gen_p1(c, Q, par, qk, sm, vr, dma, sl)
         s += "        }\n"
         first = False
     s += "        else static_assert(Q < 0, \"fa_fwd_w4_asm.inc: phase-1 variant not generated\");\n"
     s += "#endif\n    }\n"
     # ---- phase 2
-    s += ("    template <int Q, int PAR, int PV, int SM, int KR, int DMA>\n"
+    s += ("    template <int Q, int PAR, int PV, int SM, int KR, int DMA, int SL = 0>\n"
           "    static __device__ __forceinline__ void p2(float c, unsigned ka0, unsigned ka1, int thr, unsigned dlds, __amdgpu_buffer_rsrc_t dsrd,\n"
           "                                              unsigned dso, unsigned dvo) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
@@ -411,9 +425,9 @@ def gen_struct(c):
           "        if constexpr (DMA != 0) {\n"
           "            dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n            dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n        }\n")
     first = True
-    for (Q, par, pv, sm, kr, dma) in p2_variants():
-        s += f"        {'if' if first else 'else if'} constexpr (Q == {Q} && PAR == {par} && PV == {pv} && SM == {sm} && KR == {kr} && DMA == {dma}) {{\n"
-        s += gen_p2(c, Q, par, pv, sm, kr, dma)
+    for (Q, par, pv, sm, kr, dma, sl) in p2_variants():
+        s += f"        {'if' if first else 'else if'} constexpr (Q == {Q} && PAR == {par} && PV == {pv} && SM == {sm} && KR == {kr} && DMA == {dma} && SL == {sl}) {{\n"
+        s += gen_p2(c, Q, par, pv, sm, kr, dma, sl)
         s += "        }\n"
         first = False
     s += "        else static_assert(Q < 0, \"fa_fwd_w4_asm.inc: phase-2 variant not generated\");\n"
