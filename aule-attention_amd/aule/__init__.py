@@ -295,11 +295,45 @@ def get_backend_info():
     return info
 
 
+def print_backend_info():
+    """Backend status report (reference: python/aule/__init__.py:516-562); this build lists its one backend, the library it
+    loaded and the device the C-ABI reports."""
+    print("=" * 60)
+    print("AULE-ATTENTION v" + __version__)
+    print("=" * 60)
+    print()
+    backends = get_available_backends()
+    print(f"Available backends: {backends}")
+    print()
+    if backends:
+        info = get_backend_info()
+        dev = info.get("hip", {})
+        print("[1] HIP (gfx950 / MI355X, hand-written kernels behind libaule.so)")
+        print(f"    GPU: {dev.get('device_name', 'Unknown')}")
+        print(f"    Library: {info.get('library')}")
+        print("    Status: FlashAttention-2 forward / backward, fp32 / fp16 / bf16")
+        print()
+    for name, err in get_backend_errors().items():
+        print(f"[-] {name.upper()}: unavailable -- {err}")
+        print()
+    print("=" * 60)
+
+
 def set_verbose(flag=True):
     global _verbose
     _verbose = bool(flag)
 
 
+def __getattr__(name):
+    # Aule / GpuTensor: the C-ABI consumer classes of the reference's vulkan.py, exported at package level like the reference does
+    # (python/aule/__init__.py:565-592).  Resolved lazily: importing them loads libaule.so, which needs a HIP device.
+    if name in ("Aule", "GpuTensor"):
+        from . import hip
+        return getattr(hip, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
 __all__ = ["flash_attention", "attention", "flash_attention_paged_amd", "flash_attention_paged",
            "flash_attention_rope", "precompute_rope_frequencies", "apply_rope_separate", "AuleError", "scaled_dot_product_attention", "install", "uninstall",
-           "get_available_backends", "get_backend_errors", "get_backend_info", "set_verbose", "__version__"]
+           "get_available_backends", "get_backend_errors", "get_backend_info", "print_backend_info", "Aule", "GpuTensor", "set_verbose",
+           "__version__"]

@@ -718,7 +718,7 @@ int set_attr_w4() {
 // Shapes the one-wave-per-SIMD forward takes (everything else: fa_fwd_ps_gfx950.hip / fa_fwd_pp_gfx950.hip).
 bool fwd_w4_applicable(const FwdArgs& a) {
     if (a.dtype != kBF16 && a.dtype != kF16) return false;
-    if (a.D != 128) return false;
+    if (a.D != 128 && a.D != 64) return false;
     if (a.window > 0 || a.rope_cos != nullptr) return false;
     if (!(a.scale > 0.f) || !(a.scale < 3.0e38f)) return false;
     if (a.causal && a.coff < 0) return false;
@@ -735,6 +735,8 @@ bool fwd_w4_applicable(const FwdArgs& a) {
 int launch_fwd_w4(const FwdArgs& a, hipStream_t stream) {
     if (a.dtype == kBF16 && a.D == 128) return launch_w4<Bf16Traits, 128>(a, stream);
     if (a.dtype == kF16 && a.D == 128) return launch_w4<F16Traits, 128>(a, stream);
+    if (a.dtype == kBF16 && a.D == 64) return launch_w4<Bf16Traits, 64>(a, stream);
+    if (a.dtype == kF16 && a.D == 64) return launch_w4<F16Traits, 64>(a, stream);
     return -1;
 }
 
@@ -749,6 +751,8 @@ int launch_fwd_w4_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_
 }
 #endif
 
-int configure_fwd_w4() { return set_attr_w4<Bf16Traits, 128>() | set_attr_w4<F16Traits, 128>(); }
+int configure_fwd_w4() {
+    return set_attr_w4<Bf16Traits, 128>() | set_attr_w4<F16Traits, 128>() | set_attr_w4<Bf16Traits, 64>() | set_attr_w4<F16Traits, 64>();
+}
 
 }  // namespace aule_hip

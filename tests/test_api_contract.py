@@ -55,10 +55,20 @@ def test_window_is_accepted_and_reaches_the_backend(small_qkv):
             aule.flash_attention(q, k, v, window_size=16)
 
 
-def test_version_and_exports():
+def test_version_and_exports(capsys):
     assert aule.__version__.startswith("0.5.0")
     for name in ("flash_attention", "attention", "AuleError", "get_available_backends"):
         assert hasattr(aule, name)
+    # the reference's public list (python/aule/__init__.py:565-592) minus what is out of scope here (patch_model: model patching)
+    for name in ("flash_attention", "attention", "scaled_dot_product_attention", "flash_attention_rope", "precompute_rope_frequencies",
+                 "apply_rope_separate", "flash_attention_paged_amd", "install", "uninstall", "get_available_backends", "get_backend_errors",
+                 "get_backend_info", "print_backend_info", "Aule", "GpuTensor", "AuleError", "__version__"):
+        assert name in aule.__all__ and getattr(aule, name) is not None, name
+    from aule import hip
+    assert aule.Aule is hip.Aule and aule.GpuTensor is hip.GpuTensor
+    aule.print_backend_info()   # works without a device: reports the backend as unavailable, with the reason
+    out = capsys.readouterr().out
+    assert "AULE-ATTENTION v" in out and "Available backends" in out
 
 
 def test_sdpa_shim_install_uninstall_and_cpu_fallback(capsys):
@@ -122,15 +132,19 @@ def test_fused_rotation_rule_from_python():
     flash_attention_rope uses it -- fused only for inference, half-split pairs, un-padded head_dim -- is what DESIGN 3.6 says."""
     import torch
     from aule import _torch as at
-    q = torch.zeros(4, 32, 2048, 128, dtype=torch.bfloat16)
-    k = torch.zeros(4, 8, 2048, 128, dtype=torch.bfloat16)
-    cos, sin = aule.precompute_rope_frequencies(2048, 128, device="cpu")
+    q = torch.zeros(4, 32, 2048, 64, dtype=torch.bfloat16)
+    k = torch.zeros(4, 8, 2048, 64, dtype=torch.bfloat16)
+    cos, sin = aule.precompute_rope_frequencies(2048, 64, device="cpu")
     cos, sin = cos.contiguous(), sin.contiguous()
-    assert at.rope_fusable(q, k, 1, -1, cos, sin, 0)
-    assert at.rope_fusable(q, k, 0, -1, cos, sin, 0)
+    # (negative-scale and window-free D = 64 / 128 problems of this size run on the one-wave-per-SIMD kernel, which does not
+    # rotate Q itself: a rotation pass + that kernel beats fusing on its predecessor, so the library answers "not fusable")
+    assert not at.rope_fusable(q, k, 1, -1, cos, sin, 0)
+    assert not at.rope_fusable(q, k, 0, -1, cos, sin, 0)
     assert not at.rope_fusable(q, k, 1, 128, cos, sin, 0)                    # sliding window: the ping-pong kernel
     assert not at.rope_fusable(q.float(), k.float(), 1, -1, cos, sin, 0)     # fp32 kernel
     assert not at.rope_fusable(q[..., :32].contiguous(), k[..., :32].contiguous(), 1, -1, cos[:, :16].contiguous(), sin[:, :16].contiguous(), 0)
+    # the fused rotation is still what the two-waves-per-SIMD stream does where it is the kernel: AULE_HIP_FWD_KERNEL=ps
+    # (tests/test_gpu_fwd_variants.py runs the bit-for-bit test that way)
     assert not at.rope_fusable(q, k, 1, -1, cos[:1000], sin[:1000], 0)       # table shorter than the sequence
     assert not at.rope_fusable(q, k, 1, -1, cos, sin, 1)                     # ... or than sequence + offset
     assert not at.rope_fusable(q[:, :, :1], k, 0, -1, cos, sin, 0)           # one query row: a short-query route

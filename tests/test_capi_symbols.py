@@ -120,7 +120,7 @@ def test_forward_routing_rule(monkeypatch):
     run badly go to one of two kernels by a MEASURED rule (tools/ppsplit_grid.py, tools/ppsplit_decode.py):
     5 = tiled kernel with packed rows + KV splits (most shapes), 4 = wave-per-chunk split-KV kernel (>= 32 units,
     <= 16 packed rows, K+V >= 100 MB); everything else 16-bit goes to a persistent tile stream when every Q block has at
-    least four KV tiles and there is no window -- the one-wave-per-SIMD kernel (8) at D = 128 with a positive scale, the
+    least four KV tiles and there is no window -- the one-wave-per-SIMD kernel (8) at D = 128 / 64 with a positive scale, the
     two-waves-per-SIMD stream (6) otherwise -- else to the ping-pong kernel (1); fp32 to 0."""
     for var in ("AULE_HIP_FWD_KERNEL", "AULE_HIP_FWD_SPLITKV", "AULE_HIP_FWD_PPSPLIT"):
         monkeypatch.delenv(var, raising=False)
@@ -168,48 +168,69 @@ def test_forward_routing_rule(monkeypatch):
     assert _route(1, 8, 8, 8192, 8192, 128) == W4                    # non-causal: 256 blocks, one per CU
     assert _route(1, 8, 8, 4096, 4096, 128) == PS_SPLIT              # non-causal: 128 blocks, each cut in two
     assert _route(1, 8, 8, 8192, 8192, 32, causal=1) == PS           # no D = 32 instances
-    assert _route(8, 32, 32, 2048, 2048, 64, dtype=1, causal=1) == PS         # D = 64 stays on the two-waves-per-SIMD stream
+    assert _route(8, 32, 32, 2048, 2048, 64, dtype=1, causal=1) == W4         # D = 64 too
     assert _route(1, 8, 8, 300, 300, 128, causal=1) == W4            # one pair whose far block is too short to cut
     assert _route(1, 3, 2, 1, 8192, 128) == -3                       # heads not divisible
     # (AULE_HIP_FWD_SPLITKV=0 is read once per process into a static, so the off-switch is not testable here;
     #  tools/split_grid.py exercises it in a process of its own)
 
 
-def test_fused_query_rotation_rule(monkeypatch):
-    """aule_attention_forward_rope_fusable() (host logic): the persistent forward kernel rotates Q itself for fp16 / bf16,
-    head_dim 64 / 128, half-split pairs, 16-byte aligned tables of pitch % 4 == 0 that cover seq_q + q_pos_offset rows;
-    everything else is refused so that the caller rotates Q with aule_rope_ex()."""
-    monkeypatch.delenv("AULE_HIP_FWD_KERNEL", raising=False)
-    monkeypatch.delenv("AULE_HIP_FWD_SOFTMAX", raising=False)
-    lib = _capi.load()
+_ROPE_RULE_CHILD = r'''
+import ctypes, os, sys
+sys.path.insert(0, os.path.join(%(root)r, "aule-attention_amd"))
+from aule import _capi
+lib = _capi.load()
 
-    def fusable(B=4, Hq=32, Hkv=32, Sq=2048, Sk=2048, D=128, dtype=2, causal=1, window=-1, rows=2048, pitch=0, pos=0,
-                layout=0, cos=0x1000, sin=0x2000, size=None):
-        d = _capi.AttnDesc()
-        d.struct_size = ctypes.sizeof(_capi.AttnDesc)
-        d.dtype = dtype
-        d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
-        d.causal, d.window_size = causal, window
-        r = _capi.AttnRope()
-        r.struct_size = ctypes.sizeof(_capi.AttnRope) if size is None else size
-        r.layout, r.table_len, r.table_pitch, r.q_pos_offset, r.cos, r.sin = layout, rows, pitch, pos, cos, sin
-        return lib.aule_attention_forward_rope_fusable(ctypes.byref(d), ctypes.byref(r))
+def fusable(B=4, Hq=32, Hkv=32, Sq=2048, Sk=2048, D=128, dtype=2, causal=1, window=-1, rows=2048, pitch=0, pos=0,
+            layout=0, cos=0x1000, sin=0x2000, size=None):
+    d = _capi.AttnDesc()
+    d.struct_size = ctypes.sizeof(_capi.AttnDesc)
+    d.dtype = dtype
+    d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
+    d.causal, d.window_size = causal, window
+    r = _capi.AttnRope()
+    r.struct_size = ctypes.sizeof(_capi.AttnRope) if size is None else size
+    r.layout, r.table_len, r.table_pitch, r.q_pos_offset, r.cos, r.sin = layout, rows, pitch, pos, cos, sin
+    return lib.aule_attention_forward_rope_fusable(ctypes.byref(d), ctypes.byref(r))
 
-    assert ctypes.sizeof(_capi.AttnRope) == 40
+assert ctypes.sizeof(_capi.AttnRope) == 40
+if os.environ.get("AULE_HIP_FWD_KERNEL") == "ps":
     assert fusable() == 1
     assert fusable(D=64, dtype=1, causal=0) == 1
     assert fusable(Sq=1024, Sk=4096, causal=2, rows=4096, pos=3072) == 1      # bottom-right: queries at Sk - Sq + i
-    assert fusable(D=32) == 0                                                  # no fused instance
-    assert fusable(dtype=0) == 0                                               # fp32 kernel
-    assert fusable(window=64) == 0                                             # ping-pong kernel
-    assert fusable(Sq=128, Sk=128) == 0                                        # fewer than four KV tiles: ping-pong kernel
-    assert fusable(Hq=8, Hkv=8, B=1, Sq=1, Sk=8192, causal=0, rows=8192) == 0  # short-query split paths
-    assert fusable(layout=1) == 0                                              # interleaved pairs: separate pass
-    assert fusable(rows=2047) == 0 and fusable(pos=1) == 0                     # table too short
-    assert fusable(pitch=66) == 0 and fusable(pitch=68) == 1                   # 16-byte rows
-    assert fusable(cos=0x1004) == 0 and fusable(sin=0) == 0                    # alignment, null
-    assert fusable(size=32) == 0
-    assert lib.aule_attention_forward_rope_fusable(None, None) == 0
+    assert fusable(pitch=68) == 1                                              # 16-byte rows
+else:
+    # problems the one-wave-per-SIMD kernel takes are never fused: a rotation pass + that kernel is faster (fa_fwd_gfx950.hip)
+    assert fusable() == 0 and fusable(D=64, dtype=1, causal=0) == 0
+    assert fusable(Sq=1024, Sk=4096, causal=2, rows=4096, pos=3072) == 0
+assert fusable(D=32) == 0                                                  # no fused instance
+assert fusable(dtype=0) == 0                                               # fp32 kernel
+assert fusable(window=64) == 0                                             # ping-pong kernel
+assert fusable(Sq=128, Sk=128) == 0                                        # fewer than four KV tiles: ping-pong kernel
+assert fusable(Hq=8, Hkv=8, B=1, Sq=1, Sk=8192, causal=0, rows=8192) == 0  # short-query split paths
+assert fusable(layout=1) == 0                                              # interleaved pairs: separate pass
+assert fusable(rows=2047) == 0 and fusable(pos=1) == 0                     # table too short
+assert fusable(pitch=66) == 0                                              # rows not 16-byte multiples
+assert fusable(cos=0x1004) == 0 and fusable(sin=0) == 0                    # alignment, null
+assert fusable(size=32) == 0
+assert lib.aule_attention_forward_rope_fusable(None, None) == 0
+print("RULE OK")
+'''
+
+
+@pytest.mark.parametrize("kernel", ["", "ps"], ids=["default", "kernel-ps"])
+def test_fused_query_rotation_rule(kernel):
+    """aule_attention_forward_rope_fusable() (host logic): the two-waves-per-SIMD stream rotates Q itself for fp16 / bf16,
+    head_dim 64 / 128, half-split pairs, 16-byte aligned tables of pitch % 4 == 0 that cover seq_q + q_pos_offset rows -- when
+    it is the kernel (AULE_HIP_FWD_KERNEL=ps; the library reads the variable once per process, hence the child); by default such
+    problems go to the one-wave-per-SIMD kernel and the answer is "rotate Q with aule_rope_ex()"."""
+    import subprocess
+    import sys
+    e = {k: v for k, v in os.environ.items() if k not in ("AULE_HIP_FWD_KERNEL", "AULE_HIP_FWD_SOFTMAX")}
+    if kernel:
+        e["AULE_HIP_FWD_KERNEL"] = kernel
+    r = subprocess.run([sys.executable, "-c", _ROPE_RULE_CHILD % {"root": ROOT}], env=e, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "RULE OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_causal_split_plan_invariants(monkeypatch):

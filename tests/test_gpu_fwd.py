@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_files, load_golden
-from util import FWD_TOL, LSE_TOL, assert_close, fwd_tol, quantize, torch_dtype
+from util import FWD_TOL, LSE_TOL, assert_close, assert_close_rows, fwd_tol, quantize, torch_dtype
 
 pytestmark = pytest.mark.gpu
 
@@ -221,7 +221,7 @@ def test_config2_full_size_sampled_rows_and_properties(torch_cuda, oracle_mod):
     qn, kn, vn = (x.float().cpu().numpy() for x in (q, k, v))
     ref, _ = oracle_mod.fwd_rows_f64(qn, kn, vn, rows, True, None)
     got = out.float().cpu().numpy().reshape(-1, D)[rows]
-    assert_close(got, ref, *fwd_tol("bf16", v.float().abs().max().item()), "C2 sampled rows")
+    assert_close_rows(got, ref, rows % S + 1, "bf16", v.float().abs().max().item(), "C2 sampled rows")
     # (2) causal prefix invariance: rows < 1024 do not depend on later keys (bit-exact: same tiles)
     out_p = aule.flash_attention(q[:, :, :1024].contiguous(), k[:, :, :1024].contiguous(),
                                  v[:, :, :1024].contiguous(), causal=True)
@@ -256,7 +256,7 @@ def test_config4_shard_sampled_rows_and_properties(torch_cuda, oracle_mod):
     ref, ref_lse = oracle_mod.fwd_rows_f64(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(),
                                            rows, True, None)
     got = out.float().cpu().numpy().reshape(-1, D)[rows]
-    assert_close(got, ref, *fwd_tol("bf16", v.float().abs().max().item()), "C4 shard sampled rows")
+    assert_close_rows(got, ref, rows % S + 1, "bf16", v.float().abs().max().item(), "C4 shard sampled rows")
     assert_close(lse.cpu().numpy().reshape(-1)[rows], ref_lse, LSE_TOL["bf16"], 1e-5, "C4 shard LSE")
     print("C4 shard achieved: out max|err| %.3e, lse max|err| %.3e"
           % (np.abs(got - ref).max(), np.abs(lse.cpu().numpy().reshape(-1)[rows] - ref_lse).max()))
@@ -292,7 +292,7 @@ def test_config5_mqa_fp16_long_noncausal_sampled_rows(torch_cuda, oracle_mod):
     ref, _ = oracle_mod.fwd_rows_f64(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(),
                                      rows, False, None)
     got = out.float().cpu().numpy().reshape(-1, D)[rows]
-    assert_close(got, ref, *fwd_tol("fp16", v.float().abs().max().item()), "C5 sampled rows")
+    assert_close_rows(got, ref, np.full(len(rows), S), "fp16", v.float().abs().max().item(), "C5 sampled rows")
     # decode-like cross attention (Sq = 1 and 64) against the same keys
     for sq in (1, 64):
         o = aule.flash_attention(q[:, :, :sq].contiguous(), k, v, causal=False)

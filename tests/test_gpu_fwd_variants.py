@@ -77,6 +77,7 @@ def test_fused_query_rotation_on_the_two_waves_per_simd_stream():
     its fused instances are exercised by running the bit-for-bit test of tests/test_gpu_rope.py with AULE_HIP_FWD_KERNEL=ps."""
     e = dict(os.environ)
     e["AULE_HIP_FWD_KERNEL"] = "ps"
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_rope.py"), "-q", "-x", "-m", "gpu", "-k",
-                        "fused_query_rotation_is_the_separate_pass"], env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_rope.py"), os.path.join(ROOT, "tests", "test_gpu_graph.py"),
+                        "-q", "-x", "-m", "gpu", "-k", "fused_query_rotation_is_the_separate_pass or fused-rope"],
+                       env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-3000:] + r.stderr[-1000:]

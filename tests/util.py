@@ -32,10 +32,41 @@ def fwd_tol(dtype, vmax, sides=1):
     comparison target is itself a 16-bit result (golden vectors from the reference kernels)."""
     atol, rtol = FWD_TOL[dtype]
     return atol + sides * UNIT_ROUNDOFF[dtype] * float(vmax), sides * rtol
+
+
+# Rows that see many keys: the P roundings average out (each weight carries relative error <= u, the weights are ~1/n: the
+# absolute error of the row is ~ u max|V| / sqrt(n)), so SURVEY.md 7.3's rule -- BASELINE.json's 1e-3 plus the rounding of O to
+# storage, rtol 2u -- holds WITHOUT the u max|V| term.  The full-size configurations (C2, C4 shard, C5, C3 forward) use it for
+# every sampled row with at least MANY_KEYS visible keys and keep fwd_tol() for the few rows at the start of a causal sequence;
+# they print what they achieved (pytest -s / the captured output on failure; DESIGN.md 4 has the table).
+MANY_KEYS = 64
+
+
+def assert_close_rows(got, ref, nkeys, dtype, vmax, what=""):
+    """got, ref: [rows, D]; nkeys[r] = keys row r sees.  Tight bound for rows with >= MANY_KEYS keys, fwd_tol() for the rest.
+    Returns (max abs error of the many-key rows, of the few-key rows) and prints them."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    nkeys = np.asarray(nkeys)
+    many = nkeys >= MANY_KEYS
+    a_t, r_t = FWD_TOL[dtype]
+    res = []
+    for name, sel, (atol, rtol) in (("rows with >= %d keys" % MANY_KEYS, many, (a_t, r_t)), ("rows with fewer keys", ~many, fwd_tol(dtype, vmax))):
+        if sel.any():
+            assert_close(got[sel], ref[sel], atol, rtol, "%s, %s" % (what, name))
+            e = np.abs(got[sel] - ref[sel])
+            res.append(float(e.max()))
+            print("%s: %s (%d): max|err| %.3e, max|err|/(atol+rtol|ref|) %.2f  [atol %.2e rtol %.2e]"
+                  % (what, name, int(sel.sum()), e.max(), (e / (atol + rtol * np.abs(ref[sel]))).max(), atol, rtol))
+        else:
+            res.append(0.0)
+    return tuple(res)
+
+
 # LSE is fp32 in every variant
 LSE_TOL = {"fp32": 1e-5, "fp16": 1e-3, "bf16": 1e-3}
 # Gradients: reference bar is 1e-2 (python/tests/test_triton.py:92-94)
-BWD_TOL = {"fp32": (2e-5, 2e-5), "fp16": (4e-3, 4e-3), "bf16": (2e-2, 2e-2)}
+BWD_TOL = {"fp32": (2e-5, 2e-5), "fp16": (4e-3, 4e-3), "bf16": (1e-2, 1e-2)}
 
 
 def assert_close(got, ref, atol, rtol, what=""):

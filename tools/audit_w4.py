@@ -81,13 +81,15 @@ def audit(path, verbose=True):
                 for r in re.findall(r"\bv(\d+)\b", t) + [x for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", t) for x in (a, b)]:
                     if int(r) >= nv:
                         problems.append(f"{name}: compiler instruction touches v{r} >= NV {nv}: `{t}`")
-        # plain tile steps: eight consecutive statements that each carry MFMAs and one LDS-DMA piece
-        is_plain = [any("offen lds" in b for b in blk) and any("v_mfma" in b for b in blk) for blk in blocks]
+        # plain tile steps: eight consecutive statements with MFMAs and embedded LDS-DMA pieces, the tile barrier inside the first
+        has_mf = [any("v_mfma" in b for b in blk) for blk in blocks]
+        has_dma = [any("offen lds" in b for b in blk) for blk in blocks]
         plain_outside, nsteps = [], 0
         k = 0
         while k + 8 <= len(blocks):
             # (the step's wait + barrier rides inside its first statement)
-            if all(is_plain[k:k + 8]) and any("s_barrier" in b for b in blocks[k]):
+            # (D = 128: a piece in every statement; D = 64: in every other one)
+            if all(has_mf[k:k + 8]) and has_dma[k] and sum(has_dma[k:k + 8]) >= 4 and any("s_barrier" in b for b in blocks[k]):
                 nsteps += 1
                 for i in range(k + 1, k + 8):
                     plain_outside += between[i]
