@@ -1079,7 +1079,7 @@ int32_t aule_hip_debug_forward_split_plan(const aule_attn_desc* d, int32_t* out,
 int32_t aule_hip_debug_forward_timeline(const aule_attn_desc* d, unsigned long long* stamps) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_init || d == nullptr || d->struct_size != sizeof(aule_attn_desc) || stamps == nullptr) return -1;
-    if (d->dtype != AULE_DTYPE_BF16 || d->head_dim != 128 || d->heads_kv == 0 || d->heads_q % d->heads_kv != 0) return -3;
+    if (d->dtype != AULE_DTYPE_BF16 || (d->head_dim != 128 && d->head_dim != 64) || d->heads_kv == 0 || d->heads_q % d->heads_kv != 0) return -3;
     FwdArgs a;
     a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->out; a.lse = d->lse;
     a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv;

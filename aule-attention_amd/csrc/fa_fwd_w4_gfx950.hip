@@ -6,8 +6,8 @@
 //
 //   * a wave owns the whole 512-register file of its SIMD: O^T (128 registers), the Q fragments (64) and ONE K tile (64)
 //     live in accumulator registers, one V tile (64) in the top arch VGPRs, all named literally by the instruction
-//     streams of fa_fwd_w4_asm.inc (generated: tools/gen_w4.py, register map in its docstring); hipcc gets v0-v191 for the
-//     scores, the packed P, the softmax temporaries and addresses (amdgpu_num_vgpr(192));
+//     streams of fa_fwd_w4_asm.inc (generated: tools/gen_w4.py, register map in its docstring) -- the scores, the packed P and
+//     the softmax temporaries too; hipcc gets v0-v51 for addresses, loop scalars and the epilogue (amdgpu_num_vgpr(52));
 //   * a wave computes TWO 32-row blocks (A, B) against every K / V fragment it reads: 48 LDS reads per 64 MFMAs;
 //   * the softmax runs in the gaps of the wave's own MFMAs: a tile step is phase 1 [S_{j+1} = K_{j+1} Q^T | softmax of
 //     S_j[B] | V_j transpose reads | LDS-DMA requests] and phase 2 [O^T += V_j^T P_j^T | softmax of S_{j+1}[A] | K_{j+2}
@@ -56,6 +56,8 @@ struct FwdW4Params {
     int pair;     // item = Q blocks (nqb-1-i, i)
     int coff;     // causal position offset (query i sits at position i + coff)
     int nitems;   // nwork * B * Hq; workgroup g takes items g, g + gridDim.x, ...
+    int rounds;   // > 0: "round order" of the causal part lists (below) with this many rounds, mper = heads per round
+    int mper;
     unsigned long long* dbg;   // timeline build only: [4 waves][kW4TLMax] tagged s_memtime stamps of workgroup 0
 };
 
@@ -157,19 +159,38 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         for (int i = tid; i < 4 * kW4TLLds; i += 256) tl_lds[i] = 0;
     }
 
-    // ---- part table: thread t describes part (t & 1) of this workgroup's item t >> 1
+    // ---- part table.  Default: thread t describes part (t & 1) of this workgroup's item t >> 1 (item = the causal pair of Q
+    // blocks (n-1-i, i) of one head: equal work per item).
+    // Round order (p.rounds > 0; causal, the XCD's W = gridDim/8 workgroups a multiple of the n Q blocks of a head): the XCD's
+    // heads are taken m = W/n at a time ("round"), workgroup w of the XCD gets Q block w/m of head w%m of the round in even
+    // rounds and block n-1-w/m in odd ones -- two consecutive rounds are one causal pair per workgroup, so the lists stay
+    // balanced, but only m heads' K/V (instead of 2m) are being walked by an XCD at any time, and the workgroups of an even
+    // round start their parts together at tile 0: the K/V re-reads that missed the 4 MB L2 (profiles/r3_fwd_c2_*) mostly go.
     const int G = (int)gridDim.x;
     const int nit = (p.nitems - (int)blockIdx.x + G - 1) / G;
-    const int nslot = 2 * nit;
+    const int nslot = p.rounds > 0 ? p.rounds : 2 * nit;
     if (tid < nslot) {
         int qb = -1;
-        const WorkItem w = decode_work((int)blockIdx.x + (tid >> 1) * G, p.B, p.Hq, p.Hkv, p.nwork, false);
-        if (p.pair) {
-            const int far = p.nqb - 1 - w.blk;       // the larger block of the pair goes first
-            if ((tid & 1) == 0) qb = far;
-            else if (far != w.blk) qb = w.blk;
-        } else if ((tid & 1) == 0) {
+        WorkItem w;
+        if (p.rounds > 0) {
+            const int W = G >> 3, wx = (int)blockIdx.x >> 3, pos = (tid & 1) ? W - 1 - wx : wx;
+            const int g = p.Hq / p.Hkv;
+            const int c = tid * p.mper + pos % p.mper;          // head of this XCD's list: kv unit c / g, head c % g of its group
+            const int unit = ((int)blockIdx.x & 7) + 8 * (c / g);
+            w.b = unit / p.Hkv;
+            w.hk = unit % p.Hkv;
+            w.h = w.hk * g + c % g;
+            w.blk = pos / p.mper;
             qb = w.blk;
+        } else {
+            w = decode_work((int)blockIdx.x + (tid >> 1) * G, p.B, p.Hq, p.Hkv, p.nwork, false);
+            if (p.pair) {
+                const int far = p.nqb - 1 - w.blk;       // the larger block of the pair goes first
+                if ((tid & 1) == 0) qb = far;
+                else if (far != w.blk) qb = w.blk;
+            } else if ((tid & 1) == 0) {
+                qb = w.blk;
+            }
         }
         tab[tid] = int4{(w.b * p.Hq + w.h) * p.Sq, (w.b * p.Hkv + w.hk) * Sk, qb, 0};
         redo[tid] = 0;
@@ -330,7 +351,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             constexpr int BLK = decltype(blk_tag)::value;
             float mx = masked ? A::template rowmax<BLK, 1>(thr) : A::template rowmax<BLK, 0>(thr);
             mx = fmaxf(mx, xhalf_fast(mx));
-            return -(mx * c);
+            return A::PRE ? -mx : -(mx * c);   // (pre form: the scores already carry c)
         };
         // (readfirstlane: hipcc sometimes moves the ring arithmetic to the vector unit; the requests want scalar registers)
         auto k_lds = [&]() __attribute__((always_inline)) { return (unsigned)w4_rfl((int)(lds0 + (unsigned)slot(1) * KT + wave1k)); };
@@ -425,10 +446,11 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             const int n = requests();
             const unsigned vap = va + (unsigned)rp * VT, kb = ka0 + (unsigned)slot(2) * KT;
             const int tB = SMB == 2 ? thr_of(1, j) : 0;
-            A::template p1<0, PAR, QK, SMB, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
-            A::template p1<1, PAR, QK, SMB, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
-            A::template p1<2, PAR, QK, SMB, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
-            A::template p1<3, PAR, QK, SMB, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
+            constexpr int SMB1 = PV == 2 ? SMB + 2 : SMB;   // tile 0: S_0 is the prologue's bare QK^T (streams: SM 3 / 4)
+            A::template p1<0, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
+            A::template p1<1, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
+            A::template p1<2, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
+            A::template p1<3, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
             stamp(0x18);
             const int tA = SMA == 2 ? thr_of(0, j + 1) : 0;
             A::template p2<0, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0);
@@ -480,6 +502,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             // for them) and the Q fragments; the epilogue's stores ride along
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             A::kread_all(kap);
+            if constexpr (!REDO) A::prescale_q(c);   // (pre form only; the second stream did it in its exact-maximum pass)
             A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
             A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
             A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
@@ -571,6 +594,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) kap[ks] = kaddr(ka0, ks);
                     A::kread_all(kap);
+                    if (j == 0) A::prescale_q(c);
                     A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
                     A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
                     A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
@@ -647,14 +671,17 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
 }
 
 // The kernels: hipcc's VGPR budget is the generator's NV (an attribute wants a literal: one wrapper per head size).
+#ifndef W4_NV_D64
+#define W4_NV_D64 84   // (52 for streams generated with W4_PRE=1: tools/w4_variants.sh)
+#endif
 template <class T, bool CAUSAL, bool TL>
 __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(52))) fa_fwd_w4_kernel_d128(const FwdW4Params p) {
     static_assert(W4Asm<T, 128>::NV == 52, "amdgpu_num_vgpr of the D = 128 kernel must be the generator's NV");
     w4_body<T, 128, CAUSAL, TL>(p);
 }
 template <class T, bool CAUSAL, bool TL>
-__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(84))) fa_fwd_w4_kernel_d64(const FwdW4Params p) {
-    static_assert(W4Asm<T, 64>::NV == 84, "amdgpu_num_vgpr of the D = 64 kernel must be the generator's NV");
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(W4_NV_D64))) fa_fwd_w4_kernel_d64(const FwdW4Params p) {
+    static_assert(W4Asm<T, 64>::NV == W4_NV_D64, "amdgpu_num_vgpr of the D = 64 kernel must be the generator's NV");
     w4_body<T, 64, CAUSAL, TL>(p);
 }
 template <class T, int D, bool CAUSAL, bool TL>
@@ -694,6 +721,19 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
     const long long rounds = (p.nitems + ncu * kW4MaxItems - 1) / (ncu * kW4MaxItems);
     long long G = ncu * rounds;
     if (G > p.nitems) G = p.nitems;
+    p.rounds = 0;
+    p.mper = 1;
+    {   // round order (w4_body): needs whole rounds -- W a multiple of the heads' Q blocks -- and an even number of them
+        static const char* const e = std::getenv("AULE_HIP_W4_ORDER");   // "pairs": the item order everywhere (A/B)
+        const int units = a.B * a.Hkv, W = (int)(G / 8), g = a.Hq / a.Hkv;
+        if (a.causal && !(e != nullptr && e[0] == 'p') && G == ncu && (G & 7) == 0 && (units & 7) == 0 && p.nqb <= W && W % p.nqb == 0) {
+            const int m = W / p.nqb, hx = units / 8 * g;
+            if (hx % (2 * m) == 0 && hx / m <= kW4MaxSlot) {
+                p.rounds = hx / m;
+                p.mper = m;
+            }
+        }
+    }
     const dim3 grid((unsigned)G), block(256);
     const size_t lds = w4_lds_bytes<D>() + (TL ? 4 * kW4TLLds * 8 : 0);
     if (a.causal)
@@ -741,13 +781,19 @@ int launch_fwd_w4(const FwdArgs& a, hipStream_t stream) {
 }
 
 #ifdef AULE_DEBUG_HOOKS
-// Debug: the bf16 D = 128 kernel with tagged s_memtime stamps of workgroup 0 (tools/timeline_w4.py).
+// Debug: the bf16 kernel (D = 128; D = 64 when built with -DW4_TL_D64) with tagged s_memtime stamps of workgroup 0
+// (tools/timeline_w4.py).
+#ifdef W4_TL_D64
+constexpr int kW4TLD = 64;
+#else
+constexpr int kW4TLD = 128;
+#endif
 int launch_fwd_w4_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream) {
-    if (a.dtype != kBF16 || a.D != 128 || !fwd_w4_applicable(a)) return -1;
-    const int lds = w4_lds_bytes<128>() + 4 * kW4TLLds * 8;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(w4_kernel<Bf16Traits, 128, true, true>()), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(w4_kernel<Bf16Traits, 128, false, true>()), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    return launch_w4<Bf16Traits, 128, true>(a, stream, dbg);
+    if (a.dtype != kBF16 || a.D != kW4TLD || !fwd_w4_applicable(a)) return -1;
+    const int lds = w4_lds_bytes<kW4TLD>() + 4 * kW4TLLds * 8;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(w4_kernel<Bf16Traits, kW4TLD, true, true>()), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(w4_kernel<Bf16Traits, kW4TLD, false, true>()), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return launch_w4<Bf16Traits, kW4TLD, true>(a, stream, dbg);
 }
 #endif
 

@@ -47,6 +47,11 @@ XFLAGS = set(filter(None, os.environ.get("W4_X", "").split(",")))
 # how x = c s - m_ref is computed (hardware finding, profiles/r3_w4_filler_costs.txt: 8-byte VOP3 instructions cost the in-order
 # wave several times what 4-byte VOP1 / VOP2 ones do next to the MFMAs)
 SCALE_FORM = os.environ.get("W4_SCALE", "fma")
+# W4_PRE=1: the pre-scaled-Q form of the D = 64 streams.  Measured (profiles/r3_w4_d64_prescale.txt): +8.5 % on C5, +4..7 % on the
+# other D = 64 shapes, the plain step 2371 -> 2099 cycles -- but rounding c q back to 16 bits moves every score by ~2^-9 (bf16) /
+# 2^-12 (fp16) of its magnitude: LSE off by 2e-3 on N(0,1) bf16 inputs, and the 4-sigma fp16 case out of tolerance (O error
+# 5.7e-2 against 6.7e-3).  Parity comes first: OFF, kept as an experiment switch (build with -DW4_NV_D64=52).
+PRE_ON = os.environ.get("W4_PRE", "0") != "0"
 CREG = "v" if "cvgpr" in XFLAGS else "s"    # register class of the scale operand (experiment)
 
 
@@ -73,7 +78,13 @@ class Cfg:
         self.NM = self.NINF - 3                        # nmA, nmB (+ one unused: keeps the tuples above 4-aligned)
         self.L = self.NM - 4                           # lA0 lA1 lB0 lB1
         self.X = self.L - 4                            # x0..x3
-        self.NV = self.X                               # hipcc's budget
+        # D = 64 "pre" form (experiment, see PRE_ON): Q is multiplied by c = scale log2(e) once per part (rounded back to 16 bits)
+        # and - m_ref enters through the C operand of the first MFMA of every score chain, so a score costs exp + add + half a
+        # cvt (2.5 VALU instead of 3.5: at D = 64 the softmax, not the matrix pipe, sets the step).  Two 16-register tuples hold
+        # - m_ref.
+        self.pre = (D == 64) and PRE_ON
+        self.NMT = self.X - 32 if self.pre else self.X  # - m_ref of block A (16 registers), block B (16)
+        self.NV = self.NMT                             # hipcc's budget
         assert self.NV % 4 == 0 and self.XA % 4 == 0, (self.NV, self.XA)
 
     def O(self, qb, d):
@@ -125,7 +136,7 @@ def kk(h, r):
     return 32 * h + (r & 3) + 8 * (r >> 2)
 
 
-def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked):
+def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked, sub=False):
     """VALU of 8 scores (registers sbase + e0 .. + 7 of 32-key half blk_h) -> packed P at pbase..+3, row sums of block qb.
     Two pairs are in flight at a time (x0 x1 | x2 x3): every consumer sits at least four instructions behind its producer
     (dependent VALU issue stalls the in-order wave, and with it the next MFMA; v_exp needs one instruction of distance anyway)."""
@@ -134,9 +145,15 @@ def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked):
     for p0 in (0, 2):
         x = {p0: (f"v{c.X}", f"v{c.X + 1}"), p0 + 1: (f"v{c.X + 2}", f"v{c.X + 3}")}
         sc = {p: (f"v{sbase + e0 + 2 * p}", f"v{sbase + e0 + 2 * p + 1}") for p in (p0, p0 + 1)}
+        src = x        # what the exponential reads
         for p in (p0, p0 + 1):
             for i in range(2):
-                if SCALE_FORM == "fma":          # one VOP3 (8 bytes)
+                if c.pre and sub:                # scores of a bare QK^T (tile 0): already in units of c, - m_ref still to come
+                    ops.append(f"v_add_f32 {x[p][i]}, {nm}, {sc[p][i]}")
+                elif c.pre:                      # the MFMA chain started from - m_ref: nothing to do
+                    if not masked:
+                        src = sc
+                elif SCALE_FORM == "fma":          # one VOP3 (8 bytes)
                     ops.append(f"v_fma_f32 {x[p][i]}, {sc[p][i]}, %[c], {nm}")
                 elif SCALE_FORM == "fmac":       # two 4-byte instructions: x = - m_ref ; x += c s
                     ops.append(f"v_mov_b32 {x[p][i]}, {nm}")
@@ -148,10 +165,10 @@ def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked):
             for p in (p0, p0 + 1):
                 for i in range(2):
                     ops.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + 2 * p + i)}, %[thr]")
-                    ops.append(f"v_cndmask_b32 {x[p][i]}, v{c.NINF}, {x[p][i]}, vcc")
+                    ops.append(f"v_cndmask_b32 {x[p][i]}, v{c.NINF}, {(x if not (c.pre and not sub) else sc)[p][i]}, vcc")
         for p in (p0, p0 + 1):
-            ops.append(f"v_exp_f32 {x[p][0]}, {x[p][0]}")
-            ops.append(f"v_exp_f32 {x[p][1]}, {x[p][1]}")
+            ops.append(f"v_exp_f32 {x[p][0]}, {src[p][0]}")
+            ops.append(f"v_exp_f32 {x[p][1]}, {src[p][1]}")
         for p in (p0, p0 + 1):
             ops.append(f"v_add_f32 {l0}, {l0}, {x[p][0]}")
             ops.append(f"v_add_f32 {l1}, {l1}, {x[p][1]}")
@@ -258,17 +275,23 @@ def dma_piece(c, Q):
 
 
 def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
-    """phase-1 statement of step PAR.  qk: MFMAs of S_{j+1}.  sm: 0 none, 1 plain, 2 masked (S_j[B]).  vr: V_j reads (ring slot in the
-    address register).  dma: this statement's piece of the K tile the step requests."""
+    """phase-1 statement of step PAR.  qk: MFMAs of S_{j+1}.  sm: 0 none, 1 plain, 2 masked (S_j[B]); 3 / 4: the same for the S_0 of
+    the part prologue's bare QK^T (the pre form still has to subtract the reference there; otherwise identical to 1 / 2).  vr: V_j
+    reads (ring slot in the address register).  dma: this statement's piece of the K tile the step requests."""
     qb, KS, DB = Q >> 1, c.KS, c.DB
     mf, clob = [], ["memory"]
+    sub = sm >= 3
+    if sub:
+        sm -= 2
     if qk:
         acc = [c.sA(0), c.sA(1)] if qb == 0 else [c.sB(0, par ^ 1), c.sB(1, par ^ 1)]
+        # pre form: every chain but the bare ones (prologue, exact-maximum pass: sm == 0) starts from - m_ref of its block
+        c0 = tup(c.NMT + 16 * qb, 16) if (c.pre and sm) else "0"
         for t in range(KS // 2):
             ks = (Q & 1) * (KS // 2) + t
             for h in range(2):
                 a = tup(acc[h], 16)
-                mf.append(f"{c.mfma} {a}, {c.K(ks, h)}, {c.Q(qb, ks)}, {'0' if ks == 0 else a}")
+                mf.append(f"{c.mfma} {a}, {c.K(ks, h)}, {c.Q(qb, ks)}, {c0 if ks == 0 else a}")
         clob += vregs(acc[0], 16) + vregs(acc[1], 16)
     lds = []
     if vr:
@@ -282,7 +305,7 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
     valu = []
     if sm:
         h = Q >> 1
-        valu = softmax_ops(c, c.sB(h, par), h, 8 * (Q & 1), c.pB(Q), 1, sm == 2)
+        valu = softmax_ops(c, c.sB(h, par), h, 8 * (Q & 1), c.pB(Q), 1, sm == 2, sub)
         clob += vregs(c.X, 4) + vregs(c.pB(Q), 4) + vregs(c.l(1, 0), 2)
         if sm == 2:
             clob.append("vcc")
@@ -309,7 +332,8 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
         lines += ["s_nop 7", "s_nop 7"]      # bare MFMAs: results are read by whatever comes next
     ins = []
     if sm:
-        ins.append(f'[c] "{CREG}"(c)')
+        if not c.pre:
+            ins.append(f'[c] "{CREG}"(c)')
         if sm == 2:
             ins.append('[thr] "v"(thr)')
     if vr:
@@ -344,7 +368,7 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
     valu = []
     if sm:
         h = Q >> 1
-        valu = softmax_ops(c, c.sA(h), h, 8 * (Q & 1), c.pA(par ^ 1, Q), 0, sm == 2)
+        valu = softmax_ops(c, c.sA(h), h, 8 * (Q & 1), c.pA(par ^ 1, Q), 0, sm == 2, pv == 0)
         clob += vregs(c.X, 4) + vregs(c.pA(par ^ 1, Q), 4) + vregs(c.l(0, 0), 2)
         if sm == 2:
             clob.append("vcc")
@@ -359,7 +383,8 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
     lines = place(mf, lds, valu, pieces, 1, len(mf) - 3 if len(mf) >= 8 else len(mf) - 1)
     ins = []
     if sm:
-        ins.append(f'[c] "{CREG}"(c)')
+        if not c.pre:
+            ins.append(f'[c] "{CREG}"(c)')
         if sm == 2:
             ins.append('[thr] "v"(thr)')
     if kr:
@@ -376,7 +401,7 @@ def p1_variants():
             for sl in range(3):
                 v.append((Q, par, 1, 1, 1, 1, sl))  # plain step (K request embedded; V_j in ring slot sl)
             for qk in (0, 1):
-                for sm in (1, 2):
+                for sm in (1, 2) if par else (1, 2, 3, 4):  # (3 / 4: tile 0 -- step 0 of a part, PAR 0)
                     v.append((Q, par, qk, sm, 1, 0, 0))     # generic steps: ring slot in the address register, requests apart
         v.append((Q, 1, 1, 0, 0, 0, 0))             # bare QK^T of tile 0 ("step -1": part prologue, exact-maximum pass)
     return sorted(set(v))
@@ -399,6 +424,7 @@ def gen_struct(c):
     name = f"W4Asm<{'Bf16Traits' if c.dt == 'bf16' else 'F16Traits'}, {c.D}>"
     s = f"template <> struct {name} {{\n"
     s += f"    static constexpr int KB0 = {c.KB0}, QB0 = {c.QB0}, NP = {c.NP}, NV = {c.NV};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n"
+    s += f"    static constexpr bool PRE = {'true' if c.pre else 'false'};   // Q pre-multiplied by c, - m_ref through the MFMAs' C operand\n"
     # ---- phase 1
     s += ("    // SL: ring slot of the tile the statement reads, as an immediate (plain steps); 0 where the address register carries it\n"
           "    template <int Q, int PAR, int QK, int SM, int VR, int DMA, int SL = 0>\n"
@@ -500,10 +526,35 @@ def gen_struct(c):
           "    static __device__ __forceinline__ void zero_sums() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
           f"        asm volatile(\"v_mov_b32 v{c.L}, 0\\n\\tv_mov_b32 v{c.L + 1}, 0\\n\\tv_mov_b32 v{c.L + 2}, 0\\n\\tv_mov_b32 v{c.L + 3}, 0\" ::: "
           + ", ".join(f'"v{c.L + i}"' for i in range(4)) + ");\n#endif\n    }\n")
+    def ref_asm(qb):
+        lines = [f"v_mov_b32 v{c.nm(qb)}, %0"]
+        cl = [f"v{c.nm(qb)}"]
+        if c.pre:
+            lines += [f"v_mov_b32 v{c.NMT + 16 * qb + i}, %0" for i in range(16)]
+            lines += ["s_nop 1"]          # VALU write -> MFMA C operand
+            cl += vregs(c.NMT + 16 * qb, 16)
+        return 'asm volatile("' + "\\n\\t".join(lines) + '" :: "v"(nm) : ' + ", ".join(f'"{x}"' for x in cl) + ");"
     s += ("    // - reference of block QB (0 = A, 1 = B)\n"
           "    template <int QB>\n    static __device__ __forceinline__ void set_ref(float nm) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
-          f"        if constexpr (QB == 0) asm volatile(\"v_mov_b32 v{c.nm(0)}, %0\" :: \"v\"(nm) : \"v{c.nm(0)}\");\n"
-          f"        else asm volatile(\"v_mov_b32 v{c.nm(1)}, %0\" :: \"v\"(nm) : \"v{c.nm(1)}\");\n#endif\n    }}\n")
+          f"        if constexpr (QB == 0) {ref_asm(0)}\n"
+          f"        else {ref_asm(1)}\n#endif\n    }}\n")
+    # ---- pre form: Q fragments times c, rounded back (the loads have landed: the caller waited)
+    lines = []
+    if c.pre:
+        t0, t1, t2 = f"v{c.X}", f"v{c.X + 1}", f"v{c.X + 2}"
+        for r in range(8 * c.KS):
+            a = f"a{c.QB0 + r}"
+            lines.append(f"v_accvgpr_read_b32 {t0}, {a}")
+            if c.dt == "bf16":
+                lines += ["s_nop 0", f"v_and_b32 {t1}, 0xffff0000, {t0}", f"v_lshlrev_b32 {t0}, 16, {t0}"]
+            else:
+                lines += ["s_nop 0", f"v_lshrrev_b32 {t1}, 16, {t0}", f"v_cvt_f32_f16 {t0}, {t0}", f"v_cvt_f32_f16 {t1}, {t1}"]
+            lines += [f"v_mul_f32 {t0}, %[c], {t0}", f"v_mul_f32 {t1}, %[c], {t1}", f"{c.cvt} {t2}, {t0}, {t1}", "s_nop 0", f"v_accvgpr_write_b32 {a}, {t2}"]
+        lines += ["s_nop 7"]             # v_accvgpr_write -> MFMA operand
+    s += "    static __device__ __forceinline__ void prescale_q(float c) {\n#if defined(__HIP_DEVICE_COMPILE__)\n        (void)c;\n"
+    if c.pre:
+        s += emit_asm(lines, [], ['[c] "s"(c)'], ["memory"] + vregs(c.X, 3) + aregs(c.QB0, 8 * c.KS), indent="        ")
+    s += "#endif\n    }\n"
     s += ("    // end of a part: row sum (both chains) and - reference of block QB\n"
           "    template <int QB>\n    static __device__ __forceinline__ void get_sums(float& l, float& nm) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
           f"        if constexpr (QB == 0) asm volatile(\"v_add_f32 %0, v{c.l(0, 0)}, v{c.l(0, 1)}\\n\\tv_mov_b32 %1, v{c.nm(0)}\" : \"=&v\"(l), \"=v\"(nm));\n"

@@ -6,6 +6,7 @@ aule_hip_debug_forward_timeline with AULE_TL=w4; debug library: cd aule-attentio
 0x33 P_0[A] done, 0x40 epilogue, 0x42 slabs written, 0x41 stores issued, 0x50 end of the stream.
 
     python tools/timeline_w4.py [causal] [B] [H] [S] [waves...]
+W4_TL_D=64 (with a debug library built with -DW4_TL_D64) and W4_TL_HKV=n: the D = 64 instance, grouped heads.
 """
 import ctypes, math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,17 +21,19 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 S = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 waves = [int(x) for x in sys.argv[5:]] or [0, 3]
-D, NW, NMAX = 128, 4, 2048
+D, NW, NMAX = int(os.environ.get("W4_TL_D", "128")), 4, 2048
+HKV = int(os.environ.get("W4_TL_HKV", "0")) or H
 lib = _capi.get_lib()
 lib.aule_hip_debug_forward_timeline.restype = ctypes.c_int32
 lib.aule_hip_debug_forward_timeline.argtypes = [ctypes.POINTER(_capi.AttnDesc), ctypes.c_void_p]
-q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+q = torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16)
+k, v = (torch.randn(B, HKV, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(2))
 out = torch.empty_like(q)
 st = torch.zeros(NW * NMAX, device="cuda", dtype=torch.int64)
 d = _capi.AttnDesc()
 d.struct_size = ctypes.sizeof(_capi.AttnDesc)
 d.dtype = 2
-d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, H, H, S, S, D
+d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, H, HKV, S, S, D
 d.scale = 1 / math.sqrt(D)
 d.causal = causal
 d.window_size = -1
