@@ -5,7 +5,9 @@
   k-cached  : attention with Q rotated in registers, K rotated earlier (KV-cache serving: the K pass is paid at append time)
 and the plain attention and the two passes alone as the floor / the price list.  Every leg is conditioned on its own
 workload (~250 ms of back-to-back launches: MI355X's clock transient), then timed over N launches with
-one event pair; TFLOP/s count the attention FLOPs only (the rotations are overhead)."""
+one event pair; TFLOP/s count the attention FLOPs only (the rotations are overhead).
+Round 3: the default forward of these shapes (one wave per SIMD) does not rotate Q; the fused legs exist on its predecessor
+(AULE_HIP_FWD_KERNEL=ps).  Run the script both ways: the question is two-pass on the default kernel against q-fused on ps."""
 import math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "aule-attention_amd"))
@@ -36,32 +38,39 @@ def run(dtype, B, Hq, Hkv, S, D, causal):
     cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
     sc = 1 / math.sqrt(D)
     code = 1 if causal else 0
-    assert at.rope_fusable(q, k, code, -1, cos, sin, 0)
+    fus = at.rope_fusable(q, k, code, -1, cos, sin, 0)
     kr = at.rope_raw(k, cos, sin); qr = at.rope_raw(q, cos, sin)
     a = at.fwd_raw(qr, kr, v, code, sc, want_lse=False)[0]
-    b = at.fwd_raw(q, kr, v, code, sc, want_lse=False, q_rope=(cos, sin, 0))[0]
-    same = bool(torch.equal(a, b))
+    same = None
+    if fus:
+        b = at.fwd_raw(q, kr, v, code, sc, want_lse=False, q_rope=(cos, sin, 0))[0]
+        same = bool(torch.equal(a, b))
     qb, kb = torch.empty_like(q), torch.empty_like(k)
     legs = [
         ("attention only", lambda: at.fwd_raw(qr, kr, v, code, sc, want_lse=False)),
         ("rope(Q) pass alone", lambda: at.rope_raw(q, cos, sin, out=qb)),
         ("rope(K) pass alone", lambda: at.rope_raw(k, cos, sin, out=kb)),
         ("two-pass: rope(Q)+rope(K)+attention", lambda: at.fwd_raw(at.rope_raw(q, cos, sin, out=qb), at.rope_raw(k, cos, sin, out=kb), v, code, sc, want_lse=False)),
-        ("q-fused: rope(K)+attention[Q rotated in registers]", lambda: at.fwd_raw(q, at.rope_raw(k, cos, sin, out=kb), v, code, sc, want_lse=False, q_rope=(cos, sin, 0))),
-        ("k-cached: attention[Q rotated in registers]", lambda: at.fwd_raw(q, kr, v, code, sc, want_lse=False, q_rope=(cos, sin, 0))),
+        ("k-cached two-pass: rope(Q)+attention", lambda: at.fwd_raw(at.rope_raw(q, cos, sin, out=qb), kr, v, code, sc, want_lse=False)),
     ]
+    if fus:
+        legs += [
+            ("q-fused: rope(K)+attention[Q rotated in registers]", lambda: at.fwd_raw(q, at.rope_raw(k, cos, sin, out=kb), v, code, sc, want_lse=False, q_rope=(cos, sin, 0))),
+            ("k-cached: attention[Q rotated in registers]", lambda: at.fwd_raw(q, kr, v, code, sc, want_lse=False, q_rope=(cos, sin, 0))),
+        ]
     fl = 4.0 * B * Hq * D * (S * (S + 1) / 2 if causal else S * S)
-    print(f"{dtype} B{B} Hq{Hq} Hkv{Hkv} S{S} D{D} causal={int(causal)}   fused == two-pass bit for bit: {same}", flush=True)
+    print(f"{dtype} B{B} Hq{Hq} Hkv{Hkv} S{S} D{D} causal={int(causal)}   fusable here: {fus}   fused == two-pass bit for bit: {same}", flush=True)
     res = {}
     for name, fn in legs:
         us = timed(fn)
         res[name] = us
         print(f"    {name:54s} {us:9.1f} us   {fl / us / 1e6:7.1f} TF", flush=True)
-    tp, qf = res[legs[3][0]], res[legs[4][0]]
-    print(f"    q-fused vs two-pass: {(tp / qf - 1) * 100:+.1f} %   (bytes saved: one read + one write of Q = {2 * q.numel() * 2 / 1e6:.0f} MB)", flush=True)
+    if fus:
+        tp, qf = res[legs[3][0]], res[legs[5][0]]
+        print(f"    q-fused vs two-pass: {(tp / qf - 1) * 100:+.1f} %   (bytes saved: one read + one write of Q = {2 * q.numel() * 2 / 1e6:.0f} MB)", flush=True)
 
 
-print("lib:", os.environ.get("AULE_LIBRARY_PATH", "(in-tree)"))
+print("lib:", os.environ.get("AULE_LIBRARY_PATH", "(in-tree)"), " AULE_HIP_FWD_KERNEL =", os.environ.get("AULE_HIP_FWD_KERNEL", "(default)"))
 run("bf16", 4, 32, 32, 2048, 128, True)     # C2-like, MHA
 run("bf16", 4, 32, 8, 2048, 128, True)      # C3-like, GQA 4:1
 run("bf16", 2, 32, 8, 8192, 128, True)      # long sequence
