@@ -2,8 +2,9 @@
 """Cycle timeline of workgroup 0 of the one-wave-per-SIMD forward (fa_fwd_w4_gfx950.hip, timeline build behind
 aule_hip_debug_forward_timeline with AULE_TL=w4; debug library: cd aule-attention_amd/csrc && make dbg).  Every stamp is
 (tag << 56) | s_memtime.  Tags: 0x10/0x11 plain step (parity), 0x20+ generic step (PAR + 2 QK + 4 SM), 0x08 idle step,
-0x18 phase 1 done, 0x19 phase 2 done (then the waits + barrier), 0x30 prologue, 0x31 S_0 done, 0x32 barrier passed,
-0x33 P_0[A] done, 0x40 epilogue, 0x42 slabs written, 0x41 stores issued, 0x50 end of the stream.
+0x18 phase 1 done, 0x19 phase 2 done (then the loop tail), 0x30 prologue, 0x31 S_0 done (wait for the part's first tiles,
+barrier, K_0 reads, bare QK^T), 0x33 P_0[A] done (references, softmax of S_0[A], K_1 reads), 0x40 epilogue, 0x42 block A stored,
+0x41 block B stored, 0x50 end of the stream.
 
     python tools/timeline_w4.py [causal] [B] [H] [S] [waves...]
 W4_TL_D=64 (with a debug library built with -DW4_TL_D64) and W4_TL_HKV=n: the D = 64 instance, grouped heads.
@@ -72,7 +73,7 @@ for w in waves:
                 seq.append(r[j][1]); j += 1
             end = r[j][1] if j < len(r) else seq[-1]
             d_ = [seq[k + 1] - seq[k] for k in range(len(seq) - 1)] + [end - seq[-1]]
-            print(f"   part {part} prologue at +{tm - t0}: K_0 read + S_0 {d_[0] if len(d_) > 0 else -1}, barrier {d_[1] if len(d_) > 1 else -1}, refs + P_0[A] + K_1 read {d_[2] if len(d_) > 2 else -1}, waits+barrier {d_[3] if len(d_) > 3 else -1}")
+            print(f"   part {part} prologue at +{tm - t0}: wait + barrier + K_0 read + S_0 {d_[0] if len(d_) > 0 else -1}, refs + P_0[A] + K_1 read {d_[1] if len(d_) > 1 else -1}, to step 0 {d_[2] if len(d_) > 2 else -1}")
             part += 1
             i = j
             continue
@@ -106,7 +107,7 @@ for w in waves:
             while j < len(r) and r[j][0] in (0x42, 0x41):
                 seq.append(r[j][1]); j += 1
             end = r[j][1] if j < len(r) else seq[-1]
-            print(f"   epilogue at +{tm - t0}: pack+slab {seq[1] - seq[0] if len(seq) > 1 else -1}, stores {seq[2] - seq[1] if len(seq) > 2 else -1}, to next {end - seq[-1]}")
+            print(f"   epilogue at +{tm - t0}: block A (pack, slab, stores) {seq[1] - seq[0] if len(seq) > 1 else -1}, block B {seq[2] - seq[1] if len(seq) > 2 else -1}, to next {end - seq[-1]}")
             i = j
             continue
         if tag == 0x50:
