@@ -290,17 +290,24 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         };
         // (K_3 of the next part is NOT prefetched: its ring slot is the one K_0 sits in until the next part's prologue has read it;
         // every part requests its own K_3 at its step 0)
+        // (the heads' base addresses change twice per part -- at its start and when the cursor crosses into the next part -- and
+        // are fetched from the kernel arguments only then: two scalar loads and their wait in every one of a part's last five
+        // steps were ~300 cycles each with the matrix pipe idle)
         auto set_k = [&](int t) __attribute__((always_inline)) {   // tile t of this part, or tile t - nt3 < 3 of the next one
-            head_lohi(P()->k, kvoff, klo, khi);
             ksoff = oob;
             if (t < nt) ksoff = (unsigned)t * KT;
-            else if (pre && t >= nt3 && t - nt3 < 3) { head_lohi(P()->k, w4_rfl(tab[n_slot].y), klo, khi); ksoff = (unsigned)(t - nt3) * KT; }
+            else if (pre && t >= nt3 && t - nt3 < 3) {
+                if (t == nt3) head_lohi(P()->k, w4_rfl(tab[n_slot].y), klo, khi);
+                ksoff = (unsigned)(t - nt3) * KT;
+            }
         };
         auto set_v = [&](int t) __attribute__((always_inline)) {   // ... or tile t - nt3 < 2 of the next one
-            head_lohi(P()->v, kvoff, vlo, vhi);
             vsoff = oob;
             if (t < nt) vsoff = (unsigned)t * VT;
-            else if (pre && t >= nt3 && t - nt3 < 2) { head_lohi(P()->v, w4_rfl(tab[n_slot].y), vlo, vhi); vsoff = (unsigned)(t - nt3) * VT; }
+            else if (pre && t >= nt3 && t - nt3 < 2) {
+                if (t == nt3) head_lohi(P()->v, w4_rfl(tab[n_slot].y), vlo, vhi);
+                vsoff = (unsigned)(t - nt3) * VT;
+            }
         };
         auto enter_part = [&](int sl) __attribute__((always_inline)) {
             const int4 e = tab[sl];
@@ -316,6 +323,8 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             jm = (min_thr + 1) >> 6;                                        // first tile that needs the mask
             n_slot = next_valid(sl);
             pre = !REDO && n_slot < nslot;
+            head_lohi(P()->k, kvoff, klo, khi);
+            head_lohi(P()->v, kvoff, vlo, vhi);
             set_k(4);
             set_v(2);
             A::zero_sums();
