@@ -147,6 +147,11 @@ DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 # Every symbol include/aule.h declares: (name, restype, argtypes)
 _FP = ctypes.POINTER(ctypes.c_float)
 _U32, _I32, _U64, _U8 = ctypes.c_uint32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint8
+class IpcHandle(ctypes.Structure):
+    """aule_ipc_handle (include/aule.h): 64 opaque bytes, a hipIpcMemHandle_t."""
+    _fields_ = [("bytes", ctypes.c_ubyte * 64)]
+
+
 SIGNATURES = [
     ("aule_init", _I32, []),
     ("aule_shutdown", None, []),
@@ -188,6 +193,11 @@ SIGNATURES = [
     ("aule_attention_forward_rope_fusable", _I32, [ctypes.POINTER(AttnDesc), ctypes.POINTER(AttnRope)]),
     ("aule_attention_forward_workspace_size", ctypes.c_uint64, [ctypes.POINTER(AttnDesc)]),
     ("aule_attention_paged_decode_workspace_size", ctypes.c_uint64, [ctypes.POINTER(PagedDesc)]),
+    ("aule_peer_alloc", _I32, [_I32, _U64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(IpcHandle)]),
+    ("aule_peer_free", _I32, [_I32, ctypes.c_void_p]),
+    ("aule_peer_open", _I32, [_I32, ctypes.POINTER(IpcHandle), ctypes.POINTER(ctypes.c_void_p)]),
+    ("aule_peer_close", _I32, [_I32, ctypes.c_void_p]),
+    ("aule_peer_copy_async", _I32, [_I32, ctypes.c_void_p, ctypes.c_void_p, _U64, ctypes.c_void_p]),
     ("aule_hip_build_info", ctypes.c_char_p, []),
     ("aule_hip_debug_forward_route", _I32, [ctypes.POINTER(AttnDesc)]),
     ("aule_hip_debug_forward_split_plan", _I32, [ctypes.POINTER(AttnDesc), ctypes.POINTER(_I32), _I32]),

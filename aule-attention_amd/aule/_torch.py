@@ -76,16 +76,21 @@ def _attn_rope(cos, sin, q_pos):
     return r
 
 
-def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1, q_rope=None):
+def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1, q_rope=None, out=None):
     """q [B,Hq,Sq,D], k/v [B,Hkv,Sk,D]: contiguous device tensors, D in SUPPORTED_HEAD_DIMS.
     Returns (out, lse or None).  Asynchronous on the current stream.
+    out: write the result there (contiguous, q's shape / dtype / device) instead of a fresh tensor -- aule.dist computes its
+    pieces straight into their place in the gathered tensor.
     q_rope = (cos, sin, q_pos): rotate Q inside the kernel (half-split pairs; K already rotated) -- only for shapes
     rope_fusable() accepts, AuleError otherwise."""
     lib = _capi.get_lib()
     _same_device("flash attention forward", q, k, v)
     B, Hq, Sq, D = q.shape
     Hkv, Sk = k.shape[1], k.shape[2]
-    out = torch.empty_like(q)
+    if out is None:
+        out = torch.empty_like(q)
+    elif out.shape != q.shape or out.dtype != q.dtype or out.device != q.device or not out.is_contiguous():
+        raise ValueError("out must be a contiguous tensor of the query's shape, dtype and device")
     lse = torch.empty((B, Hq, Sq), device=q.device, dtype=torch.float32) if want_lse else None
     if q.numel() == 0:
         return out, lse

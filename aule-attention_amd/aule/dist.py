@@ -14,11 +14,17 @@ every GPU pair has its own xGMI link (7 links x ~153 GB/s per GPU), so
   * a ring all-gather moves (n-1)/n of the tensor over ONE link per hop: config 4, 3.76 GB / 153 GB/s = 24.5 ms;
   * a direct exchange (every rank sends its shard to all 7 peers at once) uses all 7 links: 0.5 GiB / 153 GB/s = 3.5 ms
 against 3.8 ms of kernel time per rank.  So (1) the local shard is computed in `chunks` pieces along its leading axis
-(contiguous views: no copies, no change to the kernels -- each piece is an ordinary batch of independent heads), and the
+(contiguous views, each piece written by the kernel straight into its place in the gathered tensor -- no change to the
+kernels: a piece is an ordinary batch of independent heads), and the
 gather of piece i is launched asynchronously (RCCL runs it on its own stream, ordered behind the kernel that produced
 it) while piece i+1 computes; (2) `transport="p2p"` posts the direct sends / receives of a piece to all peers as one
 batch (torch.distributed.batch_isend_irecv -> one RCCL group: all links busy, and shards of different sizes need no
-padding), `transport="allgather"` posts one all-gather per piece into per-rank views of the final tensor.  Expected
+padding), `transport="allgather"` posts one all_gather_into_tensor per piece into a contiguous staging tensor that one
+strided copy moves to its place (the collective's output is rank-major, the gathered tensor shard-major), and
+`transport="peer"` leaves RCCL out of the data path altogether: the gathered tensor lives in a buffer every peer has mapped
+(include/aule.h aule_peer_*: hipMalloc + hipIpcGetMemHandle here, hipIpcOpenMemHandle there), and a finished piece is
+copied straight into the same place of every peer's buffer by one hipMemcpyAsync per peer on that peer's own stream -- seven
+independent xGMI links, no algorithm choice, no protocol thresholds (class PeerExchange below).  Expected
 end-to-end cost of the gather at config 4: ~0.4 ms exposed (the last piece) instead of 3.5 ms (p2p) / 24.5 ms (ring).
 Every rank ends with the full [B, Hq, Sq, D] tensor; pass gather=False to keep the shard (what a data-parallel model does:
 it never needs the other ranks' attention outputs).  The backward needs no collective at all: dQ, dK, dV are per unit.
@@ -62,6 +68,19 @@ def local_shard(q, k, v, rank: int, world: int):
     return mode, qf, kf, vf
 
 
+def shard_layout(batch: int, heads_q: int, heads_kv: int, world: int):
+    """Where every rank's shard sits in the flattened [B*Hq, Sq, D] output: (mode, n_lead, row0, per_lead, step) -- n_lead[r] =
+    extent of rank r's shard along its leading axis (batch items, or query heads of the flattened unit axis), row0[r] = its first
+    output row, per_lead = output rows per leading index, step = granularity of a piece (a query group stays whole)."""
+    g = heads_q // heads_kv
+    mode, ranges = shard_plan(batch, heads_kv, world)
+    per_lead = heads_q if mode == "batch" else 1
+    units_to_lead = 1 if mode == "batch" else g
+    n_lead = [(e - s) * units_to_lead for s, e in ranges]
+    row0 = [s * units_to_lead * per_lead for s, _ in ranges]
+    return mode, n_lead, row0, per_lead, (1 if mode == "batch" else g)
+
+
 def chunk_ranges(n: int, chunks: int) -> List[Tuple[int, int]]:
     """Split range(n) into at most `chunks` contiguous non-empty pieces of near-equal size."""
     chunks = max(1, min(int(chunks), n))
@@ -82,12 +101,14 @@ def flash_attention_sharded(q, k, v, causal: bool = True, scale: Optional[float]
                             transport: str = "auto"):
     """Every rank holds the same full q, k, v (or at least its own shard's rows); each computes its share with `attn_fn`
     (default aule.flash_attention) in `chunks` pieces and, if `gather`, every rank receives the full output: the exchange of
-    piece i overlaps the computation of piece i+1 (module docstring).  transport: "allgather", "p2p" or "auto" (p2p when
-    the shards differ in size, all-gather otherwise).  Returns the full [B,Hq,Sq,D] output (gather=True) or this rank's
+    piece i overlaps the computation of piece i+1 (module docstring).  transport: "allgather", "p2p", "peer" (direct copies into the peers' mapped buffers; the
+    result then lives in a cached exchange buffer and stays valid until the second-next "peer" exchange of the same size) or
+    "auto" (p2p when the shards differ in size, all-gather otherwise).  Returns the full [B,Hq,Sq,D] output (gather=True) or this rank's
     shard.  Inference path (no autograd through the collective).  chunks=1, transport="allgather" is the single blocking
     collective of round 1."""
     import torch
     import torch.distributed as dist
+    into = _into_ok(q, attn_fn)
     if attn_fn is None:
         from . import flash_attention as attn_fn
     world = dist.get_world_size(group)
@@ -96,20 +117,17 @@ def flash_attention_sharded(q, k, v, causal: bool = True, scale: Optional[float]
     Hkv = k.shape[1]
     g = Hq // Hkv
     mode, qs, ks, vs = local_shard(q, k, v, rank, world)
-    _, ranges = shard_plan(B, Hkv, world)
-    # rows of the flattened [B*Hq, Sq, D] output each rank owns; a "piece" is a range of the shard's leading axis
+    _, n_lead, row0, per_lead, _ = shard_layout(B, Hq, Hkv, world)
     lead = 0 if mode == "batch" else 1                      # batch items, or heads of the single flattened batch item
-    per_lead = Hq if mode == "batch" else 1                 # flattened output rows per leading index
-    units_to_lead = 1 if mode == "batch" else g
-    n_lead = [(e - s) * units_to_lead for s, e in ranges]   # leading extent per rank
-    row0 = [s * units_to_lead * per_lead for s, _ in ranges]
 
-    def run(sl):
+    def run(sl, out=None):
         qq = qs[sl] if lead == 0 else qs[:, sl]
         if lead == 0:
             kk, vv = ks[sl], vs[sl]
         else:   # heads of one flattened batch item: the KV heads of the same units
             kk, vv = ks[:, sl.start // g:(sl.stop + g - 1) // g], vs[:, sl.start // g:(sl.stop + g - 1) // g]
+        if out is not None:
+            return _attn_into(qq, kk, vv, causal, scale, out.view(qq.shape))
         return attn_fn(qq.contiguous(), kk.contiguous(), vv.contiguous(), causal=causal, scale=scale)
 
     if not gather:
@@ -117,7 +135,7 @@ def flash_attention_sharded(q, k, v, causal: bool = True, scale: Optional[float]
             return qs.new_empty(qs.shape)
         return run(slice(0, n_lead[rank]))
     full = _compute_and_exchange(run, n_lead, row0, per_lead, g if lead == 1 else 1, rank, world, (B * Hq, Sq, D),
-                                 q.dtype, q.device, chunks, transport, group)
+                                 q.dtype, q.device, chunks, transport, group, into=into)
     return full.reshape(B, Hq, Sq, D)
 
 
@@ -127,43 +145,222 @@ def attention_and_gather(q, k, v, causal: bool = True, scale: Optional[float] = 
     caller and bench.py have): q [Bl,Hq,Sq,D], k / v [Bl,Hkv,Sk,D] local; returns [world*Bl,Hq,Sq,D] on every rank,
     rank r's rows at [r*Bl, (r+1)*Bl)."""
     import torch.distributed as dist
+    into = _into_ok(q, attn_fn)
     if attn_fn is None:
         from . import flash_attention as attn_fn
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     Bl, Hq, Sq, D = q.shape
 
-    def run(sl):
+    def run(sl, out=None):
+        if out is not None:
+            return _attn_into(q[sl], k[sl], v[sl], causal, scale, out.view(q[sl].shape))
         return attn_fn(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), causal=causal, scale=scale)
 
     full = _compute_and_exchange(run, [Bl] * world, [r * Bl * Hq for r in range(world)], Hq, 1, rank, world,
-                                 (world * Bl * Hq, Sq, D), q.dtype, q.device, chunks, transport, group)
+                                 (world * Bl * Hq, Sq, D), q.dtype, q.device, chunks, transport, group, into=into)
     return full.reshape(world * Bl, Hq, Sq, D)
 
 
-def _compute_and_exchange(run, n_lead, row0, per_lead, step, rank, world, shape, dtype, device, chunks, transport, group):
-    """run(slice over the shard's leading axis) -> that piece's output; n_lead[r] = leading extent of rank r's shard,
-    row0[r] = its first row in the flattened [rows, Sq, D] result, per_lead = rows per leading index, step = granularity of
-    a piece (a query group stays whole).  Computes this rank's pieces and exchanges them, piece i's exchange overlapping
-    piece i+1's kernels."""
+def _into_ok(t, attn_fn):
+    """Can the default attention write its result straight into a view of the gathered tensor?  (Device tensors of a dtype
+    and head_dim the kernels take natively; a caller-supplied attn_fn returns its own tensor.)"""
+    if attn_fn is not None or not getattr(t, "is_cuda", False):
+        return False
+    from . import _torch as at
+    return t.dtype in at._DTYPES and t.shape[-1] in at.SUPPORTED_HEAD_DIMS
+
+
+def _attn_into(q, k, v, causal, scale, out):
+    """aule.flash_attention (inference form: no autograd node, no LSE) with the result written to `out`."""
+    import math
+    from . import _torch as at
+    sc = float(scale) if scale is not None else 1.0 / math.sqrt(q.shape[-1])
+    at.fwd_raw(q.contiguous(), k.contiguous(), v.contiguous(), at.causal_code(causal), sc, want_lse=False, out=out)
+    return out
+
+
+def peer_copy_plan(n_lead, row0, per_lead, step, rank, chunks, row_bytes):
+    """The pieces of rank `rank`'s shard as byte ranges of the gathered [rows, Sq, D] tensor: [(lead_a, lead_b, byte offset,
+    bytes)].  Every rank's buffer has the same layout, so a piece goes to the SAME offset of every peer's buffer -- the
+    offset arithmetic of transport="peer" in one place (tests/test_dist_gloo.py checks that the ranks' plans tile the tensor
+    exactly once)."""
+    out = []
+    for a, b in chunk_ranges(n_lead[rank] // step, chunks):
+        a, b = a * step, b * step
+        out.append((a, b, (row0[rank] + a * per_lead) * row_bytes, (b - a) * per_lead * row_bytes))
+    return out
+
+
+class PeerExchange:
+    """The gathered tensor of transport="peer": a device buffer of this rank that every peer has mapped, plus this rank's
+    mappings of the peers' buffers and one stream per peer.  Built collectively (every rank of `group` must construct it with
+    the same nbytes); cached by _compute_and_exchange per (group, bytes, device), two buffers alternating, so a result stays
+    valid until the second-next exchange of the same size on the same group."""
+
+    def __init__(self, nbytes, device, group):
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        from . import _capi
+        self.lib = _capi.load()
+        self.nbytes, self.device, self.group = int(nbytes), device, group
+        self.dev = device.index if device.index is not None else torch.cuda.current_device()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.ptr = ctypes.c_void_p()
+        h = _capi.IpcHandle()
+        err = None
+        rc = self.lib.aule_peer_alloc(self.dev, self.nbytes, ctypes.byref(self.ptr), ctypes.byref(h))
+        if rc != 0:
+            err = self.lib.aule_get_error().decode()
+            self.ptr = ctypes.c_void_p()
+        got = [None] * self.world
+        dist.all_gather_object(got, (err, bytes(h.bytes)), group=group)
+        self.remote = [None] * self.world
+        if err is None and all(e is None for e, _ in got):
+            for r, (_, hb) in enumerate(got):
+                if r == self.rank:
+                    continue
+                hh = _capi.IpcHandle()
+                ctypes.memmove(hh.bytes, hb, 64)
+                p = ctypes.c_void_p()
+                if self.lib.aule_peer_open(self.dev, ctypes.byref(hh), ctypes.byref(p)) != 0:
+                    err = self.lib.aule_get_error().decode()
+                    break
+                self.remote[r] = p
+        # every rank learns whether every rank is set up (a rank that failed must not leave the others waiting in the exchange)
+        oks = [None] * self.world
+        dist.all_gather_object(oks, err if err is not None else next((e for e, _ in got if e is not None), None), group=group)
+        bad = next((e for e in oks if e is not None), None)
+        if bad is not None:
+            self.close()
+            raise _capi.AuleError(f"peer exchange set-up failed on some rank: {bad}")
+        self.streams = [torch.cuda.Stream(device=device) if r != self.rank else None for r in range(self.world)]
+        self._arr = _RawDeviceBytes(self.ptr.value, self.nbytes)
+        self.bytes_view = torch.as_tensor(self._arr, device=device)    # uint8 [nbytes], zero-copy
+
+    def tensor(self, shape, dtype):
+        return self.bytes_view.view(dtype).reshape(shape)
+
+    def send(self, offset, nbytes, event):
+        """Copy [offset, offset + nbytes) of this rank's buffer to the same place of every peer's, each on its own stream,
+        behind `event` (recorded on the stream that produced the bytes)."""
+        import ctypes
+        from . import _capi
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            st = self.streams[r]
+            st.wait_event(event)
+            _capi.check(self.lib.aule_peer_copy_async(self.dev, ctypes.c_void_p(self.remote[r].value + offset),
+                                                      ctypes.c_void_p(self.ptr.value + offset), nbytes,
+                                                      ctypes.c_void_p(st.cuda_stream)), "aule_peer_copy_async")
+
+    def finish(self):
+        """Returns when every rank's copies have landed everywhere: each rank waits for its own outgoing copies, then the ranks
+        meet (a one-element all-reduce: control only, no payload)."""
+        import torch
+        import torch.distributed as dist
+        for st in self.streams:
+            if st is not None:
+                st.synchronize()
+        flag = torch.zeros(1, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(flag, group=self.group)
+
+    def close(self):
+        for r, p in enumerate(getattr(self, "remote", [])):
+            if p is not None:
+                self.lib.aule_peer_close(self.dev, p)
+                self.remote[r] = None
+        if getattr(self, "ptr", None) is not None and self.ptr.value:
+            self.lib.aule_peer_free(self.dev, self.ptr)
+            self.ptr.value = None
+
+
+class _RawDeviceBytes:
+    """A device allocation as a uint8 array for torch.as_tensor (CUDA array interface v3)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3,
+                                         "strides": None}
+
+
+_peer_cache = {}
+
+
+def _peer_exchange(nbytes, device, group):
+    key = (id(group) if group is not None else 0, int(nbytes), str(device))
+    ent = _peer_cache.get(key)
+    if ent is None:
+        ent = _peer_cache[key] = {"bufs": [PeerExchange(nbytes, device, group), PeerExchange(nbytes, device, group)], "n": 0}
+    ent["n"] += 1
+    return ent["bufs"][ent["n"] & 1]
+
+
+def release_peer_buffers():
+    """Close every cached peer-exchange buffer (collective in spirit: call it on every rank before the process group goes)."""
+    for ent in _peer_cache.values():
+        for b in ent["bufs"]:
+            b.close()
+    _peer_cache.clear()
+
+
+def _compute_and_exchange(run, n_lead, row0, per_lead, step, rank, world, shape, dtype, device, chunks, transport, group,
+                          into=False):
+    """run(slice over the shard's leading axis, out) -> that piece's output (written to `out` when into=True and out is given);
+    n_lead[r] = leading extent of rank r's shard, row0[r] = its first row in the flattened [rows, Sq, D] result, per_lead = rows
+    per leading index, step = granularity of a piece (a query group stays whole).  Computes this rank's pieces and exchanges
+    them, piece i's exchange overlapping piece i+1's kernels."""
     import torch
     import torch.distributed as dist
     Sq, D = shape[1], shape[2]
     if transport == "auto":
         transport = "allgather" if len(set(n_lead)) == 1 else "p2p"
-    if transport not in ("allgather", "p2p"):
-        raise ValueError(f"transport must be 'auto', 'allgather' or 'p2p', got {transport!r}")
+    if transport not in ("allgather", "p2p", "peer"):
+        raise ValueError(f"transport must be 'auto', 'allgather', 'p2p' or 'peer', got {transport!r}")
     if transport == "allgather" and len(set(n_lead)) != 1:
-        raise ValueError("transport='allgather' needs equal shards; use 'p2p' (or 'auto') for a ragged split")
+        raise ValueError("transport='allgather' needs equal shards; use 'p2p', 'peer' (or 'auto') for a ragged split")
+
+    def piece_of(full, a, b):
+        """piece [a, b) of this rank's shard, computed into its place in `full` when the attention can do that"""
+        view = full[row0[rank] + a * per_lead: row0[rank] + b * per_lead]
+        if into:
+            run(slice(a, b), view)
+        else:
+            view.copy_(run(slice(a, b), None).reshape(-1, Sq, D))
+        return view
+
+    if transport == "peer":
+        if device.type != "cuda":
+            raise ValueError("transport='peer' exchanges device buffers; these tensors are on " + str(device))
+        row_bytes = Sq * D * torch.empty((), dtype=dtype).element_size()
+        px = _peer_exchange(shape[0] * row_bytes, device, group)
+        full = px.tensor(shape, dtype)
+        cur = torch.cuda.current_stream(device)
+        for a, b, off, nb in peer_copy_plan(n_lead, row0, per_lead, step, rank, chunks, row_bytes):
+            piece_of(full, a, b)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            px.send(off, nb, ev)
+        px.finish()
+        return full
 
     full = torch.empty(shape, dtype=dtype, device=device)
     works = []
     if transport == "allgather":
-        pieces = [(a * step, b * step) for a, b in chunk_ranges(n_lead[rank] // step, chunks)]
-        for a, b in pieces:
-            piece = run(slice(a, b)).reshape(-1, Sq, D)
-            views = [full[row0[r] + a * per_lead: row0[r] + b * per_lead] for r in range(world)]
-            works.append(dist.all_gather(views, piece, group=group, async_op=True))
+        # equal shards: full is [world, shard rows, Sq, D].  Piece i of every rank is gathered into ONE contiguous
+        # [world, piece rows, Sq, D] staging tensor (all_gather_into_tensor: no per-rank temporaries inside the process group,
+        # which is what a list of strided views costs) and lands in `full` with one strided copy behind the collective.
+        shard_rows = n_lead[rank] * per_lead
+        full4 = full.view(world, shard_rows, Sq, D)
+        staged = []
+        for a, b in [(a * step, b * step) for a, b in chunk_ranges(n_lead[rank] // step, chunks)]:
+            piece = piece_of(full, a, b)
+            stage = torch.empty((world * (b - a) * per_lead, Sq, D), dtype=dtype, device=device)   # rank-major concatenation
+            staged.append((dist.all_gather_into_tensor(stage, piece, group=group, async_op=True), stage, a * per_lead, b * per_lead))
+        for w, stage, ra, rb in staged:
+            w.wait()
+            full4[:, ra:rb].copy_(stage.view(world, rb - ra, Sq, D))
     else:
         # every rank cuts ITS shard into the same number of pieces (possibly of different sizes); piece i of every rank
         # is exchanged in one batch of sends / receives
@@ -172,9 +369,7 @@ def _compute_and_exchange(run, n_lead, row0, per_lead, step, rank, world, shape,
                 for n in n_lead]
         for i in range(npiece):
             a, b = cuts[rank][i]
-            piece = run(slice(a, b)).reshape(-1, Sq, D) if b > a else None
-            if piece is not None:
-                full[row0[rank] + a * per_lead: row0[rank] + b * per_lead].copy_(piece)
+            piece = piece_of(full, a, b) if b > a else None      # in place: no second copy of the local piece
             ops = []
             for r in range(world):
                 if r == rank:

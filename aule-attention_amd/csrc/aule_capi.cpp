@@ -970,6 +970,64 @@ int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
     return 0;
 }
 
+// ---- direct peer exchange (include/aule.h; consumer: aule/dist.py, transport="peer")
+static_assert(sizeof(aule_ipc_handle) == sizeof(hipIpcMemHandle_t), "aule_ipc_handle must carry a hipIpcMemHandle_t");
+
+int32_t aule_peer_alloc(int32_t device, uint64_t bytes, void** ptr, aule_ipc_handle* handle) {
+    if (ptr == nullptr || handle == nullptr || bytes == 0) { set_error("aule_peer_alloc: bad argument"); return -1; }
+    DeviceGuard g(device);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { set_error("aule_peer_alloc: hipMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e)); return -2; }
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+        set_error("aule_peer_alloc: hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
+        (void)hipFree(p);
+        return -4;
+    }
+    std::memcpy(handle->bytes, &h, sizeof(h));
+    *ptr = p;
+    return 0;
+}
+
+int32_t aule_peer_free(int32_t device, void* ptr) {
+    if (ptr == nullptr) return 0;
+    DeviceGuard g(device);
+    const hipError_t e = hipFree(ptr);
+    if (e != hipSuccess) { set_error("aule_peer_free: %s", hipGetErrorString(e)); return -4; }
+    return 0;
+}
+
+int32_t aule_peer_open(int32_t device, const aule_ipc_handle* handle, void** ptr) {
+    if (ptr == nullptr || handle == nullptr) { set_error("aule_peer_open: bad argument"); return -1; }
+    DeviceGuard g(device);
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle->bytes, sizeof(h));
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { set_error("aule_peer_open: hipIpcOpenMemHandle: %s", hipGetErrorString(e)); return -4; }
+    *ptr = p;
+    return 0;
+}
+
+int32_t aule_peer_close(int32_t device, void* ptr) {
+    if (ptr == nullptr) return 0;
+    DeviceGuard g(device);
+    const hipError_t e = hipIpcCloseMemHandle(ptr);
+    if (e != hipSuccess) { set_error("aule_peer_close: %s", hipGetErrorString(e)); return -4; }
+    return 0;
+}
+
+int32_t aule_peer_copy_async(int32_t device, void* dst, const void* src, uint64_t bytes, void* stream) {
+    if (bytes == 0) return 0;
+    if (dst == nullptr || src == nullptr) { set_error("aule_peer_copy_async: bad argument"); return -1; }
+    DeviceGuard g(device);
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("aule_peer_copy_async: %s", hipGetErrorString(e)); return -4; }
+    return 0;
+}
+
 const char* aule_hip_build_info(void) { return "aule-hip gfx950 abi2"; }   // abi2: workspace fields in the fwd / paged descriptors
 
 uint64_t aule_attention_forward_workspace_size(const aule_attn_desc* d) {

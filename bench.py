@@ -336,14 +336,23 @@ def main():
                                                                                   chunks=nch, transport="allgather")
             variants["chunked_p2p"] = lambda: adist.attention_and_gather(q, k, v, causal=causal, attn_fn=attn_nograd,
                                                                            chunks=nch, transport="p2p")
+            # (d) no RCCL in the data path: every piece copied straight into the peers' mapped buffers (aule_peer_* of the
+            # C-ABI, one hipMemcpyAsync per peer and piece on per-peer streams).  Its set-up is collective and agrees on
+            # failure across the ranks, so a node where IPC mapping does not work reports the reason instead of hanging.
+            variants["chunked_peer"] = lambda: adist.attention_and_gather(q, k, v, causal=causal, chunks=nch, transport="peer")
         gsteps = max(1, min(args.steps, 20))
         result["gather"] = {"bytes_per_rank": out.numel() * out.element_size(), "steps": gsteps}
         for name, fn in variants.items():
-            for _ in range(2):
-                fn()
+            try:
+                for _ in range(2):
+                    fn()
+            except aule.AuleError as e:     # (raised on every rank alike: aule.dist.PeerExchange)
+                result["gather"][name] = {"error": str(e)[:300]}
+                continue
             gwall, _ = timed(fn, gsteps)
             result["gather"][name] = {"ms_per_step": gwall * 1e3 / gsteps, "value": f_step * n_gpus * gsteps / gwall / 1e12,
                                       "exposed_ms": gwall * 1e3 / gsteps - ms_per_step}
+        adist.release_peer_buffers()
         del gathered
 
     if rank == 0 and n_gpus == 1 and not args.no_extra and args.config == "c2":

@@ -266,6 +266,20 @@ int32_t aule_hip_debug_forward_route(const aule_attn_desc* desc);
 /* capacity needed), 0 when the shape does not take that route.  Host logic only.                                       */
 int32_t aule_hip_debug_forward_split_plan(const aule_attn_desc* desc, int32_t* out, int32_t cap);
 
+/* ---- Direct peer exchange between the per-GPU processes of one node (additive; no counterpart in the reference, which  */
+/* is single-device: SURVEY.md 8e).  A rank allocates its receive buffer here, publishes the 64-byte handle by any means    */
+/* (aule.dist uses the process group), opens its peers' handles, and copies pieces of its output straight into their        */
+/* buffers over xGMI -- no RCCL algorithm choice in the data path.  Every call: 0, or -1 bad argument / -2 allocation /     */
+/* -4 HIP error with the text in aule_get_error().  No aule_init() needed; `device` < 0 = the current device.               */
+typedef struct aule_ipc_handle { unsigned char bytes[64]; } aule_ipc_handle;   /* = hipIpcMemHandle_t */
+int32_t aule_peer_alloc(int32_t device, uint64_t bytes, void** ptr, aule_ipc_handle* handle);   /* hipMalloc + hipIpcGetMemHandle */
+int32_t aule_peer_free(int32_t device, void* ptr);
+int32_t aule_peer_open(int32_t device, const aule_ipc_handle* handle, void** ptr);              /* another process's buffer, mapped here */
+int32_t aule_peer_close(int32_t device, void* ptr);
+/* dst / src: device pointers (local, or a peer's from aule_peer_open) + byte offsets applied by the caller; asynchronous on */
+/* `stream` (a hipStream_t of `device`).                                                                                      */
+int32_t aule_peer_copy_async(int32_t device, void* dst, const void* src, uint64_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,11 @@ def _worker(rank, world, port, case, q):
             ok = False                                  # a ragged split must be refused by the all-gather transport
         except ValueError:
             pass
+    try:
+        adist.flash_attention_sharded(tq, tk, tv, causal=causal, attn_fn=attn, transport="peer")
+        ok = False                                      # the peer transport exchanges device buffers: host tensors are refused
+    except ValueError:
+        pass
     shard = adist.flash_attention_sharded(tq, tk, tv, causal=causal, gather=False, attn_fn=attn)
     q.put((rank, ok, tuple(shard.shape)))
     dist.barrier()
@@ -149,3 +154,32 @@ def test_local_shards_gathered(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,world", [(8, 32, 32, 8), (4, 4, 2, 2), (3, 4, 2, 2), (1, 6, 2, 2), (1, 8, 1, 2), (2, 12, 6, 3),
+                                            (7, 2, 2, 3), (64, 32, 32, 8), (5, 8, 4, 8)])
+@pytest.mark.parametrize("chunks", [1, 3, 4])
+def test_peer_copy_plans_tile_the_gathered_tensor(B, Hq, Hkv, world, chunks):
+    """transport="peer": rank r copies piece (offset, bytes) of ITS buffer to the same offset of every peer's buffer.  The
+    ranks' plans must tile the [B*Hq, Sq, D] tensor exactly once, pieces must lie inside the rank's own rows, and a query
+    group must never be cut (the offset arithmetic of the exchange, without a device)."""
+    sys.path.insert(0, os.path.join(ROOT, "aule-attention_amd"))
+    from aule import dist as adist
+    Sq, D, elt = 48, 64, 2
+    row_bytes = Sq * D * elt
+    mode, n_lead, row0, per_lead, step = adist.shard_layout(B, Hq, Hkv, world)
+    covered = []
+    for r in range(world):
+        plan = adist.peer_copy_plan(n_lead, row0, per_lead, step, r, chunks, row_bytes)
+        assert len(plan) <= max(1, chunks)
+        lo, hi = row0[r] * row_bytes, (row0[r] + n_lead[r] * per_lead) * row_bytes
+        for a, b, off, nb in plan:
+            assert b > a and a % step == 0 and b % step == 0
+            assert lo <= off and off + nb <= hi and nb == (b - a) * per_lead * row_bytes
+            covered.append((off, off + nb))
+    covered.sort()
+    pos = 0
+    for a, b in covered:
+        assert a == pos, (covered, pos)
+        pos = b
+    assert pos == B * Hq * row_bytes

@@ -32,8 +32,8 @@ def test_bench_under_torchrun_one_rank():
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["unit"] == "TFLOP/s"
     # the output exchange, three ways (one blocking all-gather; pieces overlapped with the kernels, as all-gathers and as
     # direct peer sends): each timed end to end
-    for name in ("blocking_all_gather", "chunked_all_gather", "chunked_p2p"):
-        assert rec["gather"][name]["ms_per_step"] > 0, name
+    for name in ("blocking_all_gather", "chunked_all_gather", "chunked_p2p", "chunked_peer"):
+        assert rec["gather"][name]["ms_per_step"] > 0, (name, rec["gather"][name])
     assert rec["steady_state"]["value"] > 0 and rec["steady_state"]["conditioning_steps"] > 0 and rec["world_size"] == 1
     assert rec["roofline"]["bound"] == "mfma" and 0 < rec["roofline"]["frac"] < 1
 
@@ -52,7 +52,7 @@ q = torch.randn(2, 8, 256, 128, device="cuda", dtype=torch.bfloat16)
 k = torch.randn(2, 2, 256, 128, device="cuda", dtype=torch.bfloat16)
 v = torch.randn(2, 2, 256, 128, device="cuda", dtype=torch.bfloat16)
 ref = aule.flash_attention(q, k, v, causal=True)
-for transport in ("auto", "allgather", "p2p"):
+for transport in ("auto", "allgather", "p2p", "peer"):
     for chunks in (1, 2, 4):
         full = adist.flash_attention_sharded(q, k, v, causal=True, chunks=chunks, transport=transport)
         assert torch.equal(full, ref), (transport, chunks)
@@ -63,3 +63,19 @@ print("OK")
 """ % ROOT
     r = _run([sys.executable, "-c", code])
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_peer_exchange_two_processes_on_one_gpu():
+    """transport="peer" end to end with TWO ranks (the box has one GPU: both use cuda:0; gloo carries the handles and the
+    final meeting, the payload goes through aule_peer_alloc / _open / _copy_async): every rank ends with the same gathered
+    tensor as the unsharded call, for equal and ragged shards, twice in a row (the cached buffers alternate).  The ranks
+    are tests/peer_exchange_worker.py."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_exchange_worker.py"), str(r), "2"], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "RANK_OK" in so, (so[-1500:], se[-2500:])
