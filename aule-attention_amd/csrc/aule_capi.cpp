@@ -448,13 +448,24 @@ int32_t aule_attention_forward_gpu(aule_tensor_handle qh, aule_tensor_handle kh,
     const float* kp = (const float*)k->ptr;
     float* rot = nullptr;   // rotated copies of Q and K (the handle tensors are the caller's and stay untouched)
     if (rc_t) {
-        // one table shared by every batch and head, indexed by position: [1, 1, >= max(Sq, Sk), D/2].  (A [B, H, S', D/2]
-        // tensor with S' < seq used to pass a flattened-row count check and was then read across head boundaries.)
+        // one table shared by every batch and head, indexed by position: a flat [positions, D/2] buffer however its three
+        // leading dimensions spell it -- [1, 1, S, D/2], [1, S, 1, D/2], [S, 1, 1, D/2] ("or similar broadcastable": the
+        // reference's attention_gpu.zig does not look at the shape at all) -- with at least max(Sq, Sk) positions.  A genuine
+        // [B, H, S', D/2] tensor (more than one leading dimension > 1) is refused: it used to pass a flattened-row count check
+        // and was then read across head boundaries.
         const uint32_t need = Sq > Sk ? Sq : Sk;
-        if ((D & 1) || rc_t->shape[3] != D / 2 || rs_t->shape[3] != D / 2 || rc_t->shape[0] != 1 || rc_t->shape[1] != 1 ||
-            rs_t->shape[0] != 1 || rs_t->shape[1] != 1 || rc_t->shape[2] < need || rs_t->shape[2] < need ||
-            rc_t->pitch != rs_t->pitch) {
-            set_error("Attention failed: error.ShapeMismatch (rot_cos / rot_sin must be [1, 1, >= seq, head_dim/2])");
+        auto positions = [](const DevTensor* t, uint32_t& n) {
+            int big = 0;
+            n = 1;
+            for (int i = 0; i < 3; ++i)
+                if (t->shape[i] != 1) { ++big; n = t->shape[i]; }
+            return big <= 1;
+        };
+        uint32_t nc = 0, ns = 0;
+        if ((D & 1) || rc_t->shape[3] != D / 2 || rs_t->shape[3] != D / 2 || !positions(rc_t, nc) || !positions(rs_t, ns) ||
+            nc < need || ns < need || rc_t->pitch != rs_t->pitch) {
+            set_error("Attention failed: error.ShapeMismatch (rot_cos / rot_sin must be one [>= seq, head_dim/2] table: "
+                      "at most one of the three leading dimensions larger than 1)");
             return -3;
         }
         const size_t nq = (size_t)B * Hq * Sq * q->pitch, nk = (size_t)B * Hkv * Sk * k->pitch;
@@ -684,8 +695,12 @@ struct RoctxRange {
                 if (h != nullptr) break;
             }
             if (h == nullptr) return (PushFn) nullptr;
-            pop_slot() = reinterpret_cast<PopFn>(dlsym(h, "roctxRangePop"));
-            return reinterpret_cast<PushFn>(dlsym(h, "roctxRangePushA"));
+            // both or neither: a push whose pop did not resolve would leave a range open on every API call
+            const PopFn pop = reinterpret_cast<PopFn>(dlsym(h, "roctxRangePop"));
+            const PushFn push = reinterpret_cast<PushFn>(dlsym(h, "roctxRangePushA"));
+            if (pop == nullptr || push == nullptr) return (PushFn) nullptr;
+            pop_slot() = pop;
+            return push;
         }();
         return fn;
     }
@@ -720,7 +735,7 @@ static void fill_fwd_args(const aule_attn_desc* d, FwdArgs& a) {
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
     a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? (int)d->seq_k - (int)d->seq_q : 0;
-    a.dtype = d->dtype;
+    a.dtype = d->dtype; a.device = d->device;
     // W >= Sq + coff masks nothing (the last query sits at position Sq - 1 + coff)
     a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
     drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
@@ -1044,7 +1059,7 @@ uint64_t aule_attention_forward_workspace_size(const aule_attn_desc* d) {
     a.scale = 1.0f;
     a.causal = d->causal != 0;
     a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? a.Sk - a.Sq : 0;
-    a.dtype = d->dtype;
+    a.dtype = d->dtype; a.device = d->device;
     a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
     drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
     return aule_hip::fwd_workspace_bytes(a);
@@ -1082,7 +1097,7 @@ static int32_t backward_timeline(const aule_attn_bwd_desc* d, unsigned long long
     a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
-    a.dtype = d->dtype;
+    a.dtype = d->dtype; a.device = d->device;
     if (dq) a.dbg_dq = stamps; else a.dbg = stamps;
     return aule_hip::launch_bwd(a, (hipStream_t)d->stream);
 }
@@ -1107,7 +1122,7 @@ int32_t aule_hip_debug_forward_route(const aule_attn_desc* d) {
     if (a.Hkv <= 0 || a.Hq % a.Hkv != 0) return -3;
     a.causal = d->causal != 0;
     a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? a.Sk - a.Sq : 0;
-    a.dtype = d->dtype;
+    a.dtype = d->dtype; a.device = d->device;
     a.scale = resolve_scale(d->scale, d->head_dim);   // (the sign of the scale picks the kernel: negative scales stay off route 8)
     a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
     drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
@@ -1123,7 +1138,7 @@ int32_t aule_hip_debug_forward_split_plan(const aule_attn_desc* d, int32_t* out,
     if (a.Hkv <= 0 || a.Hq % a.Hkv != 0) return -3;
     a.causal = d->causal != 0;
     a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? a.Sk - a.Sq : 0;
-    a.dtype = d->dtype;
+    a.dtype = d->dtype; a.device = d->device;
     a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
     drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
     if (aule_hip::fwd_route(a) != 7) return 0;
@@ -1144,7 +1159,7 @@ int32_t aule_hip_debug_forward_timeline(const aule_attn_desc* d, unsigned long l
     a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
-    a.dtype = d->dtype;
+    a.dtype = d->dtype; a.device = d->device;
     if (const char* e = getenv("AULE_TL")) {
         if (e[0] == 'p' && e[1] == 's')  // persistent tile stream: 8 waves x 2048 tagged stamps (tools/timeline_ps.py)
             return aule_hip::launch_fwd_ps_timeline(a, stamps, (hipStream_t)d->stream);

@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
                 const __amdgpu_buffer_rsrc_t crs = make_srd(p.rcos, tbytes), srs = make_srd(p.rsin, tbytes);
                 int lane_o = lane;
                 asm volatile("" : "+v"(lane_o));
-                const int toff = (q0 + (lane_o & 31) + p.rpos) * (p.rpitch * 4) + (lane_o >> 5) * 32;
+                const unsigned toff = (unsigned)(q0 + (lane_o & 31) + p.rpos) * (unsigned)(p.rpitch * 4) + (unsigned)((lane_o >> 5) * 32);   // (< 2^32: fwd_ps_rope_fusable)
                 constexpr int HK = KS / 2, BATCH = HK < AULE_PS_ROPE_BATCH ? HK : AULE_PS_ROPE_BATCH;
 #pragma unroll
                 for (int k0 = 0; k0 < HK; k0 += BATCH) {
@@ -980,13 +980,6 @@ __global__ void __launch_bounds__(512, D <= 64 ? 4 : 2) fa_fwd_ps_kernel(const F
     }
 }
 
-static int cu_count() {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
-    return n;
-}
-
 template <class T, int D, bool RAWOK>
 int launch_ps(const FwdArgs& a, hipStream_t stream) {
     FwdPSParams p;
@@ -1006,7 +999,7 @@ int launch_ps(const FwdArgs& a, hipStream_t stream) {
     p.rcos = a.rope_cos; p.rsin = a.rope_sin; p.rrows = a.rope_rows; p.rpitch = a.rope_pitch; p.rpos = a.rope_pos;
     p.part = nullptr; p.part_rows = 0; p.npiece = 0; p.magic = 0; p.pcoff = 0;
     // one workgroup per CU (two for D <= 64); more only when a workgroup's list would not fit its part table
-    const long long ncu = (long long)cu_count() * (D <= 64 ? 2 : 1);
+    const long long ncu = (long long)device_cu_count(a.device) * (D <= 64 ? 2 : 1);
     const long long rounds = (p.nitems + ncu * kMaxItems - 1) / (ncu * kMaxItems);
     long long G = ncu * rounds;
     if (G > p.nitems) G = p.nitems;
@@ -1139,7 +1132,7 @@ static PSSplitPlan ps_split_plan(const FwdArgs& a, int slots) {
 
 template <class T, int D, bool RAWOK>
 int launch_ps_split(const FwdArgs& a, hipStream_t stream) {
-    const PSSplitPlan s = ps_split_plan(a, cu_count());
+    const PSSplitPlan s = ps_split_plan(a, device_cu_count(a.device));
     if (a.query_ws != nullptr) {
         *a.query_ws = s.bytes;
         return 0;
@@ -1228,7 +1221,7 @@ int launch_fwd_ps_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_
     p.coff = a.causal ? a.coff : 0;
     p.nitems = p.nwork * a.B * a.Hq;
     p.dbg = dbg;
-    const long long ncu = cu_count();
+    const long long ncu = device_cu_count(a.device);
     const long long rounds = (p.nitems + ncu * kMaxItems - 1) / (ncu * kMaxItems);
     long long G = ncu * rounds;
     if (G > p.nitems) G = p.nitems;
@@ -1278,7 +1271,7 @@ bool fwd_ps_split_applicable(const FwdArgs& a) {
     if (ps_split_max_pieces() < 2 || (a.D != 64 && a.D != 128) || a.rope_cos != nullptr || !fwd_ps_applicable(a)) return false;
     if ((long long)a.Sk >= 65535LL * kKVTile) return false;                               // tile indices are 16-bit in the table
     if ((long long)a.Sq * (a.D + kPartPad) * 4 >= (1LL << 32)) return false;              // partial rows of a head: 32-bit offsets
-    return ps_split_plan(a, cu_count()).ok;
+    return ps_split_plan(a, device_cu_count(a.device)).ok;
 }
 
 int launch_fwd_ps_split(const FwdArgs& a, hipStream_t stream) {
@@ -1297,7 +1290,7 @@ int launch_fwd_ps_split(const FwdArgs& a, hipStream_t stream) {
 // ntf, ntn, b[0 .. kMaxPieces]}; returns the ints written, 0 when the shape does not take the path.
 int fwd_ps_split_plan_dump(const FwdArgs& a, int* out, int cap) {
     if (!fwd_ps_split_applicable(a)) return 0;
-    const PSSplitPlan s = ps_split_plan(a, cu_count());
+    const PSSplitPlan s = ps_split_plan(a, device_cu_count(a.device));
     const int per = 2 + kMaxPieces + 1, need = 2 + s.nwork * per;
     if (out == nullptr || cap < need) return -need;
     out[0] = s.n; out[1] = s.nwork;

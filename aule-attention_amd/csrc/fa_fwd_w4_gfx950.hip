@@ -701,18 +701,6 @@ constexpr auto w4_kernel() {
 
 #pragma clang diagnostic pop
 
-// CU count of the current device, queried once per device id (the launch path asks on every call)
-static int w4_cu_count() {
-    static int cached[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cached[dev] > 0) return cached[dev];
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
-    cached[dev] = n;
-    return n;
-}
-
 template <class T, int D, bool TL = false>
 int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nullptr) {
     FwdW4Params p;
@@ -726,7 +714,7 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
     p.nitems = p.nwork * a.B * a.Hq;
     p.dbg = dbg;
     // one workgroup per CU; more only when a workgroup's list would not fit its part table
-    const long long ncu = w4_cu_count();
+    const long long ncu = device_cu_count(a.device);
     const long long rounds = (p.nitems + ncu * kW4MaxItems - 1) / (ncu * kW4MaxItems);
     long long G = ncu * rounds;
     if (G > p.nitems) G = p.nitems;

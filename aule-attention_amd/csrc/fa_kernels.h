@@ -40,7 +40,23 @@ struct FwdArgs {
     const float* rope_cos = nullptr;
     const float* rope_sin = nullptr;
     int rope_rows = 0, rope_pitch = 0, rope_pos = 0;
+    int device = -1;   // the descriptor's device ordinal (-1: the current device): the grid-sizing queries ask THAT device's CU
+                       // count, also from the entry points that never switch devices (workspace size, route, fusable)
 };
+
+// Compute units of `device` (-1: the current one), asked once per device id and process: launch paths call this several times
+// per launch (route, plan, grid).
+inline int device_cu_count(int device) {
+    static int cached[64] = {};
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev < 0 || dev >= 64) return 256;
+    if (cached[dev] > 0) return cached[dev];
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    cached[dev] = n;
+    return n;
+}
 
 // The workspace of one launch: the caller's buffer, or hipMallocAsync / hipFreeAsync on the launch stream.
 struct ScopedWorkspace {

@@ -171,9 +171,18 @@ def test_rope_through_the_c_abi_handles(oracle_mod):
         out2 = a.attention(q2, k2, v2, rot_cos=c2, rot_sin=s2, causal=True)
         with pytest.raises(Exception):
             a.attention(q, k, v, rot_cos=cos[:4].reshape(1, 1, 4, half), rot_sin=sin[:4].reshape(1, 1, 4, half))  # short
+        # "[1, 1, S, D/2] or similar broadcastable" (the reference's engine reads the table as a flat [positions, D/2] buffer):
+        # the position axis may sit in any of the three leading dimensions ...
+        alt = [a.attention(q, k, v, rot_cos=cos.reshape(shp), rot_sin=sin.reshape(shp), causal=False)
+               for shp in ((1, S, 1, half), (S, 1, 1, half))]
+        # ... but a per-head table is not one table: refused, not read across heads
+        with pytest.raises(Exception):
+            a.attention(q, k, v, rot_cos=np.tile(cos, (2, 1)).reshape(1, 2, S, half), rot_sin=np.tile(sin, (2, 1)).reshape(1, 2, S, half))
     qr, kr = oracle_mod.rope_f64(q, cos, sin, "interleaved"), oracle_mod.rope_f64(k, cos, sin, "interleaved")
     ref, _ = oracle_mod.fwd_f64(qr, kr, v, False)
     assert_close(out, ref, 1e-5, 1e-5, "rope handles")              # the reference's own bar is 1e-3 (:104)
+    for o in alt:
+        assert np.array_equal(o, out)
     ref_base, _ = oracle_mod.fwd_f64(q, k, v, False)
     assert_close(base, ref_base, 1e-5, 1e-5, "no rope")
     ref2, _ = oracle_mod.fwd_f64(oracle_mod.rope_f64(q2, c2, s2, "interleaved"), oracle_mod.rope_f64(k2, c2, s2, "interleaved"),
