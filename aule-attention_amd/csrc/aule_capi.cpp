@@ -1097,7 +1097,7 @@ static int32_t backward_timeline(const aule_attn_bwd_desc* d, unsigned long long
     a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
     a.scale = resolve_scale(d->scale, d->head_dim);
     a.causal = d->causal != 0;
-    a.dtype = d->dtype; a.device = d->device;
+    a.dtype = d->dtype;
     if (dq) a.dbg_dq = stamps; else a.dbg = stamps;
     return aule_hip::launch_bwd(a, (hipStream_t)d->stream);
 }

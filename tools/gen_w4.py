@@ -43,6 +43,7 @@ OUT = os.environ.get("W4_OUT", os.path.join(ROOT, "aule-attention_amd", "csrc", 
 # Timing experiments only (tools/w4_experiments.sh; results are garbage): W4_X = comma list of
 #   noexp   v_exp_f32 -> v_mov_b32          nolds   no operand reads in the tile steps (stale fragments)
 #   nodma   no LDS-DMA pieces in the plain step     novalu  no softmax arithmetic at all      nocvt  no packing
+#   nobarrier / novmcnt   the plain step without its s_barrier / its counted wait (racy: cycles only)
 XFLAGS = set(filter(None, os.environ.get("W4_X", "").split(",")))
 # how x = c s - m_ref is computed (hardware finding, profiles/r3_w4_filler_costs.txt: 8-byte VOP3 instructions cost the in-order
 # wave several times what 4-byte VOP1 / VOP2 ones do next to the MFMAs)
@@ -323,7 +324,9 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
         # wait for the tiles requested two steps ago (everything but the previous step's 2 NP pieces) and the barrier sit
         # behind them -- the matrix pipe keeps running while the workgroup meets.  V reads and requests come after it.
         lines = ["s_waitcnt lgkmcnt(0)"] + place(mf, lds, valu, pieces, 2, len(mf) - 2 if len(mf) >= 8 else len(mf) - 1, 2 if len(mf) >= 8 else 1,
-                                               (1 if len(mf) >= 8 else 0, [f"s_waitcnt vmcnt({2 * c.NP})", "s_barrier"]))
+                                               (1 if len(mf) >= 8 else 0, [x for x in (f"s_waitcnt vmcnt({2 * c.NP})", "s_barrier")
+                                                                            if not (("nobarrier" in XFLAGS and x == "s_barrier") or
+                                                                                    ("novmcnt" in XFLAGS and "vmcnt" in x))] or ["s_nop 0"]))
     else:
         lines = place(mf, lds, valu, pieces, 2, len(mf) - 3 if len(mf) >= 8 else len(mf) - 1)
     if vr and Q == 3:
