@@ -53,6 +53,14 @@ SCALE_FORM = os.environ.get("W4_SCALE", "fma")
 # 2^-12 (fp16) of its magnitude: LSE off by 2e-3 on N(0,1) bf16 inputs, and the 4-sigma fp16 case out of tolerance (O error
 # 5.7e-2 against 6.7e-3).  Parity comes first: OFF, kept as an experiment switch (build with -DW4_NV_D64=52).
 PRE_ON = os.environ.get("W4_PRE", "0") != "0"
+# Order of a statement's softmax arithmetic and how the fillers are dealt to the MFMA gaps:
+#   quad  two pairs of scores at a time (4 fma, 4 exp, adds, packs), fillers dealt by COUNT             (the round's first builds)
+#   pipe  software-pipelined over the 8 scores (one v_exp_f32 per slot, its fma two slots ahead, its add one behind), fillers
+#         dealt by ISSUE COST against what an MFMA hides: profiles/r3_probe_fillers.txt -- ~26 cycles per gap, plain VALU 4,
+#         v_exp_f32 8, ds_read_b64_tr_b16 8, ds_read_b128 16, an LDS-DMA piece ~31; four v_exp_f32 in one gap (what quad
+#         produces) overrun it by 10+ cycles
+ORDER = os.environ.get("W4_ORDER", "pipe")
+PLACE = os.environ.get("W4_PLACE", "count")    # (cost: by the probe's issue costs -- measured WORSE than the even count: profiles/r3_w4_placement_ab.txt)
 CREG = "v" if "cvgpr" in XFLAGS else "s"    # register class of the scale operand (experiment)
 
 
@@ -78,7 +86,13 @@ class Cfg:
         self.NINF = self.XA - 1
         self.NM = self.NINF - 3                        # nmA, nmB (+ one unused: keeps the tuples above 4-aligned)
         self.L = self.NM - 4                           # lA0 lA1 lB0 lB1
-        self.X = self.L - 4                            # x0..x3
+        self.X = self.L - 4                            # x0 .. x3
+        # softmax temporaries.  pipe order: scores k - 3 .. k + 1 are live in slot k -> five; the fifth one is the pad register of
+        # the reference pair: hipcc's budget stays at NV (two registers fewer and it spills to scratch; -inf cannot become a
+        # literal: v_cndmask_b32 already reads vcc over the constant bus)
+        self.order = ORDER if D == 128 else "quad"     # (D = 64, same box: pipe -0.7 % on three shapes, quad stays)
+        self.T = [self.X + i for i in range(4)] + ([self.NINF - 1] if self.order == "pipe" else [])
+        self.NT = len(self.T)
         # D = 64 "pre" form (experiment, see PRE_ON): Q is multiplied by c = scale log2(e) once per part (rounded back to 16 bits)
         # and - m_ref enters through the C operand of the first MFMA of every score chain, so a score costs exp + add + half a
         # cvt (2.5 VALU instead of 3.5: at D = 64 the softmax, not the matrix pipe, sets the step).  Two 16-register tuples hold
@@ -86,7 +100,7 @@ class Cfg:
         self.pre = (D == 64) and PRE_ON
         self.NMT = self.X - 32 if self.pre else self.X  # - m_ref of block A (16 registers), block B (16)
         self.NV = self.NMT                             # hipcc's budget
-        assert self.NV % 4 == 0 and self.XA % 4 == 0, (self.NV, self.XA)
+        assert self.NV % 2 == 0 and self.XA % 4 == 0, (self.NV, self.XA)
 
     def O(self, qb, d):
         b = (qb * self.DB + d) * 16
@@ -139,41 +153,84 @@ def kk(h, r):
 
 def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked, sub=False):
     """VALU of 8 scores (registers sbase + e0 .. + 7 of 32-key half blk_h) -> packed P at pbase..+3, row sums of block qb.
-    Two pairs are in flight at a time (x0 x1 | x2 x3): every consumer sits at least four instructions behind its producer
-    (dependent VALU issue stalls the in-order wave, and with it the next MFMA; v_exp needs one instruction of distance anyway)."""
+    quad: two pairs in flight at a time (x0 x1 | x2 x3).  pipe: slot k = [exp of score k-1 | add of score k-2 | pack of the pair
+    that completed | scale of score k+2], so every consumer sits at least a slot behind its producer (dependent VALU issue stalls
+    the in-order wave, and with it the next MFMA; v_exp needs one instruction of distance anyway) and the 8-cycle v_exp_f32 are
+    spread one per slot."""
+    nm, l = f"v{c.nm(qb)}", (f"v{c.l(qb, 0)}", f"v{c.l(qb, 1)}")
+    sc = [f"v{sbase + e0 + i}" for i in range(8)]
     ops = []
-    nm, l0, l1 = f"v{c.nm(qb)}", f"v{c.l(qb, 0)}", f"v{c.l(qb, 1)}"
-    for p0 in (0, 2):
-        x = {p0: (f"v{c.X}", f"v{c.X + 1}"), p0 + 1: (f"v{c.X + 2}", f"v{c.X + 3}")}
-        sc = {p: (f"v{sbase + e0 + 2 * p}", f"v{sbase + e0 + 2 * p + 1}") for p in (p0, p0 + 1)}
-        src = x        # what the exponential reads
-        for p in (p0, p0 + 1):
-            for i in range(2):
-                if c.pre and sub:                # scores of a bare QK^T (tile 0): already in units of c, - m_ref still to come
-                    ops.append(f"v_add_f32 {x[p][i]}, {nm}, {sc[p][i]}")
-                elif c.pre:                      # the MFMA chain started from - m_ref: nothing to do
-                    if not masked:
-                        src = sc
-                elif SCALE_FORM == "fma":          # one VOP3 (8 bytes)
-                    ops.append(f"v_fma_f32 {x[p][i]}, {sc[p][i]}, %[c], {nm}")
-                elif SCALE_FORM == "fmac":       # two 4-byte instructions: x = - m_ref ; x += c s
-                    ops.append(f"v_mov_b32 {x[p][i]}, {nm}")
-                    ops.append(f"v_fmac_f32 {x[p][i]}, %[c], {sc[p][i]}")
-                elif SCALE_FORM == "mulsub":
-                    ops.append(f"v_mul_f32 {x[p][i]}, %[c], {sc[p][i]}")
-                    ops.append(f"v_add_f32 {x[p][i]}, {nm}, {x[p][i]}")
-        if masked:
+    if c.order == "pipe":
+        x = [f"v{c.T[i % c.NT]}" for i in range(8)]
+        need_x = (not c.pre) or sub or masked          # does the score get a temporary before the exponential?
+
+        def F(i):
+            o = []
+            if c.pre and sub:
+                o.append(f"v_add_f32 {x[i]}, {nm}, {sc[i]}")
+            elif not c.pre:
+                if SCALE_FORM == "fma":
+                    o.append(f"v_fma_f32 {x[i]}, {sc[i]}, %[c], {nm}")
+                elif SCALE_FORM == "fmac":
+                    o += [f"v_mov_b32 {x[i]}, {nm}", f"v_fmac_f32 {x[i]}, %[c], {sc[i]}"]
+                else:
+                    o += [f"v_mul_f32 {x[i]}, %[c], {sc[i]}", f"v_add_f32 {x[i]}, {nm}, {x[i]}"]
+            if masked:
+                o.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + i)}, %[thr]")
+                o.append(f"v_cndmask_b32 {x[i]}, v{c.NINF}, {x[i] if (not c.pre or sub) else sc[i]}, vcc")
+            return o
+
+        def E(i):
+            return [f"v_exp_f32 {x[i]}, {x[i] if need_x else sc[i]}"]
+
+        def A(i):
+            return [f"v_add_f32 {l[i & 1]}, {l[i & 1]}, {x[i]}"]
+
+        def C(p):
+            return [f"{c.cvt} v{pbase + p}, {x[2 * p]}, {x[2 * p + 1]}"]
+
+        ops += F(0) + F(1)
+        for k in range(1, 11):
+            if 0 <= k - 1 < 8:
+                ops += E(k - 1)
+            if 0 <= k - 2 < 8:
+                ops += A(k - 2)
+            if k >= 3 and (k - 3) % 2 == 0 and (k - 3) // 2 < 4:    # pair p = (k - 3) / 2: the exponentials of scores 2p, 2p + 1 were
+                ops += C((k - 3) // 2)                              # issued in slots 2p + 1, 2p + 2; frees their temporaries ...
+            if k + 1 < 8:
+                ops += F(k + 1)                                     # ... for score k + 1 (NT = 5 temporaries: i mod 5)
+    else:
+        for p0 in (0, 2):
+            x = {p0: (f"v{c.X}", f"v{c.X + 1}"), p0 + 1: (f"v{c.X + 2}", f"v{c.X + 3}")}
+            scp = {p: (sc[2 * p], sc[2 * p + 1]) for p in (p0, p0 + 1)}
+            src = x        # what the exponential reads
             for p in (p0, p0 + 1):
                 for i in range(2):
-                    ops.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + 2 * p + i)}, %[thr]")
-                    ops.append(f"v_cndmask_b32 {x[p][i]}, v{c.NINF}, {(x if not (c.pre and not sub) else sc)[p][i]}, vcc")
-        for p in (p0, p0 + 1):
-            ops.append(f"v_exp_f32 {x[p][0]}, {src[p][0]}")
-            ops.append(f"v_exp_f32 {x[p][1]}, {src[p][1]}")
-        for p in (p0, p0 + 1):
-            ops.append(f"v_add_f32 {l0}, {l0}, {x[p][0]}")
-            ops.append(f"v_add_f32 {l1}, {l1}, {x[p][1]}")
-            ops.append(f"{c.cvt} v{pbase + p}, {x[p][0]}, {x[p][1]}")
+                    if c.pre and sub:                # scores of a bare QK^T (tile 0): already in units of c, - m_ref still to come
+                        ops.append(f"v_add_f32 {x[p][i]}, {nm}, {scp[p][i]}")
+                    elif c.pre:                      # the MFMA chain started from - m_ref: nothing to do
+                        if not masked:
+                            src = scp
+                    elif SCALE_FORM == "fma":          # one VOP3 (8 bytes)
+                        ops.append(f"v_fma_f32 {x[p][i]}, {scp[p][i]}, %[c], {nm}")
+                    elif SCALE_FORM == "fmac":       # two 4-byte instructions: x = - m_ref ; x += c s
+                        ops.append(f"v_mov_b32 {x[p][i]}, {nm}")
+                        ops.append(f"v_fmac_f32 {x[p][i]}, %[c], {scp[p][i]}")
+                    elif SCALE_FORM == "mulsub":
+                        ops.append(f"v_mul_f32 {x[p][i]}, %[c], {scp[p][i]}")
+                        ops.append(f"v_add_f32 {x[p][i]}, {nm}, {x[p][i]}")
+            if masked:
+                for p in (p0, p0 + 1):
+                    for i in range(2):
+                        ops.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + 2 * p + i)}, %[thr]")
+                        ops.append(f"v_cndmask_b32 {x[p][i]}, v{c.NINF}, {(x if not (c.pre and not sub) else scp)[p][i]}, vcc")
+            for p in (p0, p0 + 1):
+                ops.append(f"v_exp_f32 {x[p][0]}, {src[p][0]}")
+                ops.append(f"v_exp_f32 {x[p][1]}, {src[p][1]}")
+            for p in (p0, p0 + 1):
+                ops.append(f"v_add_f32 {l[0]}, {l[0]}, {x[p][0]}")
+                ops.append(f"v_add_f32 {l[1]}, {l[1]}, {x[p][1]}")
+                ops.append(f"{c.cvt} v{pbase + p}, {x[p][0]}, {x[p][1]}")
     if "noexp" in XFLAGS:
         ops = [o.replace("v_exp_f32", "v_mov_b32") for o in ops]
     if "dropexp" in XFLAGS:
@@ -187,6 +244,20 @@ def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked, sub=False):
     if "novalu" in XFLAGS:
         ops = []
     return ops
+
+
+def issue_cost(op):
+    """cycles of the wave's issue an instruction takes next to an MFMA (profiles/r3_probe_fillers.txt)"""
+    m = op.split()[0]
+    if m == "v_exp_f32":
+        return 8
+    if m.startswith("ds_read_b64_tr"):
+        return 8
+    if m == "ds_read_b128":
+        return 16
+    if m.startswith("buffer_load"):
+        return 24
+    return 4
 
 
 def place(mfmas, lds, valu, dma, lds_per_gap, dma_gap, lds_first_gap=0, after_gap=None):
@@ -208,6 +279,8 @@ def place(mfmas, lds, valu, dma, lds_per_gap, dma_gap, lds_first_gap=0, after_ga
     lds, valu = list(lds), list(valu)
     if dma and not valu:
         valu = ["s_nop 0"]      # (the instruction between the M0 write and the request)
+    if PLACE == "cost":
+        return place_by_cost(mfmas, lds, valu, dma, dma_gap, lds_first_gap, after_gap, lds_per_gap)
     nl = [0] * n
     rest = len(lds)
     for g in range(lds_first_gap, n):
@@ -219,10 +292,10 @@ def place(mfmas, lds, valu, dma, lds_per_gap, dma_gap, lds_first_gap=0, after_ga
     normal = [g for g in range(n) if not (dma and g == dma_gap)]
     nv = [0] * n
     left = len(valu) - (1 if dma else 0)
-    total = left + sum(nl)
+    total = left + LDSW * sum(nl)
     for i, g in enumerate(normal):      # even share of (LDS + VALU) over the normal gaps, the remainder to the late ones
         share = total * (i + 1) // len(normal) - total * i // len(normal)
-        nv[g] = max(0, share - nl[g])
+        nv[g] = max(0, share - LDSW * nl[g])
     # rounding: hand what is left over to (or take the excess from) the late gaps
     diff = left - sum(nv)
     g = len(normal) - 1
@@ -247,6 +320,60 @@ def place(mfmas, lds, valu, dma, lds_per_gap, dma_gap, lds_first_gap=0, after_ga
         if after_gap is not None and g == after_gap[0]:
             out += after_gap[1]
     assert not lds and not valu, (len(lds), len(valu))
+    return out
+
+
+GAP_BUDGET = int(os.environ.get("W4_GAP", "26"))    # cycles of other issue an MFMA hides
+LDS_SPREAD = os.environ.get("W4_LDS", "early") == "spread"
+# count placer knobs (A/B experiments; defaults = what ships): LDS reads per gap in phase 1 / phase 2, how far from the statement's
+# end the DMA gap sits, the weight of an LDS read in the per-gap count
+LDSPG1 = int(os.environ.get("W4_LDSPG1", "2"))
+LDSPG2 = int(os.environ.get("W4_LDSPG2", "1"))
+DMAGAP = int(os.environ.get("W4_DMAGAP", "1"))
+LDSW = int(os.environ.get("W4_LDSW", "1"))
+
+
+def place_by_cost(mfmas, lds, valu, dma, dma_gap, lds_first_gap, after_gap, lds_per_gap=1):
+    """Deal the fillers to the MFMA gaps by issue cost (issue_cost): the LDS reads spread evenly over the gaps they may use, the
+    DMA piece in its own gap with the one VALU its M0 write needs, the VALU -- in program order -- filling every gap up to the
+    common level that makes the whole statement fit (at least GAP_BUDGET).  The last gap takes what is left."""
+    n = len(mfmas)
+    glds = [[] for _ in range(n)]
+    elig = [g for g in range(lds_first_gap, n) if not (dma and g == dma_gap)]
+    if LDS_SPREAD:
+        for i, op in enumerate(lds):                   # evenly: read i goes to eligible gap floor(i * len / count)
+            glds[elig[i * len(elig) // len(lds)]].append(op)
+    else:                                              # early, lds_per_gap each: a read issued late in the statement has its latency
+        for i, op in enumerate(lds):                   # exposed at the statement's (or the next step's) lgkmcnt(0)
+            glds[elig[min(i // lds_per_gap, len(elig) - 1)]].append(op)
+    fixed = [sum(issue_cost(o) for o in glds[g]) for g in range(n)]
+    if dma:
+        fixed[dma_gap] += 4 + 4 + 24               # s_add m0, the VALU behind it, the request
+    total = sum(fixed) + sum(issue_cost(o) for o in valu) - (4 if dma else 0)
+    level = max(GAP_BUDGET, -(-total // n))
+    gv = [[] for _ in range(n)]
+    v = list(valu)
+    if dma:
+        pass
+    for g in range(n):
+        if dma and g == dma_gap:
+            gv[g].append(v.pop(0) if v else "s_nop 0")
+            continue
+        acc = fixed[g]
+        while v and (acc + issue_cost(v[0]) <= level or g == n - 1):
+            acc += issue_cost(v[0])
+            gv[g].append(v.pop(0))
+    gv[n - 1] += v      # (program order is kept: what is left goes behind everything else, also behind a DMA piece in the last gap)
+    out = []
+    for g in range(n):
+        out.append(mfmas[g])
+        out += glds[g]
+        if dma and g == dma_gap:
+            out += [dma[0][0], gv[g][0], dma[0][1]] + gv[g][1:]
+        else:
+            out += gv[g]
+        if after_gap is not None and g == after_gap[0]:
+            out += after_gap[1]
     return out
 
 
@@ -307,7 +434,7 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
     if sm:
         h = Q >> 1
         valu = softmax_ops(c, c.sB(h, par), h, 8 * (Q & 1), c.pB(Q), 1, sm == 2, sub)
-        clob += vregs(c.X, 4) + vregs(c.pB(Q), 4) + vregs(c.l(1, 0), 2)
+        clob += [f'v{t}' for t in c.T] + vregs(c.pB(Q), 4) + vregs(c.l(1, 0), 2)
         if sm == 2:
             clob.append("vcc")
     pieces = []
@@ -328,7 +455,7 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
                                                                             if not (("nobarrier" in XFLAGS and x == "s_barrier") or
                                                                                     ("novmcnt" in XFLAGS and "vmcnt" in x))] or ["s_nop 0"]))
     else:
-        lines = place(mf, lds, valu, pieces, 2, len(mf) - 3 if len(mf) >= 8 else len(mf) - 1)
+        lines = place(mf, lds, valu, pieces, LDSPG1, len(mf) - DMAGAP if len(mf) >= 8 else len(mf) - 1)
     if vr and Q == 3:
         lines.append("s_waitcnt lgkmcnt(0)")
     if qk and not sm:
@@ -372,7 +499,7 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
     if sm:
         h = Q >> 1
         valu = softmax_ops(c, c.sA(h), h, 8 * (Q & 1), c.pA(par ^ 1, Q), 0, sm == 2, pv == 0)
-        clob += vregs(c.X, 4) + vregs(c.pA(par ^ 1, Q), 4) + vregs(c.l(0, 0), 2)
+        clob += [f'v{t}' for t in c.T] + vregs(c.pA(par ^ 1, Q), 4) + vregs(c.l(0, 0), 2)
         if sm == 2:
             clob.append("vcc")
     pieces = []
@@ -383,7 +510,7 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
         lds = []
     if "nodma" in XFLAGS:
         pieces = []
-    lines = place(mf, lds, valu, pieces, 1, len(mf) - 3 if len(mf) >= 8 else len(mf) - 1)
+    lines = place(mf, lds, valu, pieces, LDSPG2, len(mf) - DMAGAP if len(mf) >= 8 else len(mf) - 1)
     ins = []
     if sm:
         if not c.pre:
