@@ -24,3 +24,23 @@ def test_generated_streams_are_current(tmp_path):
 def test_compiled_kernel_keeps_out_of_the_literal_registers():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_w4.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("clean"), r.stdout[-4000:] + r.stderr[-2000:]
+
+
+def test_hazard_lint_catches_what_it_is_for():
+    """audit_w4.lint_blocks on hand-made statements: the three hazards inline asm must keep by itself are flagged, a legal
+    order is not."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_w4 as a
+    bad = a.lint_blocks([
+        ["v_exp_f32 v52, v52", "v_add_f32 v56, v56, v52"],
+        ["v_mfma_f32_32x32x16_bf16 v[64:79], a[200:203], a[132:135], v[64:79]", "v_fma_f32 v52, v64, s17, v61"],
+        ["s_add_u32 m0, s48, 0", "buffer_load_dwordx4 v4, s[24:27], s77 offen lds"],
+        ["v_cvt_pk_bf16_f32 v144, v52, v53", "v_mfma_f32_32x32x16_bf16 a[0:15], v[192:195], v[144:147], a[0:15]"],
+    ])
+    assert len(bad) == 4 and "v_exp_f32" in bad[0] and "v_mfma" in bad[1] and "M0" in bad[2] and "v_cvt_pk" in bad[3]
+    ok = a.lint_blocks([
+        ["v_exp_f32 v52, v52", "v_exp_f32 v53, v53", "v_add_f32 v56, v56, v52",
+         "v_mfma_f32_32x32x16_bf16 v[64:79], a[200:203], a[132:135], v[64:79]", "v_fma_f32 v54, v100, s17, v61",
+         "s_add_u32 m0, s48, 0", "v_add_f32 v57, v57, v53", "buffer_load_dwordx4 v4, s[24:27], s77 offen lds"],
+    ])
+    assert ok == []

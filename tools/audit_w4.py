@@ -6,7 +6,9 @@ their registers literally, so hipcc must keep out of them.  Compiles the file to
   * no v_accvgpr_* and no scratch_* instruction outside the ;;#ASMSTART / ;;#ASMEND brackets;
   * hipcc's own VGPRs stay below the generator's budget NV (amdgpu_num_vgpr);
   * the plain tile step (the statements that carry an LDS-DMA piece) is free of v_readlane / v_writelane (SGPR spills) and of
-    compiler-made s_waitcnt vmcnt.
+    compiler-made s_waitcnt vmcnt;
+  * the hazards the inline-asm statements must keep by themselves (lint_blocks: v_exp_f32 -> next reader, MFMA result -> reader
+    right behind it, M0 write -> LDS-DMA request, packed P -> MFMA).
     python tools/audit_w4.py [--keep DIR]      exit code 0 = clean
 """
 import os, re, subprocess, sys, tempfile
@@ -37,6 +39,54 @@ def kernels(text):
             if "s_endpgm" in l:
                 cur = None
     return res
+
+
+def _regs(tok):
+    """register numbers of one operand: v5 -> {('v', 5)}, a[0:15] -> {('a', 0) .. ('a', 15)}"""
+    m = re.fullmatch(r"([va])(\d+)", tok)
+    if m:
+        return {(m.group(1), int(m.group(2)))}
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok)
+    if m:
+        return {(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    return set()
+
+
+def lint_blocks(blocks):
+    """Hazards inline asm has to keep by itself (hipcc's hazard recogniser does not look inside), checked on the instruction
+    order of the COMPILED statements:
+      * the result of a v_exp_f32 (transcendental unit) is not read by the very next instruction;
+      * an MFMA's result is not read by a VALU / LDS / memory instruction within the next 2 instructions of the same statement
+        (the streams keep every such reader at least 8 MFMAs away; this catches a placement bug, not a cycle count);
+      * one instruction sits between an M0 write and the buffer_load ... lds that uses it;
+      * a v_cvt_pk result (packed P) is not consumed by an MFMA in the next instruction."""
+    out = []
+    for bi, blk in enumerate(blocks):
+        ins = [t for t in blk if t and not t.startswith(";")]
+        parsed = []
+        for t in ins:
+            parts = t.replace(",", " ").split()
+            op, ops = parts[0], parts[1:]
+            dst = _regs(ops[0]) if ops and (op.startswith("v_") or op.startswith("ds_read") or (op.startswith("buffer_load") and "lds" not in t)) else set()
+            src = set()
+            for o in ops[1:] if dst else ops:
+                src |= _regs(o)
+            if op.startswith("v_mfma"):      # D, A, B, C: all but the first are sources
+                dst = _regs(ops[0]); src = set().union(*[_regs(o) for o in ops[1:4]])
+            parsed.append((op, dst, src, t))
+        for i, (op, dst, src, t) in enumerate(parsed):
+            nxt = parsed[i + 1:i + 3]
+            if op == "v_exp_f32" and nxt and (dst & nxt[0][2]):
+                out.append(f"asm statement {bi}: `{nxt[0][3]}` reads the result of `{t}` in the next instruction")
+            if op.startswith("v_mfma"):
+                for (op2, d2, s2, t2) in nxt:
+                    if not op2.startswith("v_mfma") and (dst & s2):
+                        out.append(f"asm statement {bi}: `{t2}` reads the result of `{t}` right behind it")
+            if op == "s_add_u32" and "m0" in t.split(",")[0] and nxt and "lds" in nxt[0][3] and nxt[0][0].startswith("buffer_load"):
+                out.append(f"asm statement {bi}: `{nxt[0][3]}` directly behind the M0 write")
+            if op.startswith("v_cvt_pk") and nxt and nxt[0][0].startswith("v_mfma") and (dst & nxt[0][2]):
+                out.append(f"asm statement {bi}: `{nxt[0][3]}` consumes `{t}` in the next instruction")
+    return out[:20]
 
 
 def audit(path, verbose=True):
@@ -81,6 +131,7 @@ def audit(path, verbose=True):
                 for r in re.findall(r"\bv(\d+)\b", t) + [x for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", t) for x in (a, b)]:
                     if int(r) >= nv:
                         problems.append(f"{name}: compiler instruction touches v{r} >= NV {nv}: `{t}`")
+        problems += [f"{name}: {p}" for p in lint_blocks(blocks)]
         # plain tile steps: eight consecutive statements with MFMAs and embedded LDS-DMA pieces, the tile barrier inside the first
         has_mf = [any("v_mfma" in b for b in blk) for blk in blocks]
         has_dma = [any("offen lds" in b for b in blk) for blk in blocks]
