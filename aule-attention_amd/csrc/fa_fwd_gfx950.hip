@@ -108,14 +108,12 @@ int fwd_route(const FwdArgs& a) {
     return use_ps(a) ? 6 : 1;
 }
 
-// The query rotation is fused by the two-waves-per-SIMD stream only.  A problem the one-wave-per-SIMD kernel would take WITHOUT
-// the tables is answered "not fusable": rotating Q in a pass of its own and running that kernel is faster than fusing on the
-// predecessor (C2: 10 us for the pass against ~35 us between the kernels), and the callers fall back to exactly that.
+// Which problems the forward rotates Q for by itself (half-split pairs, K already rotated): what the one-wave-per-SIMD kernel
+// takes (its applicability rule looks at the table geometry too), and what the two-waves-per-SIMD stream takes as before.
 bool fwd_rope_fusable(const FwdArgs& a) {
-    FwdArgs plain = a;
-    plain.rope_cos = plain.rope_sin = nullptr;
-    if (use_w4(plain)) return false;
-    return fwd_route(a) == 6 && fwd_ps_rope_fusable(a);
+    const int r = fwd_route(a);
+    if (r == 8) return true;
+    return r == 6 && fwd_ps_rope_fusable(a);
 }
 
 uint64_t fwd_workspace_bytes(FwdArgs a) {
@@ -134,7 +132,7 @@ uint64_t paged_workspace_bytes(PagedArgs a) {
 
 int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (a.query_ws != nullptr) *a.query_ws = 0;
-    if (a.rope_cos != nullptr && !fwd_rope_fusable(a)) return -1;   // only the stream kernel rotates Q itself
+    if (a.rope_cos != nullptr && !fwd_rope_fusable(a)) return -1;   // only the two stream kernels rotate Q themselves
     const int sq = a.dtype == kF32 ? 0 : short_query_route(a);
     if (sq == 4) return launch_fwd_splitkv(a, stream);
     if (sq == 5) return launch_fwd_pp_split(a, stream);

@@ -25,7 +25,7 @@
 // row maximum as reference (one extra QK^T-only pass over its tiles), so the fast path is the only softmax code.
 //
 // Covers: bf16 / fp16, D = 128 / 64, causal (top-left or shifted by coff >= 0) and non-causal, scale > 0, any Sq, every part
-// with at least 4 KV tiles, no window, no fused rotation -- everything else stays on the predecessors.
+// with at least 4 KV tiles, no window; optional fused query rotation (half-split pairs) -- everything else stays on the predecessors.
 #include <cstdlib>
 #include <type_traits>
 
@@ -58,6 +58,11 @@ struct FwdW4Params {
     int nitems;   // nwork * B * Hq; workgroup g takes items g, g + gridDim.x, ...
     int rounds;   // > 0: "round order" of the causal part lists (below) with this many rounds, mper = heads per round
     int mper;
+    // fused query rotation (half-split pairs, rope_gfx950.hip's arithmetic; K arrives rotated): tables [rrows][rpitch] fp32, query i
+    // of a head reads row i + rpos; rcos == nullptr: none
+    const float* rcos;
+    const float* rsin;
+    int rrows, rpitch, rpos;
     unsigned long long* dbg;   // timeline build only: [4 waves][kW4TLMax] tagged s_memtime stamps of workgroup 0
 };
 
@@ -144,6 +149,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     };
     const int Sk = p.Sk, coff = p.coff;
     const float c = p.c;
+    const bool rope = p.rcos != nullptr;
     int tl_n = 0;
     unsigned long long* const tl_lds = reinterpret_cast<unsigned long long*>(smem + TLDS + kW4MaxSlot * 20 + 16);   // TL only
     auto stamp = [&](int tag) __attribute__((always_inline)) {   // timeline build: (tag << 56) | shader clock
@@ -355,6 +361,17 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             const unsigned vo = (unsigned)((q_b * kQBlock + wave * 64 + (lane_o & 31)) * RB + (lane_o >> 5) * 16);
             A::load_q(qrs, vo, vo + 32 * RB);
         };
+        // the cos / sin rows of the wave's 64 queries of Q block q_b -> the score / weight registers (dead between two parts);
+        // rows beyond the table read as 0 (descriptor bounds): they belong to queries >= Sq, whose Q is 0 already
+        auto issue_rope = [&](int q_b) __attribute__((always_inline)) {
+            const KernargPtr pp = P();
+            const unsigned tbytes = (unsigned)pp->rrows * (unsigned)pp->rpitch * 4u;
+            const __amdgpu_buffer_rsrc_t crs = make_srd(pp->rcos, (unsigned)w4_rfl((int)tbytes)), srs = make_srd(pp->rsin, (unsigned)w4_rfl((int)tbytes));
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const unsigned vo = (unsigned)(q_b * kQBlock + wave * 64 + (lane_o & 31) + pp->rpos) * (unsigned)(pp->rpitch * 4) + (unsigned)((lane_o >> 5) * 32);
+            A::rope_request(crs, srs, vo, vo + 32u * (unsigned)(pp->rpitch * 4));
+        };
         // - m_ref of block BLK from the scores of tile 0 (lane-local 32 values + the other half's)
         auto neg_ref = [&](auto blk_tag, bool masked, int thr) __attribute__((always_inline)) {
             constexpr int BLK = decltype(blk_tag)::value;
@@ -511,7 +528,10 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             // for them) and the Q fragments; the epilogue's stores ride along
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             A::kread_all(kap);
-            if constexpr (!REDO) A::prescale_q(c);   // (pre form only; the second stream did it in its exact-maximum pass)
+            if constexpr (!REDO) {
+                if (rope) A::rope_rotate();          // (the second stream rotated in its exact-maximum pass)
+                A::prescale_q(c);                    // (pre form only)
+            }
             A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
             A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
             A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
@@ -544,6 +564,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         auto epilogue = [&]() __attribute__((always_inline)) {
             stamp(0x40);
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the last PV MFMAs -> v_accvgpr_read
+            if (rope && pre) issue_rope(w4_rfl(tab[n_slot].z));   // (the next prologue's vmcnt(0) covers them)
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const int l31o = lane_o & 31, hio = lane_o >> 5;
@@ -594,6 +615,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             const __amdgpu_buffer_rsrc_t ksrd = make_srd(nullptr, 0);   // (unused operand)
             float mA = -INFINITY, mB = -INFINITY;   // in units of c
             issue_q(qoff, qb);
+            if (rope) issue_rope(qb);
             for (int j = 0; j < nt; ++j) {
                 __syncthreads();
                 A::dma_tile(lds0 + wave1k, head_srd(P()->k, kvoff, Sk), (unsigned)j * KT, kvo);
@@ -603,7 +625,10 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) kap[ks] = kaddr(ka0, ks);
                     A::kread_all(kap);
-                    if (j == 0) A::prescale_q(c);
+                    if (j == 0) {
+                        if (rope) A::rope_rotate();
+                        A::prescale_q(c);
+                    }
                     A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
                     A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
                     A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
@@ -623,7 +648,10 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         for (;;) {
             if (REDO || cold) {   // nothing of this part is in flight: K_0, K_1, K_2, V_0, V_1
                 if constexpr (REDO) max_pass();
-                else issue_q(qoff, qb);
+                else {
+                    issue_q(qoff, qb);
+                    if (rope) issue_rope(qb);
+                }
                 const __amdgpu_buffer_rsrc_t k0 = head_srd(P()->k, kvoff, Sk), v0 = head_srd(P()->v, kvoff, Sk);
                 A::dma_tile(ring_lds(0, 0), k0, 0u, kvo);
                 A::dma_tile(ring_lds(0, 1), k0, (unsigned)KT, kvo);
@@ -713,6 +741,8 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
     p.coff = a.causal ? a.coff : 0;
     p.nitems = p.nwork * a.B * a.Hq;
     p.dbg = dbg;
+    p.rcos = a.rope_cos; p.rsin = a.rope_sin;
+    p.rrows = a.rope_rows; p.rpitch = a.rope_pitch; p.rpos = a.rope_pos;
     // one workgroup per CU; more only when a workgroup's list would not fit its part table
     const long long ncu = device_cu_count(a.device);
     const long long rounds = (p.nitems + ncu * kW4MaxItems - 1) / (ncu * kW4MaxItems);
@@ -756,7 +786,15 @@ int set_attr_w4() {
 bool fwd_w4_applicable(const FwdArgs& a) {
     if (a.dtype != kBF16 && a.dtype != kF16) return false;
     if (a.D != 128 && a.D != 64) return false;
-    if (a.window > 0 || a.rope_cos != nullptr) return false;
+    if (a.window > 0) return false;
+    if (a.rope_cos != nullptr) {   // fused query rotation: table geometry the 32-bit row offsets of the requests can address
+        if (a.rope_sin == nullptr || a.rope_pitch < a.D / 2 || (a.rope_pitch & 3) != 0) return false;
+        if ((reinterpret_cast<uintptr_t>(a.rope_cos) | reinterpret_cast<uintptr_t>(a.rope_sin)) & 15) return false;
+        if (a.rope_pos < 0 || (long long)a.rope_rows < (long long)a.Sq + a.rope_pos) return false;
+        // (rows of padding lanes -- up to the end of the last 256-row block -- index past the table: their offsets must not wrap)
+        const long long last = ((long long)(a.Sq + kQBlock - 1) / kQBlock * kQBlock + a.rope_pos) * a.rope_pitch * 4;
+        if ((long long)a.rope_rows * a.rope_pitch * 4 >= (1LL << 32) || last >= (1LL << 32)) return false;
+    }
     if (!(a.scale > 0.f) || !(a.scale < 3.0e38f)) return false;
     if (a.causal && a.coff < 0) return false;
     // every part needs >= 4 KV tiles (its prologue consumes tiles 0 and 1 and requests tile 2 before the first plain step):

@@ -428,8 +428,8 @@ def main():
         _, ms7 = timed(step7, 20)
         result["extra"].update({"rope_attn_c2_tflops": fwd_flops(B7, H7, S7, S7, D7, True) / (ms7 / 20 * 1e-3) / 1e12,
                                 "rope_attn_c2_ms_per_step": ms7 / 20,
-                                "rope_attn_c2_workload": "RoPE + attention, B=4 H=32 S=2048 D=128 bf16 causal, inference: rope(Q) + rope(K) passes + the "
-                                                         "one-wave-per-SIMD forward (attention FLOPs only; D = 64 fuses the Q rotation)"})
+                                "rope_attn_c2_workload": "RoPE + attention, B=4 H=32 S=2048 D=128 bf16 causal, inference: rope(K) pass + the "
+                                                         "one-wave-per-SIMD forward with Q rotated inside it (attention FLOPs only)"})
         del q7, k7, v7
 
     if rank == 0:

@@ -136,15 +136,11 @@ def test_fused_rotation_rule_from_python():
     k = torch.zeros(4, 8, 2048, 64, dtype=torch.bfloat16)
     cos, sin = aule.precompute_rope_frequencies(2048, 64, device="cpu")
     cos, sin = cos.contiguous(), sin.contiguous()
-    # (negative-scale and window-free D = 64 / 128 problems of this size run on the one-wave-per-SIMD kernel, which does not
-    # rotate Q itself: a rotation pass + that kernel beats fusing on its predecessor, so the library answers "not fusable")
-    assert not at.rope_fusable(q, k, 1, -1, cos, sin, 0)
-    assert not at.rope_fusable(q, k, 0, -1, cos, sin, 0)
+    assert at.rope_fusable(q, k, 1, -1, cos, sin, 0)
+    assert at.rope_fusable(q, k, 0, -1, cos, sin, 0)
     assert not at.rope_fusable(q, k, 1, 128, cos, sin, 0)                    # sliding window: the ping-pong kernel
     assert not at.rope_fusable(q.float(), k.float(), 1, -1, cos, sin, 0)     # fp32 kernel
     assert not at.rope_fusable(q[..., :32].contiguous(), k[..., :32].contiguous(), 1, -1, cos[:, :16].contiguous(), sin[:, :16].contiguous(), 0)
-    # the fused rotation is still what the two-waves-per-SIMD stream does where it is the kernel: AULE_HIP_FWD_KERNEL=ps
-    # (tests/test_gpu_fwd_variants.py runs the bit-for-bit test that way)
     assert not at.rope_fusable(q, k, 1, -1, cos[:1000], sin[:1000], 0)       # table shorter than the sequence
     assert not at.rope_fusable(q, k, 1, -1, cos, sin, 1)                     # ... or than sequence + offset
     assert not at.rope_fusable(q[:, :, :1], k, 0, -1, cos, sin, 0)           # one query row: a short-query route

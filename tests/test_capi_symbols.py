@@ -194,15 +194,12 @@ def fusable(B=4, Hq=32, Hkv=32, Sq=2048, Sk=2048, D=128, dtype=2, causal=1, wind
     return lib.aule_attention_forward_rope_fusable(ctypes.byref(d), ctypes.byref(r))
 
 assert ctypes.sizeof(_capi.AttnRope) == 40
-if os.environ.get("AULE_HIP_FWD_KERNEL") == "ps":
-    assert fusable() == 1
-    assert fusable(D=64, dtype=1, causal=0) == 1
-    assert fusable(Sq=1024, Sk=4096, causal=2, rows=4096, pos=3072) == 1      # bottom-right: queries at Sk - Sq + i
-    assert fusable(pitch=68) == 1                                              # 16-byte rows
-else:
-    # problems the one-wave-per-SIMD kernel takes are never fused: a rotation pass + that kernel is faster (fa_fwd_gfx950.hip)
-    assert fusable() == 0 and fusable(D=64, dtype=1, causal=0) == 0
-    assert fusable(Sq=1024, Sk=4096, causal=2, rows=4096, pos=3072) == 0
+# (both stream kernels rotate Q themselves: the one-wave-per-SIMD kernel by default, its predecessor under AULE_HIP_FWD_KERNEL=ps)
+assert fusable() == 1
+assert fusable(D=64, dtype=1, causal=0) == 1
+assert fusable(Sq=1024, Sk=4096, causal=2, rows=4096, pos=3072) == 1      # bottom-right: queries at Sk - Sq + i
+assert fusable(pitch=68) == 1                                              # 16-byte rows
+assert fusable(B=1, Hq=8, Hkv=8, Sq=8192, Sk=8192, rows=8192) == 1         # small causal grid (split over the keys)
 assert fusable(D=32) == 0                                                  # no fused instance
 assert fusable(dtype=0) == 0                                               # fp32 kernel
 assert fusable(window=64) == 0                                             # ping-pong kernel
@@ -220,10 +217,10 @@ print("RULE OK")
 
 @pytest.mark.parametrize("kernel", ["", "ps"], ids=["default", "kernel-ps"])
 def test_fused_query_rotation_rule(kernel):
-    """aule_attention_forward_rope_fusable() (host logic): the two-waves-per-SIMD stream rotates Q itself for fp16 / bf16,
-    head_dim 64 / 128, half-split pairs, 16-byte aligned tables of pitch % 4 == 0 that cover seq_q + q_pos_offset rows -- when
-    it is the kernel (AULE_HIP_FWD_KERNEL=ps; the library reads the variable once per process, hence the child); by default such
-    problems go to the one-wave-per-SIMD kernel and the answer is "rotate Q with aule_rope_ex()"."""
+    """aule_attention_forward_rope_fusable() (host logic): the two stream kernels rotate Q themselves for fp16 / bf16, head_dim
+    64 / 128, half-split pairs, 16-byte aligned tables of pitch % 4 == 0 that cover seq_q + q_pos_offset rows -- the
+    one-wave-per-SIMD kernel by default, its predecessor under AULE_HIP_FWD_KERNEL=ps (the library reads the variable once per
+    process, hence the child)."""
     import subprocess
     import sys
     e = {k: v for k, v in os.environ.items() if k not in ("AULE_HIP_FWD_KERNEL", "AULE_HIP_FWD_SOFTMAX")}

@@ -24,9 +24,8 @@ SHAPES = [  # name, B, Hq, Hkv, Sq, Sk, D, dtype, causal
     ("route7-causal-split", 1, 8, 8, 4096, 4096, 128, "bf16", True),      # stream kernel over pieces + merge kernel, caller workspace
     ("route7-noncausal-split", 1, 8, 8, 2048, 2048, 128, "fp16", False),
     ("route8-one-wave-per-simd", 4, 16, 16, 1024, 1024, 128, "bf16", True),   # the D = 128 default: several parts per workgroup
-    ("route6-fused-rope", 4, 16, 16, 1024, 1024, 128, "bf16", True),      # the forward that rotates Q itself (tables captured too):
-                                                                          # only with AULE_HIP_FWD_KERNEL=ps -- by default the library
-                                                                          # prefers a rotation pass + the one-wave-per-SIMD kernel
+    ("route8-fused-rope", 4, 16, 16, 1024, 1024, 128, "bf16", True),      # the forward that rotates Q itself (tables captured too);
+                                                                          # with AULE_HIP_FWD_KERNEL=ps: on the predecessor (route 6)
 ]
 
 
@@ -67,9 +66,7 @@ def test_forward_capture_replays_bit_identical(shape):
         import aule
         cos, sin = aule.precompute_rope_frequencies(Sk, D)
         rope = (cos.contiguous(), sin.contiguous(), 0)
-        if not at.rope_fusable(q, k, 1, -1, rope[0], rope[1], 0):
-            assert os.environ.get("AULE_HIP_FWD_KERNEL", "") != "ps"
-            pytest.skip("the fused query rotation belongs to the two-waves-per-SIMD stream (AULE_HIP_FWD_KERNEL=ps; tests/test_gpu_fwd_variants.py)")
+        assert at.rope_fusable(q, k, 1, -1, rope[0], rope[1], 0)
     eager, eager_lse = at.fwd_raw(q, k, v, causal, sc, q_rope=rope)
     torch.cuda.synchronize()
     g, outs = _capture(torch, lambda: at.fwd_raw(q, k, v, causal, sc, q_rope=rope))

@@ -232,11 +232,10 @@ def test_fused_query_rotation_is_the_separate_pass_bit_for_bit(case, oracle_mod,
     qoff = Sk - Sq if causal == "bottom-right" else 0
     tq, tk, tv, tc, ts = _dev(torch, q, dtype), _dev(torch, k, dtype), _dev(torch, v, dtype), _dev(torch, cos), _dev(torch, sin)
     code = at.causal_code(causal)
-    # D = 64 / 128 problems of this kind run on the one-wave-per-SIMD kernel, which does not rotate Q itself: the library answers
-    # "not fusable" there (a rotation pass + that kernel beats fusing on its predecessor) and every route below is the two passes;
-    # with AULE_HIP_FWD_KERNEL=ps (tests/test_gpu_fwd_variants.py runs this test that way) the rotation is fused
+    # both stream kernels rotate Q themselves: the one-wave-per-SIMD kernel by default (table rows land in its score registers
+    # between two parts), its predecessor with AULE_HIP_FWD_KERNEL=ps (tests/test_gpu_fwd_variants.py runs this test that way too)
     fus = at.rope_fusable(tq, tk, code, -1, tc, ts, qoff)
-    assert fus == (os.environ.get("AULE_HIP_FWD_KERNEL", "") == "ps")
+    assert fus
     sc = 1.0 / math.sqrt(D)
     kr = at.rope_raw(tk, tc, ts, "half", False, 0)
     qr = at.rope_raw(tq, tc, ts, "half", False, qoff)

@@ -606,6 +606,64 @@ def gen_struct(c):
     s += "    static __device__ __forceinline__ void load_q(__amdgpu_buffer_rsrc_t srd, unsigned vo0, unsigned vo1) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
     s += emit_asm(lines, [], ['[srd] "s"(srd)', '[vo0] "v"(vo0)', '[vo1] "v"(vo1)'], ["memory"] + aregs(c.QB0, 8 * c.KS), indent="        ")
     s += "#endif\n    }\n"
+    # ---- fused query rotation (half-split pairs; K arrives rotated): the cos / sin rows of this wave's 64 queries land in the
+    #      score / weight registers, which are dead between two parts (requested at the start of the previous part's epilogue).
+    #      Lane (q, hi) holds d = 16 ks + 8 hi .. + 7 of its row in fragment ks; its partner d + D/2 is the same position of fragment
+    #      ks + KS/2: the rotation is lane-local.  Arithmetic and rounding of rope_gfx950.hip (fa_device.h rope_pair):
+    #      y1 = fma(x1, c, -(x2 s)), y2 = fma(x1, s, x2 c), one rounding to the I/O type.
+    HK = c.KS // 2
+    LZ = c.XA                                   # landing zone: [(qb HK + ks) 4 + {cos lo, cos hi, sin lo, sin hi}] x 4 registers
+    assert LZ + 2 * HK * 16 <= c.VB0
+    lines = ["s_nop 4"]
+    for qb in range(2):
+        for ks in range(HK):
+            b = LZ + (qb * HK + ks) * 16
+            for t, srd in enumerate(("%[cs]", "%[cs]", "%[ss]", "%[ss]")):
+                lines.append(f"buffer_load_dwordx4 v[{b + 4 * t}:{b + 4 * t + 3}], %[vo{qb}], {srd}, 0 offen offset:{64 * ks + 16 * (t & 1)}")
+    s += ("    static __device__ __forceinline__ void rope_request(__amdgpu_buffer_rsrc_t cs, __amdgpu_buffer_rsrc_t ss, unsigned vo0, unsigned vo1) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n")
+    s += emit_asm(lines, [], ['[cs] "s"(cs)', '[ss] "s"(ss)', '[vo0] "v"(vo0)', '[vo1] "v"(vo1)'], ["memory"] + vregs(LZ, 2 * HK * 16), indent="        ")
+    s += "#endif\n    }\n"
+    # four dword pairs at a time, each with its own eight temporaries (the V fragment registers: V_0 is read in step 0, behind the
+    # prologue), interleaved instruction by instruction: one pair alone is a dependent chain of 18 instructions
+    NWAY = 4
+    assert c.VB0 + 8 * NWAY <= 256
+
+    def pair_ops(qb, ks, r, tb):
+        T0, T1, X1L, X1H, X2L, X2H, TA, TB = (tb + i for i in range(8))
+        bz = LZ + (qb * HK + ks) * 16
+        a1 = c.QB0 + (qb * c.KS + ks) * 4 + r
+        a2 = c.QB0 + (qb * c.KS + ks + HK) * 4 + r
+        e = 2 * r                                   # elements e, e + 1 of the lane's eight
+        cl, ch = bz + (e >> 2) * 4 + (e & 3), bz + (e >> 2) * 4 + (e & 3) + 1
+        sl, sh = cl + 8, ch + 8
+        o = [f"v_accvgpr_read_b32 v{T0}, a{a1}", f"v_accvgpr_read_b32 v{T1}, a{a2}"]
+        if c.dt == "bf16":
+            o += [f"v_lshlrev_b32 v{X1L}, 16, v{T0}", f"v_and_b32 v{X1H}, 0xffff0000, v{T0}",
+                  f"v_lshlrev_b32 v{X2L}, 16, v{T1}", f"v_and_b32 v{X2H}, 0xffff0000, v{T1}"]
+        else:
+            o += [f"v_cvt_f32_f16 v{X1L}, v{T0}", f"v_lshrrev_b32 v{T0}, 16, v{T0}", f"v_cvt_f32_f16 v{X2L}, v{T1}",
+                  f"v_lshrrev_b32 v{T1}, 16, v{T1}", f"v_cvt_f32_f16 v{X1H}, v{T0}", f"v_cvt_f32_f16 v{X2H}, v{T1}"]
+        o += [f"v_mul_f32 v{TA}, v{X2L}, v{sl}", f"v_mul_f32 v{TB}, v{X2H}, v{sh}",
+              f"v_mul_f32 v{X2L}, v{X2L}, v{cl}", f"v_mul_f32 v{X2H}, v{X2H}, v{ch}",
+              f"v_fma_f32 v{TA}, v{X1L}, v{cl}, -v{TA}", f"v_fma_f32 v{TB}, v{X1H}, v{ch}, -v{TB}",
+              f"v_fma_f32 v{X2L}, v{X1L}, v{sl}, v{X2L}", f"v_fma_f32 v{X2H}, v{X1H}, v{sh}, v{X2H}",
+              f"{c.cvt} v{T0}, v{TA}, v{TB}", f"{c.cvt} v{T1}, v{X2L}, v{X2H}",
+              f"v_accvgpr_write_b32 a{a1}, v{T0}", f"v_accvgpr_write_b32 a{a2}, v{T1}"]
+        return o
+
+    pairs = [(qb, ks, r) for qb in range(2) for ks in range(HK) for r in range(4)]
+    lines = []
+    for g0 in range(0, len(pairs), NWAY):
+        lists = [pair_ops(*pairs[g0 + w], c.VB0 + 8 * w) for w in range(min(NWAY, len(pairs) - g0))]
+        for i in range(max(len(l) for l in lists)):
+            for l in lists:
+                if i < len(l):
+                    lines.append(l[i])
+    lines += ["s_nop 7"]                                          # v_accvgpr_write -> MFMA operand
+    s += "    static __device__ __forceinline__ void rope_rotate() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+    s += emit_asm(lines, [], [], ["memory"] + vregs(c.VB0, 8 * NWAY) + aregs(c.QB0, 8 * c.KS), indent="        ")
+    s += "#endif\n    }\n"
     # ---- LDS-DMA of this wave's pieces of one tile (everywhere but the plain step)
     lines = ["s_nop 4"]
     for i in range(c.NP):
