@@ -271,3 +271,32 @@ def test_fused_query_rotation_rejections():
     cos = torch.ones(500, 64, device="cuda"); sin = torch.zeros(500, 64, device="cuda")   # table shorter than Sq
     with pytest.raises(_capi.AuleError, match="not fused"):
         at.fwd_raw(q, q, q, 1, 0.1, q_rope=(cos, sin, 0))
+
+
+@pytest.mark.parametrize("dtype,B,Hq,Hkv,S,D,causal,mag", [
+    ("bf16", 4, 32, 8, 2048, 128, True, 5.0),      # several parts per workgroup, some of them re-run
+    ("fp16", 8, 32, 16, 768, 128, True, 6.0),      # fp16: weights overflow the fixed reference
+    ("bf16", 4, 16, 16, 1024, 64, False, 10.0),    # D = 64
+])
+def test_fused_rotation_through_the_exact_maximum_stream(dtype, B, Hq, Hkv, S, D, causal, mag):
+    """Inputs scaled until the fixed-reference range verdict fails (the one-wave-per-SIMD kernel then re-runs those parts in a
+    second stream whose exact-maximum pass has to rotate Q as well): fused == rotation pass + plain forward, bit for bit, on
+    full grids (a small grid would take the split route for the plain call and round differently), and finite."""
+    import torch
+    import aule
+    from aule import _torch as at
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    g = torch.Generator(device="cuda").manual_seed(3)
+    q = (torch.randn(B, Hq, S, D, device="cuda", generator=g) * mag).to(dt)
+    k = (torch.randn(B, Hkv, S, D, device="cuda", generator=g) * mag).to(dt)
+    v = torch.randn(B, Hkv, S, D, device="cuda", generator=g).to(dt)
+    cos, sin = aule.precompute_rope_frequencies(S, D, device="cuda")
+    cos, sin = cos.contiguous(), sin.contiguous()
+    code = 1 if causal else 0
+    assert at.rope_fusable(q, k, code, -1, cos, sin, 0)
+    sc = 1.0 / math.sqrt(D)
+    kr, qr = at.rope_raw(k, cos, sin), at.rope_raw(q, cos, sin)
+    two, lse2 = at.fwd_raw(qr, kr, v, code, sc, want_lse=True)
+    fused, lse1 = at.fwd_raw(q, kr, v, code, sc, want_lse=True, q_rope=(cos, sin, 0))
+    assert torch.isfinite(fused.float()).all() and torch.isfinite(lse1).all()
+    assert torch.equal(fused, two) and torch.equal(lse1, lse2)
