@@ -1,0 +1,351 @@
+// fa_bwd_dkv4_gfx950.hip -- dK / dV of the FlashAttention-2 backward (16-bit I/O, D = 128), ONE WAVE PER SIMD.
+//
+// Replaces the dK/dV half of python/aule/triton_flash_amd.py:247-351 (_flash_attn_bwd_amd) where it applies; everything else
+// stays on fa_bwd_gfx950.hip's kernel (8 waves x 32 keys, two waves per SIMD, lock-step: 44 % MFMA-busy, its tile period set by
+// a 940-cycle barrier arrival spread and dependent issue -- DESIGN.md 3.4).  Here
+//
+//   * workgroup = 4 waves x 32 key rows = a 128-key KV block (causal: the pair (i, n-1-i)); a wave owns the whole 512-register
+//     file: dV^T and dK^T (128 accumulator registers), its K and V fragments (64: V no longer goes through an LDS slab), the
+//     row-major fragments of the query block in flight (64) in the accumulator file; scores, weights, transposed fragments,
+//     L' and delta in arch VGPRs -- all named literally by fa_bwd_dkv4_asm.inc (generated: tools/gen_bw4.py, map in its docstring);
+//   * the wave walks a STREAM of 32-row query blocks -- every query head of the GQA group, every block that sees the KV block --
+//     software-pipelined: iteration i = [S, dP of block i+1 | arithmetic of block i | its 32 transpose reads] barrier [dV, dK of
+//     block i | row-major reads of block i+2 | L', delta of block i+2 | LDS-DMA requests of block i+4];
+//   * query blocks arrive by LDS-DMA in four images each (Q and dO, row-major swizzled + [q/4][d/16][4][16] sub-tiles: the
+//     predecessor's layouts) into a 4-slot ring (128 KB): block i+4 goes where block i was; a block is requested two iterations
+//     before its first reader, the phase boundary waits with a counted vmcnt;
+//   * 128-key blocks make twice as many work items as the predecessor's 256-key blocks: at C3 (B4, 32q/8kv, S2048) the paired
+//     causal grid is exactly 256 workgroups with the whole GQA group inside each -- no head split, no fp32 partials, no reduce
+//     kernel.
+//
+// Covers bf16 / fp16, D = 128, causal (coff >= 0) and non-causal, no window; deterministic (no atomics).
+#include <cstdlib>
+#include <type_traits>
+
+#include "fa_device.h"
+#include "fa_kernels.h"
+#include "fa_fwd_tile.h"
+
+namespace aule_hip {
+namespace {
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#include "fa_bwd_dkv4_asm.inc"
+
+struct Dkv4Params {
+    const void* q;
+    const void* k;
+    const void* v;
+    const void* dout;
+    const float* lse;
+    const float* delta;
+    void* dk;
+    void* dv;
+    int B, Hq, Hkv, Sq, Sk;
+    float c;       // scale * log2(e) (sign kept: no maximum is taken here)
+    float scale;   // applied to dK at the end
+    int nblk;      // work items per (batch, kv head): KV blocks, or pairs of them (causal)
+    int coff;      // causal position offset (query i sits at position i + coff)
+    unsigned long long* dbg;   // timeline build: {iterations, cycles of [phase 1 + boundary], cycles of [phase 2]} of workgroup 0's waves
+};
+
+constexpr int kKvBlock4 = 128;   // 4 waves x 32 key rows
+constexpr int kQB = 32;          // query rows per block of the stream
+
+template <int N>
+__device__ __forceinline__ float dkv4_acc_read() {
+    float x = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "n"(N));
+#endif
+    return x;
+}
+
+// accumulator block BASE + 16 d .. of the wave's key row -> the row's d = 32 d + 8 g + 4 hi .. + 3 (8-byte stores)
+template <class T, int BASE, int I = 0>
+__device__ __forceinline__ void dkv4_store_rows(char* row, int hi, float sc) {
+    if constexpr (I < 16) {
+        constexpr int d = I / 4, g4 = I % 4, N = BASE + 16 * d + 4 * g4;
+        u32x2_t u;
+        u[0] = T::pack2(dkv4_acc_read<N>() * sc, dkv4_acc_read<N + 1>() * sc);
+        u[1] = T::pack2(dkv4_acc_read<N + 2>() * sc, dkv4_acc_read<N + 3>() * sc);
+        *reinterpret_cast<u32x2_t*>(row + (32 * d + 8 * g4 + 4 * hi) * 2) = u;
+        dkv4_store_rows<T, BASE, I + 1>(row, hi, sc);
+    }
+}
+
+__device__ __forceinline__ int dkv4_rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+template <class T, bool CAUSAL, bool TL>
+__device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
+    constexpr int D = 128;
+    using A = Bw4Asm<T, D>;
+    using std::integral_constant;
+    constexpr int RB = 2 * D, CPR = RB / 16, KS = D / 16;
+    constexpr int IMG = A::IMG, SLOT = A::SLOT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = dkv4_rfl(tid >> 6);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#else
+    const unsigned lds0 = 0;
+#endif
+    const int g = p.Hq / p.Hkv;
+    const int Sq = p.Sq, Sk = p.Sk, coff = p.coff;
+    const float c = p.c;
+    const int nkb = (Sk + kKvBlock4 - 1) / kKvBlock4;
+    const WorkItem w = decode_work(blockIdx.x, p.B, p.Hkv, p.Hkv, p.nblk, false);
+    const size_t kvbase = (size_t)(w.b * p.Hkv + w.hk) * Sk;
+
+    // lane constants
+    const unsigned tr_off = (unsigned)(hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8);
+    const unsigned a_sw = (unsigned)(l31 * RB + (((l31 & (CPR - 1)) ^ hi) * 16));   // row-major image: chunk (2 ks + hi) ^ swz(row) = a_sw ^ 32 ks
+    // per-lane source offsets of this wave's two pieces (64 chunks each) of an image: row-major swizzled / sub-tiled
+    unsigned vorm[2], vost[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int q = (2 * wave + h) * 64 + lane;
+        const int r = q / CPR, cs = q % CPR;
+        vorm[h] = (unsigned)(r * RB + (cs ^ (r & (CPR - 1))) * 16);
+        const int bidx = q >> 3;
+        vost[h] = (unsigned)(((bidx / (D / 16)) * 4 + ((q >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (q & 1)) * 16);
+    }
+    const unsigned lvo = (unsigned)(hi * 16);   // L' / delta: rows 8 g + 4 hi .. + 3 of the block per dwordx4
+    const unsigned oob = 0x7ffffff0u;            // a scalar offset beyond every descriptor: the request writes zeros / the load reads 0
+
+    unsigned long long tl_a = 0, tl_b = 0, tl_n = 0;
+    const int nparts = (CAUSAL && (nkb - 1 - w.blk) != w.blk) ? 2 : 1;
+    for (int part = 0; part < nparts; ++part) {
+        const int kb = CAUSAL ? (part == 0 ? nkb - 1 - w.blk : w.blk) : w.blk;   // (the block with more query blocks first)
+        const int n0w = kb * kKvBlock4 + wave * 32;
+        const int kvrow = n0w + l31;
+        {
+            const __amdgpu_buffer_rsrc_t krs = make_srd(reinterpret_cast<const char*>(p.k) + kvbase * RB, (unsigned)Sk * RB);
+            const __amdgpu_buffer_rsrc_t vrs = make_srd(reinterpret_cast<const char*>(p.v) + kvbase * RB, (unsigned)Sk * RB);
+            A::load_kv(krs, vrs, (unsigned)(kvrow * RB + hi * 16));
+        }
+        A::zero_acc();
+
+        const int nq32 = (Sq + kQB - 1) / kQB;
+        const int first_qt = CAUSAL ? max(0, kb * kKvBlock4 - coff) / kQB : 0;
+        const int ntq = nq32 > first_qt ? nq32 - first_qt : 0;
+        const int nit = ntq * g;   // flattened (query head of the group, query block) stream
+
+        // block x of the stream: head x / ntq of the group, query block first_qt + x % ntq -- kept as cursors that advance with
+        // the stream: (blocks left in the head, global row of the block inside the group's rows).  ONE descriptor per tensor
+        // for the whole group, the head and the block go into the request's scalar offset: per-head descriptors cost ~90 scalar
+        // instructions per iteration between the MFMA statements.  (A ragged last block of a head then reads the first rows
+        // of the NEXT head of the group instead of zeros; its weights are masked to exactly 0, and those rows belong to the
+        // same dK / dV sum anyway.  Beyond the group's last head the descriptor's bounds return 0.)
+        const size_t grows = (size_t)(w.b * p.Hq + w.hk * g) * Sq;   // first row of the group's first head
+        const __amdgpu_buffer_rsrc_t qrs = make_srd(reinterpret_cast<const char*>(p.q) + grows * RB, (unsigned)dkv4_rfl(g * Sq * RB));
+        const __amdgpu_buffer_rsrc_t grs = make_srd(reinterpret_cast<const char*>(p.dout) + grows * RB, (unsigned)dkv4_rfl(g * Sq * RB));
+        const __amdgpu_buffer_rsrc_t lrs = make_srd(p.lse + grows, (unsigned)dkv4_rfl(g * Sq * 4));
+        const __amdgpu_buffer_rsrc_t drs = make_srd(p.delta + grows, (unsigned)dkv4_rfl(g * Sq * 4));
+        struct Cur { int left, row, t; };   // blocks left in this head (this one included), row of the block in the group, block in the head
+        const int row_first = first_qt * kQB;
+        const int row_wrap = Sq - (ntq - 1) * kQB;   // from a head's last block to the next head's first one
+        auto adv = [&](Cur& cu) __attribute__((always_inline)) {
+            if (--cu.left == 0) { cu.left = ntq; cu.row += row_wrap; cu.t = 0; }
+            else { cu.row += kQB; ++cu.t; }
+        };
+        const int row_end = g * Sq;   // a cursor at or beyond it points behind the stream
+        auto blk_off = [&](const Cur& cu) __attribute__((always_inline)) { return cu.row < row_end ? (unsigned)cu.row * (unsigned)RB : oob; };
+        auto scal_off = [&](const Cur& cu) __attribute__((always_inline)) { return cu.row < row_end ? (unsigned)cu.row * 4u : oob; };
+        auto slot_lds = [&](int x) __attribute__((always_inline)) { return lds0 + (unsigned)(x & 3) * SLOT; };
+        // mask of block x for this lane: rows [lo, lo + wd) of the block are valid (as crow(r) + 4 hi); need = somebody needs it
+        auto mask_need = [&](const Cur& cu) __attribute__((always_inline)) {   // (scalar) does anybody's lane need a mask in this block?
+            const int q0 = (first_qt + cu.t) * kQB;
+            return (CAUSAL && q0 + coff < n0w + 31) || (q0 + kQB > Sq) || (n0w + 32 > Sk);
+        };
+        auto mask_of = [&](const Cur& cu, int& lo, int& wd) __attribute__((always_inline)) {
+            const int q0 = (first_qt + cu.t) * kQB;
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int kr = n0w + (lane_o & 31);
+            const int lo_r = CAUSAL ? max(0, kr - coff - q0) : 0;
+            const int hi_r = min(kQB, Sq - q0);
+            lo = lo_r - 4 * (lane_o >> 5);
+            wd = (kr < Sk && hi_r > lo_r) ? hi_r - lo_r : 0;
+        };
+
+        if (nit > 0) {
+            // ---- stream start: blocks 0 .. 3 requested, L' / delta of blocks 0 and 1, the fragments of block 0, S_0 / dP_0
+            Cur cur{ntq, row_first, 0}, c2 = cur, c4 = cur;   // blocks i, i + 2, i + 4 of the stream
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                A::dma_block(slot_lds(x) + (unsigned)wave * 2048u, qrs, grs, blk_off(c4), vorm[0], vorm[1], vost[0], vost[1]);
+                adv(c4);
+            }
+            A::template load_scal<0, 1>(lrs, drs, lvo, scal_off(c2));
+            adv(c2);
+            A::template load_scal<1, 0>(lrs, drs, lvo, scal_off(c2));
+            adv(c2);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            const __amdgpu_buffer_rsrc_t nosrd = make_srd(nullptr, 0);
+            auto rm_reads = [&](int x) __attribute__((always_inline)) {   // row-major fragments of block x -> the accumulator file
+                const unsigned b = slot_lds(x) + a_sw;
+                A::template p2<0, 0, 0, 1, 0, 0>(b ^ 0u, b ^ 32u, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0, 0, 0);
+                A::template p2<1, 0, 0, 1, 0, 0>(b ^ 64u, b ^ 96u, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0, 0, 0);
+                A::template p2<2, 0, 0, 1, 0, 0>(b ^ 128u, b ^ 160u, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0, 0, 0);
+                A::template p2<3, 0, 0, 1, 0, 0>(b ^ 192u, b ^ 224u, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            rm_reads(0);
+            A::template p1<0, 1, 1, 0, 0>(c, 0, 0, 0);   // S_0, dP_0 (parity 0 buffers)
+            A::template p1<1, 1, 1, 0, 0>(c, 0, 0, 0);
+            A::template p1<2, 1, 1, 0, 0>(c, 0, 0, 0);
+            A::template p1<3, 1, 1, 0, 0>(c, 0, 0, 0);
+            if (nit > 1) rm_reads(1);
+
+            // ---- the stream
+            auto iteration = [&](auto par_tag, int i) __attribute__((always_inline)) {
+                constexpr int PAR = decltype(par_tag)::value;
+                unsigned long long t0 = 0;
+                if constexpr (TL) t0 = __builtin_amdgcn_s_memtime();
+                int lo = 0, wd = 0;
+                const bool masked = mask_need(cur);
+                if (masked) mask_of(cur, lo, wd);
+                const unsigned trb = slot_lds(i) + tr_off;
+                const bool qk = i + 1 < nit;
+#define DKV4_P1(QK, AR)                                   \
+    A::template p1<0, PAR, QK, AR, 1>(c, lo, wd, trb);     \
+    A::template p1<1, PAR, QK, AR, 1>(c, lo, wd, trb);     \
+    A::template p1<2, PAR, QK, AR, 1>(c, lo, wd, trb);     \
+    A::template p1<3, PAR, QK, AR, 1>(c, lo, wd, trb);
+                if (qk) {
+                    if (masked) { DKV4_P1(1, 2) } else { DKV4_P1(1, 1) }
+                } else {
+                    if (masked) { DKV4_P1(0, 2) } else { DKV4_P1(0, 1) }
+                }
+#undef DKV4_P1
+                // block i + 2 has landed for everybody (all but this wave's newest NP requests -- block i + 3 -- are complete:
+                // the scalars of block i + 1 among them); every wave is done with the images of block i
+                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                unsigned long long t1 = 0;
+                if constexpr (TL) { t1 = __builtin_amdgcn_s_memtime(); tl_a += t1 - t0; }
+                const unsigned b = slot_lds(i + 2) + a_sw;
+                {
+                    const unsigned lso = scal_off(c2), dso = blk_off(c4);
+                    const unsigned dl = slot_lds(i) + (unsigned)wave * 2048u;   // (block i + 4 takes block i's slot)
+                    A::template p2<0, PAR, 1, 1, 1, 1>(b ^ 0u, b ^ 32u, lrs, drs, lvo, lso, dl, qrs, grs, dso, vorm[0], vorm[1], vost[0], vost[1]);
+                    A::template p2<1, PAR, 1, 1, 1, 1>(b ^ 64u, b ^ 96u, lrs, drs, lvo, lso, dl, qrs, grs, dso, vorm[0], vorm[1], vost[0], vost[1]);
+                    A::template p2<2, PAR, 1, 1, 1, 1>(b ^ 128u, b ^ 160u, lrs, drs, lvo, lso, dl, qrs, grs, dso, vorm[0], vorm[1], vost[0], vost[1]);
+                    A::template p2<3, PAR, 1, 1, 1, 1>(b ^ 192u, b ^ 224u, lrs, drs, lvo, lso, dl, qrs, grs, dso, vorm[0], vorm[1], vost[0], vost[1]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments of block i + 2 (phase 1 of the next iteration reads them)
+                adv(cur); adv(c2); adv(c4);
+                if constexpr (TL) { tl_b += __builtin_amdgcn_s_memtime() - t1; ++tl_n; }
+            };
+            for (int i = 0; i < nit; i += 2) {
+                iteration(integral_constant<int, 0>{}, i);
+                if (i + 1 < nit) iteration(integral_constant<int, 1>{}, i + 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // the out-of-range requests of the last iterations too
+        }
+
+        // ---- dK (scaled), dV of the wave's key rows
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the last MFMAs -> v_accvgpr_read
+        if (kvrow < Sk) {
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const size_t row = kvbase + (size_t)(n0w + (lane_o & 31));
+            dkv4_store_rows<T, 0>(reinterpret_cast<char*>(p.dv) + row * RB, lane_o >> 5, 1.0f);
+            dkv4_store_rows<T, 64>(reinterpret_cast<char*>(p.dk) + row * RB, lane_o >> 5, p.scale);
+        }
+        __syncthreads();
+    }
+    if constexpr (TL) {
+        if (blockIdx.x == 0 && lane == 0) {
+            p.dbg[wave * 4 + 0] = tl_n; p.dbg[wave * 4 + 1] = tl_a; p.dbg[wave * 4 + 2] = tl_b;
+        }
+    }
+}
+
+template <class T, bool CAUSAL, bool TL = false>
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(40))) fa_bwd_dkv4_kernel(const Dkv4Params p) {
+    static_assert(Bw4Asm<T, 128>::NV == 40, "amdgpu_num_vgpr must be the generator's NV");
+    dkv4_body<T, CAUSAL, TL>(p);
+}
+
+#pragma clang diagnostic pop
+
+constexpr int kDkv4Lds = 4 * Bw4Asm<Bf16Traits, 128>::SLOT;
+
+template <class T>
+int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
+    Dkv4Params p;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.dout = a.dout; p.lse = a.lse; p.delta = a.delta;
+    p.dk = a.dk; p.dv = a.dv;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
+    p.c = a.scale * kLog2e;
+    p.scale = a.scale;
+    p.coff = a.causal ? a.coff : 0;
+    const int nkb = (a.Sk + kKvBlock4 - 1) / kKvBlock4;
+    p.nblk = a.causal ? (nkb + 1) / 2 : nkb;
+    const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv)), block(256);
+    p.dbg = a.dbg;
+#ifdef AULE_DEBUG_HOOKS
+    if constexpr (std::is_same<T, Bf16Traits>::value) {
+        if (a.dbg != nullptr) {   // timeline build (tools/timeline_dkv4.py)
+            if (a.causal) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv4Lds);
+                hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, true, true>), grid, block, kDkv4Lds, stream, p);
+            } else {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv4Lds);
+                hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, false, true>), grid, block, kDkv4Lds, stream, p);
+            }
+            return (int)hipGetLastError();
+        }
+    }
+#endif
+    if (a.causal)
+        hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, true>), grid, block, kDkv4Lds, stream, p);
+    else
+        hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, false>), grid, block, kDkv4Lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// Shapes the one-wave-per-SIMD dK/dV kernel takes: 16-bit, D = 128, no window, causal offset >= 0, and enough work items to
+// cover the chip with the whole GQA group inside a workgroup (otherwise the predecessor splits the group over workgroups).
+bool bwd_dkv4_applicable(const BwdArgs& a) {
+    // AULE_HIP_BWD_DKV=old: the two-waves-per-SIMD kernel everywhere (A/B); =new: this kernel wherever it CAN run (tests)
+    static const int mode = [] {
+        const char* e = std::getenv("AULE_HIP_BWD_DKV");
+        return e == nullptr ? 0 : (e[0] == 'o' ? 1 : (e[0] == 'n' ? 2 : 0));
+    }();
+    if (mode == 1) return false;
+    if (a.dtype != kBF16 && a.dtype != kF16) return false;
+    if (a.D != 128 || a.window > 0) return false;
+    if (a.causal && a.coff < 0) return false;
+    if (a.Hkv <= 0 || a.Hq % a.Hkv != 0) return false;
+    // one descriptor covers the rows of a whole GQA group; byte offsets inside it are 32-bit
+    if ((long long)(a.Hq / a.Hkv) * a.Sq * a.D * 2 >= (1LL << 31) || (long long)a.Sk * a.D * 2 >= (1LL << 31)) return false;
+    if (mode == 2) return true;
+    // Where it pays (same box, tools/bwd_ab.py): grouped heads -- the whole group runs inside one workgroup, so there is no head
+    // split, no fp32 partials and no reduce kernel (C3: 533 -> 491 us, fp16 MQA S8192: 1824 -> 1740) -- on grids that cover the
+    // chip.  For plain MHA the two kernels are within 1 % of each other (the predecessor stays).
+    const int nkb = (a.Sk + kKvBlock4 - 1) / kKvBlock4;
+    const long long items = (long long)a.B * a.Hkv * (a.causal ? (nkb + 1) / 2 : nkb);
+    return a.Hq > a.Hkv && items >= 192;
+}
+
+int launch_bwd_dkv4(const BwdArgs& a, hipStream_t stream) {
+    if (a.dtype == kBF16) return launch_dkv4<Bf16Traits>(a, stream);
+    if (a.dtype == kF16) return launch_dkv4<F16Traits>(a, stream);
+    return -1;
+}
+
+int configure_bwd_dkv4() {
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<Bf16Traits, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv4Lds);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<Bf16Traits, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv4Lds);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<F16Traits, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv4Lds);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<F16Traits, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv4Lds);
+    return rc;
+}
+
+}  // namespace aule_hip

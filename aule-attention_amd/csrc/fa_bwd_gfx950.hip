@@ -26,6 +26,10 @@
 #include "fa_kernels.h"
 
 namespace aule_hip {
+static bool dkv4_timeline_wanted() { const char* e = std::getenv("AULE_TL"); return e != nullptr && e[0] == 'd' && e[1] == 'k'; }   // AULE_TL=dkv4 (debug library)
+bool bwd_dkv4_applicable(const BwdArgs& a);          // fa_bwd_dkv4_gfx950.hip: the one-wave-per-SIMD dK/dV kernel
+int launch_bwd_dkv4(const BwdArgs& a, hipStream_t stream);
+int configure_bwd_dkv4();
 namespace {
 
 // ------------------------------------------------------------------ delta ----
@@ -1085,6 +1089,8 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
         int rc = (int)hipGetLastError();
         if (rc) return rc;
     }
+    if (D == 128 && (a.dbg == nullptr || dkv4_timeline_wanted()) && bwd_dkv4_applicable(a))   // one wave per SIMD, 128-key blocks, no head split: fa_bwd_dkv4_gfx950.hip
+        return launch_bwd_dkv4(a, stream);
     {
         const int nkb = (a.Sk + kKvBlock - 1) / kKvBlock;
         p.nblk = a.causal ? (nkb + 1) / 2 : nkb;  // causal: one workgroup per block pair (i, n-1-i)
@@ -1190,6 +1196,7 @@ int configure_bwd() {
     rc |= set_attr_bwd<F16Traits, 64>();
     rc |= set_attr_bwd<F16Traits, 32>();
     rc |= configure_bwd_f32();
+    rc |= configure_bwd_dkv4();
     return rc;
 }
 

@@ -4,6 +4,7 @@ dQ, dK, dV from aule_attention_backward_ex are compared with the reference's rec
 gradients (tests/golden/tr_*), with the fp64 oracle on seeded inputs, and with torch
 autograd through a plain fp32 softmax(QK^T)V (config #3: GQA 32q/8kv S=2048 D=128 bf16)."""
 import math
+import os
 import zlib
 
 import numpy as np
@@ -59,6 +60,12 @@ SWEEP = [
     ("bf16", 1, 4, 2, 130, 70, 128, True, None),
     ("bf16", 1, 4, 2, 70, 300, 128, True, None),      # Sk >> Sq causal: late KV blocks get zero grads
     ("bf16", 1, 2, 2, 1, 1, 128, True, None),
+    # shapes for the one-wave-per-SIMD dK/dV kernel (it takes them by itself on full grids of grouped heads; the variant test
+    # below forces it on everything it can run): several 128-key blocks and pairs, ragged rows and keys, the GQA loop
+    ("bf16", 2, 8, 2, 640, 640, 128, True, None),
+    ("bf16", 1, 8, 2, 515, 771, 128, False, None),
+    ("fp16", 2, 4, 1, 1000, 1000, 128, True, 0.11),
+    ("bf16", 1, 2, 2, 333, 1100, 128, True, None),
     ("bf16", 1, 4, 4, 512, 512, 64, True, None),
     ("bf16", 1, 6, 3, 97, 161, 64, False, 0.5),
     ("bf16", 1, 4, 4, 192, 192, 32, True, None),
@@ -158,3 +165,17 @@ def test_backward_deterministic(torch_cuda):
         grads.append((a.grad, b.grad, c.grad))
     for x, y in zip(*grads):
         assert torch.equal(x, y)
+
+
+def test_backward_on_the_one_wave_per_simd_dkdv_kernel():
+    """fa_bwd_dkv4_gfx950.hip takes grouped-head problems on full grids by itself (C3 above); AULE_HIP_BWD_DKV=new forces it onto
+    every problem it can run (D = 128, 16-bit, no window, causal offset >= 0) so that the sweep, the reference's golden
+    gradients, the bottom-right cases and the determinism test exercise its masks, its stream start / tail and its GQA loop."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    e = dict(os.environ)
+    e["AULE_HIP_BWD_DKV"] = "new"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_bwd.py"), os.path.join(ROOT, "tests", "test_gpu_bottom_right.py"),
+                        "-q", "-x", "-m", "gpu", "-k", "not one_wave_per_simd_dkdv"], env=e, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0 and "passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]

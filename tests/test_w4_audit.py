@@ -44,3 +44,43 @@ def test_hazard_lint_catches_what_it_is_for():
          "s_add_u32 m0, s48, 0", "v_add_f32 v57, v57, v53", "buffer_load_dwordx4 v4, s[24:27], s77 offen lds"],
     ])
     assert ok == []
+
+
+def test_dkv4_streams_current_and_kernel_clean(tmp_path):
+    """The one-wave-per-SIMD dK/dV kernel (fa_bwd_dkv4_gfx950.hip, streams from tools/gen_bw4.py): the committed streams are what the
+    generator writes, and the compiled kernels have no scratch, no spills, no compiler-made accumulator access and stay below the
+    generator's VGPR budget outside the statements."""
+    import re
+    out = tmp_path / "fa_bwd_dkv4_asm.inc"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_bw4.py")], env=dict(os.environ, BW4_OUT=str(out)), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out.read_text() == open(os.path.join(ROOT, "aule-attention_amd", "csrc", "fa_bwd_dkv4_asm.inc")).read(), "fa_bwd_dkv4_asm.inc is stale: run python tools/gen_bw4.py"
+    nv = int(re.search(r"NV = (\d+)", out.read_text()).group(1))
+    s = tmp_path / "dkv4.s"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-inline-asm", "-S", "--cuda-device-only", "-o", str(s),
+                        os.path.join(ROOT, "aule-attention_amd", "csrc", "fa_bwd_dkv4_gfx950.hip")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = s.read_text()
+    assert len(re.findall(r"\.private_segment_fixed_size: 0\n", text)) == 4 and ".private_segment_fixed_size: " in text
+    for key in ("vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size"):
+        assert set(re.findall(r"\." + key + r":\s+(\d+)", text)) == {"0"}, key
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_w4 as a
+    inasm, problems, blocks, cur = False, [], [], []
+    for l in text.split("\n"):
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            inasm, cur = True, []
+        elif t.startswith(";;#ASMEND"):
+            inasm = False
+            blocks.append(cur)
+        elif inasm:
+            cur.append(t)
+        elif t and not t.startswith(";") and not t.startswith("."):
+            if "v_accvgpr" in t or t.startswith("scratch_"):
+                problems.append(t)
+            for x in re.findall(r"\bv(\d+)\b", t) + [y for p, q in re.findall(r"\bv\[(\d+):(\d+)\]", t) for y in (p, q)]:
+                if int(x) >= nv:
+                    problems.append(t)
+    assert not problems, problems[:5]
+    assert a.lint_blocks(blocks) == []

@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""Writes aule-attention_amd/csrc/fa_bwd_dkv4_asm.inc: the instruction streams of the one-wave-per-SIMD dK/dV kernel
+(fa_bwd_dkv4_gfx950.hip).  Run it after editing; the output is committed (the build does not need Python).
+
+Workgroup = 4 waves, one per SIMD; a wave owns 32 key rows of a 128-key KV block and the whole 512-register file, and walks a
+stream of 32-row query blocks (all query heads of the GQA group, every block that sees the KV block).  Per block b:
+
+    S_b  = Q_b K^T        dP_b = dO_b V^T                  (16 MFMAs: A = row-major fragments of Q_b / dO_b, B = K / V fragments)
+    P_b  = exp2(c S_b - L'_b)      dS_b = P_b (dP_b - delta_b)              (16 scores per lane; lane = key, registers = rows)
+    dV^T += dO_b^T P_b    dK^T += Q_b^T dS_b               (16 MFMAs: A = transposed fragments of dO_b / Q_b, B = packed P / dS)
+
+software-pipelined over the stream: iteration i is
+
+    phase 1   S_{i+1}, dP_{i+1}   |  the arithmetic of block i  |  32 transpose reads of block i
+    ---- s_waitcnt vmcnt(NP) lgkmcnt(0); s_barrier ----       (block i + 2 has landed; everybody is done with block i's images)
+    phase 2   dV, dK of block i   |  16 row-major reads of block i + 2 (into accumulator registers)  |  L', delta of block i + 2
+                                     requested, L' of block i + 1 scaled  |  the LDS-DMA requests of block i + 4 (its slot = block i's)
+
+Register map (D = 128; every register of the loop is named literally, hipcc keeps v0 .. v(NV-1): amdgpu_num_vgpr):
+
+    accumulator file                                arch VGPRs
+    a[0:63]     dV^T, block d at a[16 d ..]         v[0:NV)     hipcc
+    a[64:127]   dK^T                                T  (8)      temporaries
+    a[128:159]  K fragments (ks at a[128 + 4 ks])   DL[2][16]   delta of the block, by block parity
+    a[160:191]  V fragments                         LD[2][16]   L' = LSE log2(e), by block parity
+    a[192:223]  Q_b row-major fragments (ks)        DS (8), P (8)   packed dS, P: B operands of phase 2
+    a[224:255]  dO_b row-major fragments            DP[2][16], S[2][16]   by block parity
+                                                    Y (32), X (32)  transposed fragments of Q_b / dO_b: step st at + 4 st
+
+Hazards kept by the strings themselves: v_exp_f32 result -> reader at least one instruction later; an M0 write and its request
+one instruction apart; everything an MFMA reads from a VALU / LDS result sits behind the phase boundary's waits.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from gen_w4 import emit_asm, vregs, aregs, tup   # noqa: E402
+
+OUT = os.environ.get("BW4_OUT", os.path.join(ROOT, "aule-attention_amd", "csrc", "fa_bwd_dkv4_asm.inc"))
+
+
+class Cfg:
+    def __init__(self, D, dt):
+        assert D == 128
+        self.D, self.dt = D, dt
+        self.RB = 2 * D
+        self.KS, self.DB = D // 16, D // 32
+        self.mfma = "v_mfma_f32_32x32x16_bf16" if dt == "bf16" else "v_mfma_f32_32x32x16_f16"
+        self.cvt = "v_cvt_pk_bf16_f32" if dt == "bf16" else "v_cvt_pk_f16_f32"
+        self.IMG = 32 * self.RB                     # one image of a 32-row block (8 KB)
+        self.SLOT = 4 * self.IMG                    # Q rm, Q st, dO rm, dO st
+        self.NP = self.SLOT // 4 // 1024            # DMA pieces per wave and block (8)
+        # accumulator file
+        self.DV, self.DK, self.KF, self.VF, self.QA, self.DA = 0, 64, 128, 160, 192, 224
+        # arch VGPRs, top down
+        self.X = 256 - 32
+        self.Y = self.X - 32
+        self.S = self.Y - 32
+        self.DP = self.S - 32
+        self.P = self.DP - 8
+        self.DS = self.P - 8
+        self.LD = self.DS - 32
+        self.DL = self.LD - 32
+        self.T = self.DL - 8
+        self.NV = self.T
+
+    def acc(self, base, i, n=16):
+        return f"a[{base + i * n}:{base + i * n + n - 1}]"
+
+    def frag(self, base, i, file="a"):
+        return f"{file}[{base + 4 * i}:{base + 4 * i + 3}]"
+
+
+def crow(r):
+    """query row (minus 4 hi) inside the 32-row block of accumulator register r"""
+    return (r & 3) + 8 * (r >> 2)
+
+
+def arith_ops(c, par, q, masked):
+    """P / dS of scores 4 q .. 4 q + 3 of block parity par.  Two pairs in flight; masked: a score outside [lo, lo + width) of its
+    lane (row constant minus the lane's first valid row, unsigned compare) gets weight 0."""
+    S, DPr, LD, DL = c.S + 16 * par, c.DP + 16 * par, c.LD + 16 * par, c.DL + 16 * par
+    t = [c.T + i for i in range(8)]
+    r0 = 4 * q
+    ops = []
+    for i in range(4):
+        ops.append(f"v_fma_f32 v{t[i]}, v{S + r0 + i}, %[c], -v{LD + r0 + i}")
+    for i in range(4):
+        ops.append(f"v_sub_f32 v{t[4 + i]}, v{DPr + r0 + i}, v{DL + r0 + i}")
+    for i in range(4):
+        ops.append(f"v_exp_f32 v{t[i]}, v{t[i]}")
+    if masked:
+        tm = c.DS + r0 // 2            # (a register of this statement's dS pair: written only by the pack at the end)
+        for i in range(4):
+            ops.append(f"v_sub_u32 v{tm}, {crow(r0 + i)}, %[lo]")
+            ops.append(f"v_cmp_gt_u32 vcc, %[wd], v{tm}")
+            ops.append(f"v_cndmask_b32 v{t[i]}, 0, v{t[i]}, vcc")
+    for i in range(4):
+        ops.append(f"v_mul_f32 v{t[4 + i]}, v{t[i]}, v{t[4 + i]}")
+    for j in range(2):
+        ops.append(f"{c.cvt} v{c.P + r0 // 2 + j}, v{t[2 * j]}, v{t[2 * j + 1]}")
+        ops.append(f"{c.cvt} v{c.DS + r0 // 2 + j}, v{t[4 + 2 * j]}, v{t[5 + 2 * j]}")
+    return ops
+
+
+def deal(mfmas, fillers):
+    """MFMA g, then an even share of the fillers (program order kept)."""
+    n = len(mfmas)
+    out = []
+    if n == 0:
+        return list(fillers)
+    k = 0
+    for g in range(n):
+        out.append(mfmas[g])
+        take = len(fillers) * (g + 1) // n - len(fillers) * g // n
+        out += fillers[k:k + take]
+        k += take
+    return out
+
+
+def gen_p1(c, q, par, qk, ar, tr):
+    """phase-1 statement q of an iteration whose current block has parity par.  qk: MFMAs of the NEXT block's S / dP (k-slices
+    2 q, 2 q + 1).  ar: 0 none, 1 plain, 2 masked arithmetic of the current block (scores 4 q ..).  tr: transpose reads of the
+    current block (steps 2 q, 2 q + 1: four ds_read_b64_tr_b16 each)."""
+    mf, clob = [], ["memory"]
+    npar = par ^ 1
+    if qk:
+        s, dp = tup(c.S + 16 * npar, 16), tup(c.DP + 16 * npar, 16)
+        for ks in (2 * q, 2 * q + 1):
+            mf.append(f"{c.mfma} {s}, {c.frag(c.QA, ks)}, {c.frag(c.KF, ks)}, {'0' if ks == 0 else s}")
+            mf.append(f"{c.mfma} {dp}, {c.frag(c.DA, ks)}, {c.frag(c.VF, ks)}, {'0' if ks == 0 else dp}")
+        clob += vregs(c.S + 16 * npar, 16) + vregs(c.DP + 16 * npar, 16)
+    valu = arith_ops(c, par, q, ar == 2) if ar else []
+    if ar:
+        clob += vregs(c.T, 8) + vregs(c.P + 2 * q, 2) + vregs(c.DS + 2 * q, 2)
+        if ar == 2:
+            clob += ["vcc"]
+    lds = []
+    if tr:
+        for st in (2 * q, 2 * q + 1):
+            kk, d = st // c.DB, st % c.DB
+            off = ((4 * kk) * (c.D // 16) + 2 * d) * 128
+            o2 = off + 2 * (c.D // 16) * 128
+            lds += [f"ds_read_b64_tr_b16 v[{c.X + 4 * st}:{c.X + 4 * st + 1}], %[trb] offset:{3 * c.IMG + off}",
+                    f"ds_read_b64_tr_b16 v[{c.X + 4 * st + 2}:{c.X + 4 * st + 3}], %[trb] offset:{3 * c.IMG + o2}",
+                    f"ds_read_b64_tr_b16 v[{c.Y + 4 * st}:{c.Y + 4 * st + 1}], %[trb] offset:{c.IMG + off}",
+                    f"ds_read_b64_tr_b16 v[{c.Y + 4 * st + 2}:{c.Y + 4 * st + 3}], %[trb] offset:{c.IMG + o2}"]
+        clob += vregs(c.X + 8 * q, 8) + vregs(c.Y + 8 * q, 8)
+    fill = lds + valu
+    lines = deal(mf, fill)
+    if qk and not fill:
+        lines += ["s_nop 7", "s_nop 7"]
+    ins = []
+    if ar:
+        ins.append('[c] "s"(c)')
+        if ar == 2:
+            ins += ['[lo] "v"(lo)', '[wd] "v"(wd)']
+    if tr:
+        ins.append('[trb] "v"(trb)')
+    return emit_asm(lines, [], ins, clob)
+
+
+def gen_p2(c, q, par, mm, rm, ld, dma):
+    """phase-2 statement q.  mm: dV / dK MFMAs of the current block (steps 2 q, 2 q + 1).  rm: row-major fragment reads of block
+    i + 2 (k-slices 2 q, 2 q + 1 of Q and dO).  ld: statement 0 requests L' of block i + 2, statement 1 its delta (four dwordx4
+    each, into the buffers of parity par), and every statement scales four L' of block i + 1 (parity par ^ 1) by log2(e).  dma:
+    statements 2 and 3 carry the eight LDS-DMA pieces of block i + 4 (image q - 2 ... : pieces 4 (q - 2) .. + 3).  All the
+    requests for scalars come before all the pieces: the phase boundary's vmcnt(NP) then covers exactly the scalars."""
+    mf, clob = [], ["memory"]
+    if mm:
+        for st in (2 * q, 2 * q + 1):
+            kk, d = st // c.DB, st % c.DB
+            dv, dk = c.acc(c.DV, d), c.acc(c.DK, d)
+            mf.append(f"{c.mfma} {dv}, {c.frag(c.X, st, 'v')}, {c.frag(c.P, kk, 'v')}, {dv}")
+            mf.append(f"{c.mfma} {dk}, {c.frag(c.Y, st, 'v')}, {c.frag(c.DS, kk, 'v')}, {dk}")
+        clob += aregs(c.DV, 64) + aregs(c.DK, 64)
+    fill = []
+    ins = []
+    if rm:
+        for t, ks in enumerate((2 * q, 2 * q + 1)):
+            fill.append(f"ds_read_b128 {c.frag(c.QA, ks)}, %[ra{t}]")
+            fill.append(f"ds_read_b128 {c.frag(c.DA, ks)}, %[ra{t}] offset:{2 * c.IMG}")
+            clob += aregs(c.QA + 4 * ks, 4) + aregs(c.DA + 4 * ks, 4)
+        ins += ['[ra0] "v"(ra0)', '[ra1] "v"(ra1)']
+    if ld:
+        if q < 2:
+            base = (c.LD if q == 0 else c.DL) + 16 * par
+            srd = "%[lsrd]" if q == 0 else "%[dsrd]"
+            for g in range(4):
+                fill.append(f"buffer_load_dwordx4 v[{base + 4 * g}:{base + 4 * g + 3}], %[lvo], {srd}, %[lso] offen offset:{32 * g}")
+            clob += vregs(base, 16)
+            ins += ['[lsrd] "s"(lsrd)' if q == 0 else '[dsrd] "s"(dsrd)', '[lvo] "v"(lvo)', '[lso] "s"(lso)']
+        for i in range(4):
+            r = c.LD + 16 * (par ^ 1) + 4 * q + i
+            fill.append(f"v_mul_f32 v{r}, 0x3fb8aa3b, v{r}")
+        clob += vregs(c.LD + 16 * (par ^ 1) + 4 * q, 4)
+    if dma and q >= 2:
+        for pi in range(4 * (q - 2), 4 * (q - 2) + 4):      # piece of this wave: image pi / 2, half pi % 2
+            img, half = pi // 2, pi % 2
+            srd = "%[qsrd]" if img < 2 else "%[gsrd]"
+            vo = f"%[vorm{half}]" if img in (0, 2) else f"%[vost{half}]"
+            fill += [f"s_add_u32 m0, %[dlds], {img * c.IMG + half * 1024}", "s_nop 0", f"buffer_load_dwordx4 {vo}, {srd}, %[dso] offen lds"]
+        clob += ["m0", "scc"]
+        ins += ['[dlds] "s"(dlds)', '[qsrd] "s"(qsrd)' if q == 2 else '[gsrd] "s"(gsrd)', '[dso] "s"(dso)',
+                '[vorm0] "v"(vorm0)', '[vorm1] "v"(vorm1)', '[vost0] "v"(vost0)', '[vost1] "v"(vost1)']
+    lines = deal(mf, fill)
+    return emit_asm(lines, [], ins, clob)
+
+
+def gen_struct(c):
+    name = f"Bw4Asm<{'Bf16Traits' if c.dt == 'bf16' else 'F16Traits'}, {c.D}>"
+    s = f"template <> struct {name} {{\n"
+    s += f"    static constexpr int NV = {c.NV}, NP = {c.NP}, SLOT = {c.SLOT}, IMG = {c.IMG};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n"
+    s += ("    template <int Q, int PAR, int QK, int AR, int TR>\n"
+          "    static __device__ __forceinline__ void p1(float c, int lo, int wd, unsigned trb) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n        (void)c; (void)lo; (void)wd; (void)trb;\n")
+    first = True
+    for q in range(4):
+        for par in range(2):
+            for (qk, ar, tr) in ((1, 1, 1), (1, 2, 1), (0, 1, 1), (0, 2, 1), (1, 0, 0)):
+                s += f"        {'if' if first else 'else if'} constexpr (Q == {q} && PAR == {par} && QK == {qk} && AR == {ar} && TR == {tr}) {{\n"
+                s += gen_p1(c, q, par, qk, ar, tr) + "        }\n"
+                first = False
+    s += "        else static_assert(Q < 0, \"fa_bwd_dkv4_asm.inc: phase-1 variant not generated\");\n#endif\n    }\n"
+    s += ("    template <int Q, int PAR, int MM, int RM, int LD, int DMA>\n"
+          "    static __device__ __forceinline__ void p2(unsigned ra0, unsigned ra1, __amdgpu_buffer_rsrc_t lsrd, __amdgpu_buffer_rsrc_t dsrd, unsigned lvo,\n"
+          "                                              unsigned lso, unsigned dlds, __amdgpu_buffer_rsrc_t qsrd, __amdgpu_buffer_rsrc_t gsrd, unsigned dso,\n"
+          "                                              unsigned vorm0, unsigned vorm1, unsigned vost0, unsigned vost1) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n"
+          "        (void)ra0; (void)ra1; (void)lsrd; (void)dsrd; (void)lvo; (void)lso; (void)dlds; (void)qsrd; (void)gsrd; (void)dso;\n"
+          "        (void)vorm0; (void)vorm1; (void)vost0; (void)vost1;\n"
+          "        if constexpr (DMA != 0) {\n            dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n            dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n        }\n"
+          "        if constexpr (LD != 0) lso = (unsigned)__builtin_amdgcn_readfirstlane((int)lso);\n")
+    first = True
+    for q in range(4):
+        for par in range(2):
+            for (mm, rm, ld, dma) in ((1, 1, 1, 1), (0, 1, 0, 0)):
+                s += f"        {'if' if first else 'else if'} constexpr (Q == {q} && PAR == {par} && MM == {mm} && RM == {rm} && LD == {ld} && DMA == {dma}) {{\n"
+                s += gen_p2(c, q, par, mm, rm, ld, dma) + "        }\n"
+                first = False
+    s += "        else static_assert(Q < 0, \"fa_bwd_dkv4_asm.inc: phase-2 variant not generated\");\n#endif\n    }\n"
+    # ---- K / V fragments of the wave's 32 key rows: lane (key, hi) holds d = 16 ks + 8 hi .. + 7 (rows >= Sk read as 0)
+    lines = ["s_nop 4"]
+    for ks in range(c.KS):
+        lines.append(f"buffer_load_dwordx4 {c.frag(c.KF, ks)}, %[vo], %[ksrd], 0 offen offset:{32 * ks}")
+        lines.append(f"buffer_load_dwordx4 {c.frag(c.VF, ks)}, %[vo], %[vsrd], 0 offen offset:{32 * ks}")
+    lines.append("s_waitcnt vmcnt(0)")
+    s += "    static __device__ __forceinline__ void load_kv(__amdgpu_buffer_rsrc_t ksrd, __amdgpu_buffer_rsrc_t vsrd, unsigned vo) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+    s += emit_asm(lines, [], ['[ksrd] "s"(ksrd)', '[vsrd] "s"(vsrd)', '[vo] "v"(vo)'], ["memory"] + aregs(c.KF, 64), indent="        ")
+    s += "#endif\n    }\n"
+    # ---- accumulators to zero
+    lines = [f"v_accvgpr_write_b32 a{i}, 0" for i in range(128)]
+    s += "    static __device__ __forceinline__ void zero_acc() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+    s += emit_asm(lines, [], [], aregs(0, 128), indent="        ")
+    s += "#endif\n    }\n"
+    # ---- L' / delta of a block straight into the buffers of parity PAR (stream start); SCALE: L' times log2(e) right away
+    s += ("    template <int PAR, int SCALE>\n    static __device__ __forceinline__ void load_scal(__amdgpu_buffer_rsrc_t lsrd, __amdgpu_buffer_rsrc_t dsrd, unsigned lvo, unsigned lso) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n        lso = (unsigned)__builtin_amdgcn_readfirstlane((int)lso);\n")
+    first = True
+    for par in range(2):
+        for scale in range(2):
+            lines = ["s_nop 4"]
+            for g in range(4):
+                lines.append(f"buffer_load_dwordx4 v[{c.LD + 16 * par + 4 * g}:{c.LD + 16 * par + 4 * g + 3}], %[lvo], %[lsrd], %[lso] offen offset:{32 * g}")
+                lines.append(f"buffer_load_dwordx4 v[{c.DL + 16 * par + 4 * g}:{c.DL + 16 * par + 4 * g + 3}], %[lvo], %[dsrd], %[lso] offen offset:{32 * g}")
+            lines.append("s_waitcnt vmcnt(0)")
+            if scale:
+                for i in range(16):
+                    lines.append(f"v_mul_f32 v{c.LD + 16 * par + i}, 0x3fb8aa3b, v{c.LD + 16 * par + i}")
+            s += f"        {'if' if first else 'else if'} constexpr (PAR == {par} && SCALE == {scale}) {{\n"
+            s += emit_asm(lines, [], ['[lsrd] "s"(lsrd)', '[dsrd] "s"(dsrd)', '[lvo] "v"(lvo)', '[lso] "s"(lso)'],
+                          ["memory"] + vregs(c.LD + 16 * par, 16) + vregs(c.DL + 16 * par, 16))
+            s += "        }\n"
+            first = False
+    s += "#endif\n    }\n"
+    # ---- the LDS-DMA pieces of one block as a statement of its own (stream start)
+    lines = ["s_nop 4"]
+    for pi in range(c.NP):
+        img, half = pi // 2, pi % 2
+        srd = "%[qsrd]" if img < 2 else "%[gsrd]"
+        vo = ("%[vorm" if img in (0, 2) else "%[vost") + f"{half}]"
+        lines += [f"s_add_u32 m0, %[dlds], {img * c.IMG + half * 1024}", "s_nop 0", f"buffer_load_dwordx4 {vo}, {srd}, %[dso] offen lds"]
+    s += ("    static __device__ __forceinline__ void dma_block(unsigned dlds, __amdgpu_buffer_rsrc_t qsrd, __amdgpu_buffer_rsrc_t gsrd, unsigned dso,\n"
+          "                                                     unsigned vorm0, unsigned vorm1, unsigned vost0, unsigned vost1) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+          "        dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n        dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n")
+    s += emit_asm(lines, [], ['[dlds] "s"(dlds)', '[qsrd] "s"(qsrd)', '[gsrd] "s"(gsrd)', '[dso] "s"(dso)', '[vorm0] "v"(vorm0)', '[vorm1] "v"(vorm1)',
+                              '[vost0] "v"(vost0)', '[vost1] "v"(vost1)'], ["memory", "m0", "scc"], indent="        ")
+    s += "#endif\n    }\n"
+    # ---- one accumulator register
+    s += "};\n\n"
+    return s
+
+
+def main():
+    hdr = ("// fa_bwd_dkv4_asm.inc -- GENERATED by tools/gen_bw4.py (do not edit; edit the generator and re-run it).\n"
+           "// Instruction streams of the one-wave-per-SIMD dK / dV kernel: register map, pipeline and hazards in the generator's docstring.\n"
+           "// Included by fa_bwd_dkv4_gfx950.hip inside namespace aule_hip::{anonymous}.\n\n"
+           "template <class T, int D> struct Bw4Asm;\n\n")
+    body = ""
+    for dt in ("bf16", "fp16"):
+        body += gen_struct(Cfg(128, dt))
+    with open(OUT, "w") as fh:
+        fh.write(hdr + body)
+    c = Cfg(128, "bf16")
+    print(f"wrote {OUT}: {len((hdr + body).splitlines())} lines; NV={c.NV} T={c.T} DL={c.DL} LD={c.LD} DS={c.DS} P={c.P} DP={c.DP} S={c.S} Y={c.Y} X={c.X}")
+
+
+if __name__ == "__main__":
+    main()
