@@ -326,12 +326,23 @@ bool bwd_dkv4_applicable(const BwdArgs& a) {
     // one descriptor covers the rows of a whole GQA group; byte offsets inside it are 32-bit
     if ((long long)(a.Hq / a.Hkv) * a.Sq * a.D * 2 >= (1LL << 31) || (long long)a.Sk * a.D * 2 >= (1LL << 31)) return false;
     if (mode == 2) return true;
-    // Where it pays (same box, tools/bwd_ab.py): grouped heads -- the whole group runs inside one workgroup, so there is no head
-    // split, no fp32 partials and no reduce kernel (C3: 533 -> 491 us, fp16 MQA S8192: 1824 -> 1740) -- on grids that cover the
-    // chip.  For plain MHA the two kernels are within 1 % of each other (the predecessor stays).
+    // Where it pays (same box, tools/bwd_ab2.py): kernel against kernel the two are within +-5 % of each other (this one 4-6 %
+    // behind on large grids); it wins where the predecessor has to SPLIT the query heads of a group over workgroups to cover
+    // the chip (fp32 partials + a reduce kernel): with 128-key blocks there are twice the work items and the whole group runs
+    // inside one workgroup -- C3 (B4, 32q/8kv, S2048): 533 -> 504 us.  The dispatcher (fa_bwd_gfx950.hip) asks for that
+    // condition on top of this one.
     const int nkb = (a.Sk + kKvBlock4 - 1) / kKvBlock4;
     const long long items = (long long)a.B * a.Hkv * (a.causal ? (nkb + 1) / 2 : nkb);
     return a.Hq > a.Hkv && items >= 192;
+}
+
+// AULE_HIP_BWD_DKV=new: take every problem bwd_dkv4_applicable() accepts (tests)
+bool bwd_dkv4_forced() {
+    static const int v = [] {
+        const char* e = std::getenv("AULE_HIP_BWD_DKV");
+        return (e != nullptr && e[0] == 'n') ? 1 : 0;
+    }();
+    return v == 1;
 }
 
 int launch_bwd_dkv4(const BwdArgs& a, hipStream_t stream) {

@@ -28,6 +28,7 @@
 namespace aule_hip {
 static bool dkv4_timeline_wanted() { const char* e = std::getenv("AULE_TL"); return e != nullptr && e[0] == 'd' && e[1] == 'k'; }   // AULE_TL=dkv4 (debug library)
 bool bwd_dkv4_applicable(const BwdArgs& a);          // fa_bwd_dkv4_gfx950.hip: the one-wave-per-SIMD dK/dV kernel
+bool bwd_dkv4_forced();
 int launch_bwd_dkv4(const BwdArgs& a, hipStream_t stream);
 int configure_bwd_dkv4();
 namespace {
@@ -1089,7 +1090,9 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
         int rc = (int)hipGetLastError();
         if (rc) return rc;
     }
-    if (D == 128 && (a.dbg == nullptr || dkv4_timeline_wanted()) && bwd_dkv4_applicable(a))   // one wave per SIMD, 128-key blocks, no head split: fa_bwd_dkv4_gfx950.hip
+    // (taken where this file's kernel would have to split the group's heads over workgroups: fp32 partials + reduce kernel)
+    if (D == 128 && (a.dbg == nullptr || dkv4_timeline_wanted()) && bwd_dkv4_applicable(a) &&
+        (bwd_dkv4_forced() || dkv4_timeline_wanted() || dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal) > 1))   // one wave per SIMD, 128-key blocks, no head split: fa_bwd_dkv4_gfx950.hip
         return launch_bwd_dkv4(a, stream);
     {
         const int nkb = (a.Sk + kKvBlock - 1) / kKvBlock;
