@@ -50,9 +50,13 @@ __global__ void __launch_bounds__(256) shadow(unsigned long long* cyc, float* ou
     if constexpr (KIND == 4) { if constexpr (NF > 0) asm volatile("v_fma_f32 v48, v49, s4, v51" ::: "v48"); if constexpr (NF > 1) asm volatile("v_exp_f32 v52, v53" ::: "v52"); if constexpr (NF > 2) asm volatile("v_add_f32 v56, v57, v58" ::: "v56"); if constexpr (NF > 3) asm volatile("v_fma_f32 v60, v61, s4, v63" ::: "v60"); if constexpr (NF > 4) asm volatile("v_exp_f32 v64, v65" ::: "v64"); if constexpr (NF > 5) asm volatile("v_add_f32 v68, v69, v70" ::: "v68"); if constexpr (NF > 6) asm volatile("v_cvt_pk_bf16_f32 v72, v73, v74" ::: "v72"); if constexpr (NF > 7) asm volatile("v_fma_f32 v76, v77, s4, v79" ::: "v76"); }
 #define LDS1(i) if constexpr (NF > i) asm volatile("ds_read_b64_tr_b16 v[%c1:%c2], %0 offset:%c3" :: "v"(la), "n"(48 + 2 * i), "n"(49 + 2 * i), "n"(256 * i) : "memory");
 #define LDS2(i) if constexpr (NF > i) asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" :: "v"(la), "n"(128 + 4 * i), "n"(131 + 4 * i), "n"(512 * i) : "memory");
+#define LDS3(i) if constexpr (NF > i) asm volatile("ds_read_b128 v[%c1:%c2], %0 offset:%c3" :: "v"(la), "n"(128 + 4 * i), "n"(131 + 4 * i), "n"(512 * i) : "memory");
+#define LDS4(i) if constexpr (NF > i) asm volatile("ds_read_b64_tr_b16 a[%c1:%c2], %0 offset:%c3" :: "v"(la), "n"(128 + 2 * i), "n"(129 + 2 * i), "n"(256 * i) : "memory");
 #define GROUP(a) asm volatile(MF(a) ::: "memory"); FILL(0) \
     if constexpr (KIND == 5) { LDS1(0) LDS1(1) LDS1(2) LDS1(3) LDS1(4) LDS1(5) LDS1(6) LDS1(7) } \
     if constexpr (KIND == 6) { LDS2(0) LDS2(1) LDS2(2) LDS2(3) LDS2(4) LDS2(5) LDS2(6) LDS2(7) } \
+    if constexpr (KIND == 9) { LDS3(0) LDS3(1) LDS3(2) LDS3(3) LDS3(4) LDS3(5) LDS3(6) LDS3(7) } \
+    if constexpr (KIND == 10) { LDS4(0) LDS4(1) LDS4(2) LDS4(3) LDS4(4) LDS4(5) LDS4(6) LDS4(7) } \
     if constexpr (KIND == 7) { asm volatile("v_exp_f32 v52, v53" ::: "v52"); asm volatile("v_fma_f32 v48, v49, s4, v51" ::: "v48"); asm volatile("v_add_f32 v56, v57, v58" ::: "v56"); if constexpr (NF > 0) asm volatile("v_cvt_pk_bf16_f32 v72, v73, v74" ::: "v72"); LDS1(1) LDS1(2) if constexpr (NF > 3) asm volatile("v_add_f32 v60, v61, v62" ::: "v60"); if constexpr (NF > 4) asm volatile("v_add_f32 v64, v61, v62" ::: "v64");} \
     if constexpr (KIND == 8) { if constexpr (NF > 0) asm volatile("s_add_u32 m0, %0, 0\n v_add_f32 v60, v61, v62\n buffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(ldsb), "v"(vo), "s"(srd) : "memory", "m0", "scc", "v60"); if constexpr (NF > 1) asm volatile("v_exp_f32 v52, v53" ::: "v52"); if constexpr (NF > 2) asm volatile("v_fma_f32 v48, v49, s4, v51" ::: "v48"); }
         REP4(GROUP("64:79") GROUP("80:95") GROUP("96:111") GROUP("112:127"))
@@ -82,6 +86,6 @@ int main() {
     double r[9] = {run(alone<0>, it), run(alone<1>, it), run(alone<2>, it), run(alone<3>, it), run(alone<4>, it), run(alone<5>, it), run(alone<6>, it), run(alone<7>, it), run(alone<8>, it)};
     for (int i = 0; i < 9; ++i) printf("alone  %-16s %6.2f cycles per instruction\n", names[i], r[i] / (64.0 * it));
     sweep<0>("v_fma_f32"); sweep<1>("v_exp_f32"); sweep<2>("v_add_f32"); sweep<3>("v_cvt_pk_bf16"); sweep<4>("softmax mix");
-    sweep<5>("ds_read_tr_b64"); sweep<6>("ds_read_b128>a"); sweep<7>("exp+fma+add +n"); sweep<8>("dma,exp,fma");
+    sweep<5>("ds_read_tr_b64"); sweep<6>("ds_read_b128>a"); sweep<7>("exp+fma+add +n"); sweep<8>("dma,exp,fma"); sweep<9>("ds_read_b128>v"); sweep<10>("ds_read_tr>a");
     return 0;
 }
