@@ -100,18 +100,20 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
     const size_t kvbase = (size_t)(w.b * p.Hkv + w.hk) * Sk;
 
     // lane constants
-    const unsigned tr_off = (unsigned)(hi * (D / 16) * 128 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8);
-    const unsigned a_sw = (unsigned)(l31 * RB + (((l31 & (CPR - 1)) ^ hi) * 16));   // row-major image: chunk (2 ks + hi) ^ swz(row) = a_sw ^ 32 ks
-    // per-lane source offsets of this wave's two pieces (64 chunks each) of an image: row-major swizzled / sub-tiled
-    unsigned vorm[2], vost[2];
+    // one image per tensor and block (layout: tools/gen_bw4.py, Cfg.PBASE): row group rg = row / 4 is a 1024-byte piece of eight
+    // [4 rows][16 d] sub-tiles at pbase(rg)
+    auto pbase = [](int rg) { return 1024 * rg + (rg & 1) * 16 + ((rg >> 1) & 1) * 128 + (rg >> 2) * 256; };
+    static_assert(A::PB1 == 1040 && A::PB2 == 2048 + 128 && A::PB4 == 4096 + 256, "piece bases of the generator");
+    const unsigned tr_off = (unsigned)(hi * 1040 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8);   // + the read's row-octet / d-slice immediate
+    const unsigned a_sub = (unsigned)(pbase(l31 >> 2) + (l31 & 3) * 32 + hi * 16);                 // row l31, d = 16 ks + 8 hi ..: + 128 ks
+    // per-lane source offsets of this wave's two pieces (row groups 2 w, 2 w + 1) of an image: LDS position = lane
+    unsigned vost[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int q = (2 * wave + h) * 64 + lane;
-        const int r = q / CPR, cs = q % CPR;
-        vorm[h] = (unsigned)(r * RB + (cs ^ (r & (CPR - 1))) * 16);
-        const int bidx = q >> 3;
-        vost[h] = (unsigned)(((bidx / (D / 16)) * 4 + ((q >> 1) & 3)) * RB + ((bidx % (D / 16)) * 2 + (q & 1)) * 16);
+        const int rg = 2 * wave + h;
+        vost[h] = (unsigned)((rg * 4 + ((lane >> 1) & 3)) * RB + ((lane >> 3) * 2 + (lane & 1)) * 16);
     }
+    const unsigned wave_pb = (unsigned)pbase(2 * wave);
     const unsigned lvo = (unsigned)(hi * 16);   // L' / delta: rows 8 g + 4 hi .. + 3 of the block per dwordx4
     const unsigned oob = 0x7ffffff0u;            // a scalar offset beyond every descriptor: the request writes zeros / the load reads 0
 
@@ -176,21 +178,21 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             Cur cur{ntq, row_first, 0}, c2 = cur, c4 = cur;   // blocks i, i + 2, i + 4 of the stream
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                A::dma_block(slot_lds(x) + (unsigned)wave * 2048u, qrs, grs, blk_off(c4), vorm[0], vorm[1], vost[0], vost[1]);
+                A::dma_block(slot_lds(x) + wave_pb, qrs, grs, blk_off(c4), vost[0], vost[1]);
                 adv(c4);
             }
-            A::template load_scal<0, 1>(lrs, drs, lvo, scal_off(c2));
+            A::template load_scal<0, 0>(lrs, drs, lvo, scal_off(c2));
             adv(c2);
             A::template load_scal<1, 0>(lrs, drs, lvo, scal_off(c2));
             adv(c2);
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             const __amdgpu_buffer_rsrc_t nosrd = make_srd(nullptr, 0);
             auto rm_reads = [&](int x) __attribute__((always_inline)) {   // row-major fragments of block x -> the accumulator file
-                const unsigned b = slot_lds(x) + a_sw;
-                A::template p2<0, 0, 0, 1, 0, 0>(b ^ 0u, b ^ 32u, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0, 0, 0);
-                A::template p2<1, 0, 0, 1, 0, 0>(b ^ 64u, b ^ 96u, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0, 0, 0);
-                A::template p2<2, 0, 0, 1, 0, 0>(b ^ 128u, b ^ 160u, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0, 0, 0);
-                A::template p2<3, 0, 0, 1, 0, 0>(b ^ 192u, b ^ 224u, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0, 0, 0);
+                const unsigned b = slot_lds(x) + a_sub;
+                A::template p2<0, 0, 0, 1, 0, 0>(b, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<1, 0, 0, 1, 0, 0>(b, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<2, 0, 0, 1, 0, 0>(b, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<3, 0, 0, 1, 0, 0>(b, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
             rm_reads(0);
@@ -223,17 +225,18 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
 #undef DKV4_P1
                 // block i + 2 has landed for everybody (all but this wave's newest NP requests -- block i + 3 -- are complete:
                 // the scalars of block i + 1 among them); every wave is done with the images of block i
-                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                static_assert(A::NP == 4, "the wait below");
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 unsigned long long t1 = 0;
                 if constexpr (TL) { t1 = __builtin_amdgcn_s_memtime(); tl_a += t1 - t0; }
-                const unsigned b = slot_lds(i + 2) + a_sw;
+                const unsigned b = slot_lds(i + 2) + a_sub;
                 {
                     const unsigned lso = scal_off(c2), dso = blk_off(c4);
-                    const unsigned dl = slot_lds(i) + (unsigned)wave * 2048u;   // (block i + 4 takes block i's slot)
-                    A::template p2<0, PAR, 1, 1, 1, 1>(b ^ 0u, b ^ 32u, lrs, drs, lvo, lso, dl, qrs, grs, dso, vorm[0], vorm[1], vost[0], vost[1]);
-                    A::template p2<1, PAR, 1, 1, 1, 1>(b ^ 64u, b ^ 96u, lrs, drs, lvo, lso, dl, qrs, grs, dso, vorm[0], vorm[1], vost[0], vost[1]);
-                    A::template p2<2, PAR, 1, 1, 1, 1>(b ^ 128u, b ^ 160u, lrs, drs, lvo, lso, dl, qrs, grs, dso, vorm[0], vorm[1], vost[0], vost[1]);
-                    A::template p2<3, PAR, 1, 1, 1, 1>(b ^ 192u, b ^ 224u, lrs, drs, lvo, lso, dl, qrs, grs, dso, vorm[0], vorm[1], vost[0], vost[1]);
+                    const unsigned dl = slot_lds(i) + wave_pb;   // (block i + 4 takes block i's slot)
+                    A::template p2<0, PAR, 1, 1, 1, 1>(b, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<1, PAR, 1, 1, 1, 1>(b, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<2, PAR, 1, 1, 1, 1>(b, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<3, PAR, 1, 1, 1, 1>(b, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments of block i + 2 (phase 1 of the next iteration reads them)
                 adv(cur); adv(c2); adv(c4);
@@ -277,7 +280,7 @@ constexpr int kDkv4Lds = 4 * Bw4Asm<Bf16Traits, 128>::SLOT;
 template <class T>
 int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
     Dkv4Params p;
-    p.q = a.q; p.k = a.k; p.v = a.v; p.dout = a.dout; p.lse = a.lse; p.delta = a.delta;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.dout = a.dout; p.lse = a.lse2; p.delta = a.delta;   // (lse: L' = LSE log2(e), written by the dQ kernel next to delta)
     p.dk = a.dk; p.dv = a.dv;
     p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
     p.c = a.scale * kLog2e;

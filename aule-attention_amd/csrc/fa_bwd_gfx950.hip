@@ -76,6 +76,7 @@ struct BwdParams {
     const float* delta;   // dkdv kernel: read (written by the dQ kernel)
     const void* o;        // dQ kernel: forward output, for delta = rowsum(O * dO)
     float* delta_out;     // dQ kernel: where it publishes delta for the dK/dV kernel
+    float* lse2_out;      // dQ kernel: where it publishes L' = LSE log2(e) (the one-wave-per-SIMD dK/dV kernel reads it scaled)
     void* dq;
     void* dk;
     void* dv;
@@ -423,7 +424,10 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
                 for (int i = 0; i < 4; ++i) part += T::lo(ov[i]) * T::lo(gv[i]) + T::hi(ov[i]) * T::hi(gv[i]);
             }
             delta = part + xhalf(part);
-            if (hi == 0 && qrow < Sq) p.delta_out[qbase + qrow] = delta;
+            if (hi == 0 && qrow < Sq) {
+                p.delta_out[qbase + qrow] = delta;
+                p.lse2_out[qbase + qrow] = -nlse2;
+            }
         }
         const int kv_lim = CAUSAL ? min(Sk - 1, qrow + coff) : Sk - 1;  // last key visible to this lane's query row
 
@@ -1058,6 +1062,7 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     BwdParams p;
     p.q = a.q; p.k = a.k; p.v = a.v; p.dout = a.dout; p.lse = a.lse; p.delta = a.delta;
     p.o = a.o; p.delta_out = a.delta;
+    p.lse2_out = reinterpret_cast<float*>(reinterpret_cast<char*>(a.delta) + delta_bytes(a.B, a.Hq, a.Sq));
     p.dq = a.dq; p.dk = a.dk; p.dv = a.dv;
     p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
     p.c = a.scale * kLog2e;
@@ -1093,12 +1098,16 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     // (taken where this file's kernel would have to split the group's heads over workgroups: fp32 partials + reduce kernel)
     if (D == 128 && (a.dbg == nullptr || dkv4_timeline_wanted()) && bwd_dkv4_applicable(a) &&
         (bwd_dkv4_forced() || dkv4_timeline_wanted() || dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal) > 1))   // one wave per SIMD, 128-key blocks, no head split: fa_bwd_dkv4_gfx950.hip
-        return launch_bwd_dkv4(a, stream);
+    {
+        BwdArgs b = a;
+        b.lse2 = p.lse2_out;
+        return launch_bwd_dkv4(b, stream);
+    }
     {
         const int nkb = (a.Sk + kKvBlock - 1) / kKvBlock;
         p.nblk = a.causal ? (nkb + 1) / 2 : nkb;  // causal: one workgroup per block pair (i, n-1-i)
         p.gsplit = dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal);
-        p.part = reinterpret_cast<float*>(reinterpret_cast<char*>(a.delta) + delta_bytes(a.B, a.Hq, a.Sq));
+        p.part = reinterpret_cast<float*>(reinterpret_cast<char*>(a.delta) + 2 * delta_bytes(a.B, a.Hq, a.Sq));
         const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv * p.gsplit)), block(512);
         p.dbg = a.dbg;
         bool tl_done = false;
@@ -1170,6 +1179,7 @@ int launch_delta_f32(const BwdArgs& a, hipStream_t stream) {
 uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype) {
     uint64_t bytes = delta_bytes(B, Hq, Sq);
     if (dtype != kF32) {
+        bytes += delta_bytes(B, Hq, Sq);   // L' = LSE log2(e), published by the dQ kernel with delta
         const int sp = dkdv_gsplit(B, Hq, Hkv, Sk, causal);
         if (sp > 1) bytes += 2ull * sp * B * Hkv * Sk * D * sizeof(float);
     }

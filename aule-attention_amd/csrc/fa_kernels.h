@@ -90,6 +90,7 @@ struct BwdArgs {
     void* dk;
     void* dv;
     float* delta;  // workspace of bwd_workspace_bytes(): delta [B,Hq,Sq] fp32 first
+    const float* lse2 = nullptr;   // internal (16-bit path): L' = LSE log2(e) [B,Hq,Sq], published by the dQ kernel behind delta
     int B, Hq, Hkv, Sq, Sk, D;
     float scale;
     int causal;

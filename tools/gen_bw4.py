@@ -48,9 +48,16 @@ class Cfg:
         self.KS, self.DB = D // 16, D // 32
         self.mfma = "v_mfma_f32_32x32x16_bf16" if dt == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dt == "bf16" else "v_cvt_pk_f16_f32"
-        self.IMG = 32 * self.RB                     # one image of a 32-row block (8 KB)
-        self.SLOT = 4 * self.IMG                    # Q rm, Q st, dO rm, dO st
-        self.NP = self.SLOT // 4 // 1024            # DMA pieces per wave and block (8)
+        # ONE image per tensor and 32-row block (round 3b; before: a swizzled row-major image for the ds_read_b128 fragments AND a
+        # sub-tiled one for the transpose reads, twice the LDS-DMA pieces).  Piece rg = the four rows 4 rg .. 4 rg + 3 as eight
+        # [4 rows][16 d] sub-tiles of 128 bytes (what a transpose read wants: a pass of 32 lanes covers two neighbouring
+        # sub-tiles, 256 contiguous bytes); the pieces sit at PBASE[rg] = 1024 rg + {0, 16, 128, 144}[rg & 3] + 256 (rg >> 2):
+        # a 16-lane pass of a ds_read_b128 (rows r .. r + 15 = four pieces, one 16-byte chunk each at (r & 3) 32 inside its
+        # sub-tile) then covers all 64 banks once.  No linear piece stride does that; the pads cost 512 bytes per image.
+        self.PBASE = [1024 * rg + (0, 16, 128, 144)[rg & 3] + 256 * (rg >> 2) for rg in range(8)]
+        self.IMG = 8704                             # >= PBASE[7] + 1024, a multiple of 256
+        self.SLOT = 2 * self.IMG                    # Q, dO
+        self.NP = 4                                 # DMA pieces per wave and block: row groups 2 w, 2 w + 1 of Q and of dO
         # accumulator file
         self.DV, self.DK, self.KF, self.VF, self.QA, self.DA = 0, 64, 128, 160, 192, 224
         # arch VGPRs, top down
@@ -140,12 +147,12 @@ def gen_p1(c, q, par, qk, ar, tr):
     if tr:
         for st in (2 * q, 2 * q + 1):
             kk, d = st // c.DB, st % c.DB
-            off = ((4 * kk) * (c.D // 16) + 2 * d) * 128
-            o2 = off + 2 * (c.D // 16) * 128
-            lds += [f"ds_read_b64_tr_b16 v[{c.X + 4 * st}:{c.X + 4 * st + 1}], %[trb] offset:{3 * c.IMG + off}",
-                    f"ds_read_b64_tr_b16 v[{c.X + 4 * st + 2}:{c.X + 4 * st + 3}], %[trb] offset:{3 * c.IMG + o2}",
-                    f"ds_read_b64_tr_b16 v[{c.Y + 4 * st}:{c.Y + 4 * st + 1}], %[trb] offset:{c.IMG + off}",
-                    f"ds_read_b64_tr_b16 v[{c.Y + 4 * st + 2}:{c.Y + 4 * st + 3}], %[trb] offset:{c.IMG + o2}"]
+            # rows 16 kk + 8 e + 4 hi .. + 3 (row group 2 (2 kk + e) + hi: the lane's constant carries PBASE[hi]), d = 32 d ..
+            off, o2 = (c.PBASE[2 * (2 * kk + e)] + 256 * d for e in (0, 1))
+            lds += [f"ds_read_b64_tr_b16 v[{c.X + 4 * st}:{c.X + 4 * st + 1}], %[trb] offset:{c.IMG + off}",
+                    f"ds_read_b64_tr_b16 v[{c.X + 4 * st + 2}:{c.X + 4 * st + 3}], %[trb] offset:{c.IMG + o2}",
+                    f"ds_read_b64_tr_b16 v[{c.Y + 4 * st}:{c.Y + 4 * st + 1}], %[trb] offset:{off}",
+                    f"ds_read_b64_tr_b16 v[{c.Y + 4 * st + 2}:{c.Y + 4 * st + 3}], %[trb] offset:{o2}"]
         clob += vregs(c.X + 8 * q, 8) + vregs(c.Y + 8 * q, 8)
     fill = lds + valu
     lines = deal(mf, fill)
@@ -164,7 +171,7 @@ def gen_p1(c, q, par, qk, ar, tr):
 def gen_p2(c, q, par, mm, rm, ld, dma):
     """phase-2 statement q.  mm: dV / dK MFMAs of the current block (steps 2 q, 2 q + 1).  rm: row-major fragment reads of block
     i + 2 (k-slices 2 q, 2 q + 1 of Q and dO).  ld: statement 0 requests L' of block i + 2, statement 1 its delta (four dwordx4
-    each, into the buffers of parity par), and every statement scales four L' of block i + 1 (parity par ^ 1) by log2(e).  dma:
+    each, into the buffers of parity par; L' = LSE log2(e) comes scaled from the dQ kernel's workspace).  dma:
     statements 2 and 3 carry the eight LDS-DMA pieces of block i + 4 (image q - 2 ... : pieces 4 (q - 2) .. + 3).  All the
     requests for scalars come before all the pieces: the phase boundary's vmcnt(NP) then covers exactly the scalars."""
     mf, clob = [], ["memory"]
@@ -178,11 +185,11 @@ def gen_p2(c, q, par, mm, rm, ld, dma):
     fill = []
     ins = []
     if rm:
-        for t, ks in enumerate((2 * q, 2 * q + 1)):
-            fill.append(f"ds_read_b128 {c.frag(c.QA, ks)}, %[ra{t}]")
-            fill.append(f"ds_read_b128 {c.frag(c.DA, ks)}, %[ra{t}] offset:{2 * c.IMG}")
+        for ks in (2 * q, 2 * q + 1):               # d = 16 ks + 8 hi ..: sub-tile ks of the lane's row group, chunk hi
+            fill.append(f"ds_read_b128 {c.frag(c.QA, ks)}, %[ra] offset:{128 * ks}")
+            fill.append(f"ds_read_b128 {c.frag(c.DA, ks)}, %[ra] offset:{c.IMG + 128 * ks}")
             clob += aregs(c.QA + 4 * ks, 4) + aregs(c.DA + 4 * ks, 4)
-        ins += ['[ra0] "v"(ra0)', '[ra1] "v"(ra1)']
+        ins += ['[ra] "v"(ra)']
     if ld:
         if q < 2:
             base = (c.LD if q == 0 else c.DL) + 16 * par
@@ -191,19 +198,14 @@ def gen_p2(c, q, par, mm, rm, ld, dma):
                 fill.append(f"buffer_load_dwordx4 v[{base + 4 * g}:{base + 4 * g + 3}], %[lvo], {srd}, %[lso] offen offset:{32 * g}")
             clob += vregs(base, 16)
             ins += ['[lsrd] "s"(lsrd)' if q == 0 else '[dsrd] "s"(dsrd)', '[lvo] "v"(lvo)', '[lso] "s"(lso)']
-        for i in range(4):
-            r = c.LD + 16 * (par ^ 1) + 4 * q + i
-            fill.append(f"v_mul_f32 v{r}, 0x3fb8aa3b, v{r}")
-        clob += vregs(c.LD + 16 * (par ^ 1) + 4 * q, 4)
     if dma and q >= 2:
-        for pi in range(4 * (q - 2), 4 * (q - 2) + 4):      # piece of this wave: image pi / 2, half pi % 2
-            img, half = pi // 2, pi % 2
-            srd = "%[qsrd]" if img < 2 else "%[gsrd]"
-            vo = f"%[vorm{half}]" if img in (0, 2) else f"%[vost{half}]"
-            fill += [f"s_add_u32 m0, %[dlds], {img * c.IMG + half * 1024}", "s_nop 0", f"buffer_load_dwordx4 {vo}, {srd}, %[dso] offen lds"]
+        img = q - 2                                         # statement 2: Q, statement 3: dO; the wave's row groups 2 w, 2 w + 1
+        srd = "%[qsrd]" if img == 0 else "%[gsrd]"            # (dlds = slot + PBASE[2 w]; PBASE[2 w + 1] - PBASE[2 w] = 1040)
+        for half in range(2):
+            fill += [f"s_add_u32 m0, %[dlds], {img * c.IMG + half * 1040}", "s_nop 0", f"buffer_load_dwordx4 %[vost{half}], {srd}, %[dso] offen lds"]
         clob += ["m0", "scc"]
         ins += ['[dlds] "s"(dlds)', '[qsrd] "s"(qsrd)' if q == 2 else '[gsrd] "s"(gsrd)', '[dso] "s"(dso)',
-                '[vorm0] "v"(vorm0)', '[vorm1] "v"(vorm1)', '[vost0] "v"(vost0)', '[vost1] "v"(vost1)']
+                '[vost0] "v"(vost0)', '[vost1] "v"(vost1)']
     lines = deal(mf, fill)
     return emit_asm(lines, [], ins, clob)
 
@@ -211,7 +213,7 @@ def gen_p2(c, q, par, mm, rm, ld, dma):
 def gen_struct(c):
     name = f"Bw4Asm<{'Bf16Traits' if c.dt == 'bf16' else 'F16Traits'}, {c.D}>"
     s = f"template <> struct {name} {{\n"
-    s += f"    static constexpr int NV = {c.NV}, NP = {c.NP}, SLOT = {c.SLOT}, IMG = {c.IMG};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n"
+    s += f"    static constexpr int NV = {c.NV}, NP = {c.NP}, SLOT = {c.SLOT}, IMG = {c.IMG}, PB1 = {c.PBASE[1]}, PB2 = {c.PBASE[2]}, PB4 = {c.PBASE[4]};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n"
     s += ("    template <int Q, int PAR, int QK, int AR, int TR>\n"
           "    static __device__ __forceinline__ void p1(float c, int lo, int wd, unsigned trb) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n        (void)c; (void)lo; (void)wd; (void)trb;\n")
@@ -224,12 +226,12 @@ def gen_struct(c):
                 first = False
     s += "        else static_assert(Q < 0, \"fa_bwd_dkv4_asm.inc: phase-1 variant not generated\");\n#endif\n    }\n"
     s += ("    template <int Q, int PAR, int MM, int RM, int LD, int DMA>\n"
-          "    static __device__ __forceinline__ void p2(unsigned ra0, unsigned ra1, __amdgpu_buffer_rsrc_t lsrd, __amdgpu_buffer_rsrc_t dsrd, unsigned lvo,\n"
+          "    static __device__ __forceinline__ void p2(unsigned ra, __amdgpu_buffer_rsrc_t lsrd, __amdgpu_buffer_rsrc_t dsrd, unsigned lvo,\n"
           "                                              unsigned lso, unsigned dlds, __amdgpu_buffer_rsrc_t qsrd, __amdgpu_buffer_rsrc_t gsrd, unsigned dso,\n"
-          "                                              unsigned vorm0, unsigned vorm1, unsigned vost0, unsigned vost1) {\n"
+          "                                              unsigned vost0, unsigned vost1) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
-          "        (void)ra0; (void)ra1; (void)lsrd; (void)dsrd; (void)lvo; (void)lso; (void)dlds; (void)qsrd; (void)gsrd; (void)dso;\n"
-          "        (void)vorm0; (void)vorm1; (void)vost0; (void)vost1;\n"
+          "        (void)ra; (void)lsrd; (void)dsrd; (void)lvo; (void)lso; (void)dlds; (void)qsrd; (void)gsrd; (void)dso;\n"
+          "        (void)vost0; (void)vost1;\n"
           "        if constexpr (DMA != 0) {\n            dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n            dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n        }\n"
           "        if constexpr (LD != 0) lso = (unsigned)__builtin_amdgcn_readfirstlane((int)lso);\n")
     first = True
@@ -278,13 +280,12 @@ def gen_struct(c):
     lines = ["s_nop 4"]
     for pi in range(c.NP):
         img, half = pi // 2, pi % 2
-        srd = "%[qsrd]" if img < 2 else "%[gsrd]"
-        vo = ("%[vorm" if img in (0, 2) else "%[vost") + f"{half}]"
-        lines += [f"s_add_u32 m0, %[dlds], {img * c.IMG + half * 1024}", "s_nop 0", f"buffer_load_dwordx4 {vo}, {srd}, %[dso] offen lds"]
+        srd = "%[qsrd]" if img == 0 else "%[gsrd]"
+        lines += [f"s_add_u32 m0, %[dlds], {img * c.IMG + half * 1040}", "s_nop 0", f"buffer_load_dwordx4 %[vost{half}], {srd}, %[dso] offen lds"]
     s += ("    static __device__ __forceinline__ void dma_block(unsigned dlds, __amdgpu_buffer_rsrc_t qsrd, __amdgpu_buffer_rsrc_t gsrd, unsigned dso,\n"
-          "                                                     unsigned vorm0, unsigned vorm1, unsigned vost0, unsigned vost1) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+          "                                                     unsigned vost0, unsigned vost1) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
           "        dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n        dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n")
-    s += emit_asm(lines, [], ['[dlds] "s"(dlds)', '[qsrd] "s"(qsrd)', '[gsrd] "s"(gsrd)', '[dso] "s"(dso)', '[vorm0] "v"(vorm0)', '[vorm1] "v"(vorm1)',
+    s += emit_asm(lines, [], ['[dlds] "s"(dlds)', '[qsrd] "s"(qsrd)', '[gsrd] "s"(gsrd)', '[dso] "s"(dso)',
                               '[vost0] "v"(vost0)', '[vost1] "v"(vost1)'], ["memory", "m0", "scc"], indent="        ")
     s += "#endif\n    }\n"
     # ---- one accumulator register
