@@ -52,6 +52,9 @@ struct Dkv4Params {
 
 constexpr int kKvBlock4 = 128;   // 4 waves x 32 key rows
 constexpr int kQB = 32;          // query rows per block of the stream
+constexpr int kRing4 = 8;        // slots of the LDS ring (17 KB each).  Blocks are requested four iterations ahead; eight slots keep a
+                                 // block's images readable through the phase 2 that requests block i + 4 (its transpose reads are
+                                 // split over both phases)
 
 template <int N>
 __device__ __forceinline__ float dkv4_acc_read() {
@@ -115,7 +118,6 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
     }
     const unsigned wave_pb = (unsigned)pbase(2 * wave);
     const unsigned lvo = (unsigned)(hi * 16);   // L' / delta: rows 8 g + 4 hi .. + 3 of the block per dwordx4
-    const unsigned oob = 0x7ffffff0u;            // a scalar offset beyond every descriptor: the request writes zeros / the load reads 0
 
     unsigned long long tl_a = 0, tl_b = 0, tl_n = 0;
     const int nparts = (CAUSAL && (nkb - 1 - w.blk) != w.blk) ? 2 : 1;
@@ -153,17 +155,19 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             if (--cu.left == 0) { cu.left = ntq; cu.row += row_wrap; cu.t = 0; }
             else { cu.row += kQB; ++cu.t; }
         };
-        const int row_end = g * Sq;   // a cursor at or beyond it points behind the stream
-        auto blk_off = [&](const Cur& cu) __attribute__((always_inline)) { return cu.row < row_end ? (unsigned)cu.row * (unsigned)RB : oob; };
-        auto scal_off = [&](const Cur& cu) __attribute__((always_inline)) { return cu.row < row_end ? (unsigned)cu.row * 4u : oob; };
-        auto slot_lds = [&](int x) __attribute__((always_inline)) { return lds0 + (unsigned)(x & 3) * SLOT; };
-        // mask of block x for this lane: rows [lo, lo + wd) of the block are valid (as crow(r) + 4 hi); need = somebody needs it
-        auto mask_need = [&](const Cur& cu) __attribute__((always_inline)) {   // (scalar) does anybody's lane need a mask in this block?
-            const int q0 = (first_qt + cu.t) * kQB;
-            return (CAUSAL && q0 + coff < n0w + 31) || (q0 + kQB > Sq) || (n0w + 32 > Sk);
-        };
-        auto mask_of = [&](const Cur& cu, int& lo, int& wd) __attribute__((always_inline)) {
-            const int q0 = (first_qt + cu.t) * kQB;
+        // (a cursor behind the stream's last block needs no special offset: the scalar offset is part of the descriptor's range
+        // check on gfx950 -- tools/probe_soffset.hip -- so rows >= g Sq read zeros / the request writes zeros)
+        auto slot_lds = [&](int x) __attribute__((always_inline)) { return lds0 + (unsigned)(x & (kRing4 - 1)) * SLOT; };
+        // Does anybody's lane need a mask in block t of a head?  The causal diagonal covers the head's first t_diag blocks (every
+        // block if the wave's 32 keys run past Sk), a ragged Sq its last one.
+        const int diag_x = CAUSAL ? n0w + 31 - coff - first_qt * kQB : 0;   // block t crosses the diagonal iff t kQB < diag_x
+        const int t_diag = (n0w + 32 > Sk) ? 0x7fffffff : (diag_x > 0 ? (diag_x + kQB - 1) / kQB : 0);
+        const int t_plain_end = (Sq % kQB) != 0 ? ntq - 1 : 0x7fffffff;   // blocks t_diag <= t < t_plain_end need no mask:
+        const unsigned t_lo = (unsigned)dkv4_rfl(t_diag);                  // ONE unsigned compare per iteration, t - t_lo < t_span
+        const unsigned t_span = (unsigned)dkv4_rfl(t_plain_end > t_diag ? t_plain_end - t_diag : 0);
+        // mask of block t for this lane: rows [lo, lo + wd) of the block are valid (as crow(r) + 4 hi)
+        auto mask_of = [&](int t, int& lo, int& wd) __attribute__((always_inline)) {
+            const int q0 = (first_qt + t) * kQB;
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const int kr = n0w + (lane_o & 31);
@@ -174,25 +178,30 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
         };
 
         if (nit > 0) {
-            // ---- stream start: blocks 0 .. 3 requested, L' / delta of blocks 0 and 1, the fragments of block 0, S_0 / dP_0
-            Cur cur{ntq, row_first, 0}, c2 = cur, c4 = cur;   // blocks i, i + 2, i + 4 of the stream
+            // ---- stream start: blocks 0 .. 3 requested, L' / delta of blocks 0 and 1, the fragments of block 0, S_0 / dP_0.
+            // ONE cursor walks the stream, four blocks ahead of the iteration (the block being requested); what an iteration needs
+            // of blocks i (its place in the head, for the mask) and i + 2 (its row, for L' / delta) are values the cursor had four /
+            // two iterations earlier, kept by block parity (the loop is unrolled by two) -- a second and a third cursor cost ten
+            // scalar instructions per iteration, and one wave per SIMD pays ~4.6 cycles of issue for every instruction.
+            Cur c4{ntq, row_first, 0};
+            int t_cur[2], t_nxt[2], row_nxt[2], row_01[2];
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                A::dma_block(slot_lds(x) + wave_pb, qrs, grs, blk_off(c4), vost[0], vost[1]);
+                A::dma_block(slot_lds(x) + wave_pb, qrs, grs, (unsigned)c4.row * (unsigned)RB, vost[0], vost[1]);
+                if (x < 2) { t_cur[x] = c4.t; row_01[x] = c4.row; }
+                else { t_nxt[x - 2] = c4.t; row_nxt[x - 2] = c4.row; }
                 adv(c4);
             }
-            A::template load_scal<0, 0>(lrs, drs, lvo, scal_off(c2));
-            adv(c2);
-            A::template load_scal<1, 0>(lrs, drs, lvo, scal_off(c2));
-            adv(c2);
+            A::template load_scal<0, 0>(lrs, drs, lvo, (unsigned)row_01[0] * 4u);
+            A::template load_scal<1, 0>(lrs, drs, lvo, (unsigned)row_01[1] * 4u);
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             const __amdgpu_buffer_rsrc_t nosrd = make_srd(nullptr, 0);
             auto rm_reads = [&](int x) __attribute__((always_inline)) {   // row-major fragments of block x -> the accumulator file
                 const unsigned b = slot_lds(x) + a_sub;
-                A::template p2<0, 0, 0, 1, 0, 0>(b, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
-                A::template p2<1, 0, 0, 1, 0, 0>(b, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
-                A::template p2<2, 0, 0, 1, 0, 0>(b, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
-                A::template p2<3, 0, 0, 1, 0, 0>(b, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<0, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<1, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<2, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<3, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
             rm_reads(0);
@@ -202,49 +211,58 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             A::template p1<3, 1, 1, 0, 0>(c, 0, 0, 0);
             if (nit > 1) rm_reads(1);
 
-            // ---- the stream
-            auto iteration = [&](auto par_tag, int i) __attribute__((always_inline)) {
-                constexpr int PAR = decltype(par_tag)::value;
+            // ---- the stream.  QK = 0: the last iteration (no next block to start)
+            auto iteration = [&](auto par_tag, auto qk_tag, int i) __attribute__((always_inline)) {
+                constexpr int PAR = decltype(par_tag)::value, QK = decltype(qk_tag)::value;
                 unsigned long long t0 = 0;
                 if constexpr (TL) t0 = __builtin_amdgcn_s_memtime();
-                int lo = 0, wd = 0;
-                const bool masked = mask_need(cur);
-                if (masked) mask_of(cur, lo, wd);
+                const int t = t_cur[PAR];
                 const unsigned trb = slot_lds(i) + tr_off;
-                const bool qk = i + 1 < nit;
-#define DKV4_P1(QK, AR)                                   \
-    A::template p1<0, PAR, QK, AR, 1>(c, lo, wd, trb);     \
-    A::template p1<1, PAR, QK, AR, 1>(c, lo, wd, trb);     \
-    A::template p1<2, PAR, QK, AR, 1>(c, lo, wd, trb);     \
-    A::template p1<3, PAR, QK, AR, 1>(c, lo, wd, trb);
-                if (qk) {
-                    if (masked) { DKV4_P1(1, 2) } else { DKV4_P1(1, 1) }
+#define DKV4_P1(AR, LO, WD)                               \
+    A::template p1<0, PAR, QK, AR, 1>(c, LO, WD, trb);     \
+    A::template p1<1, PAR, QK, AR, 1>(c, LO, WD, trb);     \
+    A::template p1<2, PAR, QK, AR, 1>(c, LO, WD, trb);     \
+    A::template p1<3, PAR, QK, AR, 1>(c, LO, WD, trb);
+                if ((unsigned)t - t_lo < t_span) {
+                    DKV4_P1(1, 0, 0)
                 } else {
-                    if (masked) { DKV4_P1(0, 2) } else { DKV4_P1(0, 1) }
+                    int lo, wd;
+                    mask_of(t, lo, wd);
+                    DKV4_P1(2, lo, wd)
                 }
 #undef DKV4_P1
                 // block i + 2 has landed for everybody (all but this wave's newest NP requests -- block i + 3 -- are complete:
-                // the scalars of block i + 1 among them); every wave is done with the images of block i
+                // the scalars of block i + 1 among them)
                 static_assert(A::NP == 4, "the wait below");
                 asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 unsigned long long t1 = 0;
                 if constexpr (TL) { t1 = __builtin_amdgcn_s_memtime(); tl_a += t1 - t0; }
                 const unsigned b = slot_lds(i + 2) + a_sub;
                 {
-                    const unsigned lso = scal_off(c2), dso = blk_off(c4);
-                    const unsigned dl = slot_lds(i) + wave_pb;   // (block i + 4 takes block i's slot)
-                    A::template p2<0, PAR, 1, 1, 1, 1>(b, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
-                    A::template p2<1, PAR, 1, 1, 1, 1>(b, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
-                    A::template p2<2, PAR, 1, 1, 1, 1>(b, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
-                    A::template p2<3, PAR, 1, 1, 1, 1>(b, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
+                    const unsigned lso = (unsigned)row_nxt[PAR] * 4u, dso = (unsigned)c4.row * (unsigned)RB;
+                    const unsigned dl = slot_lds(i + 4) + wave_pb;
+                    A::template p2<0, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<1, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<2, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<3, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments of block i + 2 (phase 1 of the next iteration reads them)
-                adv(cur); adv(c2); adv(c4);
+                t_cur[PAR] = t_nxt[PAR]; t_nxt[PAR] = c4.t; row_nxt[PAR] = c4.row;
+                adv(c4);
                 if constexpr (TL) { tl_b += __builtin_amdgcn_s_memtime() - t1; ++tl_n; }
             };
-            for (int i = 0; i < nit; i += 2) {
-                iteration(integral_constant<int, 0>{}, i);
-                if (i + 1 < nit) iteration(integral_constant<int, 1>{}, i + 1);
+            using I0 = integral_constant<int, 0>;
+            using I1 = integral_constant<int, 1>;
+            int i = 0;
+            for (; i + 2 < nit; i += 2) {
+                iteration(I0{}, I1{}, i);
+                iteration(I1{}, I1{}, i + 1);
+            }
+            if (nit - i == 2) {
+                iteration(I0{}, I1{}, i);
+                iteration(I1{}, I0{}, i + 1);
+            } else {
+                iteration(I0{}, I0{}, i);
             }
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // the out-of-range requests of the last iterations too
         }
@@ -275,7 +293,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(40))) f
 
 #pragma clang diagnostic pop
 
-constexpr int kDkv4Lds = 4 * Bw4Asm<Bf16Traits, 128>::SLOT;
+constexpr int kDkv4Lds = kRing4 * Bw4Asm<Bf16Traits, 128>::SLOT;
 
 template <class T>
 int launch_dkv4(const BwdArgs& a, hipStream_t stream) {

@@ -126,10 +126,24 @@ def deal(mfmas, fillers):
     return out
 
 
+def tr_reads(c, st):
+    """the four transpose reads of step st (k-step st / DB = 16 query rows, d-slice st % DB) of the current block: dO -> X, Q -> Y"""
+    kk, d = st // c.DB, st % c.DB
+    # rows 16 kk + 8 e + 4 hi .. + 3 (row group 2 (2 kk + e) + hi: the lane's constant carries PBASE[hi]), d = 32 d ..
+    off, o2 = (c.PBASE[2 * (2 * kk + e)] + 256 * d for e in (0, 1))
+    return [f"ds_read_b64_tr_b16 v[{c.X + 4 * st}:{c.X + 4 * st + 1}], %[trb] offset:{c.IMG + off}",
+            f"ds_read_b64_tr_b16 v[{c.X + 4 * st + 2}:{c.X + 4 * st + 3}], %[trb] offset:{c.IMG + o2}",
+            f"ds_read_b64_tr_b16 v[{c.Y + 4 * st}:{c.Y + 4 * st + 1}], %[trb] offset:{off}",
+            f"ds_read_b64_tr_b16 v[{c.Y + 4 * st + 2}:{c.Y + 4 * st + 3}], %[trb] offset:{o2}"]
+
+
+RM_SPLIT = (2, 2, 6, 6)        # ds_read_b128 of block i + 2 per phase-2 statement (16: k-slices 0 .. 7 of Q, dO)
+
+
 def gen_p1(c, q, par, qk, ar, tr):
     """phase-1 statement q of an iteration whose current block has parity par.  qk: MFMAs of the NEXT block's S / dP (k-slices
     2 q, 2 q + 1).  ar: 0 none, 1 plain, 2 masked arithmetic of the current block (scores 4 q ..).  tr: transpose reads of the
-    current block (steps 2 q, 2 q + 1: four ds_read_b64_tr_b16 each)."""
+    current block (step q of 0 .. 3: four ds_read_b64_tr_b16; steps 4 .. 7 are read in phase 2)."""
     mf, clob = [], ["memory"]
     npar = par ^ 1
     if qk:
@@ -144,16 +158,9 @@ def gen_p1(c, q, par, qk, ar, tr):
         if ar == 2:
             clob += ["vcc"]
     lds = []
-    if tr:
-        for st in (2 * q, 2 * q + 1):
-            kk, d = st // c.DB, st % c.DB
-            # rows 16 kk + 8 e + 4 hi .. + 3 (row group 2 (2 kk + e) + hi: the lane's constant carries PBASE[hi]), d = 32 d ..
-            off, o2 = (c.PBASE[2 * (2 * kk + e)] + 256 * d for e in (0, 1))
-            lds += [f"ds_read_b64_tr_b16 v[{c.X + 4 * st}:{c.X + 4 * st + 1}], %[trb] offset:{c.IMG + off}",
-                    f"ds_read_b64_tr_b16 v[{c.X + 4 * st + 2}:{c.X + 4 * st + 3}], %[trb] offset:{c.IMG + o2}",
-                    f"ds_read_b64_tr_b16 v[{c.Y + 4 * st}:{c.Y + 4 * st + 1}], %[trb] offset:{off}",
-                    f"ds_read_b64_tr_b16 v[{c.Y + 4 * st + 2}:{c.Y + 4 * st + 3}], %[trb] offset:{o2}"]
-        clob += vregs(c.X + 8 * q, 8) + vregs(c.Y + 8 * q, 8)
+    if tr:                                         # phase 1 carries steps 0 .. 3 (one per statement), phase 2 the other four
+        lds += tr_reads(c, q)
+        clob += vregs(c.X + 4 * q, 4) + vregs(c.Y + 4 * q, 4)
     fill = lds + valu
     lines = deal(mf, fill)
     if qk and not fill:
@@ -184,11 +191,24 @@ def gen_p2(c, q, par, mm, rm, ld, dma):
         clob += aregs(c.DV, 64) + aregs(c.DK, 64)
     fill = []
     ins = []
+    pre = []
+    if mm and q >= 2:
+        # steps 2 q, 2 q + 1 were requested in statement q - 2; LDS returns in order, what may still be out: the reads issued after
+        # them (q = 2: statement 0's row-major reads + all of statement 1's LDS reads; q = 3: statement 1's row-major reads + 2's)
+        later = RM_SPLIT[0] + 8 + RM_SPLIT[1] if q == 2 else RM_SPLIT[1] + RM_SPLIT[2]
+        pre.append(f"s_waitcnt lgkmcnt({min(later, 15)})")
+    if mm and q < 2:
+        for st in (4 + 2 * q, 5 + 2 * q):
+            fill += tr_reads(c, st)
+            clob += vregs(c.X + 4 * st, 4) + vregs(c.Y + 4 * st, 4)
+        ins.append('[trb] "v"(trb)')
     if rm:
-        for ks in (2 * q, 2 * q + 1):               # d = 16 ks + 8 hi ..: sub-tile ks of the lane's row group, chunk hi
-            fill.append(f"ds_read_b128 {c.frag(c.QA, ks)}, %[ra] offset:{128 * ks}")
-            fill.append(f"ds_read_b128 {c.frag(c.DA, ks)}, %[ra] offset:{c.IMG + 128 * ks}")
-            clob += aregs(c.QA + 4 * ks, 4) + aregs(c.DA + 4 * ks, 4)
+        order = [(ks, t) for ks in range(c.KS) for t in (0, 1)]       # (k-slice, Q / dO)
+        lo = sum(RM_SPLIT[:q]) if mm else 4 * q
+        n = RM_SPLIT[q] if mm else 4
+        for ks, t in order[lo:lo + n]:               # d = 16 ks + 8 hi ..: sub-tile ks of the lane's row group, chunk hi
+            fill.append(f"ds_read_b128 {c.frag(c.DA if t else c.QA, ks)}, %[ra] offset:{t * c.IMG + 128 * ks}")
+            clob += aregs((c.DA if t else c.QA) + 4 * ks, 4)
         ins += ['[ra] "v"(ra)']
     if ld:
         if q < 2:
@@ -206,7 +226,21 @@ def gen_p2(c, q, par, mm, rm, ld, dma):
         clob += ["m0", "scc"]
         ins += ['[dlds] "s"(dlds)', '[qsrd] "s"(qsrd)' if q == 2 else '[gsrd] "s"(gsrd)', '[dso] "s"(dso)',
                 '[vost0] "v"(vost0)', '[vost1] "v"(vost1)']
-    lines = deal(mf, fill)
+    lines = pre + deal(mf, fill)
+    if dma and q >= 2:
+        # the M0 write of a piece goes in front of the MFMA that precedes its request (the MFMA is the instruction an M0 write
+        # and the request that reads it have to be apart): no s_nop -- every instruction costs this wave ~4.6 cycles of issue
+        out = []
+        for ln in lines:
+            if ln == "s_nop 0":
+                continue
+            if ln.startswith("s_add_u32 m0"):
+                k = max(j for j, o in enumerate(out) if o.startswith("v_mfma"))
+                assert not any(o.startswith("s_add_u32 m0") or "lds" in o.split()[-1] for o in out[k:]), out[k:]
+                out.insert(k, ln)
+            else:
+                out.append(ln)
+        lines = out
     return emit_asm(lines, [], ins, clob)
 
 
@@ -226,11 +260,11 @@ def gen_struct(c):
                 first = False
     s += "        else static_assert(Q < 0, \"fa_bwd_dkv4_asm.inc: phase-1 variant not generated\");\n#endif\n    }\n"
     s += ("    template <int Q, int PAR, int MM, int RM, int LD, int DMA>\n"
-          "    static __device__ __forceinline__ void p2(unsigned ra, __amdgpu_buffer_rsrc_t lsrd, __amdgpu_buffer_rsrc_t dsrd, unsigned lvo,\n"
+          "    static __device__ __forceinline__ void p2(unsigned ra, unsigned trb, __amdgpu_buffer_rsrc_t lsrd, __amdgpu_buffer_rsrc_t dsrd, unsigned lvo,\n"
           "                                              unsigned lso, unsigned dlds, __amdgpu_buffer_rsrc_t qsrd, __amdgpu_buffer_rsrc_t gsrd, unsigned dso,\n"
           "                                              unsigned vost0, unsigned vost1) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
-          "        (void)ra; (void)lsrd; (void)dsrd; (void)lvo; (void)lso; (void)dlds; (void)qsrd; (void)gsrd; (void)dso;\n"
+          "        (void)ra; (void)trb; (void)lsrd; (void)dsrd; (void)lvo; (void)lso; (void)dlds; (void)qsrd; (void)gsrd; (void)dso;\n"
           "        (void)vost0; (void)vost1;\n"
           "        if constexpr (DMA != 0) {\n            dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n            dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n        }\n"
           "        if constexpr (LD != 0) lso = (unsigned)__builtin_amdgcn_readfirstlane((int)lso);\n")
