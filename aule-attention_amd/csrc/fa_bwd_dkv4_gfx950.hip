@@ -194,14 +194,15 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             }
             A::template load_scal<0, 0>(lrs, drs, lvo, (unsigned)row_01[0] * 4u);
             A::template load_scal<1, 0>(lrs, drs, lvo, (unsigned)row_01[1] * 4u);
+            A::load_delta_x(drs, lvo, (unsigned)row_nxt[0] * 4u);   // - delta of block 2: parked until dP_0 has read block 0's
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             const __amdgpu_buffer_rsrc_t nosrd = make_srd(nullptr, 0);
             auto rm_reads = [&](int x) __attribute__((always_inline)) {   // row-major fragments of block x -> the accumulator file
                 const unsigned b = slot_lds(x) + a_sub;
-                A::template p2<0, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
-                A::template p2<1, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
-                A::template p2<2, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
-                A::template p2<3, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<0, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<1, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<2, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<3, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
             rm_reads(0);
@@ -209,6 +210,7 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             A::template p1<1, 1, 1, 0, 0>(c, 0, 0, 0);
             A::template p1<2, 1, 1, 0, 0>(c, 0, 0, 0);
             A::template p1<3, 1, 1, 0, 0>(c, 0, 0, 0);
+            A::mov_delta_x();
             if (nit > 1) rm_reads(1);
 
             // ---- the stream.  QK = 0: the last iteration (no next block to start)
@@ -239,12 +241,12 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
                 if constexpr (TL) { t1 = __builtin_amdgcn_s_memtime(); tl_a += t1 - t0; }
                 const unsigned b = slot_lds(i + 2) + a_sub;
                 {
-                    const unsigned lso = (unsigned)row_nxt[PAR] * 4u, dso = (unsigned)c4.row * (unsigned)RB;
+                    const unsigned lso = (unsigned)row_nxt[PAR] * 4u, lso3 = (unsigned)row_nxt[PAR ^ 1] * 4u, dso = (unsigned)c4.row * (unsigned)RB;
                     const unsigned dl = slot_lds(i + 4) + wave_pb;
-                    A::template p2<0, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
-                    A::template p2<1, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
-                    A::template p2<2, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
-                    A::template p2<3, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<0, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<1, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<2, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<3, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments of block i + 2 (phase 1 of the next iteration reads them)
                 t_cur[PAR] = t_nxt[PAR]; t_nxt[PAR] = c4.t; row_nxt[PAR] = c4.row;
@@ -298,7 +300,7 @@ constexpr int kDkv4Lds = kRing4 * Bw4Asm<Bf16Traits, 128>::SLOT;
 template <class T>
 int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
     Dkv4Params p;
-    p.q = a.q; p.k = a.k; p.v = a.v; p.dout = a.dout; p.lse = a.lse2; p.delta = a.delta;   // (lse: L' = LSE log2(e), written by the dQ kernel next to delta)
+    p.q = a.q; p.k = a.k; p.v = a.v; p.dout = a.dout; p.lse = a.lse2; p.delta = a.ndelta;   // (L' = LSE log2(e) and - delta, written by the dQ kernel behind delta)
     p.dk = a.dk; p.dv = a.dv;
     p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
     p.c = a.scale * kLog2e;

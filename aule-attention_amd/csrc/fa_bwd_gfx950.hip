@@ -77,6 +77,7 @@ struct BwdParams {
     const void* o;        // dQ kernel: forward output, for delta = rowsum(O * dO)
     float* delta_out;     // dQ kernel: where it publishes delta for the dK/dV kernel
     float* lse2_out;      // dQ kernel: where it publishes L' = LSE log2(e) (the one-wave-per-SIMD dK/dV kernel reads it scaled)
+    float* ndelta_out;    // dQ kernel: ... and - delta (that kernel starts its dP product from it)
     void* dq;
     void* dk;
     void* dv;
@@ -427,6 +428,7 @@ __global__ void __launch_bounds__(512) fa_bwd_dq_kernel(const BwdParams p) {
             if (hi == 0 && qrow < Sq) {
                 p.delta_out[qbase + qrow] = delta;
                 p.lse2_out[qbase + qrow] = -nlse2;
+                p.ndelta_out[qbase + qrow] = -delta;
             }
         }
         const int kv_lim = CAUSAL ? min(Sk - 1, qrow + coff) : Sk - 1;  // last key visible to this lane's query row
@@ -1063,13 +1065,21 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     p.q = a.q; p.k = a.k; p.v = a.v; p.dout = a.dout; p.lse = a.lse; p.delta = a.delta;
     p.o = a.o; p.delta_out = a.delta;
     p.lse2_out = reinterpret_cast<float*>(reinterpret_cast<char*>(a.delta) + delta_bytes(a.B, a.Hq, a.Sq));
+    p.ndelta_out = reinterpret_cast<float*>(reinterpret_cast<char*>(a.delta) + 2 * delta_bytes(a.B, a.Hq, a.Sq));
     p.dq = a.dq; p.dk = a.dk; p.dv = a.dv;
     p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
     p.c = a.scale * kLog2e;
     p.scale = a.scale;
     p.window = a.window > 0 ? a.window : 0;
     p.coff = a.causal ? a.coff : 0;
-    {
+#ifdef AULE_DEBUG_HOOKS
+    // debug library only: AULE_DBG_BWD_ONLY=dq / =dkv launches one of the two kernels (per-kernel times from tools/cbench.cpp
+    // without a profiler; the workspace keeps delta / L' of an earlier full call)
+    static const int only = [] { const char* e = std::getenv("AULE_DBG_BWD_ONLY"); return e == nullptr ? 0 : (e[1] == 'q' ? 1 : 2); }();
+#else
+    constexpr int only = 0;
+#endif
+    if (only != 2) {
         const int nqb = (a.Sq + kDqQBlock - 1) / kDqQBlock;
         p.nblk = a.causal ? (nqb + 1) / 2 : nqb;  // causal: one workgroup per Q-block pair (i, n-1-i)
         p.gsplit = 1;
@@ -1095,19 +1105,21 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
         int rc = (int)hipGetLastError();
         if (rc) return rc;
     }
+    if (only == 1) return 0;
     // (taken where this file's kernel would have to split the group's heads over workgroups: fp32 partials + reduce kernel)
     if (D == 128 && (a.dbg == nullptr || dkv4_timeline_wanted()) && bwd_dkv4_applicable(a) &&
         (bwd_dkv4_forced() || dkv4_timeline_wanted() || dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal) > 1))   // one wave per SIMD, 128-key blocks, no head split: fa_bwd_dkv4_gfx950.hip
     {
         BwdArgs b = a;
         b.lse2 = p.lse2_out;
+        b.ndelta = p.ndelta_out;
         return launch_bwd_dkv4(b, stream);
     }
     {
         const int nkb = (a.Sk + kKvBlock - 1) / kKvBlock;
         p.nblk = a.causal ? (nkb + 1) / 2 : nkb;  // causal: one workgroup per block pair (i, n-1-i)
         p.gsplit = dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal);
-        p.part = reinterpret_cast<float*>(reinterpret_cast<char*>(a.delta) + 2 * delta_bytes(a.B, a.Hq, a.Sq));
+        p.part = reinterpret_cast<float*>(reinterpret_cast<char*>(a.delta) + 3 * delta_bytes(a.B, a.Hq, a.Sq));
         const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv * p.gsplit)), block(512);
         p.dbg = a.dbg;
         bool tl_done = false;
@@ -1179,7 +1191,7 @@ int launch_delta_f32(const BwdArgs& a, hipStream_t stream) {
 uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype) {
     uint64_t bytes = delta_bytes(B, Hq, Sq);
     if (dtype != kF32) {
-        bytes += delta_bytes(B, Hq, Sq);   // L' = LSE log2(e), published by the dQ kernel with delta
+        bytes += 2 * delta_bytes(B, Hq, Sq);   // L' = LSE log2(e) and - delta, published by the dQ kernel with delta
         const int sp = dkdv_gsplit(B, Hq, Hkv, Sk, causal);
         if (sp > 1) bytes += 2ull * sp * B * Hkv * Sk * D * sizeof(float);
     }

@@ -91,6 +91,7 @@ struct BwdArgs {
     void* dv;
     float* delta;  // workspace of bwd_workspace_bytes(): delta [B,Hq,Sq] fp32 first
     const float* lse2 = nullptr;   // internal (16-bit path): L' = LSE log2(e) [B,Hq,Sq], published by the dQ kernel behind delta
+    const float* ndelta = nullptr; // internal (16-bit path): - delta, behind L' (the C operand the one-wave-per-SIMD dK/dV kernel starts dP from)
     int B, Hq, Hkv, Sq, Sk, D;
     float scale;
     int causal;

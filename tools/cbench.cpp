@@ -1,7 +1,7 @@
 // tools/cbench.cpp -- times aule_attention_forward_ex / aule_attention_backward_ex through the C-ABI without Python:
 // a GPU box pays 1-2 minutes for its first `import torch`, this binary starts in under a second (kernel A/B loops).
 //   hipcc -O2 --offload-arch=gfx950 -Iinclude tools/cbench.cpp -o build/cbench -ldl
-//   build/cbench <lib.so> <fwd|bwd|tl> B Hq Hkv Sq Sk D <bf16|fp16> <causal 0|1|2> [reps=30] [warm=10]
+//   build/cbench <lib.so> <fwd|bwd|tl> B Hq Hkv Sq Sk D <bf16|fp16> <causal 0|1|2> [reps=30] [warm=10] [batch=1]
 // Prints the median / min of the per-launch HIP-event times and a checksum of every output (the same inputs on every run: two
 // builds that should agree bit for bit print the same sums).
 #include <hip/hip_runtime.h>
@@ -57,13 +57,15 @@ int main(int argc, char** argv) {
     const int bf16 = argv[9][0] == 'b';
     const int causal = atoi(argv[10]);
     const int reps = argc > 11 ? atoi(argv[11]) : 30, warm = argc > 12 ? atoi(argv[12]) : 10;
+    const int batch = argc > 13 ? atoi(argv[13]) : 1;   // calls per timed region, back to back (no host sync in between): time / batch
     if (init() != 0) { fprintf(stderr, "aule_init: %s\n", err ? err() : "?"); return 1; }
     const size_t nq = (size_t)B * Hq * Sq * D, nk = (size_t)B * Hkv * Sk * D, nl = (size_t)B * Hq * Sq;
     uint16_t *q, *k, *v, *o, *dout, *dq, *dk, *dv; float* lse; void* ws = nullptr;
     CK(hipMalloc(&q, nq * 2)); CK(hipMalloc(&k, nk * 2)); CK(hipMalloc(&v, nk * 2)); CK(hipMalloc(&o, nq * 2)); CK(hipMalloc(&dout, nq * 2));
     CK(hipMalloc(&dq, nq * 2)); CK(hipMalloc(&dk, nk * 2)); CK(hipMalloc(&dv, nk * 2)); CK(hipMalloc(&lse, nl * 4));
-    fill16<<<1024, 256>>>(q, nq, 0x1234u, bf16, 1.f); fill16<<<1024, 256>>>(k, nk, 0x5678u, bf16, 1.f);
-    fill16<<<1024, 256>>>(v, nk, 0x9abcu, bf16, 1.f); fill16<<<1024, 256>>>(dout, nq, 0xdef0u, bf16, 1.f);
+    const float amp = getenv("CB_AMP") ? (float)atof(getenv("CB_AMP")) : 1.f;   // CB_AMP=0: all-zero inputs (how much of the time is data-dependent power?)
+    fill16<<<1024, 256>>>(q, nq, 0x1234u, bf16, amp); fill16<<<1024, 256>>>(k, nk, 0x5678u, bf16, amp);
+    fill16<<<1024, 256>>>(v, nk, 0x9abcu, bf16, amp); fill16<<<1024, 256>>>(dout, nq, 0xdef0u, bf16, amp);
     CK(hipDeviceSynchronize());
     aule_attn_desc fd; memset(&fd, 0, sizeof fd);
     fd.struct_size = sizeof fd; fd.dtype = bf16 ? AULE_DTYPE_BF16 : AULE_DTYPE_F16;
@@ -98,12 +100,12 @@ int main(int argc, char** argv) {
     std::vector<float> ms;
     for (int i = 0; i < warm + reps; ++i) {
         CK(hipEventRecord(e0, nullptr));
-        rc = do_bwd ? bwd(&bd) : fwd(&fd);
+        for (int j = 0; j < batch; ++j) rc = do_bwd ? bwd(&bd) : fwd(&fd);
         CK(hipEventRecord(e1, nullptr));
         if (rc != 0) { fprintf(stderr, "rc %d: %s\n", rc, err ? err() : "?"); return 1; }
         CK(hipEventSynchronize(e1));
         float t; CK(hipEventElapsedTime(&t, e0, e1));
-        if (i >= warm) ms.push_back(t);
+        if (i >= warm) ms.push_back(t / batch);
     }
     std::sort(ms.begin(), ms.end());
     const double flops = 4.0 * B * Hq * (double)Sq * Sk * D * (causal ? 0.5 : 1.0) * (do_bwd ? 2.5 : 1.0);

@@ -6,7 +6,8 @@ Workgroup = 4 waves, one per SIMD; a wave owns 32 key rows of a 128-key KV block
 stream of 32-row query blocks (all query heads of the GQA group, every block that sees the KV block).  Per block b:
 
     S_b  = Q_b K^T        dP_b = dO_b V^T                  (16 MFMAs: A = row-major fragments of Q_b / dO_b, B = K / V fragments)
-    P_b  = exp2(c S_b - L'_b)      dS_b = P_b (dP_b - delta_b)              (16 scores per lane; lane = key, registers = rows)
+    P_b  = exp2(c S_b - L'_b)      dS_b = P_b (dP_b - delta_b)              (16 scores per lane; lane = key, registers = rows;
+                                                                             - delta_b is the C operand of dP_b's first MFMA)
     dV^T += dO_b^T P_b    dK^T += Q_b^T dS_b               (16 MFMAs: A = transposed fragments of dO_b / Q_b, B = packed P / dS)
 
 software-pipelined over the stream: iteration i is
@@ -94,8 +95,6 @@ def arith_ops(c, par, q, masked):
     for i in range(4):
         ops.append(f"v_fma_f32 v{t[i]}, v{S + r0 + i}, %[c], -v{LD + r0 + i}")
     for i in range(4):
-        ops.append(f"v_sub_f32 v{t[4 + i]}, v{DPr + r0 + i}, v{DL + r0 + i}")
-    for i in range(4):
         ops.append(f"v_exp_f32 v{t[i]}, v{t[i]}")
     if masked:
         tm = c.DS + r0 // 2            # (a register of this statement's dS pair: written only by the pack at the end)
@@ -104,7 +103,7 @@ def arith_ops(c, par, q, masked):
             ops.append(f"v_cmp_gt_u32 vcc, %[wd], v{tm}")
             ops.append(f"v_cndmask_b32 v{t[i]}, 0, v{t[i]}, vcc")
     for i in range(4):
-        ops.append(f"v_mul_f32 v{t[4 + i]}, v{t[i]}, v{t[4 + i]}")
+        ops.append(f"v_mul_f32 v{t[4 + i]}, v{t[i]}, v{DPr + r0 + i}")      # dS = P (dP - delta): the MFMA chain of dP started from - delta
     for j in range(2):
         ops.append(f"{c.cvt} v{c.P + r0 // 2 + j}, v{t[2 * j]}, v{t[2 * j + 1]}")
         ops.append(f"{c.cvt} v{c.DS + r0 // 2 + j}, v{t[4 + 2 * j]}, v{t[5 + 2 * j]}")
@@ -150,7 +149,7 @@ def gen_p1(c, q, par, qk, ar, tr):
         s, dp = tup(c.S + 16 * npar, 16), tup(c.DP + 16 * npar, 16)
         for ks in (2 * q, 2 * q + 1):
             mf.append(f"{c.mfma} {s}, {c.frag(c.QA, ks)}, {c.frag(c.KF, ks)}, {'0' if ks == 0 else s}")
-            mf.append(f"{c.mfma} {dp}, {c.frag(c.DA, ks)}, {c.frag(c.VF, ks)}, {'0' if ks == 0 else dp}")
+            mf.append(f"{c.mfma} {dp}, {c.frag(c.DA, ks)}, {c.frag(c.VF, ks)}, {tup(c.DL + 16 * npar, 16) if ks == 0 else dp}")
         clob += vregs(c.S + 16 * npar, 16) + vregs(c.DP + 16 * npar, 16)
     valu = arith_ops(c, par, q, ar == 2) if ar else []
     if ar:
@@ -212,12 +211,16 @@ def gen_p2(c, q, par, mm, rm, ld, dma):
         ins += ['[ra] "v"(ra)']
     if ld:
         if q < 2:
-            base = (c.LD if q == 0 else c.DL) + 16 * par
+            # L' of block i + 2 (its arithmetic runs in iteration i + 2); - delta of block i + 3 (the C operand of dP_{i+3}'s first
+            # MFMA in iteration i + 2; the buffer of the other parity: - delta_{i+1} was consumed in this iteration's phase 1)
+            base = c.LD + 16 * par if q == 0 else c.DL + 16 * (par ^ 1)
             srd = "%[lsrd]" if q == 0 else "%[dsrd]"
+            so = "%[lso]" if q == 0 else "%[lso3]"
             for g in range(4):
-                fill.append(f"buffer_load_dwordx4 v[{base + 4 * g}:{base + 4 * g + 3}], %[lvo], {srd}, %[lso] offen offset:{32 * g}")
+                fill.append(f"buffer_load_dwordx4 v[{base + 4 * g}:{base + 4 * g + 3}], %[lvo], {srd}, {so} offen offset:{32 * g}")
             clob += vregs(base, 16)
-            ins += ['[lsrd] "s"(lsrd)' if q == 0 else '[dsrd] "s"(dsrd)', '[lvo] "v"(lvo)', '[lso] "s"(lso)']
+            ins += ['[lsrd] "s"(lsrd)', '[lso] "s"(lso)'] if q == 0 else ['[dsrd] "s"(dsrd)', '[lso3] "s"(lso3)']
+            ins += ['[lvo] "v"(lvo)']
     if dma and q >= 2:
         img = q - 2                                         # statement 2: Q, statement 3: dO; the wave's row groups 2 w, 2 w + 1
         srd = "%[qsrd]" if img == 0 else "%[gsrd]"            # (dlds = slot + PBASE[2 w]; PBASE[2 w + 1] - PBASE[2 w] = 1040)
@@ -261,13 +264,13 @@ def gen_struct(c):
     s += "        else static_assert(Q < 0, \"fa_bwd_dkv4_asm.inc: phase-1 variant not generated\");\n#endif\n    }\n"
     s += ("    template <int Q, int PAR, int MM, int RM, int LD, int DMA>\n"
           "    static __device__ __forceinline__ void p2(unsigned ra, unsigned trb, __amdgpu_buffer_rsrc_t lsrd, __amdgpu_buffer_rsrc_t dsrd, unsigned lvo,\n"
-          "                                              unsigned lso, unsigned dlds, __amdgpu_buffer_rsrc_t qsrd, __amdgpu_buffer_rsrc_t gsrd, unsigned dso,\n"
+          "                                              unsigned lso, unsigned lso3, unsigned dlds, __amdgpu_buffer_rsrc_t qsrd, __amdgpu_buffer_rsrc_t gsrd, unsigned dso,\n"
           "                                              unsigned vost0, unsigned vost1) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
-          "        (void)ra; (void)trb; (void)lsrd; (void)dsrd; (void)lvo; (void)lso; (void)dlds; (void)qsrd; (void)gsrd; (void)dso;\n"
+          "        (void)ra; (void)trb; (void)lsrd; (void)dsrd; (void)lvo; (void)lso; (void)lso3; (void)dlds; (void)qsrd; (void)gsrd; (void)dso;\n"
           "        (void)vost0; (void)vost1;\n"
           "        if constexpr (DMA != 0) {\n            dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n            dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n        }\n"
-          "        if constexpr (LD != 0) lso = (unsigned)__builtin_amdgcn_readfirstlane((int)lso);\n")
+          "        if constexpr (LD != 0) {\n            lso = (unsigned)__builtin_amdgcn_readfirstlane((int)lso);\n            lso3 = (unsigned)__builtin_amdgcn_readfirstlane((int)lso3);\n        }\n")
     first = True
     for q in range(4):
         for par in range(2):
@@ -309,6 +312,16 @@ def gen_struct(c):
                           ["memory"] + vregs(c.LD + 16 * par, 16) + vregs(c.DL + 16 * par, 16))
             s += "        }\n"
             first = False
+    s += "#endif\n    }\n"
+    # ---- stream start: - delta of block 2 (the C operand of dP_2 in iteration 1) parked in X, moved to DL[0] once dP_0 is under way
+    lines = ["s_nop 4"] + [f"buffer_load_dwordx4 v[{c.X + 4 * g}:{c.X + 4 * g + 3}], %[lvo], %[dsrd], %[lso] offen offset:{32 * g}" for g in range(4)]
+    s += ("    static __device__ __forceinline__ void load_delta_x(__amdgpu_buffer_rsrc_t dsrd, unsigned lvo, unsigned lso) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n        lso = (unsigned)__builtin_amdgcn_readfirstlane((int)lso);\n")
+    s += emit_asm(lines, [], ['[dsrd] "s"(dsrd)', '[lvo] "v"(lvo)', '[lso] "s"(lso)'], ["memory"] + vregs(c.X, 16), indent="        ")
+    s += "#endif\n    }\n"
+    lines = ["s_nop 7", "s_nop 7"] + [f"v_mov_b32 v{c.DL + i}, v{c.X + i}" for i in range(16)]
+    s += "    static __device__ __forceinline__ void mov_delta_x() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+    s += emit_asm(lines, [], [], ["memory"] + vregs(c.DL, 16), indent="        ")
     s += "#endif\n    }\n"
     # ---- the LDS-DMA pieces of one block as a statement of its own (stream start)
     lines = ["s_nop 4"]
