@@ -85,8 +85,8 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
     constexpr int D = 128;
     using A = Bw4Asm<T, D>;
     using std::integral_constant;
-    constexpr int RB = 2 * D, CPR = RB / 16, KS = D / 16;
-    constexpr int IMG = A::IMG, SLOT = A::SLOT;
+    constexpr int RB = 2 * D;
+    constexpr int SLOT = A::SLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = dkv4_rfl(tid >> 6);
@@ -333,8 +333,8 @@ int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-// Shapes the one-wave-per-SIMD dK/dV kernel takes: 16-bit, D = 128, no window, causal offset >= 0, and enough work items to
-// cover the chip with the whole GQA group inside a workgroup (otherwise the predecessor splits the group over workgroups).
+// Shapes the one-wave-per-SIMD dK/dV kernel CAN take: 16-bit, D = 128, no window, causal offset >= 0, a GQA group's rows inside
+// one 2 GB descriptor.  Whether it is taken: bwd_dkv4_items() against the predecessor's grid, in the dispatcher (fa_bwd_gfx950.hip).
 bool bwd_dkv4_applicable(const BwdArgs& a) {
     // AULE_HIP_BWD_DKV=old: the two-waves-per-SIMD kernel everywhere (A/B); =new: this kernel wherever it CAN run (tests)
     static const int mode = [] {
@@ -348,15 +348,13 @@ bool bwd_dkv4_applicable(const BwdArgs& a) {
     if (a.Hkv <= 0 || a.Hq % a.Hkv != 0) return false;
     // one descriptor covers the rows of a whole GQA group; byte offsets inside it are 32-bit
     if ((long long)(a.Hq / a.Hkv) * a.Sq * a.D * 2 >= (1LL << 31) || (long long)a.Sk * a.D * 2 >= (1LL << 31)) return false;
-    if (mode == 2) return true;
-    // Where it pays (same box, tools/bwd_ab2.py): kernel against kernel the two are within +-5 % of each other (this one 4-6 %
-    // behind on large grids); it wins where the predecessor has to SPLIT the query heads of a group over workgroups to cover
-    // the chip (fp32 partials + a reduce kernel): with 128-key blocks there are twice the work items and the whole group runs
-    // inside one workgroup -- C3 (B4, 32q/8kv, S2048): 533 -> 504 us.  The dispatcher (fa_bwd_gfx950.hip) asks for that
-    // condition on top of this one.
+    return true;
+}
+
+// Work items of this kernel's grid: (batch, KV head, 128-key block -- causal: pair of blocks); the whole GQA group runs inside one.
+long long bwd_dkv4_items(const BwdArgs& a) {
     const int nkb = (a.Sk + kKvBlock4 - 1) / kKvBlock4;
-    const long long items = (long long)a.B * a.Hkv * (a.causal ? (nkb + 1) / 2 : nkb);
-    return a.Hq > a.Hkv && items >= 192;
+    return (long long)a.B * a.Hkv * (a.causal ? (nkb + 1) / 2 : nkb);
 }
 
 // AULE_HIP_BWD_DKV=new: take every problem bwd_dkv4_applicable() accepts (tests)

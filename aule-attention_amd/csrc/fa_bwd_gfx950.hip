@@ -29,6 +29,7 @@ namespace aule_hip {
 static bool dkv4_timeline_wanted() { const char* e = std::getenv("AULE_TL"); return e != nullptr && e[0] == 'd' && e[1] == 'k'; }   // AULE_TL=dkv4 (debug library)
 bool bwd_dkv4_applicable(const BwdArgs& a);          // fa_bwd_dkv4_gfx950.hip: the one-wave-per-SIMD dK/dV kernel
 bool bwd_dkv4_forced();
+long long bwd_dkv4_items(const BwdArgs& a);
 int launch_bwd_dkv4(const BwdArgs& a, hipStream_t stream);
 int configure_bwd_dkv4();
 namespace {
@@ -1106,9 +1107,20 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
         if (rc) return rc;
     }
     if (only == 1) return 0;
-    // (taken where this file's kernel would have to split the group's heads over workgroups: fp32 partials + reduce kernel)
-    if (D == 128 && (a.dbg == nullptr || dkv4_timeline_wanted()) && bwd_dkv4_applicable(a) &&
-        (bwd_dkv4_forced() || dkv4_timeline_wanted() || dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal) > 1))   // one wave per SIMD, 128-key blocks, no head split: fa_bwd_dkv4_gfx950.hip
+    // The one-wave-per-SIMD dK/dV kernel (fa_bwd_dkv4_gfx950.hip: 128-key blocks, the whole GQA group inside a workgroup, no head
+    // split / partials / reduce) wherever it covers the chip (>= 192 work items) or has at least as many work items as this
+    // file's kernel would (256-key blocks x head split).  Same box, whole backward, tools/cb_rule.sh: ahead on every shape of the
+    // spread (MHA / GQA, causal or not, ragged, fp16: -0.5 .. -24 %); what stays here is the tiny grid with a big group (fp16 MQA
+    // 32/1 S8192: 32 work items there against 512 here).
+    const auto use_dkv4 = [&] {
+        if (D != 128 || !(a.dbg == nullptr || dkv4_timeline_wanted()) || !bwd_dkv4_applicable(a)) return false;
+        if (bwd_dkv4_forced() || dkv4_timeline_wanted()) return true;
+        const int nkb = (a.Sk + kKvBlock - 1) / kKvBlock;
+        const long long here = (long long)a.B * a.Hkv * (a.causal ? (nkb + 1) / 2 : nkb) * dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal);
+        const long long there = bwd_dkv4_items(a);
+        return there >= 192 || there >= here;
+    };
+    if (use_dkv4())
     {
         BwdArgs b = a;
         b.lse2 = p.lse2_out;

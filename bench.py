@@ -405,7 +405,7 @@ def main():
                            "c3_bwd_ms": bwd_ms, "c3_bwd_tflops": 2.5 * f3f / (bwd_ms * 1e-3) / 1e12,
                            "c3_bwd_frac": 2.5 * f3f / (bwd_ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
                            "c3_workload": "GQA 32q/8kv B=4 S=2048 D=128 bf16 causal fwd+bwd (autograd); bwd = step - fwd-only step "
-                                          "(dQ / dK,dV / reduce kernel split: profiles/r2_fwdbwd_c3_*)"}
+                                          "(dQ / dK,dV kernel split: profiles/r3_fwdbwd_c3_*)"}
         del q3, k3, v3, d3
         B5, H5, K5, S5, _, D5, _, _, _ = CONFIGS["c5"]
         q5 = torch.randn(B5, H5, S5, D5, device=dev, dtype=torch.float16, generator=g3).requires_grad_(True)
@@ -451,6 +451,24 @@ def main():
                                 "rope_attn_c2_workload": "RoPE + attention, B=4 H=32 S=2048 D=128 bf16 causal, inference: rope(K) pass + the "
                                                          "one-wave-per-SIMD forward with Q rotated inside it (attention FLOPs only)"})
         del q7, k7, v7
+        # Power: the same C2 forward on ALL-ZERO inputs (the same launch, the same instruction stream, the same MFMA count; no
+        # data-dependent switching in the matrix pipes, the register files and LDS).  The distance between this figure and
+        # `steady_state` is what the chip's power cap costs on N(0,1) data: the clock it sustains, not the kernel's schedule
+        # (the backward kernels show the same ratio: tools/cbench.cpp with CB_AMP=0).
+        qz, kz, vz = (torch.zeros(B, h, Sq, D, device=dev, dtype=tdt) for h in (Hq, Hkv, Hkv))
+
+        def stepz():
+            with torch.no_grad():
+                aule.flash_attention(qz, kz, vz, causal=causal)
+
+        condition(stepz, args.condition_ms)
+        _, msz = timed(stepz, 20)
+        tz = fwd_flops(B, Hq, Sq, Sk, D, causal) / (msz / 20 * 1e-3) / 1e12
+        result["extra"].update({"c2_zero_inputs_fwd_tflops": tz, "c2_zero_inputs_frac_of_peak": tz / PEAK_TFLOPS[dtype],
+                                "c2_zero_inputs_ms_per_step": msz / 20,
+                                "c2_zero_inputs_note": "the C2 forward on all-zero q, k, v (LSE not stored): the kernel's schedule without the "
+                                                       "data-dependent power of N(0,1) inputs -- NOT a throughput claim"})
+        del qz, kz, vz
 
     if rank == 0:
         # the reference harness counts 4*B*H*S^2*D with NO causal discount (tests/benchmark_attention.zig:68-75):
