@@ -30,6 +30,10 @@ static bool dkv4_timeline_wanted() { const char* e = std::getenv("AULE_TL"); ret
 bool bwd_dkv4_applicable(const BwdArgs& a);          // fa_bwd_dkv4_gfx950.hip: the one-wave-per-SIMD dK/dV kernel
 bool bwd_dkv4_forced();
 long long bwd_dkv4_items(const BwdArgs& a);
+bool bwd_dq4_applicable(const BwdArgs& a);           // fa_bwd_dq4_gfx950.hip: the one-wave-per-SIMD dQ kernel
+int bwd_dq4_mode();
+int launch_bwd_dq4(const BwdArgs& a, float* lse2_out, float* ndelta_out, hipStream_t stream);
+int configure_bwd_dq4();
 int launch_bwd_dkv4(const BwdArgs& a, hipStream_t stream);
 int configure_bwd_dkv4();
 namespace {
@@ -1080,7 +1084,13 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
 #else
     constexpr int only = 0;
 #endif
-    if (only != 2) {
+    // The one-wave-per-SIMD dQ kernel (fa_bwd_dq4_gfx950.hip: 64 query rows per wave, every K / V fragment read feeds two row
+    // blocks): opt-in this round (AULE_HIP_BWD_DQ=new) -- see DESIGN.md 7 item 3.
+    const bool use_dq4 = D == 128 && a.dbg_dq == nullptr && bwd_dq4_mode() == 2 && bwd_dq4_applicable(a);
+    if (only != 2 && use_dq4) {
+        int rc = launch_bwd_dq4(a, p.lse2_out, p.ndelta_out, stream);
+        if (rc) return rc;
+    } else if (only != 2) {
         const int nqb = (a.Sq + kDqQBlock - 1) / kDqQBlock;
         p.nblk = a.causal ? (nqb + 1) / 2 : nqb;  // causal: one workgroup per Q-block pair (i, n-1-i)
         p.gsplit = 1;
@@ -1234,6 +1244,7 @@ int configure_bwd() {
     rc |= set_attr_bwd<F16Traits, 32>();
     rc |= configure_bwd_f32();
     rc |= configure_bwd_dkv4();
+    rc |= configure_bwd_dq4();
     return rc;
 }
 

@@ -167,17 +167,21 @@ def test_backward_deterministic(torch_cuda):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("which", ["new", "old"])
+@pytest.mark.parametrize("which", ["new", "old", "dq4"])
 def test_backward_on_the_one_wave_per_simd_dkdv_kernel(which):
     """fa_bwd_dkv4_gfx950.hip is the dK/dV kernel of every D = 128 16-bit problem without a window whose grid it covers (the
     dispatcher's rule in fa_bwd_gfx950.hip); its predecessor keeps the rest.  AULE_HIP_BWD_DKV=new forces it onto every problem it
     CAN run, =old pins the predecessor everywhere: the sweep, the reference's golden gradients, the bottom-right cases and the
-    determinism test then exercise the masks, the stream start / tail and the GQA loop of either kernel on all of them."""
+    determinism test then exercise the masks, the stream start / tail and the GQA loop of either kernel on all of them.  "dq4": the
+    same suites with the one-wave-per-SIMD dQ kernel (fa_bwd_dq4_gfx950.hip, opt-in: AULE_HIP_BWD_DQ=new) in front of the dK/dV kernel."""
     import subprocess
     import sys
     from conftest import ROOT
     e = dict(os.environ)
-    e["AULE_HIP_BWD_DKV"] = which
+    if which == "dq4":
+        e["AULE_HIP_BWD_DQ"] = "new"
+    else:
+        e["AULE_HIP_BWD_DKV"] = which
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_bwd.py"), os.path.join(ROOT, "tests", "test_gpu_bottom_right.py"),
                         "-q", "-x", "-m", "gpu", "-k", "not one_wave_per_simd_dkdv"], env=e, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and "passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]

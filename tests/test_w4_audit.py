@@ -7,6 +7,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -46,19 +48,21 @@ def test_hazard_lint_catches_what_it_is_for():
     assert ok == []
 
 
-def test_dkv4_streams_current_and_kernel_clean(tmp_path):
-    """The one-wave-per-SIMD dK/dV kernel (fa_bwd_dkv4_gfx950.hip, streams from tools/gen_bw4.py): the committed streams are what the
-    generator writes, and the compiled kernels have no scratch, no spills, no compiler-made accumulator access and stay below the
-    generator's VGPR budget outside the statements."""
+@pytest.mark.parametrize("gen,env,inc,hip", [("gen_bw4.py", "BW4_OUT", "fa_bwd_dkv4_asm.inc", "fa_bwd_dkv4_gfx950.hip"),
+                                              ("gen_dq4.py", "DQ4_OUT", "fa_bwd_dq4_asm.inc", "fa_bwd_dq4_gfx950.hip")])
+def test_backward_streams_current_and_kernels_clean(tmp_path, gen, env, inc, hip):
+    """The one-wave-per-SIMD backward kernels (dK/dV: fa_bwd_dkv4_gfx950.hip, streams from tools/gen_bw4.py; dQ: fa_bwd_dq4_gfx950.hip,
+    tools/gen_dq4.py): the committed streams are what the generator writes, and the compiled kernels have no scratch, no spills, no
+    compiler-made accumulator access and stay below the generator's VGPR budget outside the statements."""
     import re
-    out = tmp_path / "fa_bwd_dkv4_asm.inc"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_bw4.py")], env=dict(os.environ, BW4_OUT=str(out)), capture_output=True, text=True, timeout=300)
+    out = tmp_path / inc
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen)], env=dict(os.environ, **{env: str(out)}), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert out.read_text() == open(os.path.join(ROOT, "aule-attention_amd", "csrc", "fa_bwd_dkv4_asm.inc")).read(), "fa_bwd_dkv4_asm.inc is stale: run python tools/gen_bw4.py"
+    assert out.read_text() == open(os.path.join(ROOT, "aule-attention_amd", "csrc", inc)).read(), f"{inc} is stale: run python tools/{gen}"
     nv = int(re.search(r"NV = (\d+)", out.read_text()).group(1))
-    s = tmp_path / "dkv4.s"
+    s = tmp_path / "kernel.s"
     r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-inline-asm", "-S", "--cuda-device-only", "-o", str(s),
-                        os.path.join(ROOT, "aule-attention_amd", "csrc", "fa_bwd_dkv4_gfx950.hip")], capture_output=True, text=True, timeout=900)
+                        os.path.join(ROOT, "aule-attention_amd", "csrc", hip)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     text = s.read_text()
     assert len(re.findall(r"\.private_segment_fixed_size: 0\n", text)) == 4 and ".private_segment_fixed_size: " in text
