@@ -9,11 +9,15 @@
 //     row-major fragments of the query block in flight (64) in the accumulator file; scores, weights, transposed fragments,
 //     L' and delta in arch VGPRs -- all named literally by fa_bwd_dkv4_asm.inc (generated: tools/gen_bw4.py, map in its docstring);
 //   * the wave walks a STREAM of 32-row query blocks -- every query head of the GQA group, every block that sees the KV block --
-//     software-pipelined: iteration i = [S, dP of block i+1 | arithmetic of block i | its 32 transpose reads] barrier [dV, dK of
-//     block i | row-major reads of block i+2 | L', delta of block i+2 | LDS-DMA requests of block i+4];
-//   * query blocks arrive by LDS-DMA in four images each (Q and dO, row-major swizzled + [q/4][d/16][4][16] sub-tiles: the
-//     predecessor's layouts) into a 4-slot ring (128 KB): block i+4 goes where block i was; a block is requested two iterations
-//     before its first reader, the phase boundary waits with a counted vmcnt;
+//     software-pipelined: iteration i = [S, dP of block i+1 | arithmetic of block i | 16 of its 32 transpose reads] barrier [dV, dK
+//     of block i | the other 16 transpose reads | row-major reads of block i+2 | L' of block i+2, - delta of block i+3 | LDS-DMA
+//     requests of block i+4];
+//   * query blocks arrive by LDS-DMA, ONE image per tensor (Q, dO: [q/4][d/16][4][16] sub-tiles with per-row-group pads, which
+//     serve the ds_read_b128 fragments and the transpose reads conflict-free: tools/gen_bw4.py) into an 8-slot ring (136 KB),
+//     requested four iterations ahead; the phase boundary waits with a counted vmcnt;
+//   * L' = LSE log2(e) and - delta come prepared from the dQ kernel's workspace; - delta is the C operand of dP's first MFMA;
+//   * one wave per SIMD pays ~4.6 cycles of issue for EVERY instruction: one stream cursor, one compare for the mask decision, no
+//     range selects (the scalar offset is range-checked), the last iteration peeled;
 //   * 128-key blocks make twice as many work items as the predecessor's 256-key blocks: at C3 (B4, 32q/8kv, S2048) the paired
 //     causal grid is exactly 256 workgroups with the whole GQA group inside each -- no head split, no fp32 partials, no reduce
 //     kernel.

@@ -30,7 +30,11 @@ namespace {
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
+#ifdef DQ4_ASM_INC          // timing variants (tools/dq4_variants.sh)
+#include DQ4_ASM_INC
+#else
 #include "fa_bwd_dq4_asm.inc"
+#endif
 
 struct Dq4Params {
     const void* q;

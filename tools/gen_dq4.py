@@ -39,6 +39,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from gen_w4 import emit_asm, vregs, aregs, tup   # noqa: E402
 
 OUT = os.environ.get("DQ4_OUT", os.path.join(ROOT, "aule-attention_amd", "csrc", "fa_bwd_dq4_asm.inc"))
+# Timing experiments only (tools/dq4_variants.sh; results are garbage): DQ4_X = comma list of
+#   nobar  no barrier / vmcnt wait     novalu  no arithmetic     nolds  no LDS reads (stale fragments), no lgkmcnt waits
+#   nodma  no LDS-DMA requests         nodq    no dQ MFMAs       nowait no lgkmcnt waits
+XFLAGS = set(x for x in os.environ.get("DQ4_X", "").split(",") if x)
 
 
 class Cfg:
@@ -247,6 +251,23 @@ def gen_iter(c, par, qk, nxt, ar, dq, pre):
         for ks in (0, 1):
             pending += [regs_of(f"v[{c.KR + 4 * ks}:{c.KR + 4 * ks + 3}]"), regs_of(f"v[{c.VR + 4 * ks}:{c.VR + 4 * ks + 3}]")]
     lines, left = with_waits(lines, pending)
+    if XFLAGS:
+        def keep(ln):
+            op = ln.split()[0]
+            if "nobar" in XFLAGS and (op == "s_barrier" or ln.startswith("s_waitcnt vmcnt")):
+                return False
+            if "novalu" in XFLAGS and op.startswith("v_") and not op.startswith("v_mfma"):
+                return False
+            if ("nolds" in XFLAGS or "nowait" in XFLAGS) and ln.startswith("s_waitcnt lgkmcnt"):
+                return False
+            if "nolds" in XFLAGS and op.startswith("ds_read"):
+                return False
+            if "nodma" in XFLAGS and (op == "s_add_u32" or (op.startswith("buffer_load") and ln.endswith("lds"))):
+                return False
+            if "nodq" in XFLAGS and op.startswith("v_mfma") and ln.split()[1].startswith("a["):
+                return False
+            return True
+        lines = [ln for ln in lines if keep(ln)]
     assert len(left) == (4 if nxt else 0), (len(left), nxt)
     assert not nxt or qk
     clob = ["memory", "m0", "scc"]
