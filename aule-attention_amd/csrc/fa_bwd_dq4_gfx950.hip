@@ -209,9 +209,25 @@ __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
             else A::template iter<0, 0, 0, 0, 0, 0>(c, ra, ra2, 0, 0, 0, 0, dlds, krs, vrs, dso, vost[0], vost[1]);
         }
 #undef DQ4_IT
-        for (int j = 1; j <= n + 1; j += 2) {
-            iteration(integral_constant<int, 1>{}, j);
-            if (j + 1 <= n + 1) iteration(integral_constant<int, 0>{}, j + 1);
+        // The steady range -- S / dP of block j with block j + 1 to follow, plain arithmetic of block j - 1, dQ of block j - 2 -- runs
+        // without the variant decision: one wave per SIMD pays ~4.6 cycles for every scalar instruction between two statements
+        // while the matrix pipe drains (profiles/r3b_bwd_dq4.txt).  Everything else goes through iteration().
+        auto steady = [&](auto par_tag, int j) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_tag)::value;
+            A::template iter<PAR, 1, 1, 1, 1, 1>(c, slot_lds(j) + a_sub, slot_lds(j + 1) + a_sub, slot_lds(j - 2) + tr_off, 0, 0, 0,
+                                                slot_lds(j + 4) + wave_pb, krs, vrs, (unsigned)((j + 4) * kKB4 * RB), vost[0], vost[1]);
+        };
+        int steady_end = min(n_w - 1, mask_lo == 0x7fffffff ? mask_lo : mask_lo + 1);   // j + 1 < n_w and block j - 1 below the diagonal
+        if (ragged_blk >= 0) steady_end = min(steady_end, ragged_blk + 1);               // ... and not the ragged last block of K
+        int j = 1;
+        iteration(integral_constant<int, 1>{}, j++);
+        for (; j + 1 < steady_end; j += 2) {      // (j is even here)
+            steady(integral_constant<int, 0>{}, j);
+            steady(integral_constant<int, 1>{}, j + 1);
+        }
+        for (; j <= n + 1; ++j) {
+            if (j & 1) iteration(integral_constant<int, 1>{}, j);
+            else iteration(integral_constant<int, 0>{}, j);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the requests behind the stream too; the ring is free
 
@@ -261,7 +277,8 @@ int launch_dq4(const BwdArgs& a, float* lse2_out, float* ndelta_out, hipStream_t
 }  // namespace
 
 // Shapes the one-wave-per-SIMD dQ kernel can take: 16-bit, D = 128, no window, causal offset >= 0, offsets inside 2 GB
-// descriptors.  AULE_HIP_BWD_DQ=new takes it wherever it can run, =old never (A/B, tests); default: see the dispatcher.
+// descriptors.  AULE_HIP_BWD_DQ=new takes it wherever it can run, =old never (A/B, tests); default: the dispatcher's grid rule
+// (fa_bwd_gfx950.hip).
 int bwd_dq4_mode() {
     static const int mode = [] {
         const char* e = std::getenv("AULE_HIP_BWD_DQ");

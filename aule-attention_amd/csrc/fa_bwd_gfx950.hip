@@ -1085,8 +1085,14 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     constexpr int only = 0;
 #endif
     // The one-wave-per-SIMD dQ kernel (fa_bwd_dq4_gfx950.hip: 64 query rows per wave, every K / V fragment read feeds two row
-    // blocks): opt-in this round (AULE_HIP_BWD_DQ=new) -- see DESIGN.md 7 item 3.
-    const bool use_dq4 = D == 128 && a.dbg_dq == nullptr && bwd_dq4_mode() == 2 && bwd_dq4_applicable(a);
+    // blocks; dQ bit-identical to this file's kernel) wherever it can run and the grid has at least 128 work items: ahead or level
+    // on all ten shapes of tools/cb_rule_dq.sh (whole backward -0.2 .. -2.5 %, the 128-item grids level), behind on grids of a few
+    // workgroups (its three-stage stream start and 64-row prologue).  AULE_HIP_BWD_DQ=old|new pin either one.
+    const auto dq4_items = [&] {
+        const int nqb = (a.Sq + kDqQBlock - 1) / kDqQBlock;
+        return (long long)a.B * a.Hq * (a.causal ? (nqb + 1) / 2 : nqb);
+    };
+    const bool use_dq4 = D == 128 && a.dbg_dq == nullptr && bwd_dq4_applicable(a) && (bwd_dq4_mode() == 2 || dq4_items() >= 128);
     if (only != 2 && use_dq4) {
         int rc = launch_bwd_dq4(a, p.lse2_out, p.ndelta_out, stream);
         if (rc) return rc;

@@ -167,19 +167,20 @@ def test_backward_deterministic(torch_cuda):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("which", ["new", "old", "dq4"])
+@pytest.mark.parametrize("which", ["new", "old", "dq4", "dq_old"])
 def test_backward_on_the_one_wave_per_simd_dkdv_kernel(which):
     """fa_bwd_dkv4_gfx950.hip is the dK/dV kernel of every D = 128 16-bit problem without a window whose grid it covers (the
     dispatcher's rule in fa_bwd_gfx950.hip); its predecessor keeps the rest.  AULE_HIP_BWD_DKV=new forces it onto every problem it
     CAN run, =old pins the predecessor everywhere: the sweep, the reference's golden gradients, the bottom-right cases and the
-    determinism test then exercise the masks, the stream start / tail and the GQA loop of either kernel on all of them.  "dq4": the
-    same suites with the one-wave-per-SIMD dQ kernel (fa_bwd_dq4_gfx950.hip, opt-in: AULE_HIP_BWD_DQ=new) in front of the dK/dV kernel."""
+    determinism test then exercise the masks, the stream start / tail and the GQA loop of either kernel on all of them.  "dq4" /
+    "dq_old": the same for the two dQ kernels (fa_bwd_dq4_gfx950.hip takes grids of >= 128 work items by itself; AULE_HIP_BWD_DQ=new
+    forces it onto every problem it can run, =old pins the predecessor)."""
     import subprocess
     import sys
     from conftest import ROOT
     e = dict(os.environ)
-    if which == "dq4":
-        e["AULE_HIP_BWD_DQ"] = "new"
+    if which in ("dq4", "dq_old"):
+        e["AULE_HIP_BWD_DQ"] = "new" if which == "dq4" else "old"
     else:
         e["AULE_HIP_BWD_DKV"] = which
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_bwd.py"), os.path.join(ROOT, "tests", "test_gpu_bottom_right.py"),
