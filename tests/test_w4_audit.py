@@ -88,3 +88,33 @@ def test_backward_streams_current_and_kernels_clean(tmp_path, gen, env, inc, hip
                     problems.append(t)
     assert not problems, problems[:5]
     assert a.lint_blocks(blocks) == []
+    if gen == "gen_dq4.py":
+        # the dQ kernel's iterations are single statements with generator-inserted counted LDS waits: re-derive them from the
+        # compiled text (statements with MFMAs; at most the four fragment reads of the previous statement out at entry)
+        its = [b for b in blocks if any(t.startswith("v_mfma") for t in b)]
+        assert len(its) >= 30
+        for b in its:
+            assert a.lint_lds_waits(b, entry_pending=4) == [], a.lint_lds_waits(b, entry_pending=4)[:3]
+            # ... and the one thing counts cannot see: a transposed K fragment (v224 ..) is requested BEFORE the MFMA that reads it
+            seen = set()
+            for t in b:
+                parts = t.replace(",", " ").split()
+                if parts and parts[0].startswith("ds_read"):
+                    seen |= a._regs(parts[1])
+                elif parts and parts[0].startswith("v_mfma"):
+                    need = {r for r in a._regs(parts[2]) if r[0] == "v" and r[1] >= 224}
+                    assert need <= seen, (t, sorted(need - seen)[:4])
+
+
+def test_lds_wait_lint_catches_a_missing_wait():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_w4 as a
+    good = ["ds_read_b128 v[56:59], v1 offset:0", "ds_read_b128 v[48:51], v1 offset:8704", "s_waitcnt lgkmcnt(1)",
+            "v_mfma_f32_32x32x16_bf16 v[160:175], v[56:59], a[128:131], 0", "s_waitcnt lgkmcnt(0)",
+            "v_mfma_f32_32x32x16_bf16 v[96:111], v[48:51], a[192:195], 0"]
+    assert a.lint_lds_waits(good) == []
+    bad = [good[0], good[1], good[2], good[3], good[5]]          # the second read is never waited for
+    assert a.lint_lds_waits(bad) and "v48" in a.lint_lds_waits(bad)[0]
+    late = ["v_mfma_f32_32x32x16_bf16 a[0:15], v[224:227], v[64:67], a[0:15]", "ds_read_b64_tr_b16 v[224:225], v2 offset:0"]
+    assert a.lint_lds_waits(late) == []                          # (a read BEHIND its would-be reader is a placement bug the counts cannot see ...)
+    assert a.lint_lds_waits(["ds_read_b64_tr_b16 v[224:225], v2 offset:0"] + late[:1])   # ... this order is what they catch

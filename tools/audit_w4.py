@@ -89,6 +89,46 @@ def lint_blocks(blocks):
     return out[:20]
 
 
+def lint_lds_waits(block, entry_pending=0):
+    """In-order check of the LDS waits of ONE compiled asm statement whose reads are all consumed inside it (the one-wave-per-SIMD dQ
+    kernel's iterations, tools/gen_dq4.py): every instruction that reads a register loaded by a ds_read of the statement must sit
+    behind an s_waitcnt lgkmcnt(n) that guarantees the read has returned (LDS returns in order: after lgkmcnt(n) all but the newest n
+    reads are back).  entry_pending: reads issued by the previous statement that may still be out at entry (counted, registers
+    unknown: they can only make a wait stricter than needed, never looser).  Returns a list of problems."""
+    out = []
+    issued = entry_pending          # LDS reads issued so far (including the unknown ones at entry)
+    done = 0                        # reads known complete
+    loaded = {}                     # register -> index of the read that loads it
+    for t in block:
+        if not t or t.startswith(";"):
+            continue
+        parts = t.replace(",", " ").split()
+        op, ops = parts[0], parts[1:]
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", t)
+            if m:
+                done = max(done, issued - int(m.group(1)))
+            continue
+        if op.startswith("ds_read"):
+            for r in _regs(ops[0]):
+                loaded[r] = issued
+            issued += 1
+            continue
+        if op.startswith("v_"):
+            srcs = ops[1:4] if op.startswith("v_mfma") else (ops if op.startswith("v_cmp") else ops[1:])
+            for o in srcs:
+                for r in _regs(o):
+                    if r in loaded and loaded[r] >= done:
+                        out.append(f"`{t}` reads {r[0]}{r[1]} before its ds_read (number {loaded[r]} of {issued}) is known to be back")
+                        break
+            if not op.startswith("v_cmp"):
+                for r in _regs(ops[0]):
+                    if r in loaded and loaded[r] >= done:
+                        out.append(f"`{t}` writes {r[0]}{r[1]} while a ds_read into it may still be out")
+                    loaded.pop(r, None)
+    return out[:10]
+
+
 def audit(path, verbose=True):
     text = open(path).read()
     problems = []
