@@ -468,6 +468,9 @@ def main():
                                 "c2_zero_inputs_ms_per_step": msz / 20,
                                 "c2_zero_inputs_note": "the C2 forward on all-zero q, k, v (LSE not stored): the kernel's schedule without the "
                                                        "data-dependent power of N(0,1) inputs -- NOT a throughput claim"})
+        if isinstance(result.get("roofline"), dict):
+            # beside frac / frac_steady: what the same kernel reaches of the peak when the power cap is out of the way
+            result["roofline"]["frac_zero_inputs"] = tz / PEAK_TFLOPS[dtype]
         del qz, kz, vz
 
     if rank == 0:
