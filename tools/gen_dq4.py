@@ -131,9 +131,15 @@ def regs_of(tok):
     return set()
 
 
-def with_waits(lines, pending):
+MERGE_KV = os.environ.get("DQ4_MERGE_KV", "1") != "0"      # one wait per k-slice for its K AND V fragment (A/B: 0 = one each)
+
+
+def with_waits(lines, pending, pair=None):
     """insert s_waitcnt lgkmcnt(n) in front of the first reader of every LDS read.  pending: registers loaded by reads that were
-    issued before the statement, oldest first (list of register sets); LDS returns in order."""
+    issued before the statement, oldest first (list of register sets); LDS returns in order.  pair: (lo, hi, delta) -- a reader of a
+    register in [lo, hi) also waits for register + delta (the S MFMAs of a k-slice wait for its V fragment too: the dP MFMAs two
+    slots later then need no s_waitcnt of their own -- one instruction per k-slice less for a read that was issued two MFMAs
+    after the K fragment's and six MFMAs ago)."""
     out = []
     issued = []                       # register sets of the LDS reads in issue order (pending first)
     done = 0                          # reads known complete: issued[:done]
@@ -151,6 +157,8 @@ def with_waits(lines, pending):
                 src |= regs_of(o)
             if op.startswith("v_mfma"):
                 src = set().union(*[regs_of(o) for o in ops[1:4]])
+                if pair is not None:
+                    src |= {(f, r + pair[2]) for (f, r) in src if f == "v" and pair[0] <= r < pair[1]}
             need = -1
             for i in range(done, len(issued)):
                 if issued[i] & src:
@@ -250,7 +258,7 @@ def gen_iter(c, par, qk, nxt, ar, dq, pre):
     if qk and pre:
         for ks in (0, 1):
             pending += [regs_of(f"v[{c.KR + 4 * ks}:{c.KR + 4 * ks + 3}]"), regs_of(f"v[{c.VR + 4 * ks}:{c.VR + 4 * ks + 3}]")]
-    lines, left = with_waits(lines, pending)
+    lines, left = with_waits(lines, pending, (c.KR, c.KR + 8, c.VR - c.KR) if MERGE_KV else None)
     if XFLAGS:
         def keep(ln):
             op = ln.split()[0]
