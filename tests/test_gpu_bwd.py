@@ -167,22 +167,19 @@ def test_backward_deterministic(torch_cuda):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("which", ["new", "old", "dq4", "dq_old"])
-def test_backward_on_the_one_wave_per_simd_dkdv_kernel(which):
-    """fa_bwd_dkv4_gfx950.hip is the dK/dV kernel of every D = 128 16-bit problem without a window whose grid it covers (the
-    dispatcher's rule in fa_bwd_gfx950.hip); its predecessor keeps the rest.  AULE_HIP_BWD_DKV=new forces it onto every problem it
-    CAN run, =old pins the predecessor everywhere: the sweep, the reference's golden gradients, the bottom-right cases and the
-    determinism test then exercise the masks, the stream start / tail and the GQA loop of either kernel on all of them.  "dq4" /
-    "dq_old": the same for the two dQ kernels (fa_bwd_dq4_gfx950.hip takes grids of >= 128 work items by itself; AULE_HIP_BWD_DQ=new
-    forces it onto every problem it can run, =old pins the predecessor)."""
+@pytest.mark.parametrize("which", ["new", "old"])
+def test_backward_on_the_one_wave_per_simd_kernels(which):
+    """fa_bwd_dkv4_gfx950.hip (dK/dV) and fa_bwd_dq4_gfx950.hip (dQ) are the backward kernels of the D = 128 16-bit problems without a
+    window whose grids they cover (the dispatcher's rules in fa_bwd_gfx950.hip); their predecessors keep the rest.
+    AULE_HIP_BWD_DKV=new + AULE_HIP_BWD_DQ=new force both onto every problem they CAN run, =old pins both predecessors everywhere:
+    the sweep, the reference's golden gradients, the bottom-right cases and the determinism test then exercise the masks, the stream
+    start / tail, the idle waves and the GQA loop of either pair on all of them."""
     import subprocess
     import sys
     from conftest import ROOT
     e = dict(os.environ)
-    if which in ("dq4", "dq_old"):
-        e["AULE_HIP_BWD_DQ"] = "new" if which == "dq4" else "old"
-    else:
-        e["AULE_HIP_BWD_DKV"] = which
+    e["AULE_HIP_BWD_DKV"] = which
+    e["AULE_HIP_BWD_DQ"] = which
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_bwd.py"), os.path.join(ROOT, "tests", "test_gpu_bottom_right.py"),
-                        "-q", "-x", "-m", "gpu", "-k", "not one_wave_per_simd_dkdv"], env=e, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+                        "-q", "-x", "-m", "gpu", "-k", "not one_wave_per_simd"], env=e, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and "passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
