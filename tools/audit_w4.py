@@ -117,12 +117,12 @@ def lint_lds_waits(block, entry_pending=0):
         if op.startswith("v_"):
             srcs = ops[1:4] if op.startswith("v_mfma") else (ops if op.startswith("v_cmp") else ops[1:])
             for o in srcs:
-                for r in _regs(o):
+                for r in sorted(_regs(o)):          # sorted: the register named in a message must not depend on the hash seed
                     if r in loaded and loaded[r] >= done:
                         out.append(f"`{t}` reads {r[0]}{r[1]} before its ds_read (number {loaded[r]} of {issued}) is known to be back")
                         break
             if not op.startswith("v_cmp"):
-                for r in _regs(ops[0]):
+                for r in sorted(_regs(ops[0])):
                     if r in loaded and loaded[r] >= done:
                         out.append(f"`{t}` writes {r[0]}{r[1]} while a ds_read into it may still be out")
                     loaded.pop(r, None)
