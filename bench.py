@@ -137,6 +137,62 @@ def cpu_baseline(budget_s=10.0):
     }
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>` -- the command the driver
+    uses -- by exec, so that rank 0's JSON line is this process's stdout and its exit code this process's.  The device count is
+    checked first: a box with fewer GPUs fails here with that message, not inside a rendezvous."""
+    if not args.dry_run:
+        import torch
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n < args.gpus:
+            raise SystemExit("bench.py: --gpus %d needs %d devices, this node shows %d" % (args.gpus, args.gpus, n))
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def dry_run(args):
+    """The bench's launch contract without a device: process group (gloo) of --gpus ranks, the rank-count assertion, K timed
+    no-op steps between barriers, MAX over ranks, rank 0 prints one line with "dry_run": true and no throughput."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 or "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        assert dist.get_world_size() == world
+    else:
+        dist = None
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher made %d rank(s)" % (args.gpus, world))
+    for _ in range(args.warmup):
+        pass
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t[0])
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "attention TFLOPS/GPU (fwd, fwd+bwd) + % MFMA roofline at S=4096,D=128", "value": None,
+                          "unit": "TFLOP/s", "n_gpus": world, "world_size": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": wall * 1e3 / max(1, args.steps), "dry_run": True}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,7 +205,15 @@ def main():
                     help="device time spent repeating the step before warm-up (0: none); see the module docstring")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / timing scaffolding only (gloo, no device, no kernels): what tests/test_bench_spawn.py drives")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_spawn(args)
+
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     import aule  # raises AuleError at first use if libaule.so / a HIP device is missing
@@ -159,6 +223,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no ROCm device visible (there is no CPU fallback)")
+    if torch.cuda.device_count() < max(args.gpus, local_rank + 1):
+        raise SystemExit("bench.py: --gpus %d needs %d devices, this node shows %d" % (args.gpus, args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run (also exercised with 1 rank)
@@ -169,9 +235,9 @@ def main():
     if dist is not None:
         assert dist.get_world_size() == world
     if args.gpus != world:
-        # (the driver launches `--gpus N` under torch.distributed.run with N ranks; a plain `python bench.py --gpus 1` has world 1)
-        raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s) (launch with python -m torch.distributed.run "
-                         "--nproc-per-node %d ...)" % (args.gpus, world, args.gpus))
+        # (the driver launches `--gpus N` under torch.distributed.run with N ranks; a plain `python bench.py --gpus N` spawns
+        # them itself: self_spawn.  What is left is a launcher that made a different number of ranks than --gpus says.)
+        raise SystemExit("bench.py: --gpus %d but the launcher made %d rank(s)" % (args.gpus, world))
     n_gpus = world
 
     B, Hq, Hkv, Sq, Sk, D, dtype, causal, mode = CONFIGS[args.config]
@@ -407,6 +473,30 @@ def main():
                            "c3_workload": "GQA 32q/8kv B=4 S=2048 D=128 bf16 causal fwd+bwd (autograd); bwd = step - fwd-only step "
                                           "(dQ / dK,dV kernel split: profiles/r3_fwdbwd_c3_*)"}
         del q3, k3, v3, d3
+        # the metric's own fwd+bwd shape: C2 (B4 H32 S4096 D128 bf16 causal) through autograd, on this run's q, k, v
+        # (the reference harness sweeps these shapes fwd+bwd: tests/benchmark_mi300x.py:207-233)
+        d2 = torch.randn(B, Hq, Sq, D, device=dev, dtype=tdt, generator=g3)
+
+        def step2():
+            q.grad = k.grad = v.grad = None
+            aule.flash_attention(q, k, v, causal=causal).backward(d2)
+
+        condition(step2, args.condition_ms)
+        _, ms2 = timed(step2, 20)
+        l2 = sorted(last_launches)
+        condition(step, args.condition_ms / 2)
+        _, ms2f = timed(step, 20)
+        t2 = 3.5 * f_fwd / (ms2 / 20 * 1e-3) / 1e12
+        bwd2_ms = (ms2 - ms2f) / 20
+        result["extra"].update({"c2_fwd_bwd_tflops": t2, "c2_fwd_bwd_frac_of_peak": t2 / PEAK_TFLOPS[dtype],
+                                "c2_fwd_bwd_ms_per_step": ms2 / 20, "c2_fwd_bwd_ms_per_step_median": l2[len(l2) // 2],
+                                "c2_fwd_ms": ms2f / 20, "c2_bwd_ms": bwd2_ms,
+                                "c2_bwd_tflops": 2.5 * f_fwd / (bwd2_ms * 1e-3) / 1e12,
+                                "c2_bwd_frac": 2.5 * f_fwd / (bwd2_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype],
+                                "c2_fwd_bwd_workload": "MHA B=4 H=32 S=4096 D=128 bf16 causal fwd+bwd (autograd): the metric's own shape; bwd = "
+                                                       "step - fwd-only step (per-kernel split: profiles/r4_fwdbwd_c2_*)"})
+        q.grad = k.grad = v.grad = None
+        del d2
         B5, H5, K5, S5, _, D5, _, _, _ = CONFIGS["c5"]
         q5 = torch.randn(B5, H5, S5, D5, device=dev, dtype=torch.float16, generator=g3).requires_grad_(True)
         k5 = torch.randn(B5, K5, S5, D5, device=dev, dtype=torch.float16, generator=g3)
