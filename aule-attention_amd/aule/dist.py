@@ -108,7 +108,7 @@ def flash_attention_sharded(q, k, v, causal: bool = True, scale: Optional[float]
     collective of round 1."""
     import torch
     import torch.distributed as dist
-    into = _into_ok(q, attn_fn)
+    into = _into_ok(q, k, v, causal, attn_fn)
     if attn_fn is None:
         from . import flash_attention as attn_fn
     world = dist.get_world_size(group)
@@ -145,7 +145,7 @@ def attention_and_gather(q, k, v, causal: bool = True, scale: Optional[float] = 
     caller and bench.py have): q [Bl,Hq,Sq,D], k / v [Bl,Hkv,Sk,D] local; returns [world*Bl,Hq,Sq,D] on every rank,
     rank r's rows at [r*Bl, (r+1)*Bl)."""
     import torch.distributed as dist
-    into = _into_ok(q, attn_fn)
+    into = _into_ok(q, k, v, causal, attn_fn)
     if attn_fn is None:
         from . import flash_attention as attn_fn
     world = dist.get_world_size(group)
@@ -162,13 +162,24 @@ def attention_and_gather(q, k, v, causal: bool = True, scale: Optional[float] = 
     return full.reshape(world * Bl, Hq, Sq, D)
 
 
-def _into_ok(t, attn_fn):
-    """Can the default attention write its result straight into a view of the gathered tensor?  (Device tensors of a dtype
-    and head_dim the kernels take natively; a caller-supplied attn_fn returns its own tensor.)"""
-    if attn_fn is not None or not getattr(t, "is_cuda", False):
+def _into_ok(q, k, v, causal, attn_fn):
+    """Can the default attention write its result straight into a view of the gathered tensor?  Only for what fwd_raw takes
+    as it is: device tensors, q / k / v of ONE dtype the kernels run natively, a head_dim they take unpadded, and a
+    bottom-right mask with seq_len_k >= seq_len_q.  The reference's shape rules are checked here (ValueError, as from
+    aule.flash_attention) because the in-place route does not pass through it; everything else -- mixed dtypes, padded head
+    dims, a caller-supplied attn_fn -- takes the copying route through aule.flash_attention, which casts and checks itself."""
+    from . import _validate
+    _validate(q, k, v)
+    if attn_fn is not None or not all(getattr(t, "is_cuda", False) for t in (q, k, v)):
         return False
     from . import _torch as at
-    return t.dtype in at._DTYPES and t.shape[-1] in at.SUPPORTED_HEAD_DIMS
+    if q.dtype not in at._DTYPES or k.dtype != q.dtype or v.dtype != q.dtype:
+        return False
+    if q.shape[-1] not in at.SUPPORTED_HEAD_DIMS:
+        return False
+    if at.causal_code(causal) == 2 and k.shape[2] < q.shape[2]:
+        return False          # (aule.flash_attention raises the ValueError on the copying route)
+    return True
 
 
 def _attn_into(q, k, v, causal, scale, out):

@@ -20,6 +20,8 @@
 //                       group reduction is the loop, not an atomic.
 // The softmax is recomputed twice (once per kernel): 7 tile matmuls instead of the
 // 5 of the atomic formulation, in exchange for no fp32 atomics on dQ.
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "fa_device.h"
@@ -1080,7 +1082,11 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
 #ifdef AULE_DEBUG_HOOKS
     // debug library only: AULE_DBG_BWD_ONLY=dq / =dkv launches one of the two kernels (per-kernel times from tools/cbench.cpp
     // without a profiler; the workspace keeps delta / L' of an earlier full call)
-    static const int only = [] { const char* e = std::getenv("AULE_DBG_BWD_ONLY"); return e == nullptr ? 0 : (e[1] == 'q' ? 1 : 2); }();
+    static const int only = [] {
+        const char* e = std::getenv("AULE_DBG_BWD_ONLY");
+        if (e == nullptr) return 0;
+        return std::strcmp(e, "dq") == 0 ? 1 : (std::strcmp(e, "dkv") == 0 ? 2 : 0);   // anything else: both kernels
+    }();
 #else
     constexpr int only = 0;
 #endif

@@ -12,6 +12,8 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace aule_hip {
 
 enum DType : int { kF32 = 0, kF16 = 1, kBF16 = 2 };
@@ -47,14 +49,15 @@ struct FwdArgs {
 // Compute units of `device` (-1: the current one), asked once per device id and process: launch paths call this several times
 // per launch (route, plan, grid).
 inline int device_cu_count(int device) {
-    static int cached[64] = {};
+    static std::atomic<int> cached[64];   // (zero-initialised; API threads may race to fill an entry with the same value)
     int dev = device;
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return 256;
     if (dev < 0 || dev >= 64) return 256;
-    if (cached[dev] > 0) return cached[dev];
+    const int have = cached[dev].load(std::memory_order_relaxed);
+    if (have > 0) return have;
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
-    cached[dev] = n;
+    cached[dev].store(n, std::memory_order_relaxed);
     return n;
 }
 

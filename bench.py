@@ -373,6 +373,11 @@ def main():
                       "traffic_source": "stored: rocprofv3 PMC passes of the last profiled run of this workload (profiles/hbm_traffic.json, "
                                         "FETCH_SIZE x2 + WRITE_SIZE per launch), not measured in this run",
                       "effective_clock_ghz_profiled": stored_profile(args.config, mode).get("effective_clock_ghz"),
+                      # stored telemetry of the last power-trace run of this workload (profiles/r4_power_trace.txt): socket power and
+                      # power limit (hwmon), shader clock while the kernel runs back to back; and what a loop of nothing but MFMAs on
+                      # N(0,1) operands sustains on this chip -- the ceiling of ANY kernel on random data, as a fraction of `peak`
+                      **{k: stored_profile(args.config, mode).get(k) for k in ("power_w", "power_cap_w", "sclk_mhz",
+                                                                                "mfma_only_random_frac_of_peak", "power_profile")},
                       "kernel_ms": kern_ms, **launch_stats(),
                       "note": "achieved = algorithmic FLOPs per step / HIP-event time per step on the launch stream (the `value` leg: "
                               "plain W + K protocol); frac_steady = the same for the conditioned leg; algorithmic bytes %d; the nominal "
