@@ -242,6 +242,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     }
     A::set_consts();
     const unsigned wave1k = (unsigned)wave * 1024u;
+    A::set_lds_base((unsigned)w4_rfl((int)(lds0 + wave1k)));   // (literal scalar register of the embedded-request steps)
     const unsigned oob = (unsigned)Sk * RB;   // a scalar offset at which every lane of a request is out of range (LDS gets zeros)
 
     // The tile barrier of step j: the wave's LDS reads of step j - 1 have returned (so a request of step j may overwrite their
@@ -302,9 +303,12 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         auto set_k = [&](int t) __attribute__((always_inline)) {   // tile t of this part, or tile t - nt3 < 3 of the next one
             ksoff = oob;
             if (t < nt) ksoff = (unsigned)t * KT;
-            else if (pre && t >= nt3 && t - nt3 < 3) {
+            else if (pre && t >= nt3 && t - nt3 <= 3) {
                 if (t == nt3) head_lohi(P()->k, w4_rfl(tab[n_slot].y), klo, khi);
-                ksoff = (unsigned)(t - nt3) * KT;
+                // (position 3 of the next part: its K_3 is not prefetched -- the slot holds K_0 until the next prologue has read
+                // it -- but the embedded-request steps ask unconditionally, and an out-of-range request would put zeros there:
+                // K_0 once more, the same bytes into the same slot)
+                ksoff = t - nt3 == 3 ? 0u : (unsigned)(t - nt3) * KT;
             }
         };
         auto set_v = [&](int t) __attribute__((always_inline)) {   // ... or tile t - nt3 < 2 of the next one
@@ -327,6 +331,10 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             na = min(nt, max(1, (vis + kKVTile - 1) / kKVTile));
             const int min_thr = CAUSAL ? min(r0 + coff, Sk - 1) : Sk - 1;   // keys EVERY row of the wave sees: 0 .. min_thr
             jm = (min_thr + 1) >> 6;                                        // first tile that needs the mask
+            // (opaque: without a mask these are the same for every part, and hipcc then evaluates every comparison of the step
+            // logic once per kernel and keeps the ~25 results -- 64-bit lane masks -- alive across the stream: 48 scalar spills
+            // and, with the spill lanes' own register, a vector spill to scratch in the non-causal D = 128 instance)
+            asm volatile("" : "+s"(nt), "+s"(nt3), "+s"(na), "+s"(jm));
             n_slot = next_valid(sl);
             pre = !REDO && n_slot < nslot;
             head_lohi(P()->k, kvoff, klo, khi);
@@ -390,36 +398,90 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         // (ring slots as immediates: SL = stream position mod 3.  Six bodies -- slot x parity -- so that between two MFMA
         // statements of a plain step hipcc has nothing to compute but the requests' scalar offsets: the first build with run-time
         // slots spent ~55 scalar instructions and half a dozen branches between two steps, with the matrix pipe idle)
+        // (round 4: every scalar operand of the requests -- descriptors, tile offsets, LDS addresses -- sits in literal registers
+        // above hipcc's budget (W4Asm::NS, set_cursors / set_lds_base); the streams advance the cursors themselves)
+        const __amdgpu_buffer_rsrc_t nosrd = make_srd(nullptr, 0);   // (unused operand of the literal-register statements)
         auto plain = [&](auto sl_tag, auto par_tag) __attribute__((always_inline)) {
             constexpr int SL = decltype(sl_tag)::value, PAR = decltype(par_tag)::value;
             stamp(0x10 + PAR);
-            const unsigned kl = lds0 + ((SL + 1) % 3) * KT + wave1k, vl = lds0 + OFF_V + ((SL + 2) % 3) * VT + wave1k;
-            const __amdgpu_buffer_rsrc_t ksrd = srd_of(klo, khi), vsrd = srd_of(vlo, vhi);
-            A::template p1<0, PAR, 1, 1, 1, 1, SL>(c, va, 0, kl, ksrd, ksoff, kvo);
-            A::template p1<1, PAR, 1, 1, 1, 1, SL>(c, va, 0, kl, ksrd, ksoff + 4096u, kvo);
-            A::template p1<2, PAR, 1, 1, 1, 1, SL>(c, va, 0, kl, ksrd, ksoff + (NP == 4 ? 8192u : 4096u), kvo);
-            A::template p1<3, PAR, 1, 1, 1, 1, SL>(c, va, 0, kl, ksrd, ksoff + 12288u, kvo);
+            A::template p1<0, PAR, 1, 1, 1, 2, SL>(c, va, 0, 0, nosrd, 0, kvo);
+            A::template p1<1, PAR, 1, 1, 1, 2, SL>(c, va, 0, 0, nosrd, 0, kvo);
+            A::template p1<2, PAR, 1, 1, 1, 2, SL>(c, va, 0, 0, nosrd, 0, kvo);
+            A::template p1<3, PAR, 1, 1, 1, 2, SL>(c, va, 0, 0, nosrd, 0, kvo);
             stamp(0x18);
             constexpr int KSL = (SL + 2) % 3;
-            A::template p2<0, PAR, 1, 1, 1, 1, KSL>(c, kaddr(ka0, 0), kaddr(ka0, KS / 4 - 1), 0, vl, vsrd, vsoff, vvo);
-            A::template p2<1, PAR, 1, 1, 1, 1, KSL>(c, kaddr(ka0, KS / 4), kaddr(ka0, 2 * (KS / 4) - 1), 0, vl, vsrd, vsoff + 4096u, vvo);
-            A::template p2<2, PAR, 1, 1, 1, 1, KSL>(c, kaddr(ka0, 2 * (KS / 4)), kaddr(ka0, 3 * (KS / 4) - 1), 0, vl, vsrd, vsoff + (NP == 4 ? 8192u : 4096u), vvo);
-            A::template p2<3, PAR, 1, 1, 1, 1, KSL>(c, kaddr(ka0, 3 * (KS / 4)), kaddr(ka0, KS - 1), 0, vl, vsrd, vsoff + 12288u, vvo);
+            A::template p2<0, PAR, 1, 1, 1, 2, KSL>(c, kaddr(ka0, 0), kaddr(ka0, KS / 4 - 1), 0, 0, nosrd, 0, vvo);
+            A::template p2<1, PAR, 1, 1, 1, 2, KSL>(c, kaddr(ka0, KS / 4), kaddr(ka0, 2 * (KS / 4) - 1), 0, 0, nosrd, 0, vvo);
+            A::template p2<2, PAR, 1, 1, 1, 2, KSL>(c, kaddr(ka0, 2 * (KS / 4)), kaddr(ka0, 3 * (KS / 4) - 1), 0, 0, nosrd, 0, vvo);
+            A::template p2<3, PAR, 1, 1, 1, 2, KSL>(c, kaddr(ka0, 3 * (KS / 4)), kaddr(ka0, KS - 1), 0, 0, nosrd, 0, vvo);
             stamp(0x19);
         };
-        // the request cursors of step j + 1, after plain step j (the ring phase is the body's business)
-        auto cursors = [&](int j) __attribute__((always_inline)) {
-            if (__builtin_expect(j + 5 < nt, 1)) {
-                ksoff += KT;
-                vsoff += VT;
-            } else {
+        // the step in front of the wave's last tile in the same form: S_{j+1}[A] is the masked tile
+        auto prediag = [&](auto sl_tag, auto par_tag, int j) __attribute__((always_inline)) {
+            constexpr int SL = decltype(sl_tag)::value, PAR = decltype(par_tag)::value;
+            stamp(0x62 + PAR);
+            A::template p1<0, PAR, 1, 1, 1, 2, SL>(c, va, 0, 0, nosrd, 0, kvo);
+            A::template p1<1, PAR, 1, 1, 1, 2, SL>(c, va, 0, 0, nosrd, 0, kvo);
+            A::template p1<2, PAR, 1, 1, 1, 2, SL>(c, va, 0, 0, nosrd, 0, kvo);
+            A::template p1<3, PAR, 1, 1, 1, 2, SL>(c, va, 0, 0, nosrd, 0, kvo);
+            stamp(0x18);
+            constexpr int KSL = (SL + 2) % 3;
+            const int tA = thr_of(0, j + 1);
+            A::template p2<0, PAR, 1, 2, 1, 2, KSL>(c, kaddr(ka0, 0), kaddr(ka0, KS / 4 - 1), tA, 0, nosrd, 0, vvo);
+            A::template p2<1, PAR, 1, 2, 1, 2, KSL>(c, kaddr(ka0, KS / 4), kaddr(ka0, 2 * (KS / 4) - 1), tA, 0, nosrd, 0, vvo);
+            A::template p2<2, PAR, 1, 2, 1, 2, KSL>(c, kaddr(ka0, 2 * (KS / 4)), kaddr(ka0, 3 * (KS / 4) - 1), tA, 0, nosrd, 0, vvo);
+            A::template p2<3, PAR, 1, 2, 1, 2, KSL>(c, kaddr(ka0, 3 * (KS / 4)), kaddr(ka0, KS - 1), tA, 0, nosrd, 0, vvo);
+            stamp(0x19);
+        };
+        // the wave's last tile: masked softmax of S_j[B] (no S_{j+1}), O^T += V_j^T P_j^T; both requests ride along
+        auto diag = [&](auto sl_tag, auto par_tag, int j) __attribute__((always_inline)) {
+            constexpr int SL = decltype(sl_tag)::value, PAR = decltype(par_tag)::value;
+            stamp(0x64 + PAR);
+            const int tB = thr_of(1, j);
+            A::template p1<0, PAR, 0, 2, 1, 2, SL>(c, va, tB, 0, nosrd, 0, kvo);
+            A::template p1<1, PAR, 0, 2, 1, 2, SL>(c, va, tB, 0, nosrd, 0, kvo);
+            A::template p1<2, PAR, 0, 2, 1, 2, SL>(c, va, tB, 0, nosrd, 0, kvo);
+            A::template p1<3, PAR, 0, 2, 1, 2, SL>(c, va, tB, 0, nosrd, 0, kvo);
+            stamp(0x18);
+            constexpr int KSL = (SL + 2) % 3;
+            A::template p2<0, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
+            A::template p2<1, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
+            A::template p2<2, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
+            A::template p2<3, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
+            stamp(0x19);
+        };
+        // step 0 of a part (stream position 0, parity 0; O starts at 0; S_0 is the prologue's bare QK^T): its tile barrier has
+        // nothing to wait for but the other waves' reads of K_0 and K_1 (the prologue's vmcnt(0) made the tiles visible)
+        auto first = [&]() __attribute__((always_inline)) {
+            stamp(0x60);
+            A::template p1<0, 0, 1, 3, 1, 3, 0>(c, va, 0, 0, nosrd, 0, kvo);
+            A::template p1<1, 0, 1, 3, 1, 2, 0>(c, va, 0, 0, nosrd, 0, kvo);
+            A::template p1<2, 0, 1, 3, 1, 2, 0>(c, va, 0, 0, nosrd, 0, kvo);
+            A::template p1<3, 0, 1, 3, 1, 2, 0>(c, va, 0, 0, nosrd, 0, kvo);
+            stamp(0x18);
+            A::template p2<0, 0, 2, 1, 1, 2, 2>(c, kaddr(ka0, 0), kaddr(ka0, KS / 4 - 1), 0, 0, nosrd, 0, vvo);
+            A::template p2<1, 0, 2, 1, 1, 2, 2>(c, kaddr(ka0, KS / 4), kaddr(ka0, 2 * (KS / 4) - 1), 0, 0, nosrd, 0, vvo);
+            A::template p2<2, 0, 2, 1, 1, 2, 2>(c, kaddr(ka0, 2 * (KS / 4)), kaddr(ka0, 3 * (KS / 4) - 1), 0, 0, nosrd, 0, vvo);
+            A::template p2<3, 0, 2, 1, 1, 2, 2>(c, kaddr(ka0, 3 * (KS / 4)), kaddr(ka0, KS - 1), 0, 0, nosrd, 0, vvo);
+            stamp(0x19);
+        };
+        // shadows -> literal registers (part start, and wherever the slow path moved them)
+        auto sync_regs = [&]() __attribute__((always_inline)) {
+            A::set_cursors((unsigned)w4_rfl((int)klo), (unsigned)w4_rfl((int)khi), (unsigned)w4_rfl((int)vlo), (unsigned)w4_rfl((int)vhi),
+                           (unsigned)w4_rfl((int)oob), (unsigned)w4_rfl((int)ksoff), (unsigned)w4_rfl((int)vsoff));
+        };
+        // after embedded-request step j: the streams moved both cursors one tile on; where the part's tiles end (its last five
+        // steps) the cursors of step j + 1 come from set_k / set_v as before and overwrite them
+        auto fix_cursors = [&](int j) __attribute__((always_inline)) {
+            if (__builtin_expect(j + 5 >= nt, 0)) {
                 set_k(j + 5);
                 set_v(j + 3);
+                sync_regs();
             }
         };
         // a run of plain steps [j, jend), j = 1 (mod 6) at entry.  Every part starts at ring phase 0 (parts are padded to a
         // multiple of three positions), so step j of ANY part uses ring slot j mod 3 and parity j mod 2: the six bodies follow
-        // each other in a fixed order and the loop between them is one compare and one branch -- a run-time choice among the
+        // each other in a fixed order and the loop between them is two compares and two branches -- a run-time choice among the
         // six came out of hipcc's structurizer as ~10 flag tests per step.
         auto plain_run = [&](int& j, int jend) __attribute__((always_inline)) {
             using I0 = integral_constant<int, 0>;
@@ -427,18 +489,40 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             using I2 = integral_constant<int, 2>;
             for (;;) {
                 if (j >= jend) break;
-                plain(I1{}, I1{}); cursors(j); ++j; rp = 2;
+                plain(I1{}, I1{}); fix_cursors(j); ++j;
                 if (j >= jend) break;
-                plain(I2{}, I0{}); cursors(j); ++j; rp = 0;
+                plain(I2{}, I0{}); fix_cursors(j); ++j;
                 if (j >= jend) break;
-                plain(I0{}, I1{}); cursors(j); ++j; rp = 1;
+                plain(I0{}, I1{}); fix_cursors(j); ++j;
                 if (j >= jend) break;
-                plain(I1{}, I0{}); cursors(j); ++j; rp = 2;
+                plain(I1{}, I0{}); fix_cursors(j); ++j;
                 if (j >= jend) break;
-                plain(I2{}, I1{}); cursors(j); ++j; rp = 0;
+                plain(I2{}, I1{}); fix_cursors(j); ++j;
                 if (j >= jend) break;
-                plain(I0{}, I0{}); cursors(j); ++j; rp = 1;
+                plain(I0{}, I0{}); fix_cursors(j); ++j;
             }
+        };
+        // the wave's last two tiles in the embedded-request form: step j (in front of the last tile) and step j + 1 (the last
+        // tile); ring slot and parity follow from the position
+        auto fast_tail = [&](int j) __attribute__((always_inline)) {
+            using I0 = integral_constant<int, 0>;
+            using I1 = integral_constant<int, 1>;
+            using I2 = integral_constant<int, 2>;
+            switch (j % 6) {
+                case 0: prediag(I0{}, I0{}, j); fix_cursors(j); diag(I1{}, I1{}, j + 1); break;
+                case 1: prediag(I1{}, I1{}, j); fix_cursors(j); diag(I2{}, I0{}, j + 1); break;
+                case 2: prediag(I2{}, I0{}, j); fix_cursors(j); diag(I0{}, I1{}, j + 1); break;
+                case 3: prediag(I0{}, I1{}, j); fix_cursors(j); diag(I1{}, I0{}, j + 1); break;
+                case 4: prediag(I1{}, I0{}, j); fix_cursors(j); diag(I2{}, I1{}, j + 1); break;
+                default: prediag(I2{}, I1{}, j); fix_cursors(j); diag(I0{}, I0{}, j + 1); break;
+            }
+            fix_cursors(j + 1);
+        };
+        // back to the shadow cursors (generic and idle steps read them): what step j asks for
+        auto leave_fast = [&](int j) __attribute__((always_inline)) {
+            set_k(j + 4);
+            set_v(j + 2);
+            rp = j % 3;
             nprev = 2 * NP;
         };
         // the requests of a step as separate statements (everywhere but the plain step); returns the pieces now in flight.  An
@@ -466,8 +550,9 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             const __amdgpu_buffer_rsrc_t ksrd = make_srd(nullptr, 0);   // (unused operand of the statements without requests)
             stamp(0x20 + PAR + 2 * QK + 4 * SMB);
             begin_n();
-            if constexpr (PV == 2)   // tile 0: K_3 goes where K_0 was (this step's tile barrier freed the slot); it is older than this
-                                     // step's own requests, so the NEXT tile barrier covers it
+            if constexpr (PV == 2 && REDO)   // tile 0 of the exact-maximum stream: K_3 goes where K_0 was (this step's tile barrier freed
+                                             // the slot); older than this step's own requests, so the NEXT tile barrier covers it.  (The
+                                             // first stream's prologue has asked for it already.)
                 A::dma_tile(ring_lds(0, 0), head_srd(P()->k, kvoff, Sk), 3u * KT, kvo);
             const int n = requests();
             const unsigned vap = va + (unsigned)rp * VT, kb = ka0 + (unsigned)slot(2) * KT;
@@ -519,6 +604,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         // part prologue = "step -1" (K_0, K_1 of the part in the ring, Q requested): S_0, the references, P_0[A]; leaves K_1 in
         // the fragment registers
         auto prologue = [&]() __attribute__((always_inline)) {
+            constexpr bool k3 = !REDO;   // (the same for every wave of the workgroup: it adds a barrier)
             stamp(0x30);
             const __amdgpu_buffer_rsrc_t ksrd = make_srd(nullptr, 0);   // (unused operand)
             unsigned kap[KS];
@@ -528,6 +614,13 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             // for them) and the Q fragments; the epilogue's stores ride along
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             A::kread_all(kap);
+            if constexpr (k3) {
+                // K_3 goes where K_0 was as soon as every wave holds K_0 in registers (round 3 asked for it in step 0, behind that
+                // step's tile barrier: four request pieces outside the MFMA gaps); older than step 0's requests, so step 1's
+                // counted wait covers it.  Every wave of the workgroup does this, whichever bodies its steps run.
+                asm volatile("s_barrier" ::: "memory");
+                A::dma_tile(ring_lds(0, 0), head_srd(P()->k, kvoff, Sk), 3u * KT, kvo);
+            }
             if constexpr (!REDO) {
                 if (rope) A::rope_rotate();          // (the second stream rotated in its exact-maximum pass)
                 A::prescale_q(c);                    // (pre form only)
@@ -555,8 +648,8 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 A::template p2<3, 1, 0, 1, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0);
             }
             stamp(0x33);
-            nprev = 0;   // (the vmcnt(0) above left nothing in flight; step 0's tile barrier follows: every wave holds K_0 and K_1 then,
-                         // and step 0 requests K_3 and K_4 into their slots)
+            nprev = k3 ? NP : 0;   // (the vmcnt(0) above left nothing else in flight; step 0's tile barrier follows: every wave holds
+                                   // K_0 and K_1 then, and step 0 requests K_4 (the exact-maximum stream: K_3 too) into their slots)
         };
 
         // ---- epilogue of a part: O = O^T / l, rounded, transposed through the wave's LDS slab (block A, then block B), whole-row
@@ -661,25 +754,31 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 cold = false;
             }
+            // Embedded-request flow (round 4): wherever the wave sees at least three tiles and none before its last one needs the
+            // mask -- every part of a causal or ragged problem but a head's first block -- step 0, the plain steps, the step in
+            // front of the last tile and the last tile all run bodies with static ring slots, literal scalar operands and the
+            // requests in their MFMA gaps.  Everything else (and the exact-maximum stream) takes the generic bodies.
+            const bool fast = !REDO && na >= 3 && jm >= na - 1;
             prologue();
             using I0 = integral_constant<int, 0>;
             using I1 = integral_constant<int, 1>;
             using I2 = integral_constant<int, 2>;
-            // plain steps: the previous step left exactly 2 NP pieces in flight (the constant their in-stream barrier waits
-            // with), tile j + 1 needs no mask and is not the wave's last; everything else runs the generic body.  (A plain step
-            // requests unconditionally -- an out-of-range request writes zeros into its ring slot -- which is harmless up to the
-            // wave's last-but-one tile: the slots that hold tiles of the NEXT part by then are not the ones it targets.)
-            const int jend = min(jm, na) - 1;
-            step_rt(I0{}, I2{}, 0);   // tile 0 (O starts at 0)
             int j = 1;
-            while (j < na) {
-                if (j < jend && nprev == 2 * NP && j % 6 == 1) {
-                    plain_run(j, jend);
-                    continue;
+            if (fast) {
+                sync_regs();
+                first();
+                fix_cursors(0);
+                plain_run(j, na - 2);
+                fast_tail(j);
+                j = na;
+                leave_fast(j);
+            } else {
+                step_rt(I0{}, I2{}, 0);   // tile 0 (O starts at 0)
+                while (j < na) {
+                    if (j & 1) step_rt(I1{}, I1{}, j);
+                    else step_rt(I0{}, I1{}, j);
+                    ++j;
                 }
-                if (j & 1) step_rt(I1{}, I1{}, j);
-                else step_rt(I0{}, I1{}, j);
-                ++j;
             }
             for (; j < nt3; ++j) idle(j);   // (tiles the wave does not see, and the padding of the part to a multiple of three positions)
             if (pre && na == nt) issue_q(w4_rfl(tab[n_slot].x), w4_rfl(tab[n_slot].z));   // (waves with idle steps asked in their first one)
@@ -708,16 +807,21 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
 }
 
 // The kernels: hipcc's VGPR budget is the generator's NV (an attribute wants a literal: one wrapper per head size).
+#ifndef W4_NS
+#define W4_NS 88   // the embedded-request steps own s[88:101] (tools/gen_w4.py NS); amdgpu_num_sgpr(NS + 8) leaves hipcc s0 .. s(NS-1): the attribute counts VCC, FLAT_SCRATCH, XNACK_MASK and rounds to the allocation granule
+#endif
 #ifndef W4_NV_D64
 #define W4_NV_D64 84   // (52 for streams generated with W4_PRE=1: tools/w4_variants.sh)
 #endif
 template <class T, bool CAUSAL, bool TL>
-__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(52))) fa_fwd_w4_kernel_d128(const FwdW4Params p) {
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(52), amdgpu_num_sgpr(W4_NS + 8))) fa_fwd_w4_kernel_d128(const FwdW4Params p) {
     static_assert(W4Asm<T, 128>::NV == 52, "amdgpu_num_vgpr of the D = 128 kernel must be the generator's NV");
+    static_assert(W4Asm<T, 128>::NS == W4_NS, "amdgpu_num_sgpr must be the generator's NS");
     w4_body<T, 128, CAUSAL, TL>(p);
 }
 template <class T, bool CAUSAL, bool TL>
-__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(W4_NV_D64))) fa_fwd_w4_kernel_d64(const FwdW4Params p) {
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(W4_NV_D64), amdgpu_num_sgpr(W4_NS + 8))) fa_fwd_w4_kernel_d64(const FwdW4Params p) {
+    static_assert(W4Asm<T, 64>::NS == W4_NS, "amdgpu_num_sgpr must be the generator's NS");
     static_assert(W4Asm<T, 64>::NV == W4_NV_D64, "amdgpu_num_vgpr of the D = 64 kernel must be the generator's NV");
     w4_body<T, 64, CAUSAL, TL>(p);
 }

@@ -62,6 +62,14 @@ PRE_ON = os.environ.get("W4_PRE", "0") != "0"
 ORDER = os.environ.get("W4_ORDER", "pipe")
 PLACE = os.environ.get("W4_PLACE", "count")    # (cost: by the probe's issue costs -- measured WORSE than the even count: profiles/r3_w4_placement_ab.txt)
 CREG = "v" if "cvgpr" in XFLAGS else "s"    # register class of the scale operand (experiment)
+# Scalar registers the streams name literally (round 4).  The kernel is compiled with amdgpu_num_sgpr(NS): hipcc allocates below,
+# the tile steps own s[NS:NS+13] -- between two MFMA statements of a step hipcc then has NOTHING to compute: no descriptor
+# rebuilds, no piece offsets, no cursor arithmetic (round 3: ~38 scalar instructions per plain step, 150-188 per generic one).
+#   s[NS:NS+3] K descriptor   s[NS+4:NS+7] V descriptor   s(NS+8) byte offset of the K tile the step requests   s(NS+9) ... V tile
+#   s(NS+10) piece offset (temporary)   s(NS+12) LDS address of this wave's piece 0 of K ring slot 0 (lds0 + 1024 wave)
+NS = int(os.environ.get("W4_NS", "88"))
+SG_KSRD, SG_VSRD, SG_KSO, SG_VSO, SG_T, SG_LDSB = NS, NS + 4, NS + 8, NS + 9, NS + 10, NS + 12
+SG_ALL = [f"s{NS + i}" for i in range(14)]
 
 
 class Cfg:
@@ -402,6 +410,17 @@ def dma_piece(c, Q):
     return None
 
 
+def lit_piece(c, which, slot, piece):
+    """One LDS-DMA piece of a tile with every scalar operand a literal register (dma >= 2): which = 'k' / 'v', slot = ring slot the
+    tile goes to.  The first string goes in front of the VALU that separates the M0 write from the request."""
+    lds = (0 if which == "k" else 3 * c.KT) + slot * c.KT + piece * 4096
+    so, srd = (SG_KSO, SG_KSRD) if which == "k" else (SG_VSO, SG_VSRD)
+    head = f"s_add_u32 m0, s{SG_LDSB}, {lds}"
+    if piece:
+        head += f"\\n\\ts_add_u32 s{SG_T}, s{so}, {piece * 4096}"
+    return (head, f"buffer_load_dwordx4 %[vo], s[{srd}:{srd + 3}], s{SG_T if piece else so} offen lds")
+
+
 def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
     """phase-1 statement of step PAR.  qk: MFMAs of S_{j+1}.  sm: 0 none, 1 plain, 2 masked (S_j[B]); 3 / 4: the same for the S_0 of
     the part prologue's bare QK^T (the pre form still has to subtract the reference there; otherwise identical to 1 / 2).  vr: V_j
@@ -439,21 +458,30 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
             clob.append("vcc")
     pieces = []
     if dma and dma_piece(c, Q) is not None:
-        pieces.append((f"s_add_u32 m0, %[lds], {dma_piece(c, Q) * 4096}", "buffer_load_dwordx4 %[vo], %[srd], %[so] offen lds"))
-        clob += ["m0", "scc"]
+        if dma >= 2:      # K_{j+4} goes to ring slot (sl + 1) mod 3
+            pieces.append(lit_piece(c, "k", (sl + 1) % 3, dma_piece(c, Q)))
+            clob += ["m0", "scc", f"s{SG_T}"]
+        else:
+            pieces.append((f"s_add_u32 m0, %[lds], {dma_piece(c, Q) * 4096}", "buffer_load_dwordx4 %[vo], %[srd], %[so] offen lds"))
+            clob += ["m0", "scc"]
     if "nolds" in XFLAGS:
         lds = []
     if "nodma" in XFLAGS:
         pieces = []
-    if dma and Q == 0:
+    # the step's tile barrier (statement 0 of the embedded-request forms).  dma 3: first step of a part -- the prologue's
+    # vmcnt(0) left nothing of this step's tiles in flight: the barrier alone (every wave has read K_0 and K_1)
+    tile_wait = [x for x in ((f"s_waitcnt vmcnt({2 * c.NP})",) if dma != 3 else ()) + ("s_barrier",)
+                 if not (("nobarrier" in XFLAGS and x == "s_barrier") or ("novmcnt" in XFLAGS and "vmcnt" in x))] or ["s_nop 0"]
+    if dma and Q == 0 and not mf:
+        # the wave's last tile (no S_{j+1}): nothing to hide the barrier behind
+        lines = ["s_waitcnt lgkmcnt(0)"] + tile_wait + place(mf, lds, valu, pieces, 2, 0)
+    elif dma and Q == 0:
         # the plain step's tile barrier: the K fragments this statement's MFMAs read were requested from LDS in the previous
         # step's phase 2 (lgkmcnt(0) first); the first two MFMAs and their softmax fillers need nothing the barrier guards, so the
         # wait for the tiles requested two steps ago (everything but the previous step's 2 NP pieces) and the barrier sit
         # behind them -- the matrix pipe keeps running while the workgroup meets.  V reads and requests come after it.
         lines = ["s_waitcnt lgkmcnt(0)"] + place(mf, lds, valu, pieces, 2, len(mf) - 2 if len(mf) >= 8 else len(mf) - 1, 2 if len(mf) >= 8 else 1,
-                                               (1 if len(mf) >= 8 else 0, [x for x in (f"s_waitcnt vmcnt({2 * c.NP})", "s_barrier")
-                                                                            if not (("nobarrier" in XFLAGS and x == "s_barrier") or
-                                                                                    ("novmcnt" in XFLAGS and "vmcnt" in x))] or ["s_nop 0"]))
+                                               (1 if len(mf) >= 8 else 0, tile_wait))
     else:
         lines = place(mf, lds, valu, pieces, LDSPG1, len(mf) - DMAGAP if len(mf) >= 8 else len(mf) - 1)
     if vr and Q == 3:
@@ -469,7 +497,7 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
     if vr:
         ins.append('[va] "v"(va)')
     if pieces:
-        ins += ['[lds] "s"(dlds)', '[srd] "s"(dsrd)', '[so] "s"(dso)', '[vo] "v"(dvo)']
+        ins += ['[vo] "v"(dvo)'] if dma >= 2 else ['[lds] "s"(dlds)', '[srd] "s"(dsrd)', '[so] "s"(dso)', '[vo] "v"(dvo)']
     return emit_asm(lines, [], ins, clob)
 
 
@@ -504,13 +532,21 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
             clob.append("vcc")
     pieces = []
     if dma and dma_piece(c, Q) is not None:
-        pieces.append((f"s_add_u32 m0, %[lds], {dma_piece(c, Q) * 4096}", "buffer_load_dwordx4 %[vo], %[srd], %[so] offen lds"))
-        clob += ["m0", "scc"]
+        if dma >= 2:      # V_{j+2} goes to ring slot sl (= the slot K_{j+2} is read from: (step position + 2) mod 3)
+            pieces.append(lit_piece(c, "v", sl, dma_piece(c, Q)))
+            clob += ["m0", "scc", f"s{SG_T}"]
+        else:
+            pieces.append((f"s_add_u32 m0, %[lds], {dma_piece(c, Q) * 4096}", "buffer_load_dwordx4 %[vo], %[srd], %[so] offen lds"))
+            clob += ["m0", "scc"]
     if "nolds" in XFLAGS:
         lds = []
     if "nodma" in XFLAGS:
         pieces = []
     lines = place(mf, lds, valu, pieces, LDSPG2, len(mf) - DMAGAP if len(mf) >= 8 else len(mf) - 1)
+    if dma >= 2 and Q == 3:
+        # the request cursors move on with the step (the kernel overrides them where a part ends: fa_fwd_w4_gfx950.hip, fix_cursors)
+        lines += [f"s_add_u32 s{SG_KSO}, s{SG_KSO}, {c.KT}", f"s_add_u32 s{SG_VSO}, s{SG_VSO}, {c.VT}"]
+        clob += [f"s{SG_KSO}", f"s{SG_VSO}", "scc"]
     ins = []
     if sm:
         if not c.pre:
@@ -520,7 +556,7 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
     if kr:
         ins += [f'[ka{t}] "v"(ka{t})' for t in range(KS // 4)]
     if pieces:
-        ins += ['[lds] "s"(dlds)', '[srd] "s"(dsrd)', '[so] "s"(dso)', '[vo] "v"(dvo)']
+        ins += ['[vo] "v"(dvo)'] if dma >= 2 else ['[lds] "s"(dlds)', '[srd] "s"(dsrd)', '[so] "s"(dso)', '[vo] "v"(dvo)']
     return emit_asm(lines, [], ins, clob)
 
 
@@ -529,11 +565,14 @@ def p1_variants():
     for Q in range(4):
         for par in range(2):
             for sl in range(3):
-                v.append((Q, par, 1, 1, 1, 1, sl))  # plain step (K request embedded; V_j in ring slot sl)
+                v.append((Q, par, 1, 1, 1, 2, sl))  # plain step (K request embedded, literal scalars; V_j in ring slot sl); also
+                                                    # phase 1 of the step in front of the wave's diagonal tile
+                v.append((Q, par, 0, 2, 1, 2, sl))  # the wave's last (diagonal) tile: masked softmax of S_j[B], no S_{j+1}
             for qk in (0, 1):
                 for sm in (1, 2) if par else (1, 2, 3, 4):  # (3 / 4: tile 0 -- step 0 of a part, PAR 0)
                     v.append((Q, par, qk, sm, 1, 0, 0))     # generic steps: ring slot in the address register, requests apart
         v.append((Q, 1, 1, 0, 0, 0, 0))             # bare QK^T of tile 0 ("step -1": part prologue, exact-maximum pass)
+        v.append((Q, 0, 1, 3, 1, 3 if Q == 0 else 2, 0))   # step 0 of a part in the embedded-request form (stream position 0, parity 0)
     return sorted(set(v))
 
 
@@ -542,11 +581,14 @@ def p2_variants():
     for Q in range(4):
         for par in range(2):
             for sl in range(3):
-                v.append((Q, par, 1, 1, 1, 1, sl))  # plain step (V request embedded; K_{j+2} in ring slot sl)
+                v.append((Q, par, 1, 1, 1, 2, sl))  # plain step (V request embedded, literal scalars; K_{j+2} in ring slot sl)
+                v.append((Q, par, 1, 2, 1, 2, sl))  # the step in front of the wave's diagonal tile: S_{j+1}[A] masked
+                v.append((Q, par, 1, 0, 0, 2, sl))  # the diagonal tile itself: O^T += V^T P^T and the V request, nothing else
             for sm in (0, 1, 2):
                 v.append((Q, par, 1, sm, 1, 0, 0))  # generic steps
         v += [(Q, 0, 2, 0, 1, 0, 0), (Q, 0, 2, 1, 1, 0, 0), (Q, 0, 2, 2, 1, 0, 0)]   # first step of a part (O starts at 0)
         v += [(Q, 1, 0, 1, 1, 0, 0), (Q, 1, 0, 2, 1, 0, 0)]                          # part prologue: P_0[A] next to the reads of K_1
+        v.append((Q, 0, 2, 1, 1, 2, 2))                                              # step 0 of a part, embedded-request form
     return sorted(set(v))
 
 
@@ -555,6 +597,19 @@ def gen_struct(c):
     s = f"template <> struct {name} {{\n"
     s += f"    static constexpr int KB0 = {c.KB0}, QB0 = {c.QB0}, NP = {c.NP}, NV = {c.NV};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n"
     s += f"    static constexpr bool PRE = {'true' if c.pre else 'false'};   // Q pre-multiplied by c, - m_ref through the MFMAs' C operand\n"
+    s += f"    static constexpr int NS = {NS};   // hipcc's SGPR budget (amdgpu_num_sgpr): the streams own s[NS:NS+13]\n"
+    # ---- the literal scalar registers of the embedded-request steps
+    lines = [f"s_mov_b32 s{SG_KSRD}, %[klo]", f"s_and_b32 s{SG_KSRD + 1}, %[khi], 0xffff", f"s_mov_b32 s{SG_KSRD + 2}, %[nrec]", f"s_mov_b32 s{SG_KSRD + 3}, 0x00020000",
+             f"s_mov_b32 s{SG_VSRD}, %[vlo]", f"s_and_b32 s{SG_VSRD + 1}, %[vhi], 0xffff", f"s_mov_b32 s{SG_VSRD + 2}, %[nrec]", f"s_mov_b32 s{SG_VSRD + 3}, 0x00020000",
+             f"s_mov_b32 s{SG_KSO}, %[kso]", f"s_mov_b32 s{SG_VSO}, %[vso]"]
+    s += ("    // K / V descriptors (raw buffers of nrec bytes at the heads' base addresses) and the request cursors -> literal registers\n"
+          "    static __device__ __forceinline__ void set_cursors(unsigned klo, unsigned khi, unsigned vlo, unsigned vhi, unsigned nrec, unsigned kso, unsigned vso) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n")
+    s += emit_asm(lines, [], ['[klo] "s"(klo)', '[khi] "s"(khi)', '[vlo] "s"(vlo)', '[vhi] "s"(vhi)', '[nrec] "s"(nrec)', '[kso] "s"(kso)', '[vso] "s"(vso)'],
+                  ["scc"] + [f"s{SG_KSRD + i}" for i in range(10)], indent="        ")
+    s += "#endif\n    }\n"
+    s += ("    static __device__ __forceinline__ void set_lds_base(unsigned a) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+          f"        asm volatile(\"s_mov_b32 s{SG_LDSB}, %0\" :: \"s\"(a) : \"s{SG_LDSB}\");\n#endif\n    }}\n")
     # ---- phase 1
     s += ("    // SL: ring slot of the tile the statement reads, as an immediate (plain steps); 0 where the address register carries it\n"
           "    template <int Q, int PAR, int QK, int SM, int VR, int DMA, int SL = 0>\n"

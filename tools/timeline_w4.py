@@ -2,6 +2,7 @@
 """Cycle timeline of workgroup 0 of the one-wave-per-SIMD forward (fa_fwd_w4_gfx950.hip, timeline build behind
 aule_hip_debug_forward_timeline with AULE_TL=w4; debug library: cd aule-attention_amd/csrc && make dbg).  Every stamp is
 (tag << 56) | s_memtime.  Tags: 0x10/0x11 plain step (parity), 0x20+ generic step (PAR + 2 QK + 4 SM), 0x08 idle step,
+0x60 / 0x62-3 / 0x64-5 step 0 / step in front of the last tile / last tile in the embedded-request form,
 0x18 phase 1 done, 0x19 phase 2 done (then the loop tail), 0x30 prologue, 0x31 S_0 done (wait for the part's first tiles,
 barrier, K_0 reads, bare QK^T), 0x33 P_0[A] done (references, softmax of S_0[A], K_1 reads), 0x40 epilogue, 0x42 block A stored,
 0x41 block B stored, 0x50 end of the stream.
@@ -77,8 +78,9 @@ for w in waves:
             part += 1
             i = j
             continue
-        if tag in (0x10, 0x11) or 0x20 <= tag < 0x30:
-            kind = "plain" if tag < 0x20 else f"gen{tag:#x}"
+        if tag in (0x10, 0x11) or 0x20 <= tag < 0x30 or 0x60 <= tag < 0x68:
+            # 0x60 step 0 / 0x62+PAR step in front of the wave's last tile / 0x64+PAR the last tile: embedded-request bodies (round 4)
+            kind = "plain" if tag < 0x20 else (f"gen{tag:#x}" if tag < 0x60 else {0x60: "first", 0x62: "prediag", 0x63: "prediag", 0x64: "diag", 0x65: "diag"}.get(tag, f"fast{tag:#x}"))
             j = i + 1
             p1 = p2 = None
             extra = []
