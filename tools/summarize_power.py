@@ -36,7 +36,7 @@ def main():
             p = d.get("power1_input", (0, 0, 0))[0]
             lo, hi = swing.get(c, (1e30, 0))
             swing[c] = (min(lo, p), max(hi, p))
-    ours = max(swing, key=lambda c: swing[c][1] - swing[c][0])
+    ours = max(swing, key=lambda c: (swing[c][1] - swing[c][0]) + swing[c][1])   # moves the most / draws the most
     print("# Socket power, power limit and shader clock WHILE the kernels run (hwmon power1_input / power1_cap / freq1_input of the")
     print("# device under test, sampled every 10 ms by tools/power_sampler.h; means over the samples after the first 500 ms of back-to-back")
     print("# launches).  The box shows the 8 cards of its node in sysfs; the device under test is the one whose power moves: %s." % ours)
