@@ -150,7 +150,6 @@ int run_fwd_f32(const float* q, const float* k, const float* v, float* o, float*
 namespace aule_hip {
 #ifdef AULE_DEBUG_HOOKS
 int launch_fwd_pp_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
-int launch_fwd_ps_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
 int launch_fwd_w4_timeline(const FwdArgs& a, unsigned long long* dbg, hipStream_t stream);
 #endif
 int configure_fwd();
@@ -1139,16 +1138,17 @@ int32_t aule_hip_debug_forward_split_plan(const aule_attn_desc* d, int32_t* out,
     a.causal = d->causal != 0;
     a.coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? a.Sk - a.Sq : 0;
     a.dtype = d->dtype; a.device = d->device;
+    a.scale = resolve_scale(d->scale, d->head_dim);
     a.window = (d->window_size > 0 && (uint32_t)d->window_size < d->seq_q + (uint32_t)a.coff) ? d->window_size : -1;
     drop_trivial_causal(a.causal, a.coff, a.Sq, a.window);
     if (aule_hip::fwd_route(a) != 7) return 0;
-    return aule_hip::fwd_ps_split_plan_dump(a, out, cap);
+    return aule_hip::fwd_split_plan_dump(a, out, cap);
 }
 
 #ifdef AULE_DEBUG_HOOKS
 /* Debug hook (debug library only): bf16 D=128 forward with per-phase s_memtime stamps of workgroup 0 written to
  * `stamps` (device pointer; 8 * 256 uint64 for the ping-pong kernel, 8 * 2048 with AULE_TL=ps for the tile stream).
- * Used by tools/timeline.py / tools/timeline_ps.py. */
+ * Used by tools/timeline.py / tools/timeline_w4.py. */
 int32_t aule_hip_debug_forward_timeline(const aule_attn_desc* d, unsigned long long* stamps) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_init || d == nullptr || d->struct_size != sizeof(aule_attn_desc) || stamps == nullptr) return -1;
@@ -1161,8 +1161,6 @@ int32_t aule_hip_debug_forward_timeline(const aule_attn_desc* d, unsigned long l
     a.causal = d->causal != 0;
     a.dtype = d->dtype; a.device = d->device;
     if (const char* e = getenv("AULE_TL")) {
-        if (e[0] == 'p' && e[1] == 's')  // persistent tile stream: 8 waves x 2048 tagged stamps (tools/timeline_ps.py)
-            return aule_hip::launch_fwd_ps_timeline(a, stamps, (hipStream_t)d->stream);
         if (e[0] == 'w' && e[1] == '4')  // one wave per SIMD: 4 waves x 2048 tagged stamps (tools/timeline_w4.py)
             return aule_hip::launch_fwd_w4_timeline(a, stamps, (hipStream_t)d->stream);
     }

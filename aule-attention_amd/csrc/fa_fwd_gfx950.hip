@@ -8,16 +8,17 @@
 // before the PV product (triton_flash_amd.py:222) ; LSE = m + ln(l) (:237).
 //
 // The kernels live in their own files; this one only picks among them (host logic):
-//   fa_fwd_ps_gfx950.hip       16-bit, persistent tile stream (the default for plain tiled problems)
-//   fa_fwd_pp_gfx950.hip       16-bit, one workgroup per Q-block pair: sliding window, fewer than four KV tiles per
-//                              Q block, and the SPLIT instances (packed rows + KV splits) for short queries
+//   fa_fwd_w4_gfx950.hip       16-bit, one wave per SIMD (4 x 64 query rows), persistent part lists: the default for tiled problems;
+//                              small grids as key-range pieces + merge (fa_fwd_split.h)
+//   fa_fwd_pp_gfx950.hip       16-bit, two waves per SIMD, one workgroup per Q-block pair: sliding window, fewer than four KV tiles
+//                              per Q block, D = 32, negative scale, and the SPLIT instances (packed rows + KV splits) for short queries
 //   fa_fwd_splitkv_gfx950.hip  16-bit, wave-per-chunk split-KV (decode streaming corner) and paged decode
 //   fa_fwd_f32.hip             fp32 I/O
-// Common design of the 16-bit kernels: workgroup = 8 wavefronts x 32 query rows; "swapped"
-// S^T = K.Q^T so that a lane owns one query row; P stays in registers as the B operand of O^T += V^T.P^T; K row-major
-// padded and V sub-tiled in LDS; all blocks of one (batch, kv-head) on one XCD.
-// (The first lock-step kernel of round 1 and the in-wave pipelined variants lost every A/B -- DESIGN.md 6 -- and were
-// removed from the library in round 2; they are in the history: fa_fwd_iw_gfx950.hip, fa_fwd_kernel<> in this file.)
+// Common to the 16-bit kernels: "swapped" S^T = K.Q^T so that a lane owns one query row; P stays in registers as
+// the B operand of O^T += V^T.P^T; K row-major and V sub-tiled in LDS; all blocks of one (batch, kv-head) on one XCD.
+// (Retired, in the history: the lock-step kernel of round 1 and the in-wave pipelined variants -- fa_fwd_iw_gfx950.hip -- in
+// round 2; the two-waves-per-SIMD persistent tile stream -- fa_fwd_ps_gfx950.hip, routes 6 and 7 of rounds 2-3 -- in round 4,
+// when the one-wave-per-SIMD kernel took its small-grid split and the ping-pong kernel its remaining shapes.)
 #include <cstdlib>
 
 #include "fa_device.h"
@@ -30,31 +31,23 @@ int launch_fwd_pp(const FwdArgs& a, hipStream_t stream);   // fa_fwd_pp_gfx950.h
 int launch_fwd_pp_split(const FwdArgs& a, hipStream_t stream);
 bool pp_split_applicable(const FwdArgs& a);
 int configure_fwd_pp();
-int launch_fwd_ps(const FwdArgs& a, hipStream_t stream);   // fa_fwd_ps_gfx950.hip (persistent tile stream)
-bool fwd_ps_applicable(const FwdArgs& a);
-bool fwd_ps_rope_fusable(const FwdArgs& a);
-bool fwd_ps_split_applicable(const FwdArgs& a);            // small causal grids: pairs cut in two, partials + merge
-int launch_fwd_ps_split(const FwdArgs& a, hipStream_t stream);
-int configure_fwd_ps();
 int launch_fwd_w4(const FwdArgs& a, hipStream_t stream);   // fa_fwd_w4_gfx950.hip (one wave per SIMD, 4 x 64 rows)
 bool fwd_w4_applicable(const FwdArgs& a);
+bool fwd_w4_split_applicable(const FwdArgs& a);            // small grids: pairs cut into key ranges, partials + merge
+int launch_fwd_w4_split(const FwdArgs& a, hipStream_t stream);
 int configure_fwd_w4();
 
-// AULE_HIP_FWD_KERNEL=pp keeps every tiled problem on the ping-pong kernel, =ps on the two-waves-per-SIMD tile stream (A/B
-// measurements against the one-wave-per-SIMD kernel)
+// AULE_HIP_FWD_KERNEL=pp keeps every tiled problem on the ping-pong kernel (A/B measurements against the one-wave-per-SIMD kernel)
 static int fwd_kernel_choice() {
     static const int v = [] {
         const char* e = getenv("AULE_HIP_FWD_KERNEL");
         if (e != nullptr && e[0] == 'p' && e[1] == 'p') return 4;
-        if (e != nullptr && e[0] == 'p' && e[1] == 's') return 6;
         return 0;
     }();
     return v;
 }
-static bool use_ps(const FwdArgs& a) { return fwd_kernel_choice() != 4 && fwd_ps_applicable(a); }
-static bool use_ps_split(const FwdArgs& a) { return fwd_kernel_choice() != 4 && fwd_ps_split_applicable(a); }
 // AULE_HIP_FWD_SOFTMAX=classic asks for the online softmax throughout: the one-wave-per-SIMD kernel has no online form (its
-// fall-back is a second pass with the exact row maximum), so such runs stay on the two-waves-per-SIMD kernels
+// fall-back is a second pass with the exact row maximum), so such runs stay on the ping-pong kernel
 static bool softmax_classic() {
     static const int v = [] {
         const char* e = getenv("AULE_HIP_FWD_SOFTMAX");
@@ -63,6 +56,7 @@ static bool softmax_classic() {
     return v == 1;
 }
 static bool use_w4(const FwdArgs& a) { return fwd_kernel_choice() == 0 && !softmax_classic() && fwd_w4_applicable(a); }
+static bool use_w4_split(const FwdArgs& a) { return fwd_kernel_choice() == 0 && !softmax_classic() && fwd_w4_split_applicable(a); }
 
 bool splitkv_applicable(const FwdArgs& a);                      // fa_fwd_splitkv_gfx950.hip
 int launch_fwd_splitkv(const FwdArgs& a, hipStream_t stream);
@@ -96,25 +90,21 @@ static int short_query_route(const FwdArgs& a) {
 }
 
 // Which kernel launch_fwd() picks for `a` (host logic only, no device work): 0 fp32, 1 ping-pong, 4 split-KV,
-// 5 ping-pong kernel with packed rows + KV splits, 6 persistent tile stream (two waves per SIMD), 7 tile stream with every
-// pair of causal Q blocks cut in two (small grids; partials + merge), 8 persistent stream with one wave per SIMD (4 x 64 rows)
-// (2 and 3 were the removed in-wave and lock-step kernels).  Lets the tests pin the path a shape exercises.
+// 5 ping-pong kernel with packed rows + KV splits, 7 one-wave-per-SIMD kernel with every pair of causal Q blocks (every
+// non-causal block) cut into key ranges (small grids; partials + merge), 8 one-wave-per-SIMD kernel (4 x 64 rows)
+// (2, 3 and 6 were the removed in-wave, lock-step and two-waves-per-SIMD stream kernels).  Lets the tests pin the path a shape
+// exercises.
 int fwd_route(const FwdArgs& a) {
     if (a.dtype == kF32) return 0;
     const int sq = short_query_route(a);
     if (sq) return sq;
-    if (use_ps_split(a)) return 7;
-    if (use_w4(a)) return 8;
-    return use_ps(a) ? 6 : 1;
+    if (use_w4_split(a)) return 7;
+    return use_w4(a) ? 8 : 1;
 }
 
 // Which problems the forward rotates Q for by itself (half-split pairs, K already rotated): what the one-wave-per-SIMD kernel
-// takes (its applicability rule looks at the table geometry too), and what the two-waves-per-SIMD stream takes as before.
-bool fwd_rope_fusable(const FwdArgs& a) {
-    const int r = fwd_route(a);
-    if (r == 8) return true;
-    return r == 6 && fwd_ps_rope_fusable(a);
-}
+// takes (its applicability rule looks at the table geometry too).
+bool fwd_rope_fusable(const FwdArgs& a) { return fwd_route(a) == 8; }
 
 uint64_t fwd_workspace_bytes(FwdArgs a) {
     uint64_t bytes = 0;
@@ -132,23 +122,21 @@ uint64_t paged_workspace_bytes(PagedArgs a) {
 
 int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (a.query_ws != nullptr) *a.query_ws = 0;
-    if (a.rope_cos != nullptr && !fwd_rope_fusable(a)) return -1;   // only the two stream kernels rotate Q themselves
+    if (a.rope_cos != nullptr && !fwd_rope_fusable(a)) return -1;   // only the one-wave-per-SIMD kernel rotates Q itself
     const int sq = a.dtype == kF32 ? 0 : short_query_route(a);
     if (sq == 4) return launch_fwd_splitkv(a, stream);
     if (sq == 5) return launch_fwd_pp_split(a, stream);
-    if (sq == 0 && a.dtype != kF32 && use_ps_split(a)) return launch_fwd_ps_split(a, stream);
+    if (sq == 0 && a.dtype != kF32 && use_w4_split(a)) return launch_fwd_w4_split(a, stream);
     if (a.query_ws != nullptr) return 0;   // single-launch paths need no workspace
     if (a.dtype == kF32) return launch_fwd_f32(a, stream);
     if (use_w4(a)) return launch_fwd_w4(a, stream);
-    if (use_ps(a)) return launch_fwd_ps(a, stream);
-    return launch_fwd_pp(a, stream);   // window, fewer than four KV tiles per Q block, AULE_HIP_FWD_KERNEL=pp
+    return launch_fwd_pp(a, stream);   // window, fewer than four KV tiles per Q block, D = 32, negative scale, AULE_HIP_FWD_KERNEL=pp
 }
 
 int configure_fwd() {
     int rc = 0;
     rc |= configure_fwd_f32();
     rc |= configure_fwd_pp();
-    rc |= configure_fwd_ps();
     rc |= configure_fwd_w4();
     return rc;
 }

@@ -32,6 +32,7 @@
 #include "fa_device.h"
 #include "fa_kernels.h"
 #include "fa_fwd_tile.h"
+#include "fa_fwd_split.h"
 
 namespace aule_hip {
 namespace {
@@ -63,6 +64,12 @@ struct FwdW4Params {
     const float* rcos;
     const float* rsin;
     int rrows, rpitch, rpos;
+    // small grids (fa_fwd_split.h): npiece > 1: an item is piece (item % npiece) of a pair of Q blocks; a part then covers a RANGE of
+    // its block's key tiles and, unless the range is the whole block, leaves fp32 partial rows instead of O
+    int npiece, pcoff;
+    unsigned magic;
+    float* part;       // [npiece][part_rows][D + kPartPad]
+    int part_rows;     // B * Hq * Sq
     unsigned long long* dbg;   // timeline build only: [4 waves][kW4TLMax] tagged s_memtime stamps of workgroup 0
 };
 
@@ -176,9 +183,21 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     const int nit = (p.nitems - (int)blockIdx.x + G - 1) / G;
     const int nslot = p.rounds > 0 ? p.rounds : 2 * nit;
     if (tid < nslot) {
-        int qb = -1;
+        int qb = -1, range = 0;   // .z = qb | (partial plane + 1) << 24 (0: O is final), .w = first tile | end tile << 16 (0: the whole block)
         WorkItem w;
-        if (p.rounds > 0) {
+        if (p.npiece > 1) {
+            // item = (pair, piece): slot 0 its range of the far block, slot 1 of the near block (non-causal: no pairing, far == near)
+            w = decode_work((int)blockIdx.x + (tid >> 1) * G, p.B, p.Hq, p.Hkv, p.npiece * p.nwork, false);
+            const int near = w.blk / p.npiece, piece = w.blk % p.npiece, far = p.pair ? p.nqb - 1 - near : near;
+            const SplitPair pr = split_cuts(far, near, Sk, p.pcoff, p.npiece, p.magic);
+            int t0, t1;
+            split_range(pr, piece, tid & 1, t0, t1);
+            if (t1 > t0) {
+                const int whole = (tid & 1) ? pr.ntn : pr.ntf;
+                qb = ((tid & 1) ? near : far) | ((t0 == 0 && t1 == whole) ? 0 : (piece + 1) << 24);
+                range = t0 | (t1 << 16);
+            }
+        } else if (p.rounds > 0) {
             const int W = G >> 3, wx = (int)blockIdx.x >> 3, pos = (tid & 1) ? W - 1 - wx : wx;
             const int g = p.Hq / p.Hkv;
             const int c = tid * p.mper + pos % p.mper;          // head of this XCD's list: kv unit c / g, head c % g of its group
@@ -198,7 +217,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 qb = w.blk;
             }
         }
-        tab[tid] = int4{(w.b * p.Hq + w.h) * p.Sq, (w.b * p.Hkv + w.hk) * Sk, qb, 0};
+        tab[tid] = int4{(w.b * p.Hq + w.h) * p.Sq, (w.b * p.Hkv + w.hk) * Sk, qb, range};
         redo[tid] = 0;
     }
     if (tid == 0) redo[kW4MaxSlot] = 0;
@@ -273,6 +292,8 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
 
         // ---- part scalars
         int qoff, kvoff, qb, nt, nt3, na, jm, r0;   // nt3: nt rounded up to a multiple of 3 (idle steps pad the part: every part starts at ring phase 0)
+        int tb = 0, pid = 0;        // first key tile of the part's range (kvoff already points at it), partial plane + 1 (0: O is final)
+        unsigned nrec = oob;        // bytes of the head's K / V behind kvoff: the descriptors' bound (rows >= Sk read as zeros)
         int n_slot;
         bool pre = false;           // the next part's K_0..K_2, V_0, V_1 and Q ride along with this part's last steps
         // ring phase: stream position mod 3.  At step j (phase rp) V_j sits in slot rp, K_{j+2} in slot rp + 2, the step requests
@@ -288,8 +309,11 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         unsigned ksoff, vsoff;
         auto srd_of = [&](unsigned lo, unsigned hi) __attribute__((always_inline)) {
             const unsigned l = (unsigned)w4_rfl((int)lo), h = (unsigned)w4_rfl((int)hi);
-            return make_srd(reinterpret_cast<const void*>((uintptr_t)(((unsigned long long)h << 32) | l)), (unsigned)w4_rfl((int)oob));
+            return make_srd(reinterpret_cast<const void*>((uintptr_t)(((unsigned long long)h << 32) | l)), (unsigned)w4_rfl((int)nrec));
         };
+        // table entry of a part: K / V row of its first key tile, its Q block
+        auto kv_row_of = [&](int sl) __attribute__((always_inline)) { return w4_rfl(tab[sl].y) + (w4_rfl(tab[sl].w) & 0xffff) * kKVTile; };
+        auto qb_of = [&](int sl) __attribute__((always_inline)) { return w4_rfl(tab[sl].z) & 0xffffff; };
         auto head_lohi = [&](const void* base, int rowoff, unsigned& lo, unsigned& hi) __attribute__((always_inline)) {
             const unsigned long long a = (unsigned long long)(uintptr_t)base + (unsigned long long)(unsigned)rowoff * RB;
             lo = (unsigned)a;
@@ -304,7 +328,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             ksoff = oob;
             if (t < nt) ksoff = (unsigned)t * KT;
             else if (pre && t >= nt3 && t - nt3 <= 3) {
-                if (t == nt3) head_lohi(P()->k, w4_rfl(tab[n_slot].y), klo, khi);
+                if (t == nt3) head_lohi(P()->k, kv_row_of(n_slot), klo, khi);
                 // (position 3 of the next part: its K_3 is not prefetched -- the slot holds K_0 until the next prologue has read
                 // it -- but the embedded-request steps ask unconditionally, and an out-of-range request would put zeros there:
                 // K_0 once more, the same bytes into the same slot)
@@ -315,22 +339,26 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             vsoff = oob;
             if (t < nt) vsoff = (unsigned)t * VT;
             else if (pre && t >= nt3 && t - nt3 < 2) {
-                if (t == nt3) head_lohi(P()->v, w4_rfl(tab[n_slot].y), vlo, vhi);
+                if (t == nt3) head_lohi(P()->v, kv_row_of(n_slot), vlo, vhi);
                 vsoff = (unsigned)(t - nt3) * VT;
             }
         };
         auto enter_part = [&](int sl) __attribute__((always_inline)) {
             const int4 e = tab[sl];
             qoff = w4_rfl(e.x);
-            kvoff = w4_rfl(e.y);
-            qb = w4_rfl(e.z);
-            nt = nt_of(qb);
+            const int ez = w4_rfl(e.z), ew = w4_rfl(e.w);
+            qb = ez & 0xffffff;
+            pid = ez >> 24;
+            tb = ew & 0xffff;                                   // (0 | 0: the whole block)
+            nt = ew != 0 ? (ew >> 16) - tb : nt_of(qb);
+            kvoff = w4_rfl(e.y) + tb * kKVTile;
+            nrec = (unsigned)(Sk - tb * kKVTile) * RB;
             nt3 = (nt + 2) / 3 * 3;
             r0 = qb * kQBlock + wave * 64;
             const int vis = CAUSAL ? min(Sk, r0 + 64 + coff) : Sk;   // keys the wave's last row sees
-            na = min(nt, max(1, (vis + kKVTile - 1) / kKVTile));
+            na = min(nt, max(1, (vis + kKVTile - 1) / kKVTile - tb));
             const int min_thr = CAUSAL ? min(r0 + coff, Sk - 1) : Sk - 1;   // keys EVERY row of the wave sees: 0 .. min_thr
-            jm = (min_thr + 1) >> 6;                                        // first tile that needs the mask
+            jm = max(0, ((min_thr + 1) >> 6) - tb);                         // first tile (of the range) that needs the mask
             // (opaque: without a mask these are the same for every part, and hipcc then evaluates every comparison of the step
             // logic once per kernel and keeps the ~25 results -- 64-bit lane masks -- alive across the stream: 48 scalar spills
             // and, with the spill lanes' own register, a vector spill to scratch in the non-causal D = 128 instance)
@@ -349,7 +377,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const int row = r0 + 32 * qbsel + (lane_o & 31) + coff;
-            return (CAUSAL ? min(row, Sk - 1) : Sk - 1) - (lane_o >> 5) * 4 - 64 * j;
+            return (CAUSAL ? min(row, Sk - 1) : Sk - 1) - (lane_o >> 5) * 4 - 64 * (j + tb);
         };
         // after step j: the ring moves on, the cursors of step j + 1 (K tile j + 5, V tile j + 3)
         auto advance = [&](int j) __attribute__((always_inline)) {
@@ -468,7 +496,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         // shadows -> literal registers (part start, and wherever the slow path moved them)
         auto sync_regs = [&]() __attribute__((always_inline)) {
             A::set_cursors((unsigned)w4_rfl((int)klo), (unsigned)w4_rfl((int)khi), (unsigned)w4_rfl((int)vlo), (unsigned)w4_rfl((int)vhi),
-                           (unsigned)w4_rfl((int)oob), (unsigned)w4_rfl((int)ksoff), (unsigned)w4_rfl((int)vsoff));
+                           (unsigned)w4_rfl((int)nrec), (unsigned)w4_rfl((int)ksoff), (unsigned)w4_rfl((int)vsoff));
         };
         // after embedded-request step j: the streams moved both cursors one tile on; where the part's tiles end (its last five
         // steps) the cursors of step j + 1 come from set_k / set_v as before and overwrite them
@@ -553,7 +581,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             if constexpr (PV == 2 && REDO)   // tile 0 of the exact-maximum stream: K_3 goes where K_0 was (this step's tile barrier freed
                                              // the slot); older than this step's own requests, so the NEXT tile barrier covers it.  (The
                                              // first stream's prologue has asked for it already.)
-                A::dma_tile(ring_lds(0, 0), head_srd(P()->k, kvoff, Sk), 3u * KT, kvo);
+                A::dma_tile(ring_lds(0, 0), head_srd(P()->k, kvoff, Sk - tb * kKVTile), 3u * KT, kvo);
             const int n = requests();
             const unsigned vap = va + (unsigned)rp * VT, kb = ka0 + (unsigned)slot(2) * KT;
             const int tB = SMB == 2 ? thr_of(1, j) : 0;
@@ -595,7 +623,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             // behind each other for ~3000 cycles -- the waves that see the whole block are then alone on that path.  (Behind the
             // step's requests, and counted: the next tile barrier does not wait for them.)
             if (pre && j == na) {
-                issue_q(w4_rfl(tab[n_slot].x), w4_rfl(tab[n_slot].z));
+                issue_q(w4_rfl(tab[n_slot].x), qb_of(n_slot));
                 n += NQ;
             }
             advance(j);
@@ -619,7 +647,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 // step's tile barrier: four request pieces outside the MFMA gaps); older than step 0's requests, so step 1's
                 // counted wait covers it.  Every wave of the workgroup does this, whichever bodies its steps run.
                 asm volatile("s_barrier" ::: "memory");
-                A::dma_tile(ring_lds(0, 0), head_srd(P()->k, kvoff, Sk), 3u * KT, kvo);
+                A::dma_tile(ring_lds(0, 0), head_srd(P()->k, kvoff, Sk - tb * kKVTile), 3u * KT, kvo);
             }
             if constexpr (!REDO) {
                 if (rope) A::rope_rotate();          // (the second stream rotated in its exact-maximum pass)
@@ -657,7 +685,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         auto epilogue = [&]() __attribute__((always_inline)) {
             stamp(0x40);
             asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the last PV MFMAs -> v_accvgpr_read
-            if (rope && pre) issue_rope(w4_rfl(tab[n_slot].z));   // (the next prologue's vmcnt(0) covers them)
+            if (rope && pre) issue_rope(qb_of(n_slot));   // (the next prologue's vmcnt(0) covers them)
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const int l31o = lane_o & 31, hio = lane_o >> 5;
@@ -666,6 +694,25 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             const __amdgpu_buffer_rsrc_t lrs = make_srd(lsep + (size_t)(unsigned)qoff, lsep != nullptr ? (unsigned)sq_of() * 4u : 0u);
             const __amdgpu_buffer_rsrc_t ors = head_srd(P()->o, qoff, sq_of());   // rows >= Sq are dropped by the bounds check
             bool bad = false;
+            // a part that covers only a range of its block's keys: un-normalised O^T rows (fp32, straight from the accumulator
+            // file), the reference in log2 units and the row sum -> plane pid - 1 of the workspace; fa_fwd_combine merges the planes
+            auto partial = [&](auto qb_tag) __attribute__((always_inline)) {
+                constexpr int QB = decltype(qb_tag)::value;
+                constexpr int PP = (D + kPartPad) * 4;   // bytes per partial row
+                const KernargPtr pp = P();
+                float* const base = pp->part + ((size_t)(unsigned)(pid - 1) * (size_t)(unsigned)pp->part_rows + (size_t)(unsigned)qoff) * (D + kPartPad);
+                const __amdgpu_buffer_rsrc_t prs = make_srd(base, (unsigned)sq_of() * (unsigned)PP);   // rows >= Sq fall outside
+                float lt, nm;
+                A::template get_sums<QB>(lt, nm);
+                lt += xhalf_fast(lt);
+                const unsigned roff = (unsigned)(r0 + 32 * QB + l31o) * PP;
+                A::template partial_store<QB>(prs, roff + 16u * (unsigned)hio);
+                const u32x2_t ml = {__builtin_bit_cast(unsigned, -nm), __builtin_bit_cast(unsigned, lt)};
+                __builtin_amdgcn_raw_buffer_store_b64(ml, prs, hio == 0 ? (int)(roff + D * 4) : 0x7ffffff0, 0, 0);
+#ifndef W4_X_NOVERDICT
+                if constexpr (!REDO) bad = bad || !((lt > 0x1p-100f) && (lt < (T::kDType == 2 ? 0x1p110f : 0x1p15f)));
+#endif
+            };
             auto half = [&](auto qb_tag) __attribute__((always_inline)) {
                 constexpr int QB = decltype(qb_tag)::value;
                 float lt, nm;
@@ -694,9 +741,15 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                     }
                 }
             };
-            half(integral_constant<int, 0>{});
-            stamp(0x42);
-            half(integral_constant<int, 1>{});
+            if (pid != 0) {
+                partial(integral_constant<int, 0>{});
+                stamp(0x42);
+                partial(integral_constant<int, 1>{});
+            } else {
+                half(integral_constant<int, 0>{});
+                stamp(0x42);
+                half(integral_constant<int, 1>{});
+            }
             if constexpr (!REDO) {
                 if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) redo[cs] = redo[kW4MaxSlot] = 1;
             }
@@ -711,7 +764,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             if (rope) issue_rope(qb);
             for (int j = 0; j < nt; ++j) {
                 __syncthreads();
-                A::dma_tile(lds0 + wave1k, head_srd(P()->k, kvoff, Sk), (unsigned)j * KT, kvo);
+                A::dma_tile(lds0 + wave1k, head_srd(P()->k, kvoff, Sk - tb * kKVTile), (unsigned)j * KT, kvo);
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 if (j < na) {
                     unsigned kap[KS];
@@ -745,7 +798,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                     issue_q(qoff, qb);
                     if (rope) issue_rope(qb);
                 }
-                const __amdgpu_buffer_rsrc_t k0 = head_srd(P()->k, kvoff, Sk), v0 = head_srd(P()->v, kvoff, Sk);
+                const __amdgpu_buffer_rsrc_t k0 = head_srd(P()->k, kvoff, Sk - tb * kKVTile), v0 = head_srd(P()->v, kvoff, Sk - tb * kKVTile);
                 A::dma_tile(ring_lds(0, 0), k0, 0u, kvo);
                 A::dma_tile(ring_lds(0, 1), k0, (unsigned)KT, kvo);
                 A::dma_tile(ring_lds(0, 2), k0, 2u * KT, kvo);
@@ -781,7 +834,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 }
             }
             for (; j < nt3; ++j) idle(j);   // (tiles the wave does not see, and the padding of the part to a multiple of three positions)
-            if (pre && na == nt) issue_q(w4_rfl(tab[n_slot].x), w4_rfl(tab[n_slot].z));   // (waves with idle steps asked in their first one)
+            if (pre && na == nt) issue_q(w4_rfl(tab[n_slot].x), qb_of(n_slot));   // (waves with idle steps asked in their first one)
             epilogue();
             if (n_slot >= nslot) break;
             cs = n_slot;
@@ -845,6 +898,7 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
     p.coff = a.causal ? a.coff : 0;
     p.nitems = p.nwork * a.B * a.Hq;
     p.dbg = dbg;
+    p.npiece = 1; p.pcoff = 0; p.magic = 0; p.part = nullptr; p.part_rows = 0;
     p.rcos = a.rope_cos; p.rsin = a.rope_sin;
     p.rrows = a.rope_rows; p.rpitch = a.rope_pitch; p.rpos = a.rope_pos;
     // one workgroup per CU; more only when a workgroup's list would not fit its part table
@@ -872,6 +926,40 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
     else
         hipLaunchKernelGGL((w4_kernel<T, D, false, TL>()), grid, block, lds, stream, p);
     return (int)hipGetLastError();
+}
+
+// Small grids: every pair of causal Q blocks (every non-causal block) as n work items of 1/n of its key tiles, partial rows, one
+// merge launch (fa_fwd_split.h; route 7).  One workgroup per item.
+template <class T, int D>
+int launch_w4_split(const FwdArgs& a, hipStream_t stream) {
+    const SplitPlan s = split_plan(a, device_cu_count(a.device));
+    if (a.query_ws != nullptr) {
+        *a.query_ws = s.bytes;
+        return 0;
+    }
+    ScopedWorkspace ws(s.bytes, a.ws, a.ws_bytes, stream);
+    if (ws.err != hipSuccess) return (int)ws.err;
+    FwdW4Params p{};
+    p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o; p.lse = a.lse;
+    p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
+    p.c = a.scale * kLog2e;
+    p.nqb = s.nqb; p.pair = a.causal ? 1 : 0; p.nwork = s.nwork; p.coff = a.causal ? a.coff : 0;
+    p.nitems = (int)s.nitems;
+    p.rounds = 0; p.mper = 1;
+    p.npiece = s.n; p.pcoff = a.causal ? a.coff : kEverything; p.magic = split_magic(s.n);
+    p.part = static_cast<float*>(ws.ptr);
+    p.part_rows = a.B * a.Hq * a.Sq;
+    const size_t lds = w4_lds_bytes<D>();
+    if (a.causal)
+        hipLaunchKernelGGL((w4_kernel<T, D, true, false>()), dim3((unsigned)s.nitems), dim3(256), lds, stream, p);
+    else
+        hipLaunchKernelGGL((w4_kernel<T, D, false, false>()), dim3((unsigned)s.nitems), dim3(256), lds, stream, p);
+    int rc = (int)hipGetLastError();
+    if (rc != 0) return rc;
+    CombineParams c{};
+    c.o = a.o; c.lse = a.lse; c.part = p.part; c.part_rows = p.part_rows;
+    c.Sq = a.Sq; c.Sk = a.Sk; c.nqb = s.nqb; c.pair = p.pair; c.pcoff = p.pcoff; c.npiece = s.n; c.magic = p.magic;
+    return launch_combine<T, D>(c, a.B * a.Hq, stream);
 }
 
 template <class T, int D>
@@ -909,6 +997,39 @@ bool fwd_w4_applicable(const FwdArgs& a) {
     if ((long long)a.B * a.Hq * a.Sq >= (1LL << 31) || (long long)a.B * a.Hkv * a.Sk >= (1LL << 31)) return false;
     if ((long long)a.Sq * a.D * 2 >= (1LL << 31) || (long long)a.Sk * a.D * 2 >= (1LL << 31)) return false;
     return true;
+}
+
+// Small grids the forward cuts along the keys (route 7).
+bool fwd_w4_split_applicable(const FwdArgs& a) {
+    if (split_max_pieces() < 2 || a.rope_cos != nullptr || !fwd_w4_applicable(a)) return false;
+    if ((long long)a.Sk >= 65535LL * kKVTile) return false;                               // tile indices are 16-bit in the part table
+    if ((long long)a.Sq * (a.D + kPartPad) * 4 >= (1LL << 32)) return false;              // partial rows of a head: 32-bit offsets
+    return split_plan(a, device_cu_count(a.device)).ok;
+}
+
+int launch_fwd_w4_split(const FwdArgs& a, hipStream_t stream) {
+    if (a.dtype == kBF16 && a.D == 128) return launch_w4_split<Bf16Traits, 128>(a, stream);
+    if (a.dtype == kF16 && a.D == 128) return launch_w4_split<F16Traits, 128>(a, stream);
+    if (a.dtype == kBF16 && a.D == 64) return launch_w4_split<Bf16Traits, 64>(a, stream);
+    if (a.dtype == kF16 && a.D == 64) return launch_w4_split<F16Traits, 64>(a, stream);
+    return -1;
+}
+
+// Host view of the split plan for the CPU tests (aule_hip_debug_forward_split_plan): out = {n, nwork, then per pair ntf, ntn,
+// b[0 .. kMaxPieces]}; returns the ints written, 0 when the shape does not take the path.
+int fwd_split_plan_dump(const FwdArgs& a, int* out, int cap) {
+    if (!fwd_w4_split_applicable(a)) return 0;
+    const SplitPlan s = split_plan(a, device_cu_count(a.device));
+    const int per = 2 + kMaxPieces + 1, need = 2 + s.nwork * per;
+    if (out == nullptr || cap < need) return -need;
+    out[0] = s.n; out[1] = s.nwork;
+    for (int near = 0; near < s.nwork; ++near) {
+        const SplitPair pr = split_cuts(a.causal ? s.nqb - 1 - near : near, near, a.Sk, a.causal ? a.coff : kEverything, s.n, split_magic(s.n));
+        int* o = out + 2 + near * per;
+        o[0] = pr.ntf; o[1] = pr.ntn;
+        for (int j = 0; j <= kMaxPieces; ++j) o[2 + j] = pr.b[j];
+    }
+    return need;
 }
 
 int launch_fwd_w4(const FwdArgs& a, hipStream_t stream) {

@@ -149,8 +149,8 @@ int launch_splitkv_combine(const FwdArgs& a, float* part, int npart, int nrt, hi
 int fwd_route(const FwdArgs& a);
 // launch_fwd honours FwdArgs::rope_* for these arguments (otherwise it refuses them: rotate Q with launch_rope first)
 bool fwd_rope_fusable(const FwdArgs& a);
-// the causal-split plan of route 7 as integers (tests): see fwd_ps_split_plan_dump in fa_fwd_ps_gfx950.hip
-int fwd_ps_split_plan_dump(const FwdArgs& a, int* out, int cap);
+// the split plan of route 7 as integers (tests): fwd_split_plan_dump in fa_fwd_w4_gfx950.hip, the plan itself in fa_fwd_split.h
+int fwd_split_plan_dump(const FwdArgs& a, int* out, int cap);
 // bytes of workspace launch_fwd / launch_paged_decode would allocate for these arguments (0: single-launch path)
 uint64_t fwd_workspace_bytes(FwdArgs a);
 uint64_t paged_workspace_bytes(PagedArgs a);   // 0 fp32, 1 ping-pong, 2 in-wave, 3 v1, 4 split-KV, 5 tiled + packed rows + KV splits (host logic only)

@@ -517,8 +517,8 @@ def main():
                                 "c5_workload": "MQA 32q/1kv B=1 S=16384 D=64 fp16 non-causal fwd (LSE stored)"})
 
         del q5, k5, v5
-        # single-sequence prefill, the small-grid corner (128 paired items on 256 CUs: route 7, pairs of Q blocks cut in
-        # two + merge), and RoPE + attention the inference way (K by the pass, Q rotated inside the kernel, 3.6)
+        # single-sequence prefill, the small-grid corner (128 paired items on 256 CUs: route 7, pairs of Q blocks cut into
+        # key ranges + merge), and RoPE + attention the inference way (K by the pass, Q rotated inside the kernel, 3.6)
         q6, k6, v6 = (torch.randn(1, 8, 8192, 128, device=dev, dtype=torch.bfloat16, generator=g3) for _ in range(3))
 
         def step6():
@@ -529,7 +529,7 @@ def main():
         _, ms6 = timed(step6, 20)
         result["extra"].update({"b1h8_s8192_fwd_tflops": fwd_flops(1, 8, 8192, 8192, 128, True) / (ms6 / 20 * 1e-3) / 1e12,
                                 "b1h8_s8192_ms_per_step": ms6 / 20,
-                                "b1h8_s8192_workload": "MHA 8 heads B=1 S=8192 D=128 bf16 causal fwd (small grid: two-waves-per-SIMD stream kernel over 256 pieces + merge kernel)"})
+                                "b1h8_s8192_workload": "MHA 8 heads B=1 S=8192 D=128 bf16 causal fwd (small grid, route 7: the one-wave-per-SIMD kernel over 256 key-range pieces + merge kernel)"})
         del q6, k6, v6
         B7, H7, S7, D7 = 4, 32, 2048, 128
         q7, k7, v7 = (torch.randn(B7, H7, S7, D7, device=dev, dtype=torch.bfloat16, generator=g3) for _ in range(3))

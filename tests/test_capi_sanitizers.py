@@ -73,7 +73,7 @@ for dtype, B, Hq, g, Sq, Sk, D, causal, W in itertools.product(
     f = lib.aule_attention_forward_rope_fusable(ctypes.byref(d), ctypes.byref(rp))
     assert f in (0, 1) and (f == 0 or (dtype in (1, 2) and D in (64, 128) and (W == -1 or W >= Sq)))   # (a window >= Sq masks nothing)
     n += 1
-assert {0, 1, 4, 5, 6, 7} <= set(routes), routes
+assert {0, 1, 4, 5, 7, 8} <= set(routes) and 6 not in routes, routes   # (6: the retired two-waves-per-SIMD stream)
 b = _capi.AttnBwdDesc()
 b.struct_size = ctypes.sizeof(_capi.AttnBwdDesc)
 for B, Hq, Hkv, S, D, causal in ((1, 1, 1, 1, 32, 0), (4, 32, 8, 2048, 128, 1), (2, 64, 1, 8192, 64, 1), (64, 32, 32, 300, 128, 0)):

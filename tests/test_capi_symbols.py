@@ -103,7 +103,7 @@ def test_product_does_not_import_oracle():
                 assert "import oracle" not in txt and "liboracle" not in txt and "oracle/" not in txt, (dp, f)
 
 
-def _route(B, Hq, Hkv, Sq, Sk, D, dtype=2, causal=0, window=-1):
+def _route(B, Hq, Hkv, Sq, Sk, D, dtype=2, causal=0, window=-1, scale=0.0):
     lib = ctypes.CDLL(_capi.find_library())
     lib.aule_hip_debug_forward_route.restype = ctypes.c_int32
     lib.aule_hip_debug_forward_route.argtypes = [ctypes.POINTER(_capi.AttnDesc)]
@@ -112,6 +112,7 @@ def _route(B, Hq, Hkv, Sq, Sk, D, dtype=2, causal=0, window=-1):
     d.dtype = dtype
     d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
     d.causal, d.window_size = causal, window
+    d.scale = scale
     return lib.aule_hip_debug_forward_route(ctypes.byref(d))
 
 
@@ -119,12 +120,13 @@ def test_forward_routing_rule(monkeypatch):
     """The dispatcher is host logic (no device needed).  Non-causal 16-bit problems that the plain tiled launch would
     run badly go to one of two kernels by a MEASURED rule (tools/ppsplit_grid.py, tools/ppsplit_decode.py):
     5 = tiled kernel with packed rows + KV splits (most shapes), 4 = wave-per-chunk split-KV kernel (>= 32 units,
-    <= 16 packed rows, K+V >= 100 MB); everything else 16-bit goes to a persistent tile stream when every Q block has at
-    least four KV tiles and there is no window -- the one-wave-per-SIMD kernel (8) at D = 128 / 64 with a positive scale, the
-    two-waves-per-SIMD stream (6) otherwise -- else to the ping-pong kernel (1); fp32 to 0."""
+    <= 16 packed rows, K+V >= 100 MB); everything else 16-bit goes to the one-wave-per-SIMD kernel (8; 7 = its small-grid form:
+    pairs of Q blocks cut into key ranges + merge) when every Q block has at least four KV tiles, there is no window, D = 128 / 64
+    and the scale is positive -- else to the ping-pong kernel (1); fp32 to 0.  (6, the two-waves-per-SIMD stream of rounds 2-3, is
+    gone.)"""
     for var in ("AULE_HIP_FWD_KERNEL", "AULE_HIP_FWD_SPLITKV", "AULE_HIP_FWD_PPSPLIT"):
         monkeypatch.delenv(var, raising=False)
-    WAVE, TILED_SPLIT, PP, PS, F32, PS_SPLIT, W4 = 4, 5, 1, 6, 0, 7, 8
+    WAVE, TILED_SPLIT, PP, F32, PS_SPLIT, W4 = 4, 5, 1, 0, 7, 8
     assert _route(1, 32, 1, 1, 16384, 64, dtype=1) == TILED_SPLIT    # C5b: 32 -> 17 us
     assert _route(1, 32, 1, 64, 16384, 64, dtype=1) == TILED_SPLIT   # C5c: 44 -> 28 us
     assert _route(8, 32, 8, 1, 2048, 128) == TILED_SPLIT             # 67 MB of K+V: below the streaming corner
@@ -162,12 +164,16 @@ def test_forward_routing_rule(monkeypatch):
     assert _route(2, 8, 8, 512, 193, 128) == W4
     # small causal grids: every pair of Q blocks cut in two when the doubled item count still fits one round of the chip
     assert _route(1, 8, 8, 8192, 8192, 128, causal=1) == PS_SPLIT    # 128 paired items on 256 CUs
-    assert _route(1, 32, 8, 2048, 2048, 128, causal=1) == PS_SPLIT   # single-sequence prefill
+    assert _route(1, 32, 8, 2048, 2048, 128, causal=1) == W4         # 128 pairs of 36 tiles: two pieces of 18 on a full chip lose (round 4)
+    assert _route(1, 16, 16, 4096, 4096, 128, causal=1) == PS_SPLIT  # 128 pairs of 68 tiles: two pieces of 34 win
+    assert _route(1, 4, 4, 2048, 2048, 128, causal=1) == PS_SPLIT    # 16 pairs: the chip is nowhere near full, two pieces of 18
     assert _route(2, 8, 8, 8192, 8192, 128, causal=1) == W4          # 256 paired items: already one per CU
-    assert _route(1, 32, 32, 2048, 2048, 64, dtype=1, causal=1) == PS_SPLIT   # D = 64: two workgroups per CU
+    assert _route(1, 32, 32, 2048, 2048, 64, dtype=1, causal=1) == W4         # D = 64, the same 128 x 36
+    assert _route(1, 8, 8, 4096, 4096, 64, dtype=1, causal=1) == PS_SPLIT     # D = 64: 64 pairs of 68 tiles, four pieces
     assert _route(1, 8, 8, 8192, 8192, 128) == W4                    # non-causal: 256 blocks, one per CU
     assert _route(1, 8, 8, 4096, 4096, 128) == PS_SPLIT              # non-causal: 128 blocks, each cut in two
-    assert _route(1, 8, 8, 8192, 8192, 32, causal=1) == PS           # no D = 32 instances
+    assert _route(1, 8, 8, 8192, 8192, 32, causal=1) == PP           # D = 32: the ping-pong kernel
+    assert _route(4, 32, 32, 4096, 4096, 128, causal=1, scale=-0.1) == PP    # negative scale too
     assert _route(8, 32, 32, 2048, 2048, 64, dtype=1, causal=1) == W4         # D = 64 too
     assert _route(1, 8, 8, 300, 300, 128, causal=1) == W4            # one pair whose far block is too short to cut
     assert _route(1, 3, 2, 1, 8192, 128) == -3                       # heads not divisible
@@ -194,7 +200,7 @@ def fusable(B=4, Hq=32, Hkv=32, Sq=2048, Sk=2048, D=128, dtype=2, causal=1, wind
     return lib.aule_attention_forward_rope_fusable(ctypes.byref(d), ctypes.byref(r))
 
 assert ctypes.sizeof(_capi.AttnRope) == 40
-# (both stream kernels rotate Q themselves: the one-wave-per-SIMD kernel by default, its predecessor under AULE_HIP_FWD_KERNEL=ps)
+# (the one-wave-per-SIMD kernel rotates Q itself)
 assert fusable() == 1
 assert fusable(D=64, dtype=1, causal=0) == 1
 assert fusable(Sq=1024, Sk=4096, causal=2, rows=4096, pos=3072) == 1      # bottom-right: queries at Sk - Sq + i
@@ -215,12 +221,11 @@ print("RULE OK")
 '''
 
 
-@pytest.mark.parametrize("kernel", ["", "ps"], ids=["default", "kernel-ps"])
+@pytest.mark.parametrize("kernel", [""], ids=["default"])
 def test_fused_query_rotation_rule(kernel):
-    """aule_attention_forward_rope_fusable() (host logic): the two stream kernels rotate Q themselves for fp16 / bf16, head_dim
-    64 / 128, half-split pairs, 16-byte aligned tables of pitch % 4 == 0 that cover seq_q + q_pos_offset rows -- the
-    one-wave-per-SIMD kernel by default, its predecessor under AULE_HIP_FWD_KERNEL=ps (the library reads the variable once per
-    process, hence the child)."""
+    """aule_attention_forward_rope_fusable() (host logic): the one-wave-per-SIMD kernel rotates Q itself for fp16 / bf16, head_dim
+    64 / 128, half-split pairs, 16-byte aligned tables of pitch % 4 == 0 that cover seq_q + q_pos_offset rows (a child process:
+    the library reads its kernel switches once per process)."""
     import subprocess
     import sys
     e = {k: v for k, v in os.environ.items() if k not in ("AULE_HIP_FWD_KERNEL", "AULE_HIP_FWD_SOFTMAX")}
@@ -231,11 +236,11 @@ def test_fused_query_rotation_rule(kernel):
 
 
 def test_causal_split_plan_invariants(monkeypatch):
-    """Route 7's plan (ps_cuts in fa_fwd_ps_gfx950.hip, through aule_hip_debug_forward_split_plan; host logic): for every pair
+    """Route 7's plan (split_cuts in fa_fwd_split.h, through aule_hip_debug_forward_split_plan; host logic): for every pair
     of Q blocks the pieces tile the pair's key tiles exactly; every range of a block has at least four tiles; a cut inside
     a block lies within the keys every row of the block sees whole; the pieces fit the chip in one round and are balanced."""
     monkeypatch.delenv("AULE_HIP_FWD_KERNEL", raising=False)
-    monkeypatch.delenv("AULE_HIP_FWD_PSSPLIT", raising=False)
+    monkeypatch.delenv("AULE_HIP_FWD_SPLIT", raising=False)
     lib = _capi.load()
     seen, ns = 0, set()
     for (B, Hq, Hkv, Sq, Sk, D, causal) in itertools.product((1, 2, 3), (4, 8, 32, 40), (1, 4), (300, 512, 777, 1024, 1792, 2048, 4096, 8192, 9000),

@@ -1,12 +1,13 @@
 """Parity of the NON-default forward kernels / softmax forms (selected by environment variables that the
 library reads once per process, hence one subprocess per variant):
 
-  AULE_HIP_FWD_KERNEL=ps        the two-waves-per-SIMD persistent tile stream (round 2's default; still the kernel behind D = 64 / 32,
-                                negative scales and the fused query rotation) instead of the one-wave-per-SIMD kernel
-  AULE_HIP_FWD_KERNEL=pp        every tiled problem on the ping-pong kernel (one workgroup per Q-block pair), the
-                                predecessor of the tile streams and still the kernel behind window / short shapes
-  AULE_HIP_FWD_SOFTMAX=classic  online softmax only (no fixed-reference pass), on the two-waves-per-SIMD stream and on the
-                                ping-pong kernel (the one-wave-per-SIMD kernel has no online form and is skipped)
+  AULE_HIP_FWD_KERNEL=pp        every tiled problem on the ping-pong kernel (two waves per SIMD, one workgroup per Q-block pair):
+                                the predecessor of the one-wave-per-SIMD kernel and still the kernel behind window / short
+                                shapes, D = 32 and negative scales
+  AULE_HIP_FWD_SOFTMAX=classic  online softmax only (no fixed-reference pass), on the ping-pong kernel (the one-wave-per-SIMD
+                                kernel has no online form and is skipped)
+  AULE_HIP_FWD_SPLIT=0          small grids without the key-range split (route 8 instead of route 7)
+(The two-waves-per-SIMD tile stream of rounds 2-3, AULE_HIP_FWD_KERNEL=ps, was retired in round 4.)
 
 Each variant runs the same seeded cases against the fp64 oracle, including a large-logit case that the
 fixed-reference pass must hand over to the online form (its row sums leave the safe range).
@@ -59,9 +60,9 @@ print("RESULT " + json.dumps(res))
 '''
 
 
-@pytest.mark.parametrize("env", [{}, {"AULE_HIP_FWD_KERNEL": "ps"}, {"AULE_HIP_FWD_KERNEL": "pp"}, {"AULE_HIP_FWD_SOFTMAX": "classic"},
-                                 {"AULE_HIP_FWD_KERNEL": "pp", "AULE_HIP_FWD_SOFTMAX": "classic"}],
-                         ids=["default", "kernel-ps", "kernel-pp", "softmax-classic", "kernel-pp-softmax-classic"])
+@pytest.mark.parametrize("env", [{}, {"AULE_HIP_FWD_KERNEL": "pp"}, {"AULE_HIP_FWD_SOFTMAX": "classic"},
+                                 {"AULE_HIP_FWD_KERNEL": "pp", "AULE_HIP_FWD_SOFTMAX": "classic"}, {"AULE_HIP_FWD_SPLIT": "0"}],
+                         ids=["default", "kernel-pp", "softmax-classic", "kernel-pp-softmax-classic", "no-key-split"])
 def test_forward_variant_matches_oracle(env):
     e = dict(os.environ)
     e.update(env)
@@ -70,14 +71,3 @@ def test_forward_variant_matches_oracle(env):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     for c in json.loads(line[7:]):
         assert c["nan"] == 0 and c["bad"] == 0 and c["lse_bad"] == 0, c
-
-
-def test_fused_query_rotation_on_the_two_waves_per_simd_stream():
-    """The query rotation is fused by the two-waves-per-SIMD stream only; at D = 128 that kernel is no longer the default, so
-    its fused instances are exercised by running the bit-for-bit test of tests/test_gpu_rope.py with AULE_HIP_FWD_KERNEL=ps."""
-    e = dict(os.environ)
-    e["AULE_HIP_FWD_KERNEL"] = "ps"
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_rope.py"), os.path.join(ROOT, "tests", "test_gpu_graph.py"),
-                        "-q", "-x", "-m", "gpu", "-k", "fused_query_rotation_is_the_separate_pass or fused-rope"],
-                       env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert r.returncode == 0 and "passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-3000:] + r.stderr[-1000:]

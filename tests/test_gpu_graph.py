@@ -21,11 +21,10 @@ SHAPES = [  # name, B, Hq, Hkv, Sq, Sk, D, dtype, causal
     ("route4-decode", 8, 32, 8, 1, 8192, 128, "bf16", False),
     ("route5-bottom-right", 2, 16, 4, 48, 4096, 128, "bf16", "bottom-right"),
     ("plain-causal", 1, 8, 8, 1024, 1024, 128, "bf16", True),
-    ("route7-causal-split", 1, 8, 8, 4096, 4096, 128, "bf16", True),      # stream kernel over pieces + merge kernel, caller workspace
+    ("route7-causal-split", 1, 8, 8, 4096, 4096, 128, "bf16", True),      # forward over key-range pieces + merge kernel, caller workspace
     ("route7-noncausal-split", 1, 8, 8, 2048, 2048, 128, "fp16", False),
     ("route8-one-wave-per-simd", 4, 16, 16, 1024, 1024, 128, "bf16", True),   # the D = 128 default: several parts per workgroup
-    ("route8-fused-rope", 4, 16, 16, 1024, 1024, 128, "bf16", True),      # the forward that rotates Q itself (tables captured too);
-                                                                          # with AULE_HIP_FWD_KERNEL=ps: on the predecessor (route 6)
+    ("route8-fused-rope", 4, 16, 16, 1024, 1024, 128, "bf16", True),      # the forward that rotates Q itself (tables captured too)
 ]
 
 

@@ -232,8 +232,7 @@ def test_fused_query_rotation_is_the_separate_pass_bit_for_bit(case, oracle_mod,
     qoff = Sk - Sq if causal == "bottom-right" else 0
     tq, tk, tv, tc, ts = _dev(torch, q, dtype), _dev(torch, k, dtype), _dev(torch, v, dtype), _dev(torch, cos), _dev(torch, sin)
     code = at.causal_code(causal)
-    # both stream kernels rotate Q themselves: the one-wave-per-SIMD kernel by default (table rows land in its score registers
-    # between two parts), its predecessor with AULE_HIP_FWD_KERNEL=ps (tests/test_gpu_fwd_variants.py runs this test that way too)
+    # the one-wave-per-SIMD kernel rotates Q itself (table rows land in its score registers between two parts): fusable == route 8 (fa_fwd_gfx950.hip)
     fus = at.rope_fusable(tq, tk, code, -1, tc, ts, qoff)
     assert fus
     sc = 1.0 / math.sqrt(D)

@@ -82,8 +82,10 @@ def test_splitkv_feeds_the_backward(oracle_mod):
         assert_close(got.float().cpu().numpy(), want, a * max(1.0, float(np.abs(want).max())), r, name)
 
 
-# ---- small causal grids: route 7, the tile stream with every pair of Q blocks cut in two (fa_fwd_ps_gfx950.hip SPLIT
-#      instances + fa_fwd_ps_combine).  The plan is arithmetic (ps_cut): which far blocks are cut, and where.
+# ---- small grids: route 7, the one-wave-per-SIMD forward with every pair of causal Q blocks (every non-causal block) cut into key
+#      ranges (fa_fwd_w4_gfx950.hip part table + fa_fwd_combine, fa_fwd_split.h).  The plan is arithmetic (split_cuts): which blocks
+#      are cut, and where.  (Rounds 2-3 ran this on the two-waves-per-SIMD stream kernel; a negative scale now takes the ping-pong
+#      kernel, whole pairs.)
 CAUSAL_SPLIT_CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, causal, scale, spike
     ("bf16", 1, 4, 4, 2048, 2048, 128, True, None, 0),              # 8 Q blocks: 4 pairs, every far block cut
     ("bf16", 1, 8, 2, 1792, 1792, 128, True, None, 0),              # 7 Q blocks: the middle block is a pair of its own
@@ -99,7 +101,7 @@ CAUSAL_SPLIT_CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, causal, scale, spike
 ]
 
 
-def _route_causal(dtype, B, Hq, Hkv, Sq, Sk, D, causal):
+def _route_causal(dtype, B, Hq, Hkv, Sq, Sk, D, causal, scale=0.0):
     import ctypes
     from aule import _capi, _torch as at
     lib = _capi.get_lib()
@@ -108,6 +110,7 @@ def _route_causal(dtype, B, Hq, Hkv, Sq, Sk, D, causal):
     d.dtype = {"fp32": 0, "fp16": 1, "bf16": 2}[dtype]
     d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
     d.causal, d.window_size = at.causal_code(causal), -1
+    d.scale = scale
     return lib.aule_hip_debug_forward_route(ctypes.byref(d))
 
 
@@ -126,7 +129,8 @@ def test_causal_split_forward_vs_oracle(case, oracle_mod):
     q, k, v = (quantize(x, dtype) for x in (q, k, v))
     sc = (1 / math.sqrt(D)) if scale is None else scale
     dev = lambda a: torch.from_numpy(a).to("cuda", torch_dtype(dtype))
-    assert _route_causal(dtype, B, Hq, Hkv, Sq, Sk, D, causal) == 7, "the dispatch rule moved this shape off the causal split"
+    want = 7 if sc > 0 else 1   # (a negative scale: the ping-pong kernel)
+    assert _route_causal(dtype, B, Hq, Hkv, Sq, Sk, D, causal, sc) == want, "the dispatch rule moved this shape off the key-range split"
     out, lse = at.fwd_raw(dev(q), dev(k), dev(v), at.causal_code(causal), sc)
     ref, ref_lse = oracle_mod.fwd_f64(q, k, v, causal, scale)
     atol, rtol = fwd_tol(dtype, np.abs(v).max())

@@ -798,6 +798,20 @@ def gen_struct(c):
     if c.pre:
         s += emit_asm(lines, [], ['[c] "s"(c)'], ["memory"] + vregs(c.X, 3) + aregs(c.QB0, 8 * c.KS), indent="        ")
     s += "#endif\n    }\n"
+    # ---- a part that covers only a RANGE of its block's key tiles (small grids: fa_fwd_split.h) leaves its un-normalised O^T as fp32
+    #      partial rows, straight from the accumulator file: lane (q, hi) owns columns 32 d + 8 g + 4 hi .. + 3 of row q in registers
+    #      4 g .. 4 g + 3 of block (QB, d); vo = byte offset of the lane's row + 16 hi.  (m_ref and l: the kernel, two dwords behind the row.)
+    s += "    template <int QB>\n    static __device__ __forceinline__ void partial_store(__amdgpu_buffer_rsrc_t srd, unsigned vo) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+    for qb in range(2):
+        lines = ["s_nop 4"]
+        for d in range(c.DB):
+            for g4 in range(4):
+                b = (qb * c.DB + d) * 16 + 4 * g4
+                lines.append(f"buffer_store_dwordx4 a[{b}:{b + 3}], %[vo], %[srd], 0 offen offset:{(32 * d + 8 * g4) * 4}")
+        s += (f"        if constexpr (QB == {qb}) {{\n" if qb == 0 else "        else {\n")
+        s += emit_asm(lines, [], ['[srd] "s"(srd)', '[vo] "v"(vo)'], ["memory"])
+        s += "        }\n"
+    s += "#endif\n    }\n"
     s += ("    // end of a part: row sum (both chains) and - reference of block QB\n"
           "    template <int QB>\n    static __device__ __forceinline__ void get_sums(float& l, float& nm) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
           f"        if constexpr (QB == 0) asm volatile(\"v_add_f32 %0, v{c.l(0, 0)}, v{c.l(0, 1)}\\n\\tv_mov_b32 %1, v{c.nm(0)}\" : \"=&v\"(l), \"=v\"(nm));\n"
