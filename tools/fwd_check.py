@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Triage and A/B timing of the persistent tile-stream forward (fa_fwd_ps_gfx950.hip, route 6).
+"""Triage and A/B timing of the tiled 16-bit forward kernels: the judge (fp64 reference on the GPU) and the timing loop that
+tools/w4_check.py, tools/w4_d64_check.py and the A/B scripts share.  (Round 2 wrote it for the two-waves-per-SIMD stream kernel,
+retired in round 4; its own `check` list pins routes that kernel had and is kept for the shapes, not the pins.)
 
-    python tools/ps_check.py check        parity on shapes that exercise every seam kind, vs an fp64 reference on the GPU
-    python tools/ps_check.py bench [tag]  per-launch times (HIP events) of the headline shapes for the kernel the
+    python tools/fwd_check.py check        parity on shapes that exercise every seam kind, vs an fp64 reference on the GPU
+    python tools/fwd_check.py bench [tag]  per-launch times (HIP events) of the headline shapes for the kernel the
                                           environment selects (AULE_HIP_FWD_KERNEL=pp: the predecessor); long warm-up
-    python tools/ps_check.py dvfs         per-launch times of the first 300 launches of C2 on an idle chip
+    python tools/fwd_check.py dvfs         per-launch times of the first 300 launches of C2 on an idle chip
 
 The fp64 reference is plain torch on the GPU (softmax(QK^T)V per sampled head): a tool-side judge for shapes the C oracle
 would take minutes on; the tests in tests/ use the oracle.

@@ -12,7 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 
-constexpr int NH = 128, SQ = 2048, D = 128, KB = 128, QT = 64, NKB = SQ / KB, NQT = SQ / QT;
+#ifndef PROBE_KB
+#define PROBE_KB 128   // keys per block (round 4: -DPROBE_KB=256 = the 256-key blocks a fused kernel would need to halve the traffic)
+#endif
+constexpr int NH = 128, SQ = 2048, D = 128, KB = PROBE_KB, QT = 64, NKB = SQ / KB, NQT = SQ / QT;
 
 template <int MODE>
 __global__ void __launch_bounds__(256) probe(float* dq, int spin) {

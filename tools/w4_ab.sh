@@ -9,7 +9,7 @@ for round in 1 2 3; do
     timeout 300 python - <<'PY' 2>&1 | grep "bf16 B"
 import sys
 sys.path.insert(0, "tools")
-import ps_check as pc
+import fwd_check as pc
 pc.bench_shape("bf16", 4, 32, 32, 4096, 128, True, warm=150, iters=100)
 pc.bench_shape("bf16", 4, 32, 32, 4096, 128, False, warm=80, iters=60)
 pc.bench_shape("bf16", 4, 32, 8, 2048, 128, True, warm=200, iters=100)

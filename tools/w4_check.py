@@ -3,13 +3,13 @@
 
     python tools/w4_check.py check [quick]   parity vs an fp64 reference on the GPU, shapes that exercise every step variant
     python tools/w4_check.py bench [tag]     per-launch times of the headline shapes for the kernel the environment selects
-                                             (AULE_HIP_FWD_KERNEL=ps: the two-waves-per-SIMD predecessor)
-The judge and the timing loop are those of tools/ps_check.py.
+                                             (AULE_HIP_FWD_KERNEL=pp: the two-waves-per-SIMD ping-pong kernel)
+The judge and the timing loop are those of tools/fwd_check.py.
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-import ps_check as pc
+import fwd_check as pc
 
 
 def run_checks(quick):
@@ -47,7 +47,7 @@ def run_checks(quick):
     if not quick:
         ok &= pc.check("bf16", 4, 32, 32, 2048, 2048, 128, True, mag=5.0, want_route=8)  # ... in the middle of long part lists
     ok &= pc.check("bf16", 2, 4, 4, 1024, 1024, 128, False, scale=0.3, want_route=8)
-    ok &= pc.check("bf16", 2, 4, 4, 1024, 1024, 128, True, scale=-0.1, want_route=6)     # negative scale stays on the predecessor
+    ok &= pc.check("bf16", 2, 4, 4, 1024, 1024, 128, True, scale=-0.1, want_route=1)     # negative scale: the ping-pong kernel
     print("ALL OK" if ok else "SOME FAILED", flush=True)
     return ok
 

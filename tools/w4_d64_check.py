@@ -1,6 +1,6 @@
 import sys
 sys.path.insert(0, "tools")
-import ps_check as pc
+import fwd_check as pc
 ok = True
 for c in [("fp16", 1, 32, 1, 4096, 4096, 64, False), ("fp16", 8, 32, 32, 2048, 2048, 64, True), ("bf16", 8, 32, 32, 2048, 2048, 64, True),
           ("bf16", 1, 4, 4, 512, 512, 64, False), ("fp16", 2, 4, 4, 600, 600, 64, True), ("bf16", 2, 8, 2, 777, 1300, 64, False),

@@ -28,8 +28,8 @@ else
   for v in $VARIANTS; do
     n=$(echo $v | tr ',' '_')
     echo "== $n"
-    AULE_LIBRARY_PATH=$R/build/variants/libaule_w4x_$n.so timeout 300 python tools/ps_check.py one bf16 4 32 32 4096 128 0 40 2>&1 | grep "bf16 B4"
-    AULE_LIBRARY_PATH=$R/build/variants/libaule_w4x_$n.so timeout 300 python tools/ps_check.py one bf16 4 32 32 4096 128 1 40 2>&1 | grep "bf16 B4"
+    AULE_LIBRARY_PATH=$R/build/variants/libaule_w4x_$n.so timeout 300 python tools/fwd_check.py one bf16 4 32 32 4096 128 0 40 2>&1 | grep "bf16 B4"
+    AULE_LIBRARY_PATH=$R/build/variants/libaule_w4x_$n.so timeout 300 python tools/fwd_check.py one bf16 4 32 32 4096 128 1 40 2>&1 | grep "bf16 B4"
     AULE_LIBRARY_PATH=$R/build/variants/libaule_w4xd_$n.so timeout 300 python tools/timeline_w4.py 0 4 32 4096 3 2>&1 | grep -m2 "plain"
   done
 fi
