@@ -292,22 +292,29 @@ def main():
         return wall, dev_ms
 
     def condition(fn, ms):
-        """Repeat the step for ~ms of device time (power / clock controller into steady state); returns (steps, ms)."""
+        """Repeat the step for ~ms of device time (power / clock controller into steady state); returns (steps, ms).
+        The step is sized from the mean of three calls AFTER two untimed ones: the first call of a new workload pays its
+        allocations (round 3 sized the loop from that call alone -- 5 ms instead of 0.6 -- and the "conditioned" extra legs
+        then ran 30 ms, not 250, and were read inside the clock transient: profiles/r4_bench_conditioning.txt)."""
         if ms <= 0:
             return 0, 0.0
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
         fn()
+        fn()
+        e0.record()
+        for _ in range(3):
+            fn()
         e1.record()
         torch.cuda.synchronize()
-        one = max(1e-3, e0.elapsed_time(e1))
+        first = e0.elapsed_time(e1)
+        one = max(1e-3, first / 3)
         n = max(1, int(ms / one))
         e0.record()
         for _ in range(n):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        return n + 1, e0.elapsed_time(e1) + one
+        return n + 5, e0.elapsed_time(e1) + first
 
     # 1. the contract's protocol, first thing, on the chip as the process finds it: W untimed steps, EXACTLY K timed steps -> `value`
     for _ in range(args.warmup):
