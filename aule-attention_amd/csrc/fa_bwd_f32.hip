@@ -40,35 +40,63 @@ struct BwdF32Params {
 constexpr int kRows = 128;  // rows per workgroup (4 waves x 32)
 constexpr int kTile = 32;
 
-// Stage a [32 x D] fp32 tile whose rows start at `row0` (clamped to nrows-1) into
-//   tr  : [D][32]  (element (r, d) at tr[d*32 + r])      -- A operand of X . Y^T products
-//   rm  : [32][D]  row-major                              -- A operand of X^T . P products
-// Either destination may be null.
+// Staging of a [32 x D] fp32 tile whose rows start at `row0` (clamped to nrows-1), round 4.
+//
+// Two LDS images, both written from ONE set of registers (thread -> row cidx & 31, four columns 4 (cidx >> 5) .. + 3):
+//   tq : the A operands of the products that contract over D (S = X Y^T): lane (row, hi) needs X[row][2 st + hi] for st = 0 .. D/2 - 1.
+//        Element (row, d) sits at tq[(((d >> 3) * 2 + (d & 1)) * 32 + row) * 4 + ((d >> 1) & 3)]: ONE ds_read_b128 hands a lane its
+//        operands of four consecutive MFMAs, 16 lanes of a pass read 256 contiguous bytes (no bank conflict).
+//   cm : the A operands of the products that contract over the tile's ROWS (dQ += dS K, dV += P^T dO, dK += dS^T Q): lane (col, hi)
+//        needs X[crow(r, hi)][col], r = 0 .. 15, i.e. four runs of four consecutive rows.  Column-major with a pitch of 36 floats
+//        (cm[col * 36 + row]): one ds_read_b128 per run, and the 16 lanes of a pass (pitch 36 = 9 x 16 bytes) cover all 64 banks once.
+// (Rounds 1-3: a [D][32] image and a row-major one, filled by two separate global loads per element and read with one ds_read_b32
+//  per MFMA -- 192-256 LDS instructions and as many fine-grained waits per tile.)
+// tile_load issues the global loads of a tile into registers, tile_store writes them to LDS: the kernels load tile t + 1 BEFORE
+// they compute tile t and store it behind the tile's closing barrier, so the global-memory latency runs under a tile's MFMAs
+// (the staging used to be load -> store -> barrier at the top of every tile, with the matrix pipes idle).
+constexpr int kCmPitch = 36;
 template <int D>
-__device__ __forceinline__ void stage_tile(const float* __restrict__ g, int row0, int nrows, float* tr, float* rm,
-                                           int tid) {
-    constexpr int C4 = D / 4, NCH = kTile * C4 / 256;
+struct TileRegs {
+    static constexpr int NCH = kTile * (D / 4) / 256;
+    f32x4_t x[NCH];
+};
+template <int D>
+__device__ __forceinline__ void tile_load(TileRegs<D>& t, const float* __restrict__ g, int row0, int nrows, int tid) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int cidx = tid + 256 * i;
-        if (tr != nullptr) {
-            const int rr = cidx & 31, dc = cidx >> 5;
-            int r = row0 + rr;
-            r = r < nrows ? r : nrows - 1;
-            const f32x4_t x = *reinterpret_cast<const f32x4_t*>(g + (size_t)r * D + 4 * dc);
-            tr[(4 * dc + 0) * 32 + rr] = x[0];
-            tr[(4 * dc + 1) * 32 + rr] = x[1];
-            tr[(4 * dc + 2) * 32 + rr] = x[2];
-            tr[(4 * dc + 3) * 32 + rr] = x[3];
+    for (int i = 0; i < TileRegs<D>::NCH; ++i) {
+        const int cidx = tid + 256 * i, rr = cidx & 31, dc = cidx >> 5;
+        int r = row0 + rr;
+        r = r < nrows ? r : nrows - 1;
+        t.x[i] = *reinterpret_cast<const f32x4_t*>(g + (size_t)r * D + 4 * dc);
+    }
+}
+template <int D>
+__device__ __forceinline__ void tile_store(const TileRegs<D>& t, float* tq, float* cm, int tid) {
+#pragma unroll
+    for (int i = 0; i < TileRegs<D>::NCH; ++i) {
+        const int cidx = tid + 256 * i, rr = cidx & 31, dc = cidx >> 5;
+        const f32x4_t x = t.x[i];
+        if (tq != nullptr) {   // d = 4 dc + e: group dc >> 1, parity e & 1, slot 2 (dc & 1) + (e >> 1)
+            float* const q0 = tq + (((dc >> 1) * 2 + 0) * 32 + rr) * 4 + 2 * (dc & 1);
+            float* const q1 = tq + (((dc >> 1) * 2 + 1) * 32 + rr) * 4 + 2 * (dc & 1);
+            *reinterpret_cast<f32x2_t*>(q0) = f32x2_t{x[0], x[2]};
+            *reinterpret_cast<f32x2_t*>(q1) = f32x2_t{x[1], x[3]};
         }
-        if (rm != nullptr) {
-            const int rr = cidx / C4, cc = cidx % C4;
-            int r = row0 + rr;
-            r = r < nrows ? r : nrows - 1;
-            *reinterpret_cast<f32x4_t*>(&rm[rr * D + 4 * cc]) =
-                *reinterpret_cast<const f32x4_t*>(g + (size_t)r * D + 4 * cc);
+        if (cm != nullptr) {
+            cm[(4 * dc + 0) * kCmPitch + rr] = x[0];
+            cm[(4 * dc + 1) * kCmPitch + rr] = x[1];
+            cm[(4 * dc + 2) * kCmPitch + rr] = x[2];
+            cm[(4 * dc + 3) * kCmPitch + rr] = x[3];
         }
     }
+}
+// the four A operands of MFMAs 4 st4 .. 4 st4 + 3 of a product over D
+__device__ __forceinline__ f32x4_t tq_read(const float* tq, int st4, int hi, int l31) {
+    return *reinterpret_cast<const f32x4_t*>(tq + ((st4 * 2 + hi) * 32 + l31) * 4);
+}
+// the four A operands of steps r = 4 q .. 4 q + 3 of a product over the rows, column `col`
+__device__ __forceinline__ f32x4_t cm_read(const float* cm, int col, int q, int hi) {
+    return *reinterpret_cast<const f32x4_t*>(cm + col * kCmPitch + 8 * q + 4 * hi);
 }
 
 // lane (row, hi) loads row[2s + hi] for s = 0..D/2-1 (B operand of the 32x32x2 MFMA)
@@ -85,9 +113,9 @@ __device__ __forceinline__ void load_b_operand(const float* rowp, int hi, float 
 template <int D, bool CAUSAL>
 __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dq_f32_kernel(const BwdF32Params p) {
     constexpr int DB = D / 32;
-    __shared__ __attribute__((aligned(16))) float Kt[D * 32];
-    __shared__ __attribute__((aligned(16))) float Krm[kTile * D];
-    __shared__ __attribute__((aligned(16))) float Vt[D * 32];
+    __shared__ __attribute__((aligned(16))) float Kt[D * 32];          // tq image of the K tile
+    __shared__ __attribute__((aligned(16))) float Kcm[D * kCmPitch];   // cm image of the K tile
+    __shared__ __attribute__((aligned(16))) float Vt[D * 32];          // tq image of the V tile
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,19 +149,32 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dq_f32_kernel(con
     const int t_lo = W > 0 ? max(0, w.blk * kRows + coff - W + 1) / kTile : 0;  // tiles before the block's window: skipped
     const int wave_kv_lo = W > 0 ? q0w + coff - W + 1 : 0;
 
+    TileRegs<D> kreg, vreg;
+    if (t_lo < nt) {
+        tile_load(kreg, kg, t_lo * kTile, Sk, tid);
+        tile_load(vreg, vg, t_lo * kTile, Sk, tid);
+    }
     for (int t = t_lo; t < nt; ++t) {
         const int kv0 = t * kTile;
-        stage_tile<D>(kg, kv0, Sk, Kt, Krm, tid);
-        stage_tile<D>(vg, kv0, Sk, Vt, nullptr, tid);
+        tile_store(kreg, Kt, Kcm, tid);
+        tile_store(vreg, Vt, static_cast<float*>(nullptr), tid);
         __syncthreads();
+        if (t + 1 < nt) {   // the next tile's rows travel while this one is computed
+            tile_load(kreg, kg, kv0 + kTile, Sk, tid);
+            tile_load(vreg, vg, kv0 + kTile, Sk, tid);
+        }
         if (kv0 < wave_kv_hi && kv0 + kTile > wave_kv_lo) {
             f32x16_t s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-            for (int st = 0; st < D / 2; ++st) {
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[(2 * st + hi) * 32 + l31], qf[st], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[(2 * st + hi) * 32 + l31], dof[st], dp, 0, 0, 0);
+            for (int st4 = 0; st4 < D / 8; ++st4) {
+                const f32x4_t ka = tq_read(Kt, st4, hi, l31), va = tq_read(Vt, st4, hi, l31);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[j], qf[4 * st4 + j], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], dof[4 * st4 + j], dp, 0, 0, 0);
+                }
             }
             const bool need_mask = (CAUSAL && (kv0 + kTile - 1 > q0w + coff)) || (kv0 + kTile > Sk) || (W > 0 && q0w + coff + 31 - kv0 >= W);
 #pragma unroll
@@ -147,11 +188,15 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dq_f32_kernel(con
                 s[r] = pv * (dp[r] - delta);  // dS^T (scale applied in the epilogue)
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kvr = crow(r, hi);
+            for (int q = 0; q < 4; ++q) {
+                f32x4_t ka[DB];
 #pragma unroll
-                for (int d = 0; d < DB; ++d)
-                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(Krm[kvr * D + 32 * d + l31], s[r], acc[d], 0, 0, 0);
+                for (int d = 0; d < DB; ++d) ka[d] = cm_read(Kcm, 32 * d + l31, q, hi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int d = 0; d < DB; ++d)
+                        acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[d][j], s[4 * q + j], acc[d], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -173,19 +218,20 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dq_f32_kernel(con
 
 template <int D>
 struct DkvF32Cfg {
-    static constexpr int IMG = kTile * D;              // floats per image
-    static constexpr int LDS = (4 * IMG + 64) * 4;     // Qt, Qrm, dOt, dOrm, scal[64]
+    static constexpr int IMG = kTile * D;              // floats per tq image
+    static constexpr int CMG = kCmPitch * D;           // floats per cm image
+    static constexpr int LDS = (2 * IMG + 2 * CMG + 64) * 4;     // Q tq, Q cm, dO tq, dO cm, scal[64]
 };
 
 template <int D, bool CAUSAL>
 __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dkdv_f32_kernel(const BwdF32Params p) {
-    constexpr int DB = D / 32, IMG = DkvF32Cfg<D>::IMG;
+    constexpr int DB = D / 32, IMG = DkvF32Cfg<D>::IMG, CMG = DkvF32Cfg<D>::CMG;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* const Qt = reinterpret_cast<float*>(smem_raw);
-    float* const Qrm = Qt + IMG;
-    float* const Gt = Qrm + IMG;
-    float* const Grm = Gt + IMG;
-    float* const scal = Grm + IMG;
+    float* const Qcm = Qt + IMG;
+    float* const Gt = Qcm + CMG;
+    float* const Gcm = Gt + IMG;
+    float* const scal = Gcm + CMG;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -216,24 +262,37 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dkdv_f32_kernel(c
 
     for (int hh = 0; hh < g; ++hh) {
         const size_t qb = (size_t)(w.b * p.Hq + w.hk * g + hh) * Sq;
-        for (int qt = first_qt; qt < ntq_all; ++qt) {
-            const int q0 = qt * kTile;
-            stage_tile<D>(p.q + qb * D, q0, Sq, Qt, Qrm, tid);
-            stage_tile<D>(p.dout + qb * D, q0, Sq, Gt, Grm, tid);
+        TileRegs<D> qreg, greg;
+        float sreg = 0.f;
+        auto load_block = [&](int q0) __attribute__((always_inline)) {
+            tile_load(qreg, p.q + qb * D, q0, Sq, tid);
+            tile_load(greg, p.dout + qb * D, q0, Sq, tid);
             if (tid < 64) {
                 int r = q0 + (tid & 31);
                 r = r < Sq ? r : Sq - 1;
-                scal[tid] = tid < 32 ? p.lse[qb + r] * kLog2e : p.delta[qb + r];
+                sreg = tid < 32 ? p.lse[qb + r] * kLog2e : p.delta[qb + r];
             }
+        };
+        if (first_qt < ntq_all) load_block(first_qt * kTile);
+        for (int qt = first_qt; qt < ntq_all; ++qt) {
+            const int q0 = qt * kTile;
+            tile_store(qreg, Qt, Qcm, tid);
+            tile_store(greg, Gt, Gcm, tid);
+            if (tid < 64) scal[tid] = sreg;
             __syncthreads();
+            if (qt + 1 < ntq_all) load_block(q0 + kTile);   // the next query block travels while this one is computed
             if ((!CAUSAL || q0 + coff + kTile - 1 >= n0w) && (W <= 0 || q0 + coff < n0w + 31 + W)) {
                 f32x16_t s, dp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-                for (int st = 0; st < D / 2; ++st) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(Qt[(2 * st + hi) * 32 + l31], kf[st], s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Gt[(2 * st + hi) * 32 + l31], vf[st], dp, 0, 0, 0);
+                for (int st4 = 0; st4 < D / 8; ++st4) {
+                    const f32x4_t qa = tq_read(Qt, st4, hi, l31), ga = tq_read(Gt, st4, hi, l31);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j], kf[4 * st4 + j], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[j], vf[4 * st4 + j], dp, 0, 0, 0);
+                    }
                 }
                 const bool need_mask = (CAUSAL && (q0 + coff < n0w + 31)) || (q0 + kTile > Sq) || (n0w + 32 > Sk) || (W > 0 && q0 + coff + kTile - 1 - n0w >= W);
 #pragma unroll
@@ -249,13 +308,20 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dkdv_f32_kernel(c
                     dp[r] = pv * (dp[r] - scal[32 + ql]);   // dS (unscaled)
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = crow(r, hi);
+                for (int q = 0; q < 4; ++q) {
+                    f32x4_t ga[DB], qa[DB];
 #pragma unroll
                     for (int d = 0; d < DB; ++d) {
-                        dv[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(Grm[ql * D + 32 * d + l31], s[r], dv[d], 0, 0, 0);
-                        dk[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qrm[ql * D + 32 * d + l31], dp[r], dk[d], 0, 0, 0);
+                        ga[d] = cm_read(Gcm, 32 * d + l31, q, hi);
+                        qa[d] = cm_read(Qcm, 32 * d + l31, q, hi);
                     }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int d = 0; d < DB; ++d) {
+                            dv[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[d][j], s[4 * q + j], dv[d], 0, 0, 0);
+                            dk[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[d][j], dp[4 * q + j], dk[d], 0, 0, 0);
+                        }
                 }
             }
             __syncthreads();
