@@ -70,6 +70,7 @@ struct FwdW4Params {
     unsigned magic;
     float* part;       // [npiece][part_rows][D + kPartPad]
     int part_rows;     // B * Hq * Sq
+    int generic;       // AULE_HIP_W4_BODIES=generic: every step through the generic bodies (the embedded-request flow off: A/B, bit-identity test)
     unsigned long long* dbg;   // timeline build only: [4 waves][kW4TLMax] tagged s_memtime stamps of workgroup 0
 };
 
@@ -811,7 +812,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             // mask -- every part of a causal or ragged problem but a head's first block -- step 0, the plain steps, the step in
             // front of the last tile and the last tile all run bodies with static ring slots, literal scalar operands and the
             // requests in their MFMA gaps.  Everything else (and the exact-maximum stream) takes the generic bodies.
-            const bool fast = !REDO && na >= 3 && jm >= na - 1;
+            const bool fast = !REDO && na >= 3 && jm >= na - 1 && P()->generic == 0;
             prologue();
             using I0 = integral_constant<int, 0>;
             using I1 = integral_constant<int, 1>;
@@ -886,6 +887,15 @@ constexpr auto w4_kernel() {
 
 #pragma clang diagnostic pop
 
+// AULE_HIP_W4_BODIES=generic: the round-3 flow (generic bodies for step 0 and the masked steps, requests as separate statements)
+static int w4_generic_bodies() {
+    static const int v = [] {
+        const char* e = std::getenv("AULE_HIP_W4_BODIES");
+        return (e != nullptr && e[0] == 'g') ? 1 : 0;
+    }();
+    return v;
+}
+
 template <class T, int D, bool TL = false>
 int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nullptr) {
     FwdW4Params p;
@@ -899,6 +909,7 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
     p.nitems = p.nwork * a.B * a.Hq;
     p.dbg = dbg;
     p.npiece = 1; p.pcoff = 0; p.magic = 0; p.part = nullptr; p.part_rows = 0;
+    p.generic = w4_generic_bodies();
     p.rcos = a.rope_cos; p.rsin = a.rope_sin;
     p.rrows = a.rope_rows; p.rpitch = a.rope_pitch; p.rpos = a.rope_pos;
     // one workgroup per CU; more only when a workgroup's list would not fit its part table
@@ -949,6 +960,7 @@ int launch_w4_split(const FwdArgs& a, hipStream_t stream) {
     p.npiece = s.n; p.pcoff = a.causal ? a.coff : kEverything; p.magic = split_magic(s.n);
     p.part = static_cast<float*>(ws.ptr);
     p.part_rows = a.B * a.Hq * a.Sq;
+    p.generic = w4_generic_bodies();
     const size_t lds = w4_lds_bytes<D>();
     if (a.causal)
         hipLaunchKernelGGL((w4_kernel<T, D, true, false>()), dim3((unsigned)s.nitems), dim3(256), lds, stream, p);

@@ -71,3 +71,48 @@ def test_forward_variant_matches_oracle(env):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     for c in json.loads(line[7:]):
         assert c["nan"] == 0 and c["bad"] == 0 and c["lse_bad"] == 0, c
+
+
+_BODIES_CHILD = r'''
+import hashlib, json, math, os, sys
+sys.path.insert(0, os.path.join(%(root)r, "aule-attention_amd"))
+import torch
+from aule import _torch as at
+CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, causal  -- every geometry of the embedded-request flow: short / long parts, ragged, pairs,
+           # bottom-right aligned and not, Sq > Sk, GQA, D = 64, small grids (key-range split), no mask at all
+    ("bf16", 1, 2, 2, 256, 256, 128, True), ("bf16", 1, 2, 2, 300, 300, 128, True), ("bf16", 2, 4, 1, 1024, 1024, 128, True),
+    ("bf16", 1, 3, 3, 1280, 1280, 128, True), ("bf16", 1, 8, 8, 512, 1024, 128, "bottom-right"), ("bf16", 2, 8, 8, 1000, 3000, 128, "bottom-right"),
+    ("bf16", 1, 8, 8, 1024, 512, 128, True), ("bf16", 1, 2, 2, 200, 333, 128, False), ("bf16", 1, 2, 2, 777, 260, 128, False),
+    ("fp16", 2, 8, 8, 1111, 1111, 64, True), ("fp16", 1, 32, 1, 2048, 2048, 64, False), ("bf16", 4, 32, 8, 2048, 2048, 128, True),
+    ("bf16", 1, 8, 8, 4096, 4096, 128, True), ("bf16", 1, 8, 8, 2048, 2048, 128, False),
+]
+out = {}
+for dtype, B, Hq, Hkv, Sq, Sk, D, causal in CASES:
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q = torch.randn(B, Hq, Sq, D, device="cuda", dtype=dt, generator=g)
+    k = torch.randn(B, Hkv, Sk, D, device="cuda", dtype=dt, generator=g)
+    v = torch.randn(B, Hkv, Sk, D, device="cuda", dtype=dt, generator=g)
+    o, lse = at.fwd_raw(q, k, v, at.causal_code(causal), 1.0 / math.sqrt(D))
+    torch.cuda.synchronize()
+    out[str((dtype, B, Hq, Hkv, Sq, Sk, D, str(causal)))] = [hashlib.sha256(o.view(torch.int16).cpu().numpy().tobytes()).hexdigest(),
+                                                            hashlib.sha256(lse.cpu().numpy().tobytes()).hexdigest()]
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_embedded_request_bodies_are_bit_identical_to_the_generic_ones():
+    """Round 4's forward runs step 0, the step in front of a wave's last tile and the last tile through bodies of the plain step's form
+    (static ring slots, literal scalar registers, requests in the MFMA gaps).  The arithmetic is the generic bodies': O and LSE of the
+    two flows (AULE_HIP_W4_BODIES=generic pins the old one) must agree bit for bit on every geometry."""
+    res = []
+    for bodies in ("", "generic"):
+        e = {k: v for k, v in os.environ.items() if k != "AULE_HIP_W4_BODIES"}
+        if bodies:
+            e["AULE_HIP_W4_BODIES"] = bodies
+        r = subprocess.run([sys.executable, "-c", _BODIES_CHILD % {"root": ROOT}], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]))
+    assert res[0].keys() == res[1].keys() and len(res[0]) == 14
+    for case in res[0]:
+        assert res[0][case] == res[1][case], case
