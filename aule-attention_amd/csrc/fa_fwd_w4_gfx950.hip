@@ -158,6 +158,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     const int Sk = p.Sk, coff = p.coff;
     const float c = p.c;
     const bool rope = p.rcos != nullptr;
+    const bool embedded = p.generic == 0;   // AULE_HIP_W4_BODIES=generic turns the embedded-request bodies and the seam off
     int tl_n = 0;
     unsigned long long* const tl_lds = reinterpret_cast<unsigned long long*>(smem + TLDS + kW4MaxSlot * 20 + 16);   // TL only
     auto stamp = [&](int tag) __attribute__((always_inline)) {   // timeline build: (tag << 56) | shader clock
@@ -505,7 +506,8 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             if (__builtin_expect(j + 5 >= nt, 0)) {
                 set_k(j + 5);
                 set_v(j + 3);
-                sync_regs();
+                if (pre && (j + 5 == nt3 || j + 3 == nt3)) sync_regs();   // the cursor crossed into the next part: its head's descriptor
+                else A::set_offsets((unsigned)w4_rfl((int)ksoff), (unsigned)w4_rfl((int)vsoff));
             }
         };
         // a run of plain steps [j, jend), j = 1 (mod 6) at entry.  Every part starts at ring phase 0 (parts are padded to a
@@ -545,7 +547,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 case 4: prediag(I1{}, I0{}, j); fix_cursors(j); diag(I2{}, I1{}, j + 1); break;
                 default: prediag(I2{}, I1{}, j); fix_cursors(j); diag(I0{}, I0{}, j + 1); break;
             }
-            fix_cursors(j + 1);
+            // (no cursors behind the last tile: leave_fast computes what the idle steps ask for)
         };
         // back to the shadow cursors (generic and idle steps read them): what step j asks for
         auto leave_fast = [&](int j) __attribute__((always_inline)) {
@@ -579,9 +581,9 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             const __amdgpu_buffer_rsrc_t ksrd = make_srd(nullptr, 0);   // (unused operand of the statements without requests)
             stamp(0x20 + PAR + 2 * QK + 4 * SMB);
             begin_n();
-            if constexpr (PV == 2 && REDO)   // tile 0 of the exact-maximum stream: K_3 goes where K_0 was (this step's tile barrier freed
-                                             // the slot); older than this step's own requests, so the NEXT tile barrier covers it.  (The
-                                             // first stream's prologue has asked for it already.)
+            if constexpr (PV == 2)   // tile 0: K_3 goes where K_0 was (this step's tile barrier freed the slot); it is older than this
+                                     // step's own requests, so the NEXT tile barrier covers it.  (The embedded-request step 0 carries
+                                     // the same four pieces in its first statement.)
                 A::dma_tile(ring_lds(0, 0), head_srd(P()->k, kvoff, Sk - tb * kKVTile), 3u * KT, kvo);
             const int n = requests();
             const unsigned vap = va + (unsigned)rp * VT, kb = ka0 + (unsigned)slot(2) * KT;
@@ -632,8 +634,12 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         };
         // part prologue = "step -1" (K_0, K_1 of the part in the ring, Q requested): S_0, the references, P_0[A]; leaves K_1 in
         // the fragment registers
-        auto prologue = [&]() __attribute__((always_inline)) {
-            constexpr bool k3 = !REDO;   // (the same for every wave of the workgroup: it adds a barrier)
+        // SEAM (round 4): when the prologue follows a finished part of the same stream, its bare QK^T carries that part's pack (O^T /
+        // l, rounded, transposed into the wave's slab: W4Asm::seam) in its MFMA gaps, and the slab rows go out between the halves --
+        // the pack used to run in the epilogue with no MFMA around, at a lone wave's ~8 cycles per instruction.  seam_tag 1: invA / invB
+        // = 1 / l of the finished part's blocks, flush(QB) = its slab -> global stores.
+        auto prologue = [&](auto seam_tag, float invA, float invB, auto&& flush) __attribute__((always_inline)) {
+            constexpr bool SEAM = decltype(seam_tag)::value != 0;
             stamp(0x30);
             const __amdgpu_buffer_rsrc_t ksrd = make_srd(nullptr, 0);   // (unused operand)
             unsigned kap[KS];
@@ -643,21 +649,30 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             // for them) and the Q fragments; the epilogue's stores ride along
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             A::kread_all(kap);
-            if constexpr (k3) {
-                // K_3 goes where K_0 was as soon as every wave holds K_0 in registers (round 3 asked for it in step 0, behind that
-                // step's tile barrier: four request pieces outside the MFMA gaps); older than step 0's requests, so step 1's
-                // counted wait covers it.  Every wave of the workgroup does this, whichever bodies its steps run.
-                asm volatile("s_barrier" ::: "memory");
-                A::dma_tile(ring_lds(0, 0), head_srd(P()->k, kvoff, Sk - tb * kKVTile), 3u * KT, kvo);
-            }
             if constexpr (!REDO) {
                 if (rope) A::rope_rotate();          // (the second stream rotated in its exact-maximum pass)
                 A::prescale_q(c);                    // (pre form only)
             }
-            A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
-            A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
-            A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
-            A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+            if constexpr (SEAM) {
+                int lane_o = lane;
+                asm volatile("" : "+v"(lane_o));
+                const unsigned dstv = lds0 + OFF_SLAB + (unsigned)wave * SLAB + (unsigned)((lane_o & 31) * RBP + 8 * (lane_o >> 5));
+                stamp(0x34);
+                A::template seam<0>(invA, dstv);
+                A::template seam<1>(invA, dstv);
+                stamp(0x35);
+                flush(integral_constant<int, 0>{});
+                stamp(0x36);
+                A::template seam<2>(invB, dstv);
+                A::template seam<3>(invB, dstv);
+                stamp(0x37);
+                flush(integral_constant<int, 1>{});
+            } else {
+                A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+                A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+                A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+                A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+            }
             stamp(0x31);
             const int tA = thr_of(0, 0);
             if constexpr (!REDO) {
@@ -677,8 +692,8 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 A::template p2<3, 1, 0, 1, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0);
             }
             stamp(0x33);
-            nprev = k3 ? NP : 0;   // (the vmcnt(0) above left nothing else in flight; step 0's tile barrier follows: every wave holds
-                                   // K_0 and K_1 then, and step 0 requests K_4 (the exact-maximum stream: K_3 too) into their slots)
+            nprev = 0;   // (the vmcnt(0) above left nothing in flight; step 0's tile barrier follows: every wave holds K_0 and K_1 then,
+                         // and step 0 requests K_3 and K_4 into their slots)
         };
 
         // ---- epilogue of a part: O = O^T / l, rounded, transposed through the wave's LDS slab (block A, then block B), whole-row
@@ -757,6 +772,34 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             stamp(0x41);
         };
 
+        // the part of the epilogue that stays in front of the seam: row sums -> 1 / l, LSE, the range verdict (the pack itself rides with
+        // the next prologue's QK^T); then the next part's scalars
+        auto seam_scalars = [&](float& invA, float& invB) __attribute__((always_inline)) {
+            stamp(0x40);
+            if (rope) issue_rope(qb_of(n_slot));   // (the next prologue's vmcnt(0) covers them; consumed before the seam statements)
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int l31o = lane_o & 31, hio = lane_o >> 5;
+            float* const lsep = P()->lse;
+            const __amdgpu_buffer_rsrc_t lrs = make_srd(lsep + (size_t)(unsigned)qoff, lsep != nullptr ? (unsigned)sq_of() * 4u : 0u);
+            bool bad = false;
+            auto one = [&](auto qb_tag, float& inv) __attribute__((always_inline)) {
+                constexpr int QB = decltype(qb_tag)::value;
+                float lt, nm;
+                A::template get_sums<QB>(lt, nm);
+                lt += xhalf_fast(lt);
+                inv = __builtin_amdgcn_rcpf(lt);
+                const float lse = (fast_log2(lt) - nm) * kLn2;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lse), lrs, hio == 0 ? (r0 + 32 * QB + l31o) * 4 : 0x7ffffff0, 0, 0);
+#ifndef W4_X_NOVERDICT
+                bad = bad || !((lt > 0x1p-100f) && (lt < (T::kDType == 2 ? 0x1p110f : 0x1p15f)));
+#endif
+            };
+            one(integral_constant<int, 0>{}, invA);
+            one(integral_constant<int, 1>{}, invB);
+            if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) redo[cs] = redo[kW4MaxSlot] = 1;
+        };
+
         // REDO only: the exact row maxima of the part, one QK^T-only pass over its tiles through ring slot 0
         auto max_pass = [&]() __attribute__((always_inline)) {
             const __amdgpu_buffer_rsrc_t ksrd = make_srd(nullptr, 0);   // (unused operand)
@@ -791,6 +834,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
 
         // ---- the stream
         bool cold = true;
+        bool seam_done = false;   // the part's prologue already ran, fused with the previous part's pack
         enter_part(cs);
         for (;;) {
             if (REDO || cold) {   // nothing of this part is in flight: K_0, K_1, K_2, V_0, V_1
@@ -812,8 +856,9 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             // mask -- every part of a causal or ragged problem but a head's first block -- step 0, the plain steps, the step in
             // front of the last tile and the last tile all run bodies with static ring slots, literal scalar operands and the
             // requests in their MFMA gaps.  Everything else (and the exact-maximum stream) takes the generic bodies.
-            const bool fast = !REDO && na >= 3 && jm >= na - 1 && P()->generic == 0;
-            prologue();
+            const bool fast = !REDO && embedded && na >= 3 && jm >= na - 1;
+            if (!seam_done) prologue(integral_constant<int, 0>{}, 0.f, 0.f, [](auto) {});
+            seam_done = false;
             using I0 = integral_constant<int, 0>;
             using I1 = integral_constant<int, 1>;
             using I2 = integral_constant<int, 2>;
@@ -836,6 +881,29 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             }
             for (; j < nt3; ++j) idle(j);   // (tiles the wave does not see, and the padding of the part to a multiple of three positions)
             if (pre && na == nt) issue_q(w4_rfl(tab[n_slot].x), qb_of(n_slot));   // (waves with idle steps asked in their first one)
+            if constexpr (!REDO) {
+                if (pre && pid == 0 && embedded) {
+                    // the seam: this part's pack inside the next part's prologue (pre: there IS a next part of this stream; pid 0: the
+                    // part's O is final -- a partial part stores its accumulators as they are)
+                    float invA, invB;
+                    seam_scalars(invA, invB);
+                    const int oq = qoff, or0 = r0;
+                    cs = n_slot;
+                    enter_part(cs);
+                    const __amdgpu_buffer_rsrc_t ors = head_srd(P()->o, oq, sq_of());   // rows >= Sq are dropped by the bounds check
+                    prologue(integral_constant<int, 1>{}, invA, invB, [&](auto qb_tag) __attribute__((always_inline)) {
+                        constexpr int QB = decltype(qb_tag)::value;
+                        int lane_o = lane;
+                        asm volatile("" : "+v"(lane_o));
+                        // (the wave's own LDS accesses are ordered: no barrier between the slab's writes, reads and next writes)
+                        const unsigned la = lds0 + OFF_SLAB + (unsigned)wave * SLAB + (unsigned)((lane_o / CPR) * RBP + (lane_o % CPR) * 16);
+                        const unsigned vo = (unsigned)((or0 + 32 * QB + lane_o / CPR) * RB + (lane_o % CPR) * 16);
+                        A::slab_out(ors, la, vo, vo + 4096u);
+                    });
+                    seam_done = true;
+                    continue;
+                }
+            }
             epilogue();
             if (n_slot >= nslot) break;
             cs = n_slot;

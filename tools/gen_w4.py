@@ -472,6 +472,15 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
     # vmcnt(0) left nothing of this step's tiles in flight: the barrier alone (every wave has read K_0 and K_1)
     tile_wait = [x for x in ((f"s_waitcnt vmcnt({2 * c.NP})",) if dma != 3 else ()) + ("s_barrier",)
                  if not (("nobarrier" in XFLAGS and x == "s_barrier") or ("novmcnt" in XFLAGS and "vmcnt" in x))] or ["s_nop 0"]
+    pre_pieces = []
+    if dma == 3:
+        # step 0 also asks for K_3 (ring slot 0: where K_0 was -- every wave has read it by this statement's barrier): four pieces in
+        # the gaps right behind the barrier, OLDER than the step's own request, so step 1's counted wait (everything but the newest
+        # 2 NP) covers them.  Constant offset: tile 3 of the part, whatever the cursor says (round 3: four bare pieces after step 0's
+        # barrier; this round's first builds: in the prologue, behind an extra barrier).
+        for pi in range(c.NP):
+            pre_pieces.append((f"s_add_u32 m0, s{SG_LDSB}, {pi * 4096}\\n\\ts_mov_b32 s{SG_T}, {3 * c.KT + pi * 4096}",
+                               f"buffer_load_dwordx4 %[vo], s[{SG_KSRD}:{SG_KSRD + 3}], s{SG_T} offen lds"))
     if dma and Q == 0 and not mf:
         # the wave's last tile (no S_{j+1}): nothing to hide the barrier behind
         lines = ["s_waitcnt lgkmcnt(0)"] + tile_wait + place(mf, lds, valu, pieces, 2, 0)
@@ -482,6 +491,23 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
         # behind them -- the matrix pipe keeps running while the workgroup meets.  V reads and requests come after it.
         lines = ["s_waitcnt lgkmcnt(0)"] + place(mf, lds, valu, pieces, 2, len(mf) - 2 if len(mf) >= 8 else len(mf) - 1, 2 if len(mf) >= 8 else 1,
                                                (1 if len(mf) >= 8 else 0, tile_wait))
+        if pre_pieces:
+            # one K_3 piece behind each of the MFMAs that follow the barrier (its M0 write, one filler of that gap, the request)
+            out, k, seen_barrier, armed = [], 0, False, False
+            for ln in lines:
+                out.append(ln)
+                if ln == "s_barrier":
+                    seen_barrier = True
+                elif seen_barrier and ln.startswith("v_mfma") and k < len(pre_pieces):
+                    armed = True
+                elif armed and not ln.startswith(("ds_read", "s_", "buffer_")):
+                    # (ln is a VALU filler: M0 write in front of it, request behind it)
+                    out.insert(len(out) - 1, pre_pieces[k][0])
+                    out.append(pre_pieces[k][1])
+                    k += 1
+                    armed = False
+            assert k == len(pre_pieces), (k, len(pre_pieces))
+            lines = out
     else:
         lines = place(mf, lds, valu, pieces, LDSPG1, len(mf) - DMAGAP if len(mf) >= 8 else len(mf) - 1)
     if vr and Q == 3:
@@ -560,6 +586,53 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
     return emit_asm(lines, [], ins, clob)
 
 
+def deal_even(mfmas, fillers):
+    """MFMA g, then an even share of the fillers (program order kept)."""
+    n, out, k = len(mfmas), [], 0
+    for g in range(n):
+        out.append(mfmas[g])
+        take = len(fillers) * (g + 1) // n - len(fillers) * g // n
+        out += fillers[k:k + take]
+        k += take
+    return out
+
+
+def gen_seam(c, Q):
+    """Statement Q of the SEAM (round 4): the next part's bare QK^T of tile 0 (the MFMAs of gen_p1(c, Q, 1, 1, 0, 0, 0)) with the pack of
+    the FINISHED part's O^T as fillers -- block Q >> 1, d-blocks DB / 2 (Q & 1) .. : accumulator -> register, times 1 / l, rounded, written
+    transposed into the wave's slab row of the lane (the epilogue's w4_pack_block, instruction for instruction, so the bytes are the same).
+    The epilogue's pack ran with no MFMA around at a lone wave's ~8 cycles per instruction (profiles/r3_w4_seam_experiments.txt); here it
+    rides in the gaps of MFMAs that have no other fillers.  Temporaries: the weight registers pA (dead between two parts; the rope tables
+    that land there are consumed before this statement)."""
+    qb, KS, DB = Q >> 1, c.KS, c.DB
+    acc = [c.sA(0), c.sA(1)] if qb == 0 else [c.sB(0, 0), c.sB(1, 0)]
+    mf = []
+    for t in range(KS // 2):
+        ks = (Q & 1) * (KS // 2) + t
+        for h in range(2):
+            a = tup(acc[h], 16)
+            mf.append(f"{c.mfma} {a}, {c.K(ks, h)}, {c.Q(qb, ks)}, {'0' if ks == 0 else a}")
+    nd = DB // 2
+    fill = []
+    for j in range(nd):
+        d = (Q & 1) * nd + j
+        n0 = (qb * DB + d) * 16
+        tb = c.PA + 16 * j
+        for i in range(16):
+            fill.append(f"v_accvgpr_read_b32 v{tb + i}, a{n0 + i}")
+        for g4 in range(4):
+            for i in range(4):
+                fill.append(f"v_mul_f32 v{tb + 4 * g4 + i}, v{tb + 4 * g4 + i}, %[inv]")
+            fill.append(f"{c.cvt} v{tb + 4 * g4}, v{tb + 4 * g4}, v{tb + 4 * g4 + 1}")
+            fill.append(f"{c.cvt} v{tb + 4 * g4 + 1}, v{tb + 4 * g4 + 2}, v{tb + 4 * g4 + 3}")
+            fill.append(f"ds_write_b64 %[dst], v[{tb + 4 * g4}:{tb + 4 * g4 + 1}] offset:{(32 * d + 8 * g4) * 2}")
+    lines = deal_even(mf, fill)
+    if Q == 3:
+        lines += ["s_nop 7", "s_nop 7"]      # the last S block is read by the row maximum that follows
+    clob = ["memory"] + vregs(acc[0], 16) + vregs(acc[1], 16) + vregs(c.PA, 16 * nd)
+    return emit_asm(lines, [], ['[inv] "v"(inv)', '[dst] "v"(dst)'], clob)
+
+
 def p1_variants():
     v = []
     for Q in range(4):
@@ -608,6 +681,8 @@ def gen_struct(c):
     s += emit_asm(lines, [], ['[klo] "s"(klo)', '[khi] "s"(khi)', '[vlo] "s"(vlo)', '[vhi] "s"(vhi)', '[nrec] "s"(nrec)', '[kso] "s"(kso)', '[vso] "s"(vso)'],
                   ["scc"] + [f"s{SG_KSRD + i}" for i in range(10)], indent="        ")
     s += "#endif\n    }\n"
+    s += ("    static __device__ __forceinline__ void set_offsets(unsigned kso, unsigned vso) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+          f"        asm volatile(\"s_mov_b32 s{SG_KSO}, %0\\n\\ts_mov_b32 s{SG_VSO}, %1\" :: \"s\"(kso), \"s\"(vso) : \"s{SG_KSO}\", \"s{SG_VSO}\");\n#endif\n    }}\n")
     s += ("    static __device__ __forceinline__ void set_lds_base(unsigned a) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
           f"        asm volatile(\"s_mov_b32 s{SG_LDSB}, %0\" :: \"s\"(a) : \"s{SG_LDSB}\");\n#endif\n    }}\n")
     # ---- phase 1
@@ -642,6 +717,25 @@ def gen_struct(c):
         s += "        }\n"
         first = False
     s += "        else static_assert(Q < 0, \"fa_fwd_w4_asm.inc: phase-2 variant not generated\");\n"
+    s += "#endif\n    }\n"
+    # ---- the seam: bare QK^T of the next part's tile 0 with the finished part's pack in its gaps
+    s += ("    template <int Q>\n    static __device__ __forceinline__ void seam(float inv, unsigned dst) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+          "        (void)inv; (void)dst;\n")
+    for Q in range(4):
+        s += f"        {'if' if Q == 0 else 'else if'} constexpr (Q == {Q}) {{\n" + gen_seam(c, Q) + "        }\n"
+    s += "#endif\n    }\n"
+    # ---- the seam: one 32-row block of O from the wave's slab to global memory, whole rows: all reads first (the pack's temporaries are
+    #      free again), ONE wait, then the stores (hipcc's form -- two reads, a wait, two stores, four times over -- was ~900 cycles)
+    CPR, RBP = c.RB // 16, c.RB + 16
+    nb = CPR // 2
+    lines = [f"ds_read_b128 v[{c.PA + 4 * i}:{c.PA + 4 * i + 3}], %[la] offset:{i * (64 // CPR) * RBP}" for i in range(nb)]
+    lines.append("s_waitcnt lgkmcnt(0)")
+    lines += [f"buffer_store_dwordx4 v[{c.PA + 4 * i}:{c.PA + 4 * i + 3}], %[vo{i // 4}], %[srd], 0 offen offset:{(i % 4) * 1024}" for i in range(nb)]
+    s += ("    // la: LDS address of the lane's chunk of the slab (row lane / CPR, chunk lane % CPR); vo0: byte offset of that chunk of row\n"
+          "    // lane / CPR of the block in the head's O, vo1 = vo0 + 4096 (D = 128: reads 4 .. 7)\n"
+          "    static __device__ __forceinline__ void slab_out(__amdgpu_buffer_rsrc_t srd, unsigned la, unsigned vo0, unsigned vo1) {\n#if defined(__HIP_DEVICE_COMPILE__)\n        (void)vo1;\n")
+    s += emit_asm(lines, [], ['[srd] "s"(srd)', '[la] "v"(la)', '[vo0] "v"(vo0)'] + (['[vo1] "v"(vo1)'] if nb > 4 else []),
+                  ["memory"] + vregs(c.PA, 4 * nb), indent="        ")
     s += "#endif\n    }\n"
     # ---- all K fragments of one tile (ring slot in the address registers): part prologue
     lines = []

@@ -70,11 +70,14 @@ for w in waves:
             flush()
             seq = [tm]
             j = i + 1
-            while j < len(r) and r[j][0] in (0x31, 0x32, 0x33):
+            while j < len(r) and r[j][0] in (0x31, 0x32, 0x33, 0x34, 0x35, 0x36, 0x37):
                 seq.append(r[j][1]); j += 1
             end = r[j][1] if j < len(r) else seq[-1]
             d_ = [seq[k + 1] - seq[k] for k in range(len(seq) - 1)] + [end - seq[-1]]
-            print(f"   part {part} prologue at +{tm - t0}: wait + barrier + K_0 read + S_0 {d_[0] if len(d_) > 0 else -1}, refs + P_0[A] + K_1 read {d_[1] if len(d_) > 1 else -1}, to step 0 {d_[2] if len(d_) > 2 else -1}")
+            if len(seq) >= 7:   # the seam form (round 4): 0x30 wait + barrier + K_0 reads + K_3 request | 0x34 QK^T half A + pack A | 0x35 slab A out | 0x36 half B + pack B | 0x37 slab B out | 0x31 refs .. | 0x33
+                print(f"   part {part} prologue (seam) at +{tm - t0}: wait + barrier + K_0 read {d_[0]}, QK^T A + pack A {d_[1]}, slab A out {d_[2]}, QK^T B + pack B {d_[3]}, slab B out {d_[4]}, refs + P_0[A] + K_1 read {d_[5]}, to step 0 {d_[6] if len(d_) > 6 else -1}")
+            else:
+                print(f"   part {part} prologue at +{tm - t0}: wait + barrier + K_0 read + S_0 {d_[0] if len(d_) > 0 else -1}, refs + P_0[A] + K_1 read {d_[1] if len(d_) > 1 else -1}, to step 0 {d_[2] if len(d_) > 2 else -1}")
             part += 1
             i = j
             continue
