@@ -158,7 +158,17 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     const int Sk = p.Sk, coff = p.coff;
     const float c = p.c;
     const bool rope = p.rcos != nullptr;
-    const bool embedded = p.generic == 0;   // AULE_HIP_W4_BODIES=generic turns the embedded-request bodies and the seam off
+    const bool embedded = p.generic == 0;
+    // K / V base pointers stay in scalar registers for the whole kernel (round 4): a head's base is then a 64-bit add where the
+    // cursors cross into the next part, not a load from the kernel-argument segment and its wait in the middle of a part's last steps
+    const void* const kbase = p.k;
+    const void* const vbase = p.v;
+    // ... and so do the Q / O / LSE pointers and Sq: every part boundary builds three descriptors from them (hipcc parks them in
+    // lanes of its spill register -- a v_readlane each -- which is still an order of magnitude cheaper than the kernel-argument loads)
+    const void* const qbase = p.q;
+    void* const obase = p.o;
+    float* const lsebase = p.lse;
+    const int Sq_k = p.Sq;   // AULE_HIP_W4_BODIES=generic turns the embedded-request bodies and the seam off
     int tl_n = 0;
     unsigned long long* const tl_lds = reinterpret_cast<unsigned long long*>(smem + TLDS + kW4MaxSlot * 20 + 16);   // TL only
     auto stamp = [&](int tag) __attribute__((always_inline)) {   // timeline build: (tag << 56) | shader clock
@@ -242,7 +252,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         const unsigned lo = (unsigned)w4_rfl((int)(unsigned)a), hi = (unsigned)w4_rfl((int)(unsigned)(a >> 32));
         return make_srd(reinterpret_cast<const void*>((uintptr_t)(((unsigned long long)hi << 32) | lo)), (unsigned)w4_rfl(rows * RB));
     };
-    auto sq_of = [&]() __attribute__((always_inline)) { return P()->Sq; };
+    auto sq_of = [&]() __attribute__((always_inline)) { return Sq_k; };
 
     // ---- lane constants: LDS addresses of the operand reads, per-lane source offsets of the DMA pieces
     constexpr int SWSH = CPR == 16 ? 0 : 1;
@@ -330,7 +340,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             ksoff = oob;
             if (t < nt) ksoff = (unsigned)t * KT;
             else if (pre && t >= nt3 && t - nt3 <= 3) {
-                if (t == nt3) head_lohi(P()->k, kv_row_of(n_slot), klo, khi);
+                if (t == nt3) head_lohi(kbase, kv_row_of(n_slot), klo, khi);
                 // (position 3 of the next part: its K_3 is not prefetched -- the slot holds K_0 until the next prologue has read
                 // it -- but the embedded-request steps ask unconditionally, and an out-of-range request would put zeros there:
                 // K_0 once more, the same bytes into the same slot)
@@ -341,7 +351,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             vsoff = oob;
             if (t < nt) vsoff = (unsigned)t * VT;
             else if (pre && t >= nt3 && t - nt3 < 2) {
-                if (t == nt3) head_lohi(P()->v, kv_row_of(n_slot), vlo, vhi);
+                if (t == nt3) head_lohi(vbase, kv_row_of(n_slot), vlo, vhi);
                 vsoff = (unsigned)(t - nt3) * VT;
             }
         };
@@ -367,8 +377,8 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             asm volatile("" : "+s"(nt), "+s"(nt3), "+s"(na), "+s"(jm));
             n_slot = next_valid(sl);
             pre = !REDO && n_slot < nslot;
-            head_lohi(P()->k, kvoff, klo, khi);
-            head_lohi(P()->v, kvoff, vlo, vhi);
+            head_lohi(kbase, kvoff, klo, khi);
+            head_lohi(vbase, kvoff, vlo, vhi);
             set_k(4);
             set_v(2);
             A::zero_sums();
@@ -393,7 +403,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             set_v(j + 3);
         };
         auto issue_q = [&](int q_off, int q_b) __attribute__((always_inline)) {   // rows >= Sq read as 0
-            const __amdgpu_buffer_rsrc_t qrs = head_srd(P()->q, q_off, sq_of());
+            const __amdgpu_buffer_rsrc_t qrs = head_srd(qbase, q_off, sq_of());
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const unsigned vo = (unsigned)((q_b * kQBlock + wave * 64 + (lane_o & 31)) * RB + (lane_o >> 5) * 16);
@@ -584,7 +594,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             if constexpr (PV == 2)   // tile 0: K_3 goes where K_0 was (this step's tile barrier freed the slot); it is older than this
                                      // step's own requests, so the NEXT tile barrier covers it.  (The embedded-request step 0 carries
                                      // the same four pieces in its first statement.)
-                A::dma_tile(ring_lds(0, 0), head_srd(P()->k, kvoff, Sk - tb * kKVTile), 3u * KT, kvo);
+                A::dma_tile(ring_lds(0, 0), head_srd(kbase, kvoff, Sk - tb * kKVTile), 3u * KT, kvo);
             const int n = requests();
             const unsigned vap = va + (unsigned)rp * VT, kb = ka0 + (unsigned)slot(2) * KT;
             const int tB = SMB == 2 ? thr_of(1, j) : 0;
@@ -620,7 +630,9 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             // latency -- the next prologue's vmcnt(0) + barrier make them visible before anything reads them.)
             if (j >= nt) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else begin_n();
+            stamp(0x09);
             int n = requests();
+            stamp(0x0a);
             // the wave's Q registers are free (its last QK^T is behind it): the next part's Q rows now, not at the seam, where the
             // four waves' 64 row-strided loads (one 16-byte chunk per lane and row: ~64 cache lines per instruction) queue up
             // behind each other for ~3000 cycles -- the waves that see the whole block are then alone on that path.  (Behind the
@@ -629,7 +641,9 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 issue_q(w4_rfl(tab[n_slot].x), qb_of(n_slot));
                 n += NQ;
             }
+            stamp(0x0b);
             advance(j);
+            stamp(0x0c);
             nprev = n;
         };
         // part prologue = "step -1" (K_0, K_1 of the part in the ring, Q requested): S_0, the references, P_0[A]; leaves K_1 in
@@ -706,9 +720,9 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             asm volatile("" : "+v"(lane_o));
             const int l31o = lane_o & 31, hio = lane_o >> 5;
             char* const slab = smem + OFF_SLAB + wave * SLAB;
-            float* const lsep = P()->lse;
+            float* const lsep = lsebase;
             const __amdgpu_buffer_rsrc_t lrs = make_srd(lsep + (size_t)(unsigned)qoff, lsep != nullptr ? (unsigned)sq_of() * 4u : 0u);
-            const __amdgpu_buffer_rsrc_t ors = head_srd(P()->o, qoff, sq_of());   // rows >= Sq are dropped by the bounds check
+            const __amdgpu_buffer_rsrc_t ors = head_srd(obase, qoff, sq_of());   // rows >= Sq are dropped by the bounds check
             bool bad = false;
             // a part that covers only a range of its block's keys: un-normalised O^T rows (fp32, straight from the accumulator
             // file), the reference in log2 units and the row sum -> plane pid - 1 of the workspace; fa_fwd_combine merges the planes
@@ -780,7 +794,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const int l31o = lane_o & 31, hio = lane_o >> 5;
-            float* const lsep = P()->lse;
+            float* const lsep = lsebase;
             const __amdgpu_buffer_rsrc_t lrs = make_srd(lsep + (size_t)(unsigned)qoff, lsep != nullptr ? (unsigned)sq_of() * 4u : 0u);
             bool bad = false;
             auto one = [&](auto qb_tag, float& inv) __attribute__((always_inline)) {
@@ -808,7 +822,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             if (rope) issue_rope(qb);
             for (int j = 0; j < nt; ++j) {
                 __syncthreads();
-                A::dma_tile(lds0 + wave1k, head_srd(P()->k, kvoff, Sk - tb * kKVTile), (unsigned)j * KT, kvo);
+                A::dma_tile(lds0 + wave1k, head_srd(kbase, kvoff, Sk - tb * kKVTile), (unsigned)j * KT, kvo);
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 if (j < na) {
                     unsigned kap[KS];
@@ -843,7 +857,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                     issue_q(qoff, qb);
                     if (rope) issue_rope(qb);
                 }
-                const __amdgpu_buffer_rsrc_t k0 = head_srd(P()->k, kvoff, Sk - tb * kKVTile), v0 = head_srd(P()->v, kvoff, Sk - tb * kKVTile);
+                const __amdgpu_buffer_rsrc_t k0 = head_srd(kbase, kvoff, Sk - tb * kKVTile), v0 = head_srd(vbase, kvoff, Sk - tb * kKVTile);
                 A::dma_tile(ring_lds(0, 0), k0, 0u, kvo);
                 A::dma_tile(ring_lds(0, 1), k0, (unsigned)KT, kvo);
                 A::dma_tile(ring_lds(0, 2), k0, 2u * KT, kvo);
@@ -890,7 +904,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                     const int oq = qoff, or0 = r0;
                     cs = n_slot;
                     enter_part(cs);
-                    const __amdgpu_buffer_rsrc_t ors = head_srd(P()->o, oq, sq_of());   // rows >= Sq are dropped by the bounds check
+                    const __amdgpu_buffer_rsrc_t ors = head_srd(obase, oq, sq_of());   // rows >= Sq are dropped by the bounds check
                     prologue(integral_constant<int, 1>{}, invA, invB, [&](auto qb_tag) __attribute__((always_inline)) {
                         constexpr int QB = decltype(qb_tag)::value;
                         int lane_o = lane;

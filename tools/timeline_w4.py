@@ -55,6 +55,8 @@ tend = max(r[-1][1] for r in rows if r)
 print(f"workgroup 0: {tend - t0} cycles from first to last stamp")
 for w in waves:
     r = rows[w]
+    if os.environ.get("RAW"):   # tag:cycles-to-next-stamp of the first stamps of the wave
+        print(f"--- wave {w} raw: " + " ".join(f"{a:#x}:{r[i + 1][1] - b}" for i, (a, b) in enumerate(r[:int(os.environ['RAW'])]) if i + 1 < len(r)))
     print(f"--- wave {w}: {len(r)} stamps, first at +{r[0][1] - t0}")
     i = 0
     part = 0
