@@ -311,6 +311,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         // ring phase: stream position mod 3.  At step j (phase rp) V_j sits in slot rp, K_{j+2} in slot rp + 2, the step requests
         // K_{j+4} into slot rp + 1 and V_{j+2} into slot rp + 2 (all mod 3); positions run on through the parts.
         int rp = 0;
+        bool q_asked = false;   // the next part's Q rows were requested inside this part's last tile
         int nprev = 0;   // pieces the previous step requested (the only vector-memory operations the next tile barrier leaves in flight)
         auto slot = [&](int d) __attribute__((always_inline)) { const int x = rp + d; return x >= 3 ? x - 3 : x; };
         // request cursors: what step j asks for (K tile j + 4, V tile j + 2); soff == oob: nothing
@@ -377,6 +378,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             asm volatile("" : "+s"(nt), "+s"(nt3), "+s"(na), "+s"(jm));
             n_slot = next_valid(sl);
             pre = !REDO && n_slot < nslot;
+            q_asked = false;
             head_lohi(kbase, kvoff, klo, khi);
             head_lohi(vbase, kvoff, vlo, vhi);
             set_k(4);
@@ -484,10 +486,23 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             A::template p1<3, PAR, 0, 2, 1, 2, SL>(c, va, tB, 0, nosrd, 0, kvo);
             stamp(0x18);
             constexpr int KSL = (SL + 2) % 3;
-            A::template p2<0, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
-            A::template p2<1, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
-            A::template p2<2, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
-            A::template p2<3, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
+            if (pre) {
+                // the next part's Q rows ride in the gaps of this tile's PV MFMAs (the Q fragments are dead since the previous step's
+                // QK^T); rows >= Sq read as 0
+                const __amdgpu_buffer_rsrc_t qrs = head_srd(qbase, w4_rfl(tab[n_slot].x), sq_of());
+                int lane_o = lane;
+                asm volatile("" : "+v"(lane_o));
+                const unsigned vo = (unsigned)((qb_of(n_slot) * kQBlock + wave * 64 + (lane_o & 31)) * RB + (lane_o >> 5) * 16);
+                A::template p2<0, PAR, 1, 0, 2, 2, KSL>(c, vo, vo + 32 * RB, 0, 0, qrs, 0, vvo);
+                A::template p2<1, PAR, 1, 0, 2, 2, KSL>(c, vo, vo + 32 * RB, 0, 0, qrs, 0, vvo);
+                A::template p2<2, PAR, 1, 0, 2, 2, KSL>(c, vo, vo + 32 * RB, 0, 0, qrs, 0, vvo);
+                A::template p2<3, PAR, 1, 0, 2, 2, KSL>(c, vo, vo + 32 * RB, 0, 0, qrs, 0, vvo);
+            } else {
+                A::template p2<0, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
+                A::template p2<1, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
+                A::template p2<2, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
+                A::template p2<3, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
+            }
             stamp(0x19);
         };
         // step 0 of a part (stream position 0, parity 0; O starts at 0; S_0 is the prologue's bare QK^T): its tile barrier has
@@ -564,7 +579,8 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             set_k(j + 4);
             set_v(j + 2);
             rp = j % 3;
-            nprev = 2 * NP;
+            nprev = pre ? 2 * NP + NQ : 2 * NP;   // (the last tile's requests, and the next part's Q rows it carried)
+            q_asked = pre;
         };
         // the requests of a step as separate statements (everywhere but the plain step); returns the pieces now in flight.  An
         // out-of-range request is skipped: at a part's last steps its ring slot may already hold a tile of the next part.
@@ -637,7 +653,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             // four waves' 64 row-strided loads (one 16-byte chunk per lane and row: ~64 cache lines per instruction) queue up
             // behind each other for ~3000 cycles -- the waves that see the whole block are then alone on that path.  (Behind the
             // step's requests, and counted: the next tile barrier does not wait for them.)
-            if (pre && j == na) {
+            if (pre && j == na && !q_asked) {
                 issue_q(w4_rfl(tab[n_slot].x), qb_of(n_slot));
                 n += NQ;
             }
@@ -894,7 +910,8 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 }
             }
             for (; j < nt3; ++j) idle(j);   // (tiles the wave does not see, and the padding of the part to a multiple of three positions)
-            if (pre && na == nt) issue_q(w4_rfl(tab[n_slot].x), qb_of(n_slot));   // (waves with idle steps asked in their first one)
+            if (pre && na == nt && !q_asked) issue_q(w4_rfl(tab[n_slot].x), qb_of(n_slot));   // (waves with idle steps asked in their first one;
+                                                                                                   // the embedded-request flow: in the last tile)
             if constexpr (!REDO) {
                 if (pre && pid == 0 && embedded) {
                     // the seam: this part's pack inside the next part's prologue (pre: there IS a next part of this stream; pid 0: the

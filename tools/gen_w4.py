@@ -542,7 +542,18 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
         for d in range(DB):
             clob += aregs((qb * DB + d) * 16, 16)
     lds = []
-    if kr:
+    qloads = []
+    if kr == 2:
+        # the wave's LAST tile (no K_{j+2} to read, the Q fragments dead since the previous step's QK^T): the next part's Q rows instead --
+        # 2 KS row-strided buffer loads straight into the accumulator file, KS / 2 per statement, in the gaps of the PV MFMAs.  (They used to
+        # be issued behind the wave's last step, with nothing to hide behind: 1600-2300 cycles of the workgroup's critical path per part,
+        # profiles/r4_w4_embedded_requests.txt.)  Block Q >> 1, k-slices KS / 2 (Q & 1) ..; %[ka0] / %[ka1]: the lane's row offsets of the two
+        # blocks, %[srd]: the next part's Q rows.
+        for t in range(KS // 2):
+            ks = (Q & 1) * (KS // 2) + t
+            qloads.append(f"buffer_load_dwordx4 {c.Q(qb, ks)}, %[ka{qb}], %[srd], 0 offen offset:{32 * ks}")
+        clob += aregs(c.QB0 + (qb * KS + (Q & 1) * (KS // 2)) * 4, 4 * (KS // 2))
+    if kr == 1:
         n = KS // 4
         for t in range(n):
             ks = Q * n + t
@@ -569,6 +580,18 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
     if "nodma" in XFLAGS:
         pieces = []
     lines = place(mf, lds, valu, pieces, LDSPG2, len(mf) - DMAGAP if len(mf) >= 8 else len(mf) - 1)
+    if qloads:
+        # one load behind each of the statement's first MFMAs (the DMA piece sits in a late gap)
+        out, k = [], 0
+        if Q == 0:
+            out.append("s_nop 4")          # (a descriptor fresh from the scalar unit -> VMEM)
+        for ln in lines:
+            out.append(ln)
+            if ln.startswith("v_mfma") and k < len(qloads):
+                out.append(qloads[k])
+                k += 1
+        assert k == len(qloads)
+        lines = out
     if dma >= 2 and Q == 3:
         # the request cursors move on with the step (the kernel overrides them where a part ends: fa_fwd_w4_gfx950.hip, fix_cursors)
         lines += [f"s_add_u32 s{SG_KSO}, s{SG_KSO}, {c.KT}", f"s_add_u32 s{SG_VSO}, s{SG_VSO}, {c.VT}"]
@@ -579,8 +602,10 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
             ins.append(f'[c] "{CREG}"(c)')
         if sm == 2:
             ins.append('[thr] "v"(thr)')
-    if kr:
+    if kr == 1:
         ins += [f'[ka{t}] "v"(ka{t})' for t in range(KS // 4)]
+    if kr == 2:
+        ins += [f'[ka{qb}] "v"(ka{qb})', '[srd] "s"(dsrd)']
     if pieces:
         ins += ['[vo] "v"(dvo)'] if dma >= 2 else ['[lds] "s"(dlds)', '[srd] "s"(dsrd)', '[so] "s"(dso)', '[vo] "v"(dvo)']
     return emit_asm(lines, [], ins, clob)
@@ -657,6 +682,7 @@ def p2_variants():
                 v.append((Q, par, 1, 1, 1, 2, sl))  # plain step (V request embedded, literal scalars; K_{j+2} in ring slot sl)
                 v.append((Q, par, 1, 2, 1, 2, sl))  # the step in front of the wave's diagonal tile: S_{j+1}[A] masked
                 v.append((Q, par, 1, 0, 0, 2, sl))  # the diagonal tile itself: O^T += V^T P^T and the V request, nothing else
+                v.append((Q, par, 1, 0, 2, 2, sl))  # ... and the next part's Q rows (KR 2)
             for sm in (0, 1, 2):
                 v.append((Q, par, 1, sm, 1, 0, 0))  # generic steps
         v += [(Q, 0, 2, 0, 1, 0, 0), (Q, 0, 2, 1, 1, 0, 0), (Q, 0, 2, 2, 1, 0, 0)]   # first step of a part (O starts at 0)
