@@ -572,15 +572,30 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 case 4: prediag(I1{}, I0{}, j); fix_cursors(j); diag(I2{}, I1{}, j + 1); break;
                 default: prediag(I2{}, I1{}, j); fix_cursors(j); diag(I0{}, I0{}, j + 1); break;
             }
-            // (no cursors behind the last tile: leave_fast computes what the idle steps ask for)
+            fix_cursors(j + 1);   // (the positions behind the last tile request in the same form: fast_pads)
         };
-        // back to the shadow cursors (generic and idle steps read them): what step j asks for
-        auto leave_fast = [&](int j) __attribute__((always_inline)) {
-            set_k(j + 4);
-            set_v(j + 2);
-            rp = j % 3;
-            nprev = pre ? 2 * NP + NQ : 2 * NP;   // (the last tile's requests, and the next part's Q rows it carried)
-            q_asked = pre;
+        // a position without arithmetic for this wave, embedded-request form: positions [j, nt3) behind the wave's last tile.  The
+        // first one waits for everything but the last tile's requests (and the next part's Q rows it carried), a later one for
+        // everything but its predecessor's; a padding position (j >= nt) has no readers and does not wait for tiles at all (what is
+        // in flight there are the next part's first tiles: the next prologue's vmcnt(0) + barrier make them visible).
+        auto fast_pads = [&](int j) __attribute__((always_inline)) {
+            constexpr int WP = 2 * NP, WQ = 2 * NP + NQ;
+            bool first_pad = true;
+            for (; j < nt3; ++j) {
+                stamp(0x08);
+                const int sl = j % 3;
+                const int wv = j >= nt ? -1 : (first_pad && pre ? WQ : WP);
+#define W4_PAD(SLT)                                                                  \
+    if (wv < 0) A::template pad<SLT, -1>(kvo, vvo);                                  \
+    else if (wv == WP) A::template pad<SLT, WP>(kvo, vvo);                            \
+    else A::template pad<SLT, WQ>(kvo, vvo);
+                if (sl == 0) { W4_PAD(0) } else if (sl == 1) { W4_PAD(1) } else { W4_PAD(2) }
+#undef W4_PAD
+                fix_cursors(j);
+                first_pad = false;
+            }
+            rp = 0;            // (parts are padded to a multiple of three positions)
+            q_asked = pre;     // (the last tile carried the next part's Q rows)
         };
         // the requests of a step as separate statements (everywhere but the plain step); returns the pieces now in flight.  An
         // out-of-range request is skipped: at a part's last steps its ring slot may already hold a tile of the next part.
@@ -899,8 +914,8 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 fix_cursors(0);
                 plain_run(j, na - 2);
                 fast_tail(j);
-                j = na;
-                leave_fast(j);
+                fast_pads(na);
+                j = nt3;
             } else {
                 step_rt(I0{}, I2{}, 0);   // tile 0 (O starts at 0)
                 while (j < na) {

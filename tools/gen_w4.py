@@ -744,6 +744,27 @@ def gen_struct(c):
         first = False
     s += "        else static_assert(Q < 0, \"fa_fwd_w4_asm.inc: phase-2 variant not generated\");\n"
     s += "#endif\n    }\n"
+    # ---- a stream position without arithmetic for this wave (a tile it does not see, a padding position of the part) in the
+    #      embedded-request form: the tile barrier and the position's two requests with literal scalar operands, one statement.
+    #      SL = position mod 3; W: the counted wait in front of the barrier (-1: none -- a padding position has no readers)
+    s += "    template <int SL, int W>\n    static __device__ __forceinline__ void pad(unsigned kvo, unsigned vvo) {\n#if defined(__HIP_DEVICE_COMPILE__)\n        (void)kvo; (void)vvo;\n"
+    first = True
+    for sl in range(3):
+        for wv in (-1, 2 * c.NP, 2 * c.NP + 2 * c.KS):
+            lines = ["s_waitcnt lgkmcnt(0)" if wv < 0 else f"s_waitcnt vmcnt({wv}) lgkmcnt(0)", "s_barrier"]
+            for which, slot, vo in (("k", (sl + 1) % 3, "%[kvo]"), ("v", (sl + 2) % 3, "%[vvo]")):
+                for pi in range(c.NP):
+                    head, load = lit_piece(c, which, slot, pi)
+                    lines.append(head)
+                    if pi == 0:
+                        lines.append("s_nop 0")            # (an instruction between the M0 write and the request)
+                    lines.append(load.replace("%[vo]", vo))
+            lines += [f"s_add_u32 s{SG_KSO}, s{SG_KSO}, {c.KT}", f"s_add_u32 s{SG_VSO}, s{SG_VSO}, {c.VT}"]
+            s += f"        {'if' if first else 'else if'} constexpr (SL == {sl} && W == {wv}) {{\n"
+            s += emit_asm(lines, [], ['[kvo] "v"(kvo)', '[vvo] "v"(vvo)'], ["memory", "m0", "scc", f"s{SG_T}", f"s{SG_KSO}", f"s{SG_VSO}"])
+            s += "        }\n"
+            first = False
+    s += "        else static_assert(SL < 0, \"fa_fwd_w4_asm.inc: pad variant not generated\");\n#endif\n    }\n"
     # ---- the seam: bare QK^T of the next part's tile 0 with the finished part's pack in its gaps
     s += ("    template <int Q>\n    static __device__ __forceinline__ void seam(float inv, unsigned dst) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
           "        (void)inv; (void)dst;\n")
