@@ -475,33 +475,28 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             A::template p2<3, PAR, 1, 2, 1, 2, KSL>(c, kaddr(ka0, 3 * (KS / 4)), kaddr(ka0, KS - 1), tA, 0, nosrd, 0, vvo);
             stamp(0x19);
         };
-        // the wave's last tile: masked softmax of S_j[B] (no S_{j+1}), O^T += V_j^T P_j^T; both requests ride along
+        // the wave's last tile (no S_{j+1}): masked softmax of S_j[B] and O^T += V_j^T P_j^T in the overlapped form -- block A's half of
+        // the PV rides with the softmax of block B (W4Asm::diag, tools/gen_w4.py:gen_diag); both requests, and the next part's Q rows
+        // (the Q fragments are dead since the previous step's QK^T; rows >= Sq read as 0), ride along
         auto diag = [&](auto sl_tag, auto par_tag, int j) __attribute__((always_inline)) {
             constexpr int SL = decltype(sl_tag)::value, PAR = decltype(par_tag)::value;
             stamp(0x64 + PAR);
             const int tB = thr_of(1, j);
-            A::template p1<0, PAR, 0, 2, 1, 2, SL>(c, va, tB, 0, nosrd, 0, kvo);
-            A::template p1<1, PAR, 0, 2, 1, 2, SL>(c, va, tB, 0, nosrd, 0, kvo);
-            A::template p1<2, PAR, 0, 2, 1, 2, SL>(c, va, tB, 0, nosrd, 0, kvo);
-            A::template p1<3, PAR, 0, 2, 1, 2, SL>(c, va, tB, 0, nosrd, 0, kvo);
+            A::template diag<0, PAR, SL, 0>(c, va, tB, kvo, 0, 0, nosrd);
+            A::template diag<1, PAR, SL, 0>(c, va, tB, kvo, 0, 0, nosrd);
+            A::template diag<2, PAR, SL, 0>(c, va, tB, kvo, 0, 0, nosrd);
+            A::template diag<3, PAR, SL, 0>(c, va, tB, kvo, 0, 0, nosrd);
             stamp(0x18);
-            constexpr int KSL = (SL + 2) % 3;
             if (pre) {
-                // the next part's Q rows ride in the gaps of this tile's PV MFMAs (the Q fragments are dead since the previous step's
-                // QK^T); rows >= Sq read as 0
                 const __amdgpu_buffer_rsrc_t qrs = head_srd(qbase, w4_rfl(tab[n_slot].x), sq_of());
                 int lane_o = lane;
                 asm volatile("" : "+v"(lane_o));
                 const unsigned vo = (unsigned)((qb_of(n_slot) * kQBlock + wave * 64 + (lane_o & 31)) * RB + (lane_o >> 5) * 16);
-                A::template p2<0, PAR, 1, 0, 2, 2, KSL>(c, vo, vo + 32 * RB, 0, 0, qrs, 0, vvo);
-                A::template p2<1, PAR, 1, 0, 2, 2, KSL>(c, vo, vo + 32 * RB, 0, 0, qrs, 0, vvo);
-                A::template p2<2, PAR, 1, 0, 2, 2, KSL>(c, vo, vo + 32 * RB, 0, 0, qrs, 0, vvo);
-                A::template p2<3, PAR, 1, 0, 2, 2, KSL>(c, vo, vo + 32 * RB, 0, 0, qrs, 0, vvo);
+                A::template diag<4, PAR, SL, 1>(c, va, tB, vvo, vo, vo + 32 * RB, qrs);
+                A::template diag<5, PAR, SL, 1>(c, va, tB, vvo, vo, vo + 32 * RB, qrs);
             } else {
-                A::template p2<0, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
-                A::template p2<1, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
-                A::template p2<2, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
-                A::template p2<3, PAR, 1, 0, 0, 2, KSL>(c, 0, 0, 0, 0, nosrd, 0, vvo);
+                A::template diag<4, PAR, SL, 0>(c, va, tB, vvo, 0, 0, nosrd);
+                A::template diag<5, PAR, SL, 0>(c, va, tB, vvo, 0, 0, nosrd);
             }
             stamp(0x19);
         };

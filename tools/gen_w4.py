@@ -658,6 +658,93 @@ def gen_seam(c, Q):
     return emit_asm(lines, [], ['[inv] "v"(inv)', '[dst] "v"(dst)'], clob)
 
 
+def gen_diag(c, I, par, sl, ql):
+    """Statement I (0 .. 5) of the wave's LAST tile in the overlapped form (round 4): the tile has no S_{j+1}, so its phase 1 -- the masked
+    softmax of S_j[B], 176 VALU and 32 transpose reads -- ran with no MFMA around (1400-1900 cycles at a lone wave's issue rate), then
+    phase 2 the 32 PV MFMAs nearly bare.  Block A's half of the PV needs nothing of this tile's arithmetic (P_j[A] is a step old), only
+    V_j's fragments: statements 1-3 carry O^T[A] += V_j^T P_j[A]^T of key slice I - 1 (read one statement earlier) next to the softmax of
+    slice I; statement 4 the last slice of block A and the first two of block B, statement 5 the rest.  Same accumulation order per
+    accumulator as the two-phase form (key slices 0 .. 3), so the bytes are the same.
+    sl: stream position mod 3 (V_j in slot sl, K request to slot sl + 1, V request to slot sl + 2).  ql: statements 4 / 5 also carry the
+    next part's Q rows (see gen_p2, kr = 2)."""
+    KS, DB = c.KS, c.DB
+    clob = ["memory"]
+    mf, lds, valu, pieces, qloads, pre, ins = [], [], [], [], [], [], []
+    def pv(qb, sk):
+        pf = tup(c.pA(par, sk), 4) if qb == 0 else tup(c.pB(sk), 4)
+        out = []
+        for d in range(DB):
+            o = c.O(qb, d)
+            out.append(f"{c.mfma} {o}, {c.V(sk, d)}, {pf}, {o}")
+        return out
+    if I < 4:
+        Q = I
+        if I == 0:
+            pre = ["s_waitcnt lgkmcnt(0)", f"s_waitcnt vmcnt({2 * c.NP})", "s_barrier"]
+        else:
+            pre = ["s_waitcnt lgkmcnt(0)"]          # V_j's slice I - 1 (requested a statement ago) is back
+            mf = pv(0, I - 1)
+            for d in range(DB):
+                clob += aregs(d * 16, 16)
+        sk = Q
+        for d in range(DB):
+            for i in range(2):
+                off = sl * c.VT + ((4 * sk) * (c.D // 16) + 2 * d) * 128 + i * 2 * (c.D // 16) * 128
+                lds.append(f"ds_read_b64_tr_b16 {c.Vhalf(sk, d, i)}, %[va] offset:{off}")
+        clob += vregs(c.VB0 + Q * DB * 4, DB * 4)
+        h = Q >> 1
+        valu = softmax_ops(c, c.sB(h, par), h, 8 * (Q & 1), c.pB(Q), 1, True, False)
+        clob += [f'v{t}' for t in c.T] + vregs(c.pB(Q), 4) + vregs(c.l(1, 0), 2) + ["vcc"]
+        if dma_piece(c, Q) is not None:
+            pieces.append(lit_piece(c, "k", (sl + 1) % 3, dma_piece(c, Q)))
+            clob += ["m0", "scc", f"s{SG_T}"]
+        ins = ['[c] "s"(c)', '[thr] "v"(thr)', '[va] "v"(va)'] + (['[vo] "v"(dvo)'] if pieces else [])
+        # few MFMAs, many fillers: the reads behind the first MFMA (their data is wanted a statement later), the VALU in even
+        # shares over the gaps, the request (M0 write / one VALU / load) in the last one
+        body = list(valu)
+        if pieces:
+            k = len(body) - 6          # near the end: the request is the slowest filler to issue
+            body = body[:k] + [pieces[0][0], body[k], pieces[0][1]] + body[k + 1:]
+        fill = lds + body
+        lines = pre + (deal_even(mf, fill) if mf else fill)
+        if I == 3:
+            lines.append("s_waitcnt lgkmcnt(0)")
+    else:
+        J = I - 4
+        if J == 0:
+            mf = pv(0, 3) + pv(1, 0) + pv(1, 1)
+        else:
+            mf = pv(1, 2) + pv(1, 3)
+        for d in range(2 * DB):
+            clob += aregs(d * 16, 16)
+        npc = c.NP // 2
+        for pi in range(J * npc, (J + 1) * npc):
+            pieces.append(lit_piece(c, "v", (sl + 2) % 3, pi))
+        clob += ["m0", "scc", f"s{SG_T}"]
+        if ql:
+            for t in range(KS):
+                ks = t
+                qb = J
+                qloads.append(f"buffer_load_dwordx4 {c.Q(qb, ks)}, %[ka{qb}], %[srd], 0 offen offset:{32 * ks}")
+            clob += aregs(c.QB0 + J * KS * 4, 4 * KS)
+            ins += [f'[ka{J}] "v"(ka{J})', '[srd] "s"(dsrd)']
+        ins += ['[vo] "v"(dvo)']
+        out, k = (["s_nop 4"] if (ql and J == 0) else []), 0
+        for g, m in enumerate(mf):
+            out.append(m)
+            if k < len(qloads):
+                out.append(qloads[k]); k += 1
+        assert k == len(qloads) or not ql, (k, len(qloads))
+        # the V pieces behind the last MFMAs (M0 write, one instruction, the request)
+        for head, load in pieces:
+            out += [head, "s_nop 0", load]
+        lines = out
+        if J == 1:
+            lines += [f"s_add_u32 s{SG_KSO}, s{SG_KSO}, {c.KT}", f"s_add_u32 s{SG_VSO}, s{SG_VSO}, {c.VT}"]
+            clob += [f"s{SG_KSO}", f"s{SG_VSO}"]
+    return emit_asm(lines, [], ins, clob)
+
+
 def p1_variants():
     v = []
     for Q in range(4):
@@ -744,6 +831,19 @@ def gen_struct(c):
         first = False
     s += "        else static_assert(Q < 0, \"fa_fwd_w4_asm.inc: phase-2 variant not generated\");\n"
     s += "#endif\n    }\n"
+    # ---- the wave's last tile, overlapped form: six statements (gen_diag)
+    s += ("    template <int I, int PAR, int SL, int QL>\n"
+          "    static __device__ __forceinline__ void diag(float c, unsigned va, int thr, unsigned dvo, unsigned ka0, unsigned ka1, __amdgpu_buffer_rsrc_t dsrd) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n        (void)c; (void)va; (void)thr; (void)dvo; (void)ka0; (void)ka1; (void)dsrd;\n")
+    first = True
+    for I in range(6):
+        for par in range(2):
+            for sl in range(3):
+                for ql in ((0, 1) if I >= 4 else (0,)):
+                    cond = f"I == {I} && PAR == {par} && SL == {sl}" + (f" && QL == {ql}" if I >= 4 else "")
+                    s += f"        {'if' if first else 'else if'} constexpr ({cond}) {{\n" + gen_diag(c, I, par, sl, ql) + "        }\n"
+                    first = False
+    s += "        else static_assert(I < 0, \"fa_fwd_w4_asm.inc: diag variant not generated\");\n#endif\n    }\n"
     # ---- a stream position without arithmetic for this wave (a tile it does not see, a padding position of the part) in the
     #      embedded-request form: the tile barrier and the position's two requests with literal scalar operands, one statement.
     #      SL = position mod 3; W: the counted wait in front of the barrier (-1: none -- a padding position has no readers)
