@@ -275,8 +275,11 @@ class PeerExchange:
         for st in self.streams:
             if st is not None:
                 st.synchronize()
-        flag = torch.zeros(1, device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        nccl = dist.get_backend(self.group) == "nccl"
+        flag = torch.zeros(1, device=self.device if nccl else "cpu")
         dist.all_reduce(flag, group=self.group)
+        if nccl:      # the all-reduce is only stream-ordered there: make the host (and so every stream it launches on) wait
+            torch.cuda.current_stream(self.device).synchronize()
 
     def close(self):
         for r, p in enumerate(getattr(self, "remote", [])):
@@ -296,20 +299,30 @@ class _RawDeviceBytes:
                                          "strides": None}
 
 
-_peer_cache = {}
+_peer_cache = {}          # insertion-ordered: the least recently used key first
+_PEER_CACHE_KEYS = 4      # distinct (group, bytes, device) triples kept; the oldest pair of buffers is closed beyond that
 
 
 def _peer_exchange(nbytes, device, group):
+    """Two alternating buffers per (group, bytes, device).  The entry holds the group object itself, so its id() cannot be
+    reused by another group while the entry lives; at most _PEER_CACHE_KEYS entries are kept (every rank runs the same
+    sequence of exchanges, so every rank evicts the same entry at the same call -- closing stays collective)."""
     key = (id(group) if group is not None else 0, int(nbytes), str(device))
-    ent = _peer_cache.get(key)
+    ent = _peer_cache.pop(key, None)
     if ent is None:
-        ent = _peer_cache[key] = {"bufs": [PeerExchange(nbytes, device, group), PeerExchange(nbytes, device, group)], "n": 0}
+        while len(_peer_cache) >= _PEER_CACHE_KEYS:
+            old = _peer_cache.pop(next(iter(_peer_cache)))
+            for b in old["bufs"]:
+                b.close()
+        ent = {"bufs": [PeerExchange(nbytes, device, group), PeerExchange(nbytes, device, group)], "n": 0, "group": group}
+    _peer_cache[key] = ent      # most recently used: last
     ent["n"] += 1
     return ent["bufs"][ent["n"] & 1]
 
 
 def release_peer_buffers():
-    """Close every cached peer-exchange buffer (collective in spirit: call it on every rank before the process group goes)."""
+    """Close every cached peer-exchange buffer (collective in spirit: call it on every rank before the process group goes).
+    Tensors returned by earlier exchanges alias those buffers and must not be used afterwards."""
     for ent in _peer_cache.values():
         for b in ent["bufs"]:
             b.close()
