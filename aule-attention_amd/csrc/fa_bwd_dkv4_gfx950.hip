@@ -1,4 +1,4 @@
-// fa_bwd_dkv4_gfx950.hip -- dK / dV of the FlashAttention-2 backward (16-bit I/O, D = 128), ONE WAVE PER SIMD.
+// fa_bwd_dkv4_gfx950.hip -- dK / dV of the FlashAttention-2 backward (16-bit I/O, D = 128 and, since round 4, D = 64), ONE WAVE PER SIMD.
 //
 // Replaces the dK/dV half of python/aule/triton_flash_amd.py:247-351 (_flash_attn_bwd_amd) where it applies; everything else
 // stays on fa_bwd_gfx950.hip's kernel (8 waves x 32 keys, two waves per SIMD, lock-step: 44 % MFMA-busy, its tile period set by
@@ -22,7 +22,11 @@
 //     causal grid is exactly 256 workgroups with the whole GQA group inside each -- no head split, no fp32 partials, no reduce
 //     kernel.
 //
-// Covers bf16 / fp16, D = 128, causal (coff >= 0) and non-causal, no window; deterministic (no atomics).
+// D = 64 (round 4): the same stream with half the MFMAs per block (16) against the same 16 scores per lane of arithmetic; a 1 KB
+// LDS-DMA piece holds two row groups there, so the image is a per-piece chunk permutation instead of per-row-group pads
+// (tools/gen_bw4.py, Cfg / chunk64), 128 accumulator registers, 72 arch VGPRs left to hipcc, a 68 KB ring.
+//
+// Covers bf16 / fp16, D = 128 / 64, causal (coff >= 0) and non-causal, no window; deterministic (no atomics).
 #include <cstdlib>
 #include <type_traits>
 
@@ -69,24 +73,23 @@ __device__ __forceinline__ float dkv4_acc_read() {
     return x;
 }
 
-// accumulator block BASE + 16 d .. of the wave's key row -> the row's d = 32 d + 8 g + 4 hi .. + 3 (8-byte stores)
-template <class T, int BASE, int I = 0>
+// accumulator block BASE + 16 d .. of the wave's key row -> the row's d = 32 d + 8 g + 4 hi .. + 3 (8-byte stores); NI = 4 (D / 32)
+template <class T, int BASE, int NI, int I = 0>
 __device__ __forceinline__ void dkv4_store_rows(char* row, int hi, float sc) {
-    if constexpr (I < 16) {
+    if constexpr (I < NI) {
         constexpr int d = I / 4, g4 = I % 4, N = BASE + 16 * d + 4 * g4;
         u32x2_t u;
         u[0] = T::pack2(dkv4_acc_read<N>() * sc, dkv4_acc_read<N + 1>() * sc);
         u[1] = T::pack2(dkv4_acc_read<N + 2>() * sc, dkv4_acc_read<N + 3>() * sc);
         *reinterpret_cast<u32x2_t*>(row + (32 * d + 8 * g4 + 4 * hi) * 2) = u;
-        dkv4_store_rows<T, BASE, I + 1>(row, hi, sc);
+        dkv4_store_rows<T, BASE, NI, I + 1>(row, hi, sc);
     }
 }
 
 __device__ __forceinline__ int dkv4_rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-template <class T, bool CAUSAL, bool TL>
+template <class T, int D, bool CAUSAL, bool TL>
 __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
-    constexpr int D = 128;
     using A = Bw4Asm<T, D>;
     using std::integral_constant;
     constexpr int RB = 2 * D;
@@ -107,20 +110,36 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
     const size_t kvbase = (size_t)(w.b * p.Hkv + w.hk) * Sk;
 
     // lane constants
-    // one image per tensor and block (layout: tools/gen_bw4.py, Cfg.PBASE): row group rg = row / 4 is a 1024-byte piece of eight
-    // [4 rows][16 d] sub-tiles at pbase(rg)
-    auto pbase = [](int rg) { return 1024 * rg + (rg & 1) * 16 + ((rg >> 1) & 1) * 128 + (rg >> 2) * 256; };
-    static_assert(A::PB1 == 1040 && A::PB2 == 2048 + 128 && A::PB4 == 4096 + 256, "piece bases of the generator");
-    const unsigned tr_off = (unsigned)(hi * 1040 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8);   // + the read's row-octet / d-slice immediate
-    const unsigned a_sub = (unsigned)(pbase(l31 >> 2) + (l31 & 3) * 32 + hi * 16);                 // row l31, d = 16 ks + 8 hi ..: + 128 ks
-    // per-lane source offsets of this wave's two pieces (row groups 2 w, 2 w + 1) of an image: LDS position = lane
-    unsigned vost[2];
+    unsigned tr_off, a_sub, a_sub1 = 0, vost[2] = {0, 0}, wave_pb;
+    if constexpr (D == 128) {
+        // one image per tensor and block (layout: tools/gen_bw4.py, Cfg.PBASE): row group rg = row / 4 is a 1024-byte piece of eight
+        // [4 rows][16 d] sub-tiles at pbase(rg)
+        auto pbase = [](int rg) { return 1024 * rg + (rg & 1) * 16 + ((rg >> 1) & 1) * 128 + (rg >> 2) * 256; };
+        static_assert(D != 128 || (A::PB1 == 1040 && A::PB2 == 2048 + 128 && A::PB4 == 4096 + 256), "piece bases of the generator");
+        tr_off = (unsigned)(hi * 1040 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8);   // + the read's row-octet / d-slice immediate
+        a_sub = (unsigned)(pbase(l31 >> 2) + (l31 & 3) * 32 + hi * 16);               // row l31, d = 16 ks + 8 hi ..: + 128 ks
+        // per-lane source offsets of this wave's two pieces (row groups 2 w, 2 w + 1) of an image: LDS position = lane
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int rg = 2 * wave + h;
-        vost[h] = (unsigned)((rg * 4 + ((lane >> 1) & 3)) * RB + ((lane >> 3) * 2 + (lane & 1)) * 16);
+        for (int h = 0; h < 2; ++h) {
+            const int rg = 2 * wave + h;
+            vost[h] = (unsigned)((rg * 4 + ((lane >> 1) & 3)) * RB + ((lane >> 3) * 2 + (lane & 1)) * 16);
+        }
+        wave_pb = (unsigned)pbase(2 * wave);
+    } else {
+        // D = 64: piece p = rows 8 p .. 8 p + 7 at 1040 p; chunk (rgl, d, b, rr, h) -- row 4 rgl + rr of the piece, columns
+        // 32 d + 16 b + 8 h .. + 7 -- at 16-byte position 32 d + chunk(rgl, b, rr, h) (tools/gen_bw4.py, chunk64)
+        static_assert(D != 64 || (A::PB1 == 1040 && A::PB2 == 2080), "piece bases of the generator");
+        auto chunk = [](int rgl, int b, int rr, int h) { return 16 * rgl + 8 * (rgl ^ b) + 2 * rr + (h ^ b); };
+        // transpose read: lane -> row group hi of the piece, sub-tile b = lane bit 4, row (lane >> 2) & 3, 8 bytes (lane & 3) of the 32
+        tr_off = (unsigned)(16 * chunk(hi, (lane >> 4) & 1, (lane >> 2) & 3, (lane >> 1) & 1) + (lane & 1) * 8);   // + piece / d-slice immediate
+        // row-major fragment of row l31, k-slice ks = 2 d + b (columns 16 ks + 8 hi ..): base of b, + 512 d
+        a_sub = (unsigned)(1040 * (l31 >> 3) + 16 * chunk((l31 >> 2) & 1, 0, l31 & 3, hi));
+        a_sub1 = (unsigned)(1040 * (l31 >> 3) + 16 * chunk((l31 >> 2) & 1, 1, l31 & 3, hi));
+        // source offset of this wave's piece (piece w of an image): lane l fills chunk l
+        const int cd = lane >> 5, g5 = lane & 31, rgl = g5 >> 4, cb = rgl ^ ((g5 >> 3) & 1), rr = (g5 >> 1) & 3, ch = (g5 & 1) ^ cb;
+        vost[0] = (unsigned)((wave * 8 + 4 * rgl + rr) * RB + (2 * cd + cb) * 32 + ch * 16);
+        wave_pb = (unsigned)(1040 * wave);
     }
-    const unsigned wave_pb = (unsigned)pbase(2 * wave);
     const unsigned lvo = (unsigned)(hi * 16);   // L' / delta: rows 8 g + 4 hi .. + 3 of the block per dwordx4
 
     unsigned long long tl_a = 0, tl_b = 0, tl_n = 0;
@@ -202,11 +221,11 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             const __amdgpu_buffer_rsrc_t nosrd = make_srd(nullptr, 0);
             auto rm_reads = [&](int x) __attribute__((always_inline)) {   // row-major fragments of block x -> the accumulator file
-                const unsigned b = slot_lds(x) + a_sub;
-                A::template p2<0, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
-                A::template p2<1, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
-                A::template p2<2, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
-                A::template p2<3, 0, 0, 1, 0, 0>(b, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                const unsigned b = slot_lds(x) + a_sub, b1 = slot_lds(x) + a_sub1;
+                A::template p2<0, 0, 0, 1, 0, 0>(b, b1, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<1, 0, 0, 1, 0, 0>(b, b1, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<2, 0, 0, 1, 0, 0>(b, b1, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                A::template p2<3, 0, 0, 1, 0, 0>(b, b1, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
             rm_reads(0);
@@ -239,18 +258,17 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
 #undef DKV4_P1
                 // block i + 2 has landed for everybody (all but this wave's newest NP requests -- block i + 3 -- are complete:
                 // the scalars of block i + 1 among them)
-                static_assert(A::NP == 4, "the wait below");
-                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(A::NP) : "memory");
                 unsigned long long t1 = 0;
                 if constexpr (TL) { t1 = __builtin_amdgcn_s_memtime(); tl_a += t1 - t0; }
-                const unsigned b = slot_lds(i + 2) + a_sub;
+                const unsigned b = slot_lds(i + 2) + a_sub, b1 = slot_lds(i + 2) + a_sub1;
                 {
                     const unsigned lso = (unsigned)row_nxt[PAR] * 4u, lso3 = (unsigned)row_nxt[PAR ^ 1] * 4u, dso = (unsigned)c4.row * (unsigned)RB;
                     const unsigned dl = slot_lds(i + 4) + wave_pb;
-                    A::template p2<0, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
-                    A::template p2<1, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
-                    A::template p2<2, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
-                    A::template p2<3, PAR, 1, 1, 1, 1>(b, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<0, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<1, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<2, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
+                    A::template p2<3, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments of block i + 2 (phase 1 of the next iteration reads them)
                 t_cur[PAR] = t_nxt[PAR]; t_nxt[PAR] = c4.t; row_nxt[PAR] = c4.row;
@@ -279,8 +297,8 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const size_t row = kvbase + (size_t)(n0w + (lane_o & 31));
-            dkv4_store_rows<T, 0>(reinterpret_cast<char*>(p.dv) + row * RB, lane_o >> 5, 1.0f);
-            dkv4_store_rows<T, 64>(reinterpret_cast<char*>(p.dk) + row * RB, lane_o >> 5, p.scale);
+            dkv4_store_rows<T, 0, D / 8>(reinterpret_cast<char*>(p.dv) + row * RB, lane_o >> 5, 1.0f);
+            dkv4_store_rows<T, D / 2, D / 8>(reinterpret_cast<char*>(p.dk) + row * RB, lane_o >> 5, p.scale);
         }
         __syncthreads();
     }
@@ -294,14 +312,22 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
 template <class T, bool CAUSAL, bool TL = false>
 __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(40))) fa_bwd_dkv4_kernel(const Dkv4Params p) {
     static_assert(Bw4Asm<T, 128>::NV == 40, "amdgpu_num_vgpr must be the generator's NV");
-    dkv4_body<T, CAUSAL, TL>(p);
+    dkv4_body<T, 128, CAUSAL, TL>(p);
+}
+
+// D = 64: 72 arch VGPRs for hipcc (the attribute takes a literal, hence a kernel of its own)
+template <class T, bool CAUSAL>
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(72))) fa_bwd_dkv4_kernel_d64(const Dkv4Params p) {
+    static_assert(Bw4Asm<T, 64>::NV == 72, "amdgpu_num_vgpr must be the generator's NV");
+    dkv4_body<T, 64, CAUSAL, false>(p);
 }
 
 #pragma clang diagnostic pop
 
-constexpr int kDkv4Lds = kRing4 * Bw4Asm<Bf16Traits, 128>::SLOT;
+template <int D>
+constexpr int kDkv4Lds = kRing4 * Bw4Asm<Bf16Traits, D>::SLOT;
 
-template <class T>
+template <class T, int D>
 int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
     Dkv4Params p;
     p.q = a.q; p.k = a.k; p.v = a.v; p.dout = a.dout; p.lse = a.lse2; p.delta = a.ndelta;   // (L' = LSE log2(e) and - delta, written by the dQ kernel behind delta)
@@ -314,30 +340,39 @@ int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
     p.nblk = a.causal ? (nkb + 1) / 2 : nkb;
     const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv)), block(256);
     p.dbg = a.dbg;
+    constexpr int LDS = kDkv4Lds<D>;
+    if constexpr (D == 64) {
+        if (a.causal)
+            hipLaunchKernelGGL((fa_bwd_dkv4_kernel_d64<T, true>), grid, block, LDS, stream, p);
+        else
+            hipLaunchKernelGGL((fa_bwd_dkv4_kernel_d64<T, false>), grid, block, LDS, stream, p);
+        return (int)hipGetLastError();
+    } else {
 #ifdef AULE_DEBUG_HOOKS
-    if constexpr (std::is_same<T, Bf16Traits>::value) {
-        if (a.dbg != nullptr) {   // timeline build (tools/timeline_dkv4.py)
-            if (a.causal) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv4Lds);
-                hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, true, true>), grid, block, kDkv4Lds, stream, p);
-            } else {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv4Lds);
-                hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, false, true>), grid, block, kDkv4Lds, stream, p);
+        if constexpr (std::is_same<T, Bf16Traits>::value) {
+            if (a.dbg != nullptr) {   // timeline build (tools/timeline_dkv4.py)
+                if (a.causal) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                    hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, true, true>), grid, block, LDS, stream, p);
+                } else {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                    hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, false, true>), grid, block, LDS, stream, p);
+                }
+                return (int)hipGetLastError();
             }
-            return (int)hipGetLastError();
         }
-    }
 #endif
-    if (a.causal)
-        hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, true>), grid, block, kDkv4Lds, stream, p);
-    else
-        hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, false>), grid, block, kDkv4Lds, stream, p);
-    return (int)hipGetLastError();
+        if (a.causal)
+            hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, true>), grid, block, LDS, stream, p);
+        else
+            hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, false>), grid, block, LDS, stream, p);
+        return (int)hipGetLastError();
+    }
 }
 
 }  // namespace
 
-// Shapes the one-wave-per-SIMD dK/dV kernel CAN take: 16-bit, D = 128, no window, causal offset >= 0, a GQA group's rows inside
+// Shapes the one-wave-per-SIMD dK/dV kernel CAN take: 16-bit, D = 128 or 64, no window, causal offset >= 0, a GQA group's rows inside
 // one 2 GB descriptor.  Whether it is taken: bwd_dkv4_items() against the predecessor's grid, in the dispatcher (fa_bwd_gfx950.hip).
 bool bwd_dkv4_applicable(const BwdArgs& a) {
     // AULE_HIP_BWD_DKV=old: the two-waves-per-SIMD kernel everywhere (A/B); =new: this kernel wherever it CAN run (tests)
@@ -347,7 +382,7 @@ bool bwd_dkv4_applicable(const BwdArgs& a) {
     }();
     if (mode == 1) return false;
     if (a.dtype != kBF16 && a.dtype != kF16) return false;
-    if (a.D != 128 || a.window > 0) return false;
+    if ((a.D != 128 && a.D != 64) || a.window > 0) return false;
     if (a.causal && a.coff < 0) return false;
     if (a.Hkv <= 0 || a.Hq % a.Hkv != 0) return false;
     // one descriptor covers the rows of a whole GQA group; byte offsets inside it are 32-bit
@@ -371,16 +406,27 @@ bool bwd_dkv4_forced() {
 }
 
 int launch_bwd_dkv4(const BwdArgs& a, hipStream_t stream) {
-    if (a.dtype == kBF16) return launch_dkv4<Bf16Traits>(a, stream);
-    if (a.dtype == kF16) return launch_dkv4<F16Traits>(a, stream);
+    if (a.D == 128) {
+        if (a.dtype == kBF16) return launch_dkv4<Bf16Traits, 128>(a, stream);
+        if (a.dtype == kF16) return launch_dkv4<F16Traits, 128>(a, stream);
+    } else if (a.D == 64) {
+        if (a.dtype == kBF16) return launch_dkv4<Bf16Traits, 64>(a, stream);
+        if (a.dtype == kF16) return launch_dkv4<F16Traits, 64>(a, stream);
+    }
     return -1;
 }
 
 int configure_bwd_dkv4() {
-    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<Bf16Traits, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv4Lds);
-    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<Bf16Traits, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv4Lds);
-    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<F16Traits, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv4Lds);
-    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<F16Traits, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv4Lds);
+    int rc = 0;
+    auto set = [&](const void* f, int lds) { rc |= (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds); };
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<Bf16Traits, true>), kDkv4Lds<128>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<Bf16Traits, false>), kDkv4Lds<128>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<F16Traits, true>), kDkv4Lds<128>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<F16Traits, false>), kDkv4Lds<128>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<Bf16Traits, true>), kDkv4Lds<64>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<Bf16Traits, false>), kDkv4Lds<64>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<F16Traits, true>), kDkv4Lds<64>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<F16Traits, false>), kDkv4Lds<64>);
     return rc;
 }
 

@@ -1135,7 +1135,7 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     // spread (MHA / GQA, causal or not, ragged, fp16: -0.5 .. -24 %); what stays here is the tiny grid with a big group (fp16 MQA
     // 32/1 S8192: 32 work items there against 512 here).
     const auto use_dkv4 = [&] {
-        if (D != 128 || !(a.dbg == nullptr || dkv4_timeline_wanted()) || !bwd_dkv4_applicable(a)) return false;
+        if ((D != 128 && D != 64) || !(a.dbg == nullptr || dkv4_timeline_wanted()) || !bwd_dkv4_applicable(a)) return false;
         if (bwd_dkv4_forced() || dkv4_timeline_wanted()) return true;
         const int nkb = (a.Sk + kKvBlock - 1) / kKvBlock;
         const long long here = (long long)a.B * a.Hkv * (a.causal ? (nkb + 1) / 2 : nkb) * dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal);

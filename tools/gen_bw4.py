@@ -43,27 +43,52 @@ OUT = os.environ.get("BW4_OUT", os.path.join(ROOT, "aule-attention_amd", "csrc",
 
 class Cfg:
     def __init__(self, D, dt):
-        assert D == 128
+        assert D in (64, 128)
         self.D, self.dt = D, dt
         self.RB = 2 * D
         self.KS, self.DB = D // 16, D // 32
         self.mfma = "v_mfma_f32_32x32x16_bf16" if dt == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dt == "bf16" else "v_cvt_pk_f16_f32"
-        # ONE image per tensor and 32-row block (round 3b; before: a swizzled row-major image for the ds_read_b128 fragments AND a
-        # sub-tiled one for the transpose reads, twice the LDS-DMA pieces).  Piece rg = the four rows 4 rg .. 4 rg + 3 as eight
-        # [4 rows][16 d] sub-tiles of 128 bytes (what a transpose read wants: a pass of 32 lanes covers two neighbouring
-        # sub-tiles, 256 contiguous bytes); the pieces sit at PBASE[rg] = 1024 rg + {0, 16, 128, 144}[rg & 3] + 256 (rg >> 2):
-        # a 16-lane pass of a ds_read_b128 (rows r .. r + 15 = four pieces, one 16-byte chunk each at (r & 3) 32 inside its
-        # sub-tile) then covers all 64 banks once.  No linear piece stride does that; the pads cost 512 bytes per image.
-        self.PBASE = [1024 * rg + (0, 16, 128, 144)[rg & 3] + 256 * (rg >> 2) for rg in range(8)]
-        self.IMG = 8704                             # >= PBASE[7] + 1024, a multiple of 256
+        if D == 128:
+            # ONE image per tensor and 32-row block (round 3b; before: a swizzled row-major image for the ds_read_b128 fragments AND a
+            # sub-tiled one for the transpose reads, twice the LDS-DMA pieces).  Piece rg = the four rows 4 rg .. 4 rg + 3 as eight
+            # [4 rows][16 d] sub-tiles of 128 bytes (what a transpose read wants: a pass of 32 lanes covers two neighbouring
+            # sub-tiles, 256 contiguous bytes); the pieces sit at PBASE[rg] = 1024 rg + {0, 16, 128, 144}[rg & 3] + 256 (rg >> 2):
+            # a 16-lane pass of a ds_read_b128 (rows r .. r + 15 = four pieces, one 16-byte chunk each at (r & 3) 32 inside its
+            # sub-tile) then covers all 64 banks once.  No linear piece stride does that; the pads cost 512 bytes per image.
+            self.PBASE = [1024 * rg + (0, 16, 128, 144)[rg & 3] + 256 * (rg >> 2) for rg in range(8)]
+            self.IMG = 8704                             # >= PBASE[7] + 1024, a multiple of 256
+            self.NP = 4                                 # DMA pieces per wave and block: row groups 2 w, 2 w + 1 of Q and of dO
+            self.RM_SPLIT = (2, 2, 6, 6)                # ds_read_b128 of block i + 2 per phase-2 statement (16: k-slices 0 .. 7 of Q, dO)
+        else:
+            # D = 64 (round 4): a row is 128 bytes, so a 1 KB LDS-DMA piece (lane-linear in LDS: lane l writes chunk l, 16 bytes)
+            # holds TWO row groups -- piece p = rows 8 p .. 8 p + 7 -- and no pad can sit between them.  The global side of a
+            # piece is per lane, so the ORDER of its 64 chunks is free: chunk (rgl = row group inside the piece, d-slice d = 32
+            # columns, b = which 16 of them, rr = row inside the group, h = which 8 of the 16) sits at chunk64() below,
+            #     32 d + 16 rgl + 8 (rgl ^ b) + 2 rr + (h ^ b),
+            # and the pieces at PBASE[p] = 1040 p (one chunk of pad each).  Then (positions mod 16 = banks / 4):
+            #   * a 16-lane pass of a ds_read_b128 -- rows r .. r + 15 = two pieces x two row groups x four rows at fixed (d, b, h) --
+            #     takes 8 (rgl ^ b) + 2 rr + const from one piece and the same + 1 from the other: 16 different values;
+            #   * a 32-lane pass of a transpose read -- one row group (rgl fixed), sub-tiles b = 0 and 1, rows rr, halves h --
+            #     takes 8 (rgl ^ b) + 2 rr + (h ^ b): 16 different values.
+            # b enters through an exclusive-or with lane bits, so the row-major reads use one lane base per b (ra / ra1) and
+            # the immediate carries only image and d; the transpose reads know b from the lane (bit 4).
+            self.PBASE = [1040 * p for p in range(4)]
+            self.IMG = 4352                             # >= PBASE[3] + 1024, a multiple of 256
+            self.NP = 2                                 # DMA pieces per wave and block: piece w of Q and of dO
+            self.RM_SPLIT = (2, 2, 2, 2)                # 8 reads: k-slices 0 .. 3 of Q, dO
         self.SLOT = 2 * self.IMG                    # Q, dO
-        self.NP = 4                                 # DMA pieces per wave and block: row groups 2 w, 2 w + 1 of Q and of dO
         # accumulator file
-        self.DV, self.DK, self.KF, self.VF, self.QA, self.DA = 0, 64, 128, 160, 192, 224
+        self.DV = 0
+        self.DK = self.DV + 16 * self.DB
+        self.KF = self.DK + 16 * self.DB
+        self.VF = self.KF + 4 * self.KS
+        self.QA = self.VF + 4 * self.KS
+        self.DA = self.QA + 4 * self.KS
         # arch VGPRs, top down
-        self.X = 256 - 32
-        self.Y = self.X - 32
+        self.NST = 2 * self.DB                      # steps of the dV / dK products (two 16-row k-steps x DB d-slices)
+        self.X = 256 - 4 * self.NST
+        self.Y = self.X - 4 * self.NST
         self.S = self.Y - 32
         self.DP = self.S - 32
         self.P = self.DP - 8
@@ -78,6 +103,11 @@ class Cfg:
 
     def frag(self, base, i, file="a"):
         return f"{file}[{base + 4 * i}:{base + 4 * i + 3}]"
+
+
+def chunk64(rgl, d, b, rr, h):
+    """D = 64: position (in 16-byte chunks) inside its 1 KB piece of rows 4 rgl + rr, columns 32 d + 16 b + 8 h .. + 7 (Cfg)"""
+    return 32 * d + 16 * rgl + 8 * (rgl ^ b) + 2 * rr + (h ^ b)
 
 
 def crow(r):
@@ -128,26 +158,27 @@ def deal(mfmas, fillers):
 def tr_reads(c, st):
     """the four transpose reads of step st (k-step st / DB = 16 query rows, d-slice st % DB) of the current block: dO -> X, Q -> Y"""
     kk, d = st // c.DB, st % c.DB
-    # rows 16 kk + 8 e + 4 hi .. + 3 (row group 2 (2 kk + e) + hi: the lane's constant carries PBASE[hi]), d = 32 d ..
-    off, o2 = (c.PBASE[2 * (2 * kk + e)] + 256 * d for e in (0, 1))
+    if c.D == 128:
+        # rows 16 kk + 8 e + 4 hi .. + 3 (row group 2 (2 kk + e) + hi: the lane's constant carries PBASE[hi]), d = 32 d ..
+        off, o2 = (c.PBASE[2 * (2 * kk + e)] + 256 * d for e in (0, 1))
+    else:
+        # rows 16 kk + 8 e + 4 hi .. + 3 = piece 2 kk + e, row group hi of it (the lane's constant carries rgl = hi, b, rr, h)
+        off, o2 = (c.PBASE[2 * kk + e] + 512 * d for e in (0, 1))
     return [f"ds_read_b64_tr_b16 v[{c.X + 4 * st}:{c.X + 4 * st + 1}], %[trb] offset:{c.IMG + off}",
             f"ds_read_b64_tr_b16 v[{c.X + 4 * st + 2}:{c.X + 4 * st + 3}], %[trb] offset:{c.IMG + o2}",
             f"ds_read_b64_tr_b16 v[{c.Y + 4 * st}:{c.Y + 4 * st + 1}], %[trb] offset:{off}",
             f"ds_read_b64_tr_b16 v[{c.Y + 4 * st + 2}:{c.Y + 4 * st + 3}], %[trb] offset:{o2}"]
 
 
-RM_SPLIT = (2, 2, 6, 6)        # ds_read_b128 of block i + 2 per phase-2 statement (16: k-slices 0 .. 7 of Q, dO)
-
-
 def gen_p1(c, q, par, qk, ar, tr):
     """phase-1 statement q of an iteration whose current block has parity par.  qk: MFMAs of the NEXT block's S / dP (k-slices
-    2 q, 2 q + 1).  ar: 0 none, 1 plain, 2 masked arithmetic of the current block (scores 4 q ..).  tr: transpose reads of the
+    2 q, 2 q + 1; D = 64: k-slice q).  ar: 0 none, 1 plain, 2 masked arithmetic of the current block (scores 4 q ..).  tr: transpose reads of the
     current block (step q of 0 .. 3: four ds_read_b64_tr_b16; steps 4 .. 7 are read in phase 2)."""
     mf, clob = [], ["memory"]
     npar = par ^ 1
     if qk:
         s, dp = tup(c.S + 16 * npar, 16), tup(c.DP + 16 * npar, 16)
-        for ks in (2 * q, 2 * q + 1):
+        for ks in range(q * c.KS // 4, (q + 1) * c.KS // 4):
             mf.append(f"{c.mfma} {s}, {c.frag(c.QA, ks)}, {c.frag(c.KF, ks)}, {'0' if ks == 0 else s}")
             mf.append(f"{c.mfma} {dp}, {c.frag(c.DA, ks)}, {c.frag(c.VF, ks)}, {tup(c.DL + 16 * npar, 16) if ks == 0 else dp}")
         clob += vregs(c.S + 16 * npar, 16) + vregs(c.DP + 16 * npar, 16)
@@ -182,33 +213,37 @@ def gen_p2(c, q, par, mm, rm, ld, dma):
     requests for scalars come before all the pieces: the phase boundary's vmcnt(NP) then covers exactly the scalars."""
     mf, clob = [], ["memory"]
     if mm:
-        for st in (2 * q, 2 * q + 1):
+        for st in range(q * c.NST // 4, (q + 1) * c.NST // 4):
             kk, d = st // c.DB, st % c.DB
             dv, dk = c.acc(c.DV, d), c.acc(c.DK, d)
             mf.append(f"{c.mfma} {dv}, {c.frag(c.X, st, 'v')}, {c.frag(c.P, kk, 'v')}, {dv}")
             mf.append(f"{c.mfma} {dk}, {c.frag(c.Y, st, 'v')}, {c.frag(c.DS, kk, 'v')}, {dk}")
-        clob += aregs(c.DV, 64) + aregs(c.DK, 64)
+        clob += aregs(c.DV, 16 * c.DB) + aregs(c.DK, 16 * c.DB)
     fill = []
     ins = []
     pre = []
-    if mm and q >= 2:
+    if mm and q >= 2 and c.NST == 8:
+        # (D = 128; at D = 64 all four steps are read in phase 1, behind the phase boundary's wait)
         # steps 2 q, 2 q + 1 were requested in statement q - 2; LDS returns in order, what may still be out: the reads issued after
         # them (q = 2: statement 0's row-major reads + all of statement 1's LDS reads; q = 3: statement 1's row-major reads + 2's)
-        later = RM_SPLIT[0] + 8 + RM_SPLIT[1] if q == 2 else RM_SPLIT[1] + RM_SPLIT[2]
+        later = c.RM_SPLIT[0] + 8 + c.RM_SPLIT[1] if q == 2 else c.RM_SPLIT[1] + c.RM_SPLIT[2]
         pre.append(f"s_waitcnt lgkmcnt({min(later, 15)})")
-    if mm and q < 2:
+    if mm and q < 2 and c.NST == 8:
         for st in (4 + 2 * q, 5 + 2 * q):
             fill += tr_reads(c, st)
             clob += vregs(c.X + 4 * st, 4) + vregs(c.Y + 4 * st, 4)
         ins.append('[trb] "v"(trb)')
     if rm:
         order = [(ks, t) for ks in range(c.KS) for t in (0, 1)]       # (k-slice, Q / dO)
-        lo = sum(RM_SPLIT[:q]) if mm else 4 * q
-        n = RM_SPLIT[q] if mm else 4
+        lo = sum(c.RM_SPLIT[:q]) if mm else len(order) // 4 * q
+        n = c.RM_SPLIT[q] if mm else len(order) // 4
         for ks, t in order[lo:lo + n]:               # d = 16 ks + 8 hi ..: sub-tile ks of the lane's row group, chunk hi
-            fill.append(f"ds_read_b128 {c.frag(c.DA if t else c.QA, ks)}, %[ra] offset:{t * c.IMG + 128 * ks}")
+            if c.D == 128:
+                fill.append(f"ds_read_b128 {c.frag(c.DA if t else c.QA, ks)}, %[ra] offset:{t * c.IMG + 128 * ks}")
+            else:                                    # k-slice ks = (d-slice ks >> 1, b = ks & 1): the lane base of that b, + 512 d
+                fill.append(f"ds_read_b128 {c.frag(c.DA if t else c.QA, ks)}, %[ra{'1' if ks & 1 else ''}] offset:{t * c.IMG + 512 * (ks >> 1)}")
             clob += aregs((c.DA if t else c.QA) + 4 * ks, 4)
-        ins += ['[ra] "v"(ra)']
+        ins += ['[ra] "v"(ra)'] + (['[ra1] "v"(ra1)'] if c.D == 64 else [])
     if ld:
         if q < 2:
             # L' of block i + 2 (its arithmetic runs in iteration i + 2); - delta of block i + 3 (the C operand of dP_{i+3}'s first
@@ -224,7 +259,7 @@ def gen_p2(c, q, par, mm, rm, ld, dma):
     if dma and q >= 2:
         img = q - 2                                         # statement 2: Q, statement 3: dO; the wave's row groups 2 w, 2 w + 1
         srd = "%[qsrd]" if img == 0 else "%[gsrd]"            # (dlds = slot + PBASE[2 w]; PBASE[2 w + 1] - PBASE[2 w] = 1040)
-        for half in range(2):
+        for half in range(c.NP // 2):                        # (D = 64: one piece per image and wave)
             fill += [f"s_add_u32 m0, %[dlds], {img * c.IMG + half * 1040}", "s_nop 0", f"buffer_load_dwordx4 %[vost{half}], {srd}, %[dso] offen lds"]
         clob += ["m0", "scc"]
         ins += ['[dlds] "s"(dlds)', '[qsrd] "s"(qsrd)' if q == 2 else '[gsrd] "s"(gsrd)', '[dso] "s"(dso)',
@@ -250,7 +285,7 @@ def gen_p2(c, q, par, mm, rm, ld, dma):
 def gen_struct(c):
     name = f"Bw4Asm<{'Bf16Traits' if c.dt == 'bf16' else 'F16Traits'}, {c.D}>"
     s = f"template <> struct {name} {{\n"
-    s += f"    static constexpr int NV = {c.NV}, NP = {c.NP}, SLOT = {c.SLOT}, IMG = {c.IMG}, PB1 = {c.PBASE[1]}, PB2 = {c.PBASE[2]}, PB4 = {c.PBASE[4]};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n"
+    s += f"    static constexpr int NV = {c.NV}, NP = {c.NP}, SLOT = {c.SLOT}, IMG = {c.IMG}, PB1 = {c.PBASE[1]}, PB2 = {c.PBASE[2]}, PB4 = {c.PBASE[4] if len(c.PBASE) > 4 else 0};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n"
     s += ("    template <int Q, int PAR, int QK, int AR, int TR>\n"
           "    static __device__ __forceinline__ void p1(float c, int lo, int wd, unsigned trb) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n        (void)c; (void)lo; (void)wd; (void)trb;\n")
@@ -263,11 +298,11 @@ def gen_struct(c):
                 first = False
     s += "        else static_assert(Q < 0, \"fa_bwd_dkv4_asm.inc: phase-1 variant not generated\");\n#endif\n    }\n"
     s += ("    template <int Q, int PAR, int MM, int RM, int LD, int DMA>\n"
-          "    static __device__ __forceinline__ void p2(unsigned ra, unsigned trb, __amdgpu_buffer_rsrc_t lsrd, __amdgpu_buffer_rsrc_t dsrd, unsigned lvo,\n"
+          "    static __device__ __forceinline__ void p2(unsigned ra, unsigned ra1, unsigned trb, __amdgpu_buffer_rsrc_t lsrd, __amdgpu_buffer_rsrc_t dsrd, unsigned lvo,\n"
           "                                              unsigned lso, unsigned lso3, unsigned dlds, __amdgpu_buffer_rsrc_t qsrd, __amdgpu_buffer_rsrc_t gsrd, unsigned dso,\n"
           "                                              unsigned vost0, unsigned vost1) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
-          "        (void)ra; (void)trb; (void)lsrd; (void)dsrd; (void)lvo; (void)lso; (void)lso3; (void)dlds; (void)qsrd; (void)gsrd; (void)dso;\n"
+          "        (void)ra; (void)ra1; (void)trb; (void)lsrd; (void)dsrd; (void)lvo; (void)lso; (void)lso3; (void)dlds; (void)qsrd; (void)gsrd; (void)dso;\n"
           "        (void)vost0; (void)vost1;\n"
           "        if constexpr (DMA != 0) {\n            dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n            dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n        }\n"
           "        if constexpr (LD != 0) {\n            lso = (unsigned)__builtin_amdgcn_readfirstlane((int)lso);\n            lso3 = (unsigned)__builtin_amdgcn_readfirstlane((int)lso3);\n        }\n")
@@ -286,12 +321,12 @@ def gen_struct(c):
         lines.append(f"buffer_load_dwordx4 {c.frag(c.VF, ks)}, %[vo], %[vsrd], 0 offen offset:{32 * ks}")
     lines.append("s_waitcnt vmcnt(0)")
     s += "    static __device__ __forceinline__ void load_kv(__amdgpu_buffer_rsrc_t ksrd, __amdgpu_buffer_rsrc_t vsrd, unsigned vo) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
-    s += emit_asm(lines, [], ['[ksrd] "s"(ksrd)', '[vsrd] "s"(vsrd)', '[vo] "v"(vo)'], ["memory"] + aregs(c.KF, 64), indent="        ")
+    s += emit_asm(lines, [], ['[ksrd] "s"(ksrd)', '[vsrd] "s"(vsrd)', '[vo] "v"(vo)'], ["memory"] + aregs(c.KF, 8 * c.KS), indent="        ")
     s += "#endif\n    }\n"
     # ---- accumulators to zero
-    lines = [f"v_accvgpr_write_b32 a{i}, 0" for i in range(128)]
+    lines = [f"v_accvgpr_write_b32 a{i}, 0" for i in range(32 * c.DB)]
     s += "    static __device__ __forceinline__ void zero_acc() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
-    s += emit_asm(lines, [], [], aregs(0, 128), indent="        ")
+    s += emit_asm(lines, [], [], aregs(0, 32 * c.DB), indent="        ")
     s += "#endif\n    }\n"
     # ---- L' / delta of a block straight into the buffers of parity PAR (stream start); SCALE: L' times log2(e) right away
     s += ("    template <int PAR, int SCALE>\n    static __device__ __forceinline__ void load_scal(__amdgpu_buffer_rsrc_t lsrd, __amdgpu_buffer_rsrc_t dsrd, unsigned lvo, unsigned lso) {\n"
@@ -326,7 +361,7 @@ def gen_struct(c):
     # ---- the LDS-DMA pieces of one block as a statement of its own (stream start)
     lines = ["s_nop 4"]
     for pi in range(c.NP):
-        img, half = pi // 2, pi % 2
+        img, half = pi // (c.NP // 2), pi % (c.NP // 2)
         srd = "%[qsrd]" if img == 0 else "%[gsrd]"
         lines += [f"s_add_u32 m0, %[dlds], {img * c.IMG + half * 1040}", "s_nop 0", f"buffer_load_dwordx4 %[vost{half}], {srd}, %[dso] offen lds"]
     s += ("    static __device__ __forceinline__ void dma_block(unsigned dlds, __amdgpu_buffer_rsrc_t qsrd, __amdgpu_buffer_rsrc_t gsrd, unsigned dso,\n"
@@ -346,11 +381,14 @@ def main():
            "// Included by fa_bwd_dkv4_gfx950.hip inside namespace aule_hip::{anonymous}.\n\n"
            "template <class T, int D> struct Bw4Asm;\n\n")
     body = ""
-    for dt in ("bf16", "fp16"):
-        body += gen_struct(Cfg(128, dt))
+    for D in (128, 64):
+        for dt in ("bf16", "fp16"):
+            body += gen_struct(Cfg(D, dt))
     with open(OUT, "w") as fh:
         fh.write(hdr + body)
-    c = Cfg(128, "bf16")
+    for D in (128, 64):
+        c = Cfg(D, "bf16")
+        print(f"D={D}: NV={c.NV} T={c.T} DL={c.DL} LD={c.LD} DS={c.DS} P={c.P} DP={c.DP} S={c.S} Y={c.Y} X={c.X}; acc DV={c.DV} DK={c.DK} KF={c.KF} VF={c.VF} QA={c.QA} DA={c.DA}")
     print(f"wrote {OUT}: {len((hdr + body).splitlines())} lines; NV={c.NV} T={c.T} DL={c.DL} LD={c.LD} DS={c.DS} P={c.P} DP={c.DP} S={c.S} Y={c.Y} X={c.X}")
 
 
