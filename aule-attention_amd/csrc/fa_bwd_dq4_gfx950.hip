@@ -1,4 +1,4 @@
-// fa_bwd_dq4_gfx950.hip -- dQ of the FlashAttention-2 backward (16-bit I/O, D = 128), ONE WAVE PER SIMD.
+// fa_bwd_dq4_gfx950.hip -- dQ of the FlashAttention-2 backward (16-bit I/O, D = 128 and, since round 4, D = 64), ONE WAVE PER SIMD.
 //
 // Replaces the dQ half of python/aule/triton_flash.py:242-350 / triton_flash_amd.py:247-351 (the reference's backward kernels)
 // where it applies; everything else stays on fa_bwd_gfx950.hip's fa_bwd_dq_kernel (8 waves x 32 rows, two waves per SIMD).
@@ -16,7 +16,11 @@
 //     its share of the requests;
 //   * delta = rowsum(O * dO), L' = LSE log2(e) and -delta are published for the dK/dV kernel exactly as the predecessor does.
 //
-// Covers bf16 / fp16, D = 128, causal (coff >= 0) and non-causal, no window; deterministic (no atomics); the accumulation order
+// D = 64 (round 4): the same statement with 24 MFMAs per KV block (16 + 8) against the same 2 x 16 scores per lane; the block image is
+// the dK/dV kernel's D = 64 one (a chunk permutation per 1 KB piece: tools/gen_bw4.py, chunk64), 128 accumulator registers, 50 arch
+// VGPRs left to hipcc, a 68 KB ring.
+//
+// Covers bf16 / fp16, D = 128 / 64, causal (coff >= 0) and non-causal, no window; deterministic (no atomics); the accumulation order
 // over the keys is the predecessor's, so dQ comes out bit-identical to it.
 #include <cstdlib>
 #include <type_traits>
@@ -68,41 +72,41 @@ __device__ __forceinline__ float dq4_acc_read() {
 }
 
 // accumulator block BASE + 16 d .. of the lane's query row -> the row's d = 32 d + 8 g + 4 hi .. + 3 (8-byte stores)
-template <class T, int BASE, int I = 0>
+template <class T, int BASE, int NI, int I = 0>
 __device__ __forceinline__ void dq4_store_rows(char* row, int hi, float sc) {
-    if constexpr (I < 16) {
+    if constexpr (I < NI) {
         constexpr int d = I / 4, g4 = I % 4, N = BASE + 16 * d + 4 * g4;
         u32x2_t u;
         u[0] = T::pack2(dq4_acc_read<N>() * sc, dq4_acc_read<N + 1>() * sc);
         u[1] = T::pack2(dq4_acc_read<N + 2>() * sc, dq4_acc_read<N + 3>() * sc);
         *reinterpret_cast<u32x2_t*>(row + (32 * d + 8 * g4 + 4 * hi) * 2) = u;
-        dq4_store_rows<T, BASE, I + 1>(row, hi, sc);
+        dq4_store_rows<T, BASE, NI, I + 1>(row, hi, sc);
     }
 }
 
 __device__ __forceinline__ int dq4_rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-// the lane's half of rowsum(O * dO) over one row block: dwords OB .. OB + 31 (O) and GB .. (dO) of the accumulator file, in the
+// the lane's half of rowsum(O * dO) over one row block: dwords OB .. OB + NI - 1 (O) and GB .. (dO) of the accumulator file, in the
 // predecessor's order (k-slice by k-slice, dword by dword: the sums come out bit-identical to fa_bwd_dq_kernel's)
-template <class T, int OB, int GB, int I = 0>
+template <class T, int OB, int GB, int NI, int I = 0>
 __device__ __forceinline__ float dq4_delta_part(float part) {
-    if constexpr (I < 32) {
+    if constexpr (I < NI) {
         unsigned ov = 0, gv = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
         // (`part` rides through the statement: without the tie hipcc issues all 64 reads first and keeps them live)
         asm volatile("v_accvgpr_read_b32 %0, a%c3\n\tv_accvgpr_read_b32 %1, a%c4" : "=v"(ov), "=v"(gv), "+v"(part) : "n"(OB + I), "n"(GB + I));
 #endif
         part += T::lo(ov) * T::lo(gv) + T::hi(ov) * T::hi(gv);
-        return dq4_delta_part<T, OB, GB, I + 1>(part);
+        return dq4_delta_part<T, OB, GB, NI, I + 1>(part);
     } else {
         return part;
     }
 }
 
-template <class T, bool CAUSAL>
+template <class T, int D, bool CAUSAL>
 __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
-    constexpr int D = 128, RB = 2 * D;
-    using A = Dq4Asm<T>;
+    constexpr int RB = 2 * D, NF = D / 4;   // NF: dwords of a row block's Q^T (dO^T, O) fragments per lane
+    using A = Dq4Asm<T, D>;
     using std::integral_constant;
     constexpr int SLOT = A::SLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,19 +129,32 @@ __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
     const __amdgpu_buffer_rsrc_t grs = make_srd(reinterpret_cast<const char*>(p.dout) + qbase * RB, (unsigned)Sq * RB);
     const __amdgpu_buffer_rsrc_t ors = make_srd(reinterpret_cast<const char*>(p.o) + qbase * RB, (unsigned)Sq * RB);
 
-    // the image of a 32-row block (layout: tools/gen_bw4.py, Cfg.PBASE): row group rg = row / 4 is a 1024-byte piece of eight
-    // [4 rows][16 d] sub-tiles at pbase(rg)
-    auto pbase = [](int rg) { return 1024 * rg + (rg & 1) * 16 + ((rg >> 1) & 1) * 128 + (rg >> 2) * 256; };
-    static_assert(A::PB1 == 1040 && A::PB2 == 2048 + 128 && A::PB4 == 4096 + 256, "piece bases of the generator");
-    const unsigned tr_off = (unsigned)(hi * 1040 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8);   // + the read's key-octet / d-block immediate
-    const unsigned a_sub = (unsigned)(pbase(l31 >> 2) + (l31 & 3) * 32 + hi * 16);                 // key row l31, d = 16 ks + 8 hi ..: + 128 ks
-    unsigned vost[2];   // per-lane source offsets of this wave's two pieces (row groups 2 w, 2 w + 1) of an image: LDS position = lane
+    // the image of a 32-row block (layout: tools/gen_bw4.py, Cfg): the lane constants of the dK/dV kernel (fa_bwd_dkv4_gfx950.hip)
+    unsigned tr_off, a_sub, a_sub1 = 0, vost[2] = {0, 0}, wave_pb;
+    if constexpr (D == 128) {
+        // row group rg = row / 4 is a 1024-byte piece of eight [4 rows][16 d] sub-tiles at pbase(rg)
+        auto pbase = [](int rg) { return 1024 * rg + (rg & 1) * 16 + ((rg >> 1) & 1) * 128 + (rg >> 2) * 256; };
+        static_assert(D != 128 || (A::PB1 == 1040 && A::PB2 == 2048 + 128 && A::PB4 == 4096 + 256), "piece bases of the generator");
+        tr_off = (unsigned)(hi * 1040 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8);   // + the read's key-octet / d-block immediate
+        a_sub = (unsigned)(pbase(l31 >> 2) + (l31 & 3) * 32 + hi * 16);               // key row l31, d = 16 ks + 8 hi ..: + 128 ks
+        // per-lane source offsets of this wave's two pieces (row groups 2 w, 2 w + 1) of an image: LDS position = lane
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int rg = 2 * wave + h;
-        vost[h] = (unsigned)((rg * 4 + ((lane >> 1) & 3)) * RB + ((lane >> 3) * 2 + (lane & 1)) * 16);
+        for (int h = 0; h < 2; ++h) {
+            const int rg = 2 * wave + h;
+            vost[h] = (unsigned)((rg * 4 + ((lane >> 1) & 3)) * RB + ((lane >> 3) * 2 + (lane & 1)) * 16);
+        }
+        wave_pb = (unsigned)pbase(2 * wave);
+    } else {
+        // D = 64: piece p = rows 8 p .. 8 p + 7 at 1040 p; chunk (rgl, d, b, rr, h) at 16-byte position 32 d + chunk(rgl, b, rr, h)
+        static_assert(D != 64 || (A::PB1 == 1040 && A::PB2 == 2080), "piece bases of the generator");
+        auto chunk = [](int rgl, int b, int rr, int h) { return 16 * rgl + 8 * (rgl ^ b) + 2 * rr + (h ^ b); };
+        tr_off = (unsigned)(16 * chunk(hi, (lane >> 4) & 1, (lane >> 2) & 3, (lane >> 1) & 1) + (lane & 1) * 8);   // + piece / d-block immediate
+        a_sub = (unsigned)(1040 * (l31 >> 3) + 16 * chunk((l31 >> 2) & 1, 0, l31 & 3, hi));    // key row l31, k-slice 2 d + b: base of b, + 512 d
+        a_sub1 = (unsigned)(1040 * (l31 >> 3) + 16 * chunk((l31 >> 2) & 1, 1, l31 & 3, hi));
+        const int cd = lane >> 5, g5 = lane & 31, rgl = g5 >> 4, cb = rgl ^ ((g5 >> 3) & 1), rr = (g5 >> 1) & 3, ch = (g5 & 1) ^ cb;
+        vost[0] = (unsigned)((wave * 8 + 4 * rgl + rr) * RB + (2 * cd + cb) * 32 + ch * 16);   // this wave's piece (piece w): lane l fills chunk l
+        wave_pb = (unsigned)(1040 * wave);
     }
-    const unsigned wave_pb = (unsigned)pbase(2 * wave);
     auto slot_lds = [&](int x) __attribute__((always_inline)) { return lds0 + (unsigned)(x & (kRingQ4 - 1)) * SLOT; };
 
     const int nparts = (CAUSAL && (nqb - 1 - w.blk) != w.blk) ? 2 : 1;
@@ -156,7 +173,7 @@ __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
         for (int rb = 0; rb < 2; ++rb) {
             const int qrow = q0w + 32 * rb + l31;
             const int qr = qrow < Sq ? qrow : Sq - 1;
-            const float part_sum = rb == 0 ? dq4_delta_part<T, 0, A::DF>(0.f) : dq4_delta_part<T, 32, A::DF + 32>(0.f);
+            const float part_sum = rb == 0 ? dq4_delta_part<T, 0, A::DF, NF>(0.f) : dq4_delta_part<T, NF, A::DF + NF, NF>(0.f);
             const float delta = part_sum + xhalf(part_sum);
             const float nlse2 = -p.lse[qbase + qr] * kLog2e;
             if (hi == 0 && qrow < Sq) {
@@ -182,9 +199,10 @@ __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
         auto iteration = [&](auto par_tag, int j) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_tag)::value;
             const unsigned ra = slot_lds(j) + a_sub, ra2 = slot_lds(j + 1) + a_sub, trb = slot_lds(j - 2) + tr_off;
+            const unsigned rab = slot_lds(j) + a_sub1, ra2b = slot_lds(j + 1) + a_sub1;   // (D = 64: the bases of the odd k-slices)
             const unsigned dlds = slot_lds(j + 4) + wave_pb, dso = (unsigned)((j + 4) * kKB4 * RB);
             const int k0 = (j - 1) * kKB4;
-#define DQ4_IT(QK, NXT, AR, DQ, PRE) A::template iter<PAR, QK, NXT, AR, DQ, PRE>(c, ra, ra2, trb, lim4[0], lim4[1], k0, dlds, krs, vrs, dso, vost[0], vost[1])
+#define DQ4_IT(QK, NXT, AR, DQ, PRE) A::template iter<PAR, QK, NXT, AR, DQ, PRE>(c, ra, rab, ra2, ra2b, trb, lim4[0], lim4[1], k0, dlds, krs, vrs, dso, vost[0], vost[1])
             const bool plain = (j - 1) < mask_lo && (j - 1) != ragged_blk;
             if (j + 1 < n_w) {            // S / dP of block j, and of block j + 1 next time
                 if (j >= 2) { if (plain) DQ4_IT(1, 1, 1, 1, 1); else DQ4_IT(1, 1, 2, 1, 1); }
@@ -202,11 +220,11 @@ __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
             }
         };
         {   // iteration 0 requests its own first fragments
-            const unsigned ra = slot_lds(0) + a_sub, ra2 = slot_lds(1) + a_sub;
+            const unsigned ra = slot_lds(0) + a_sub, ra2 = slot_lds(1) + a_sub, rab = slot_lds(0) + a_sub1, ra2b = slot_lds(1) + a_sub1;
             const unsigned dlds = slot_lds(4) + wave_pb, dso = (unsigned)(4 * kKB4 * RB);
-            if (n_w > 1) A::template iter<0, 1, 1, 0, 0, 0>(c, ra, ra2, 0, 0, 0, 0, dlds, krs, vrs, dso, vost[0], vost[1]);
-            else if (n_w > 0) A::template iter<0, 1, 0, 0, 0, 0>(c, ra, ra2, 0, 0, 0, 0, dlds, krs, vrs, dso, vost[0], vost[1]);
-            else A::template iter<0, 0, 0, 0, 0, 0>(c, ra, ra2, 0, 0, 0, 0, dlds, krs, vrs, dso, vost[0], vost[1]);
+            if (n_w > 1) A::template iter<0, 1, 1, 0, 0, 0>(c, ra, rab, ra2, ra2b, 0, 0, 0, 0, dlds, krs, vrs, dso, vost[0], vost[1]);
+            else if (n_w > 0) A::template iter<0, 1, 0, 0, 0, 0>(c, ra, rab, ra2, ra2b, 0, 0, 0, 0, dlds, krs, vrs, dso, vost[0], vost[1]);
+            else A::template iter<0, 0, 0, 0, 0, 0>(c, ra, rab, ra2, ra2b, 0, 0, 0, 0, dlds, krs, vrs, dso, vost[0], vost[1]);
         }
 #undef DQ4_IT
         // The steady range -- S / dP of block j with block j + 1 to follow, plain arithmetic of block j - 1, dQ of block j - 2 -- runs
@@ -214,7 +232,8 @@ __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
         // while the matrix pipe drains (profiles/r3b_bwd_dq4.txt).  Everything else goes through iteration().
         auto steady = [&](auto par_tag, int j) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_tag)::value;
-            A::template iter<PAR, 1, 1, 1, 1, 1>(c, slot_lds(j) + a_sub, slot_lds(j + 1) + a_sub, slot_lds(j - 2) + tr_off, 0, 0, 0,
+            A::template iter<PAR, 1, 1, 1, 1, 1>(c, slot_lds(j) + a_sub, slot_lds(j) + a_sub1, slot_lds(j + 1) + a_sub, slot_lds(j + 1) + a_sub1,
+                                                slot_lds(j - 2) + tr_off, 0, 0, 0,
                                                 slot_lds(j + 4) + wave_pb, krs, vrs, (unsigned)((j + 4) * kKB4 * RB), vost[0], vost[1]);
         };
         int steady_end = min(n_w - 1, mask_lo == 0x7fffffff ? mask_lo : mask_lo + 1);   // j + 1 < n_w and block j - 1 below the diagonal
@@ -237,8 +256,8 @@ __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const int r0 = q0w + (lane_o & 31);
-            if (r0 < Sq) dq4_store_rows<T, 0>(reinterpret_cast<char*>(p.dq) + (qbase + r0) * RB, lane_o >> 5, p.scale);
-            if (r0 + 32 < Sq) dq4_store_rows<T, 64>(reinterpret_cast<char*>(p.dq) + (qbase + r0 + 32) * RB, lane_o >> 5, p.scale);
+            if (r0 < Sq) dq4_store_rows<T, 0, D / 8>(reinterpret_cast<char*>(p.dq) + (qbase + r0) * RB, lane_o >> 5, p.scale);
+            if (r0 + 32 < Sq) dq4_store_rows<T, D / 2, D / 8>(reinterpret_cast<char*>(p.dq) + (qbase + r0 + 32) * RB, lane_o >> 5, p.scale);
         }
         __syncthreads();
     }
@@ -246,15 +265,23 @@ __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
 
 template <class T, bool CAUSAL>
 __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(34))) fa_bwd_dq4_kernel(const Dq4Params p) {
-    static_assert(Dq4Asm<T>::NV == 34, "amdgpu_num_vgpr must be the generator's NV");
-    dq4_body<T, CAUSAL>(p);
+    static_assert(Dq4Asm<T, 128>::NV == 34, "amdgpu_num_vgpr must be the generator's NV");
+    dq4_body<T, 128, CAUSAL>(p);
+}
+
+// D = 64: 50 arch VGPRs for hipcc (the attribute takes a literal, hence a kernel of its own)
+template <class T, bool CAUSAL>
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(50))) fa_bwd_dq4_kernel_d64(const Dq4Params p) {
+    static_assert(Dq4Asm<T, 64>::NV == 50, "amdgpu_num_vgpr must be the generator's NV");
+    dq4_body<T, 64, CAUSAL>(p);
 }
 
 #pragma clang diagnostic pop
 
-constexpr int kDq4Lds = kRingQ4 * Dq4Asm<Bf16Traits>::SLOT;
+template <int D>
+constexpr int kDq4Lds = kRingQ4 * Dq4Asm<Bf16Traits, D>::SLOT;
 
-template <class T>
+template <class T, int D>
 int launch_dq4(const BwdArgs& a, float* lse2_out, float* ndelta_out, hipStream_t stream) {
     Dq4Params p;
     p.q = a.q; p.k = a.k; p.v = a.v; p.dout = a.dout; p.o = a.o; p.lse = a.lse;
@@ -267,16 +294,23 @@ int launch_dq4(const BwdArgs& a, float* lse2_out, float* ndelta_out, hipStream_t
     const int nqb = (a.Sq + kQBlock4 - 1) / kQBlock4;
     p.nblk = a.causal ? (nqb + 1) / 2 : nqb;
     const dim3 grid((unsigned)(p.nblk * a.B * a.Hq)), block(256);
-    if (a.causal)
-        hipLaunchKernelGGL((fa_bwd_dq4_kernel<T, true>), grid, block, kDq4Lds, stream, p);
-    else
-        hipLaunchKernelGGL((fa_bwd_dq4_kernel<T, false>), grid, block, kDq4Lds, stream, p);
+    if constexpr (D == 64) {
+        if (a.causal)
+            hipLaunchKernelGGL((fa_bwd_dq4_kernel_d64<T, true>), grid, block, kDq4Lds<64>, stream, p);
+        else
+            hipLaunchKernelGGL((fa_bwd_dq4_kernel_d64<T, false>), grid, block, kDq4Lds<64>, stream, p);
+    } else {
+        if (a.causal)
+            hipLaunchKernelGGL((fa_bwd_dq4_kernel<T, true>), grid, block, kDq4Lds<128>, stream, p);
+        else
+            hipLaunchKernelGGL((fa_bwd_dq4_kernel<T, false>), grid, block, kDq4Lds<128>, stream, p);
+    }
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
-// Shapes the one-wave-per-SIMD dQ kernel can take: 16-bit, D = 128, no window, causal offset >= 0, offsets inside 2 GB
+// Shapes the one-wave-per-SIMD dQ kernel can take: 16-bit, D = 128 or 64, no window, causal offset >= 0, offsets inside 2 GB
 // descriptors.  AULE_HIP_BWD_DQ=new takes it wherever it can run, =old never (A/B, tests); default: the dispatcher's grid rule
 // (fa_bwd_gfx950.hip).
 int bwd_dq4_mode() {
@@ -290,7 +324,7 @@ int bwd_dq4_mode() {
 bool bwd_dq4_applicable(const BwdArgs& a) {
     if (bwd_dq4_mode() == 1) return false;
     if (a.dtype != kBF16 && a.dtype != kF16) return false;
-    if (a.D != 128 || a.window > 0) return false;
+    if ((a.D != 128 && a.D != 64) || a.window > 0) return false;
     if (a.causal && a.coff < 0) return false;
     if (a.Hkv <= 0 || a.Hq % a.Hkv != 0) return false;
     if ((long long)a.Sq * a.D * 2 >= (1LL << 31) || ((long long)a.Sk + 6 * kKB4) * a.D * 2 >= (1LL << 31)) return false;
@@ -298,16 +332,27 @@ bool bwd_dq4_applicable(const BwdArgs& a) {
 }
 
 int launch_bwd_dq4(const BwdArgs& a, float* lse2_out, float* ndelta_out, hipStream_t stream) {
-    if (a.dtype == kBF16) return launch_dq4<Bf16Traits>(a, lse2_out, ndelta_out, stream);
-    if (a.dtype == kF16) return launch_dq4<F16Traits>(a, lse2_out, ndelta_out, stream);
+    if (a.D == 128) {
+        if (a.dtype == kBF16) return launch_dq4<Bf16Traits, 128>(a, lse2_out, ndelta_out, stream);
+        if (a.dtype == kF16) return launch_dq4<F16Traits, 128>(a, lse2_out, ndelta_out, stream);
+    } else if (a.D == 64) {
+        if (a.dtype == kBF16) return launch_dq4<Bf16Traits, 64>(a, lse2_out, ndelta_out, stream);
+        if (a.dtype == kF16) return launch_dq4<F16Traits, 64>(a, lse2_out, ndelta_out, stream);
+    }
     return -1;
 }
 
 int configure_bwd_dq4() {
-    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dq4_kernel<Bf16Traits, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDq4Lds);
-    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dq4_kernel<Bf16Traits, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDq4Lds);
-    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dq4_kernel<F16Traits, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDq4Lds);
-    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dq4_kernel<F16Traits, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDq4Lds);
+    int rc = 0;
+    auto set = [&](const void* f, int lds) { rc |= (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds); };
+    set(reinterpret_cast<const void*>(&fa_bwd_dq4_kernel<Bf16Traits, true>), kDq4Lds<128>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dq4_kernel<Bf16Traits, false>), kDq4Lds<128>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dq4_kernel<F16Traits, true>), kDq4Lds<128>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dq4_kernel<F16Traits, false>), kDq4Lds<128>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dq4_kernel_d64<Bf16Traits, true>), kDq4Lds<64>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dq4_kernel_d64<Bf16Traits, false>), kDq4Lds<64>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dq4_kernel_d64<F16Traits, true>), kDq4Lds<64>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dq4_kernel_d64<F16Traits, false>), kDq4Lds<64>);
     return rc;
 }
 

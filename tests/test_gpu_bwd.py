@@ -68,6 +68,11 @@ SWEEP = [
     ("bf16", 1, 2, 2, 333, 1100, 128, True, None),
     ("bf16", 1, 4, 4, 512, 512, 64, True, None),
     ("bf16", 1, 6, 3, 97, 161, 64, False, 0.5),
+    # ... and their D = 64 instances (round 4: another LDS image, half the MFMAs per block, another register map)
+    ("bf16", 2, 8, 2, 640, 640, 64, True, None),
+    ("bf16", 1, 8, 2, 515, 771, 64, False, None),
+    ("fp16", 2, 4, 1, 1000, 1000, 64, True, 0.11),
+    ("bf16", 1, 2, 2, 333, 1100, 64, True, None),
     ("bf16", 1, 4, 4, 192, 192, 32, True, None),
     ("fp16", 1, 4, 1, 384, 384, 64, False, None),
     ("fp16", 1, 4, 4, 300, 300, 128, True, None),
@@ -169,7 +174,7 @@ def test_backward_deterministic(torch_cuda):
 
 @pytest.mark.parametrize("which", ["new", "old"])
 def test_backward_on_the_one_wave_per_simd_kernels(which):
-    """fa_bwd_dkv4_gfx950.hip (dK/dV) and fa_bwd_dq4_gfx950.hip (dQ) are the backward kernels of the D = 128 16-bit problems without a
+    """fa_bwd_dkv4_gfx950.hip (dK/dV) and fa_bwd_dq4_gfx950.hip (dQ) are the backward kernels of the D = 128 / D = 64 16-bit problems without a
     window whose grids they cover (the dispatcher's rules in fa_bwd_gfx950.hip); their predecessors keep the rest.
     AULE_HIP_BWD_DKV=new + AULE_HIP_BWD_DQ=new force both onto every problem they CAN run, =old pins both predecessors everywhere:
     the sweep, the reference's golden gradients, the bottom-right cases and the determinism test then exercise the masks, the stream

@@ -59,51 +59,62 @@ def test_backward_streams_current_and_kernels_clean(tmp_path, gen, env, inc, hip
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen)], env=dict(os.environ, **{env: str(out)}), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert out.read_text() == open(os.path.join(ROOT, "aule-attention_amd", "csrc", inc)).read(), f"{inc} is stale: run python tools/{gen}"
-    nv = int(re.search(r"NV = (\d+)", out.read_text()).group(1))
+    # hipcc's VGPR budget per head dim (the struct of every (type, D) states its NV; the D = 64 kernels carry _d64 in their names)
+    nvs = {int(d): int(n) for d, n in re.findall(r"struct \w+<\w+, (\d+)> \{\n    static constexpr int NV = (\d+)", out.read_text())}
+    assert set(nvs) == {64, 128}, nvs
+    kt0 = {128: 224, 64: 240}            # dQ kernel: first register of the transposed K fragments
     s = tmp_path / "kernel.s"
     r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-inline-asm", "-S", "--cuda-device-only", "-o", str(s),
                         os.path.join(ROOT, "aule-attention_amd", "csrc", hip)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     text = s.read_text()
-    assert len(re.findall(r"\.private_segment_fixed_size: 0\n", text)) == 4 and ".private_segment_fixed_size: " in text
+    assert len(re.findall(r"\.private_segment_fixed_size: 0\n", text)) == 8 and ".private_segment_fixed_size: " in text
     for key in ("vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size"):
         assert set(re.findall(r"\." + key + r":\s+(\d+)", text)) == {"0"}, key
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import audit_w4 as a
-    inasm, problems, blocks, cur = False, [], [], []
-    for l in text.split("\n"):
-        t = l.strip()
-        if t.startswith(";;#ASMSTART"):
-            inasm, cur = True, []
-        elif t.startswith(";;#ASMEND"):
-            inasm = False
-            blocks.append(cur)
-        elif inasm:
-            cur.append(t)
-        elif t and not t.startswith(";") and not t.startswith("."):
-            if "v_accvgpr" in t or t.startswith("scratch_"):
-                problems.append(t)
-            for x in re.findall(r"\bv(\d+)\b", t) + [y for p, q in re.findall(r"\bv\[(\d+):(\d+)\]", t) for y in (p, q)]:
-                if int(x) >= nv:
+    # the code of each kernel: from its label to s_endpgm
+    kernels = re.findall(r"^(_ZN\S*kernel\S*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
+    assert len(kernels) == 8, [k for k, _ in kernels]
+    nits = 0
+    for name, body in kernels:
+        D = 64 if "_d64" in name else 128
+        nv = nvs[D]
+        inasm, problems, blocks, cur = False, [], [], []
+        for l in body.split("\n"):
+            t = l.strip()
+            if t.startswith(";;#ASMSTART"):
+                inasm, cur = True, []
+            elif t.startswith(";;#ASMEND"):
+                inasm = False
+                blocks.append(cur)
+            elif inasm:
+                cur.append(t)
+            elif t and not t.startswith(";") and not t.startswith("."):
+                if "v_accvgpr" in t or t.startswith("scratch_"):
                     problems.append(t)
-    assert not problems, problems[:5]
-    assert a.lint_blocks(blocks) == []
-    if gen == "gen_dq4.py":
-        # the dQ kernel's iterations are single statements with generator-inserted counted LDS waits: re-derive them from the
-        # compiled text (statements with MFMAs; at most the four fragment reads of the previous statement out at entry)
-        its = [b for b in blocks if any(t.startswith("v_mfma") for t in b)]
-        assert len(its) >= 30
-        for b in its:
-            assert a.lint_lds_waits(b, entry_pending=4) == [], a.lint_lds_waits(b, entry_pending=4)[:3]
-            # ... and the one thing counts cannot see: a transposed K fragment (v224 ..) is requested BEFORE the MFMA that reads it
-            seen = set()
-            for t in b:
-                parts = t.replace(",", " ").split()
-                if parts and parts[0].startswith("ds_read"):
-                    seen |= a._regs(parts[1])
-                elif parts and parts[0].startswith("v_mfma"):
-                    need = {r for r in a._regs(parts[2]) if r[0] == "v" and r[1] >= 224}
-                    assert need <= seen, (t, sorted(need - seen)[:4])
+                for x in re.findall(r"\bv(\d+)\b", t) + [y for p, q in re.findall(r"\bv\[(\d+):(\d+)\]", t) for y in (p, q)]:
+                    if int(x) >= nv:
+                        problems.append(t)
+        assert not problems, (name, problems[:5])
+        assert a.lint_blocks(blocks) == [], name
+        if gen == "gen_dq4.py":
+            # the dQ kernel's iterations are single statements with generator-inserted counted LDS waits: re-derive them from the
+            # compiled text (statements with MFMAs; at most the four fragment reads of the previous statement out at entry)
+            its = [b for b in blocks if any(t.startswith("v_mfma") for t in b)]
+            nits += len(its)
+            for b in its:
+                assert a.lint_lds_waits(b, entry_pending=4) == [], a.lint_lds_waits(b, entry_pending=4)[:3]
+                # ... and the one thing counts cannot see: a transposed K fragment (v224 .. / v240 ..) is requested BEFORE the MFMA that reads it
+                seen = set()
+                for t in b:
+                    parts = t.replace(",", " ").split()
+                    if parts and parts[0].startswith("ds_read"):
+                        seen |= a._regs(parts[1])
+                    elif parts and parts[0].startswith("v_mfma"):
+                        need = {r for r in a._regs(parts[2]) if r[0] == "v" and r[1] >= kt0[D]}
+                        assert need <= seen, (t, sorted(need - seen)[:4])
+    assert gen != "gen_dq4.py" or nits >= 60
 
 
 def test_lds_wait_lint_catches_a_missing_wait():

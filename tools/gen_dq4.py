@@ -46,19 +46,27 @@ XFLAGS = set(x for x in os.environ.get("DQ4_X", "").split(",") if x)
 
 
 class Cfg:
-    def __init__(self, dt):
-        self.D, self.dt = 128, dt
-        self.RB, self.KS, self.DB = 256, 8, 4
+    def __init__(self, D, dt):
+        assert D in (64, 128)
+        self.D, self.dt = D, dt
+        self.RB, self.KS, self.DB = 2 * D, D // 16, D // 32
         self.mfma = "v_mfma_f32_32x32x16_bf16" if dt == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dt == "bf16" else "v_cvt_pk_f16_f32"
-        # the dK/dV kernel's image of a 32-row block (tools/gen_bw4.py: padded sub-tiles, one image serves ds_read_b128 and
-        # the transpose reads): K_b at 0, V_b at IMG of the block's ring slot
-        self.PBASE = [1024 * rg + (0, 16, 128, 144)[rg & 3] + 256 * (rg >> 2) for rg in range(8)]
-        self.IMG = 8704
+        # the dK/dV kernel's image of a 32-row block (tools/gen_bw4.py: D = 128 padded sub-tiles, D = 64 a chunk permutation per
+        # 1 KB piece; one image serves ds_read_b128 and the transpose reads): K_b at 0, V_b at IMG of the block's ring slot
+        if D == 128:
+            self.PBASE = [1024 * rg + (0, 16, 128, 144)[rg & 3] + 256 * (rg >> 2) for rg in range(8)]
+            self.IMG = 8704
+            self.NP = 4                              # LDS-DMA pieces per wave and block (row groups 2 w, 2 w + 1 of K and of V)
+        else:
+            self.PBASE = [1040 * p for p in range(4)]
+            self.IMG = 4352
+            self.NP = 2                              # piece w (rows 8 w .. 8 w + 7) of K and of V
         self.SLOT = 2 * self.IMG
-        self.NP = 4                                  # LDS-DMA pieces per wave and block (row groups 2 w, 2 w + 1 of K and of V)
-        self.DQ, self.QF, self.DF = 0, 128, 192      # accumulator file
-        self.KT = 256 - 32                           # arch VGPRs, top down
+        self.DQ = 0                                  # accumulator file: dQ^T (2 row blocks x DB x 16), Q^T, dO^T fragments (2 x KS x 4 each)
+        self.QF = self.DQ + 32 * self.DB
+        self.DF = self.QF + 8 * self.KS
+        self.KT = 256 - 8 * self.DB                  # arch VGPRs, top down
         self.S = self.KT - 64
         self.DP = self.S - 64
         self.DS = self.DP - 32
@@ -109,15 +117,24 @@ def arith_ops(c, par, rb, q, masked):
 
 def tr_reads(c, kk, d):
     """the two transpose reads of (16-key step kk, d block d) of block j - 2's K image -> KT + 4 (4 kk + d) .. + 3"""
-    b = c.KT + 4 * (4 * kk + d)
-    off, o2 = (c.PBASE[2 * (2 * kk + e)] + 256 * d for e in (0, 1))
+    b = c.KT + 4 * (c.DB * kk + d)
+    if c.D == 128:
+        off, o2 = (c.PBASE[2 * (2 * kk + e)] + 256 * d for e in (0, 1))
+    else:
+        off, o2 = (c.PBASE[2 * kk + e] + 512 * d for e in (0, 1))
     return [f"ds_read_b64_tr_b16 v[{b}:{b + 1}], %[trb] offset:{off}", f"ds_read_b64_tr_b16 v[{b + 2}:{b + 3}], %[trb] offset:{o2}"]
 
 
 def rm_reads(c, ks, base):
     """row-major fragments of k-slice ks (d = 16 ks + 8 hi ..) of a block: K -> KR, V -> VR (buffer ks & 1)"""
-    return [f"ds_read_b128 v[{c.KR + 4 * (ks & 1)}:{c.KR + 4 * (ks & 1) + 3}], {base} offset:{128 * ks}",
-            f"ds_read_b128 v[{c.VR + 4 * (ks & 1)}:{c.VR + 4 * (ks & 1) + 3}], {base} offset:{c.IMG + 128 * ks}"]
+    if c.D == 128:
+        off = 128 * ks
+    else:       # k-slice ks = (d-slice ks >> 1, b = ks & 1): the lane base of that b ("%[ra]" -> "%[rab]"), + 512 d
+        off = 512 * (ks >> 1)
+        if ks & 1:
+            base = base[:-1] + "b]"
+    return [f"ds_read_b128 v[{c.KR + 4 * (ks & 1)}:{c.KR + 4 * (ks & 1) + 3}], {base} offset:{off}",
+            f"ds_read_b128 v[{c.VR + 4 * (ks & 1)}:{c.VR + 4 * (ks & 1) + 3}], {base} offset:{c.IMG + off}"]
 
 
 def regs_of(tok):
@@ -181,10 +198,10 @@ def gen_iter(c, par, qk, nxt, ar, dq, pre):
             grp = []
             for rb in (0, 1):
                 s = tup(c.s(par, rb), 16)
-                grp.append(f"{c.mfma} {s}, v[{c.KR + 4 * (ks & 1)}:{c.KR + 4 * (ks & 1) + 3}], a[{c.QF + 32 * rb + 4 * ks}:{c.QF + 32 * rb + 4 * ks + 3}], {'0' if ks == 0 else s}")
+                grp.append(f"{c.mfma} {s}, v[{c.KR + 4 * (ks & 1)}:{c.KR + 4 * (ks & 1) + 3}], a[{c.QF + 4 * c.KS * rb + 4 * ks}:{c.QF + 4 * c.KS * rb + 4 * ks + 3}], {'0' if ks == 0 else s}")
             for rb in (0, 1):
                 d = tup(c.dp(par, rb), 16)
-                grp.append(f"{c.mfma} {d}, v[{c.VR + 4 * (ks & 1)}:{c.VR + 4 * (ks & 1) + 3}], a[{c.DF + 32 * rb + 4 * ks}:{c.DF + 32 * rb + 4 * ks + 3}], {'0' if ks == 0 else d}")
+                grp.append(f"{c.mfma} {d}, v[{c.VR + 4 * (ks & 1)}:{c.VR + 4 * (ks & 1) + 3}], a[{c.DF + 4 * c.KS * rb + 4 * ks}:{c.DF + 4 * c.KS * rb + 4 * ks + 3}], {'0' if ks == 0 else d}")
             for i, m in enumerate(grp):
                 # behind the last MFMA that reads a buffer of k-slice ks: the read of k-slice ks + 2 into it (K behind the two S
                 # MFMAs, V behind the two dP MFMAs: six MFMAs ahead of its first reader)
@@ -197,8 +214,8 @@ def gen_iter(c, par, qk, nxt, ar, dq, pre):
         for kk in range(2):
             for d in range(c.DB):
                 for rb in (0, 1):
-                    acc = f"a[{c.DQ + 64 * rb + 16 * d}:{c.DQ + 64 * rb + 16 * d + 15}]"
-                    kt = c.KT + 4 * (4 * kk + d)
+                    acc = f"a[{c.DQ + 16 * c.DB * rb + 16 * d}:{c.DQ + 16 * c.DB * rb + 16 * d + 15}]"
+                    kt = c.KT + 4 * (c.DB * kk + d)
                     b = c.ds(par, rb) + 4 * kk       # block j - 2 has parity par
                     mf.append((f"{c.mfma} {acc}, v[{kt}:{kt + 3}], v[{b}:{b + 3}], {acc}", []))
     # floating fillers, in program order: transpose reads first (their MFMAs come last), then the arithmetic
@@ -212,7 +229,7 @@ def gen_iter(c, par, qk, nxt, ar, dq, pre):
         for rb in (0, 1):
             for q in range(4):
                 fl += arith_ops(c, par ^ 1, rb, q, ar == 2)
-    head = ["s_waitcnt vmcnt(8)", "s_barrier"]      # all but the two newest blocks' pieces of this wave: blocks <= j + 1 have landed
+    head = [f"s_waitcnt vmcnt({2 * c.NP})", "s_barrier"]      # all but the two newest blocks' pieces of this wave: blocks <= j + 1 have landed
     if ar == 2:
         head += [f"v_subrev_u32 v{c.THR}, %[k0], %[lim0]", f"v_subrev_u32 v{c.THR + 1}, %[k0], %[lim1]"]   # thr = lim - k0
     if qk and not pre:
@@ -222,7 +239,7 @@ def gen_iter(c, par, qk, nxt, ar, dq, pre):
     # tail: the LDS-DMA requests of block j + 4 and the next block's first fragments
     dma = []
     for img in (0, 1):
-        for half in (0, 1):
+        for half in range(c.NP // 2):
             dma.append((f"s_add_u32 m0, %[dlds], {img * c.IMG + half * 1040}",
                         f"buffer_load_dwordx4 %[vost{half}], {'%[ksrd]' if img == 0 else '%[vsrd]'}, %[dso] offen lds"))
     nx = (rm_reads(c, 0, "%[ra2]") + rm_reads(c, 1, "%[ra2]")) if nxt else []
@@ -238,14 +255,14 @@ def gen_iter(c, par, qk, nxt, ar, dq, pre):
         # over the gaps; the next block's fragments behind the last MFMA that reads KR / VR (or at the very end)
         k = 0
         for g, (m, pin) in enumerate(mf):
-            di = g - (n - 4)
+            di = g - (n - len(dma))
             if di >= 0:
                 lines.append(dma[di][0])
             lines.append(m)
             if di >= 0:
                 lines.append(dma[di][1])
             lines += pin
-            if dq and qk and g < 8:
+            if dq and qk and g < len(trs) // 2:
                 lines += trs[2 * g:2 * g + 2]      # the transpose reads ride on the first eight gaps, 24 MFMAs ahead of their readers
             if nx and g == ndq0 - 1:
                 lines += nx
@@ -288,12 +305,16 @@ def gen_iter(c, par, qk, nxt, ar, dq, pre):
         if ar == 2:
             clob += ["vcc"] + vregs(c.THR, 2)
     if dq:
-        clob += vregs(c.KT, 32) + aregs(c.DQ, 128)
+        clob += vregs(c.KT, 8 * c.DB) + aregs(c.DQ, 32 * c.DB)
     ins = ['[dlds] "s"(dlds)', '[ksrd] "s"(ksrd)', '[vsrd] "s"(vsrd)', '[dso] "s"(dso)', '[vost0] "v"(vost0)', '[vost1] "v"(vost1)']
     if qk:
         ins.append('[ra] "v"(ra)')
+        if c.D == 64:
+            ins.append('[rab] "v"(rab)')
     if nxt:
         ins.append('[ra2] "v"(ra2)')
+        if c.D == 64:
+            ins.append('[ra2b] "v"(ra2b)')
     if ar:
         ins.append('[c] "s"(c)')
         if ar == 2:
@@ -304,17 +325,17 @@ def gen_iter(c, par, qk, nxt, ar, dq, pre):
 
 
 def gen_struct(c):
-    name = f"Dq4Asm<{'Bf16Traits' if c.dt == 'bf16' else 'F16Traits'}>"
+    name = f"Dq4Asm<{'Bf16Traits' if c.dt == 'bf16' else 'F16Traits'}, {c.D}>"
     s = f"template <> struct {name} {{\n"
-    s += (f"    static constexpr int NV = {c.NV}, NP = {c.NP}, SLOT = {c.SLOT}, IMG = {c.IMG}, PB1 = {c.PBASE[1]}, PB2 = {c.PBASE[2]}, PB4 = {c.PBASE[4]};\n"
+    s += (f"    static constexpr int NV = {c.NV}, NP = {c.NP}, SLOT = {c.SLOT}, IMG = {c.IMG}, PB1 = {c.PBASE[1]}, PB2 = {c.PBASE[2]}, PB4 = {c.PBASE[4] if len(c.PBASE) > 4 else 0};\n"
           f"    static constexpr int SC = {c.SC}, QF = {c.QF}, DF = {c.DF};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n")
     s += ("    // iteration j (PAR = j & 1): S / dP of block j (QK; PRE: its first fragments were requested by the previous statement),\n"
           "    // arithmetic of block j - 1 (AR: 1 plain, 2 masked), dQ of block j - 2 (DQ), first fragments of block j + 1 (NXT)\n"
           "    template <int PAR, int QK, int NXT, int AR, int DQ, int PRE>\n"
-          "    static __device__ __forceinline__ void iter(float c, unsigned ra, unsigned ra2, unsigned trb, int lim0, int lim1, int k0, unsigned dlds,\n"
+          "    static __device__ __forceinline__ void iter(float c, unsigned ra, unsigned rab, unsigned ra2, unsigned ra2b, unsigned trb, int lim0, int lim1, int k0, unsigned dlds,\n"
           "                                                __amdgpu_buffer_rsrc_t ksrd, __amdgpu_buffer_rsrc_t vsrd, unsigned dso, unsigned vost0, unsigned vost1) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
-          "        (void)c; (void)ra; (void)ra2; (void)trb; (void)lim0; (void)lim1; (void)k0;\n"
+          "        (void)c; (void)ra; (void)rab; (void)ra2; (void)ra2b; (void)trb; (void)lim0; (void)lim1; (void)k0;\n"
           "        dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n        dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n"
           "        k0 = __builtin_amdgcn_readfirstlane(k0);\n")
     first = True
@@ -332,24 +353,24 @@ def gen_struct(c):
     lines = ["s_nop 4"]
     for rb in (0, 1):
         for ks in range(c.KS):
-            lines.append(f"buffer_load_dwordx4 a[{c.QF + 32 * rb + 4 * ks}:{c.QF + 32 * rb + 4 * ks + 3}], %[vo{rb}], %[qsrd], 0 offen offset:{32 * ks}")
-            lines.append(f"buffer_load_dwordx4 a[{c.DF + 32 * rb + 4 * ks}:{c.DF + 32 * rb + 4 * ks + 3}], %[vo{rb}], %[gsrd], 0 offen offset:{32 * ks}")
+            lines.append(f"buffer_load_dwordx4 a[{c.QF + 4 * c.KS * rb + 4 * ks}:{c.QF + 4 * c.KS * rb + 4 * ks + 3}], %[vo{rb}], %[qsrd], 0 offen offset:{32 * ks}")
+            lines.append(f"buffer_load_dwordx4 a[{c.DF + 4 * c.KS * rb + 4 * ks}:{c.DF + 4 * c.KS * rb + 4 * ks + 3}], %[vo{rb}], %[gsrd], 0 offen offset:{32 * ks}")
             # (the same fragments of O, for delta = rowsum(O * dO), into the dQ accumulators: zeroed afterwards)
-            lines.append(f"buffer_load_dwordx4 a[{32 * rb + 4 * ks}:{32 * rb + 4 * ks + 3}], %[vo{rb}], %[osrd], 0 offen offset:{32 * ks}")
+            lines.append(f"buffer_load_dwordx4 a[{4 * c.KS * rb + 4 * ks}:{4 * c.KS * rb + 4 * ks + 3}], %[vo{rb}], %[osrd], 0 offen offset:{32 * ks}")
     lines.append("s_waitcnt vmcnt(0)")
     s += ("    static __device__ __forceinline__ void load_frags(__amdgpu_buffer_rsrc_t qsrd, __amdgpu_buffer_rsrc_t gsrd, __amdgpu_buffer_rsrc_t osrd, unsigned vo0, unsigned vo1) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n")
-    s += emit_asm(lines, [], ['[qsrd] "s"(qsrd)', '[gsrd] "s"(gsrd)', '[osrd] "s"(osrd)', '[vo0] "v"(vo0)', '[vo1] "v"(vo1)'], ["memory"] + aregs(c.QF, 128) + aregs(0, 64), indent="        ")
+    s += emit_asm(lines, [], ['[qsrd] "s"(qsrd)', '[gsrd] "s"(gsrd)', '[osrd] "s"(osrd)', '[vo0] "v"(vo0)', '[vo1] "v"(vo1)'], ["memory"] + aregs(c.QF, 16 * c.KS) + aregs(0, 8 * c.KS), indent="        ")
     s += "#endif\n    }\n"
     # ---- accumulators to zero
-    lines = [f"v_accvgpr_write_b32 a{i}, 0" for i in range(128)]
+    lines = [f"v_accvgpr_write_b32 a{i}, 0" for i in range(32 * c.DB)]
     s += "    static __device__ __forceinline__ void zero_acc() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
-    s += emit_asm(lines, [], [], aregs(0, 128), indent="        ")
+    s += emit_asm(lines, [], [], aregs(0, 32 * c.DB), indent="        ")
     s += "#endif\n    }\n"
     # ---- the LDS-DMA pieces of one block as a statement of its own (stream start)
     lines = ["s_nop 4"]
     for img in (0, 1):
-        for half in (0, 1):
+        for half in range(c.NP // 2):
             lines += [f"s_add_u32 m0, %[dlds], {img * c.IMG + half * 1040}", "s_nop 0",
                       f"buffer_load_dwordx4 %[vost{half}], {'%[ksrd]' if img == 0 else '%[vsrd]'}, %[dso] offen lds"]
     s += ("    static __device__ __forceinline__ void dma_block(unsigned dlds, __amdgpu_buffer_rsrc_t ksrd, __amdgpu_buffer_rsrc_t vsrd, unsigned dso,\n"
@@ -371,13 +392,16 @@ def main():
     hdr = ("// fa_bwd_dq4_asm.inc -- GENERATED by tools/gen_dq4.py (do not edit; edit the generator and re-run it).\n"
            "// Instruction streams of the one-wave-per-SIMD dQ kernel: register map, pipeline and hazards in the generator's docstring.\n"
            "// Included by fa_bwd_dq4_gfx950.hip inside namespace aule_hip::{anonymous}.\n\n"
-           "template <class T> struct Dq4Asm;\n\n")
+           "template <class T, int D> struct Dq4Asm;\n\n")
     body = ""
-    for dt in ("bf16", "fp16"):
-        body += gen_struct(Cfg(dt))
+    for D in (128, 64):
+        for dt in ("bf16", "fp16"):
+            body += gen_struct(Cfg(D, dt))
     with open(OUT, "w") as fh:
         fh.write(hdr + body)
-    c = Cfg("bf16")
+    for D in (128, 64):
+        c = Cfg(D, "bf16")
+        print(f"D={D}: NV={c.NV} THR={c.THR} SC={c.SC} T={c.T} VR={c.VR} KR={c.KR} DS={c.DS} DP={c.DP} S={c.S} KT={c.KT}; acc DQ={c.DQ} QF={c.QF} DF={c.DF}")
     print(f"wrote {OUT}: {len((hdr + body).splitlines())} lines; NV={c.NV} THR={c.THR} SC={c.SC} T={c.T} VR={c.VR} KR={c.KR} DS={c.DS} DP={c.DP} S={c.S} KT={c.KT}")
 
 
