@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dq_f32_kernel(con
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const WorkItem w = decode_work(blockIdx.x, p.B, p.Hq, p.Hkv, p.nblk, CAUSAL);
+    const WorkItem w = decode_work_ranked(blockIdx.x, p.B, p.Hq, p.Hkv, p.nblk, CAUSAL);   // (causal: every unit's last block first)
     const int Sq = p.Sq, Sk = p.Sk;
     const int q0w = w.blk * kRows + wave * 32;
     const int qrow = q0w + l31;
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dkdv_f32_kernel(c
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = p.Hq / p.Hkv;
-    const WorkItem w = decode_work(blockIdx.x, p.B, p.Hkv, p.Hkv, p.nblk, false);
+    const WorkItem w = decode_work_ranked(blockIdx.x, p.B, p.Hkv, p.Hkv, p.nblk, false);   // (key block 0 sees the most queries: first)
     const int Sq = p.Sq, Sk = p.Sk;
     const int n0w = w.blk * kRows + wave * 32;
     const int kvrow = n0w + l31;

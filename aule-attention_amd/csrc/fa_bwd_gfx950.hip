@@ -1098,7 +1098,8 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
         const int nqb = (a.Sq + kDqQBlock - 1) / kDqQBlock;
         return (long long)a.B * a.Hq * (a.causal ? (nqb + 1) / 2 : nqb);
     };
-    const bool use_dq4 = (D == 128 || D == 64) && a.dbg_dq == nullptr && bwd_dq4_applicable(a) && (bwd_dq4_mode() == 2 || dq4_items() >= 128);
+    // D = 64 (round 4): ahead on small grids too (16 .. 64 work items: +1.9 .. +7.5 % on the whole backward, profiles/r4_bwd_d64_dkv4.txt) -- no grid rule there.
+    const bool use_dq4 = (D == 128 || D == 64) && a.dbg_dq == nullptr && bwd_dq4_applicable(a) && (bwd_dq4_mode() == 2 || D == 64 || dq4_items() >= 128);
     if (only != 2 && use_dq4) {
         int rc = launch_bwd_dq4(a, p.lse2_out, p.ndelta_out, stream);
         if (rc) return rc;

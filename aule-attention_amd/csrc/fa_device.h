@@ -149,4 +149,36 @@ __device__ __forceinline__ WorkItem decode_work(int bid, int B, int Hq, int Hkv,
     return w;
 }
 
+// The same work items in RANK order: block rank 0 of every unit (and every query head of its group), then rank 1 of every unit, ...
+// (descending: rank r = block nblk - 1 - r).  For causal kernels that do not pair their blocks -- the fp32 forward and backward: a
+// workgroup's time grows with its block index -- decode_work's per-unit sawtooth (64, 60, .., 4 | 64, 60, .. tiles at S = 2048) leaves
+// an XCD's in-order dispatch with a long tail: list scheduling of 16 units on 32 one-workgroup CUs reaches 91 % of the ideal, on 64
+// slots (two workgroups per CU) 80 %; all units' heaviest blocks first is within 1 % (round 4: tools/README.md, f32 kernels).  A unit
+// still belongs to one XCD (its K / V stay in that XCD's L2).
+__device__ __forceinline__ WorkItem decode_work_ranked(int bid, int B, int Hq, int Hkv, int nblk, bool descending) {
+    const int g = Hq / Hkv;
+    const int units = B * Hkv;
+    int unit, hq, rank;
+    if ((units & 7) == 0) {
+        const int xcd = bid & 7, j = bid >> 3;
+        const int per_rank = (units >> 3) * g;   // work items of one rank on this XCD
+        rank = j / per_rank;
+        const int r = j % per_rank;
+        unit = xcd + 8 * (r / g);
+        hq = r % g;
+    } else {
+        const int per_rank = units * g;
+        rank = bid / per_rank;
+        const int r = bid % per_rank;
+        unit = r / g;
+        hq = r % g;
+    }
+    WorkItem w;
+    w.b = unit / Hkv;
+    w.hk = unit % Hkv;
+    w.h = w.hk * g + hq;
+    w.blk = descending ? (nblk - 1 - rank) : rank;
+    return w;
+}
+
 }  // namespace aule_hip

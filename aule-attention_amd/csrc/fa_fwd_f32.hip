@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256, 2) fa_fwd_f32_kernel(const FwdF32Params p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
 
-    const WorkItem w = decode_work(blockIdx.x, p.B, p.Hq, p.Hkv, p.nqb, CAUSAL);
+    const WorkItem w = decode_work_ranked(blockIdx.x, p.B, p.Hq, p.Hkv, p.nqb, CAUSAL);   // (causal: every unit's last block first)
     const int Sq = p.Sq, Sk = p.Sk;
     const int q0w = w.blk * kQB + wave * 32;
     const int qrow = q0w + l31;

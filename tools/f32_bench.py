@@ -33,3 +33,5 @@ print("lib:", os.environ.get("AULE_LIBRARY_PATH", "(in-tree)"))
 run(1, 8, 8, 2048, 64, True); run(4, 32, 32, 2048, 64, True); run(4, 32, 32, 2048, 128, True); run(4, 32, 32, 2048, 128, False)
 run(2, 32, 8, 4096, 128, True); run(1, 8, 8, 256, 64, True)
 run(4, 32, 32, 2048, 64, True, True); run(4, 32, 32, 2048, 128, True, True)
+# the legacy C-ABI benchmark's shape (the reference's tests/benchmark_attention.zig:18-21: B4 H8 S512 D64, non-causal there) and a GQA one
+run(4, 8, 8, 512, 64, False); run(4, 8, 8, 512, 64, False, True); run(4, 8, 8, 512, 64, True, True); run(2, 32, 8, 4096, 128, True, True); run(4, 32, 32, 2048, 128, False, True)
