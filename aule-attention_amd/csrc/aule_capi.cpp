@@ -1145,6 +1145,15 @@ int32_t aule_hip_debug_forward_split_plan(const aule_attn_desc* d, int32_t* out,
     return aule_hip::fwd_split_plan_dump(a, out, cap);
 }
 
+int32_t aule_hip_debug_work_order(int32_t ranked, int32_t bid, int32_t batch, int32_t heads_q, int32_t heads_kv, int32_t nblk, int32_t flag, int32_t* out4) {
+    if (out4 == nullptr || batch <= 0 || heads_kv <= 0 || heads_q <= 0 || heads_q % heads_kv != 0 || nblk <= 0) return -3;
+    if (bid < 0 || (int64_t)bid >= (int64_t)batch * heads_q * nblk) return -3;
+    int o[4];
+    aule_hip::work_order_dump(ranked, bid, batch, heads_q, heads_kv, nblk, flag, o);
+    for (int i = 0; i < 4; ++i) out4[i] = o[i];
+    return 0;
+}
+
 #ifdef AULE_DEBUG_HOOKS
 /* Debug hook (debug library only): bf16 D=128 forward with per-phase s_memtime stamps of workgroup 0 written to
  * `stamps` (device pointer; 8 * 256 uint64 for the ping-pong kernel, 8 * 2048 with AULE_TL=ps for the tile stream).

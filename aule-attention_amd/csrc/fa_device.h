@@ -127,7 +127,7 @@ struct WorkItem {
     int b, hk, h, blk;
 };
 
-__device__ __forceinline__ WorkItem decode_work(int bid, int B, int Hq, int Hkv, int nblk, bool heavy_first) {
+__host__ __device__ __forceinline__ WorkItem decode_work(int bid, int B, int Hq, int Hkv, int nblk, bool heavy_first) {
     const int g = Hq / Hkv;
     const int per_unit = g * nblk;
     const int units = B * Hkv;
@@ -155,7 +155,7 @@ __device__ __forceinline__ WorkItem decode_work(int bid, int B, int Hq, int Hkv,
 // an XCD's in-order dispatch with a long tail: list scheduling of 16 units on 32 one-workgroup CUs reaches 91 % of the ideal, on 64
 // slots (two workgroups per CU) 80 %; all units' heaviest blocks first is within 1 % (round 4: tools/README.md, f32 kernels).  A unit
 // still belongs to one XCD (its K / V stay in that XCD's L2).
-__device__ __forceinline__ WorkItem decode_work_ranked(int bid, int B, int Hq, int Hkv, int nblk, bool descending) {
+__host__ __device__ __forceinline__ WorkItem decode_work_ranked(int bid, int B, int Hq, int Hkv, int nblk, bool descending) {
     const int g = Hq / Hkv;
     const int units = B * Hkv;
     int unit, hq, rank;

@@ -225,4 +225,9 @@ int launch_fwd_f32(const FwdArgs& a, hipStream_t stream) {
 
 int configure_fwd_f32() { return 0; }
 
+void work_order_dump(int ranked, int bid, int B, int Hq, int Hkv, int nblk, int flag, int* out4) {
+    const WorkItem w = ranked ? decode_work_ranked(bid, B, Hq, Hkv, nblk, flag != 0) : decode_work(bid, B, Hq, Hkv, nblk, flag != 0);
+    out4[0] = w.b; out4[1] = w.hk; out4[2] = w.h; out4[3] = w.blk;
+}
+
 }  // namespace aule_hip

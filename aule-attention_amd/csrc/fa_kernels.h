@@ -151,6 +151,8 @@ int fwd_route(const FwdArgs& a);
 bool fwd_rope_fusable(const FwdArgs& a);
 // the split plan of route 7 as integers (tests): fwd_split_plan_dump in fa_fwd_w4_gfx950.hip, the plan itself in fa_fwd_split.h
 int fwd_split_plan_dump(const FwdArgs& a, int* out, int cap);
+// blockIdx -> (batch, kv head, q head, block) of decode_work (ranked = 0) / decode_work_ranked (1) on the host (tests): fa_fwd_f32.hip
+void work_order_dump(int ranked, int bid, int B, int Hq, int Hkv, int nblk, int flag, int* out4);
 // bytes of workspace launch_fwd / launch_paged_decode would allocate for these arguments (0: single-launch path)
 uint64_t fwd_workspace_bytes(FwdArgs a);
 uint64_t paged_workspace_bytes(PagedArgs a);   // 0 fp32, 1 ping-pong, 2 in-wave, 3 v1, 4 split-KV, 5 tiled + packed rows + KV splits (host logic only)

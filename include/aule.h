@@ -258,13 +258,17 @@ uint64_t aule_attention_backward_workspace_size(const aule_attn_bwd_desc* desc);
 /* Build/ABI identification: "aule-hip gfx950 <abi>" */
 const char* aule_hip_build_info(void);
 /* Debug (not part of the drop-in ABI): forward kernel aule_attention_forward_ex would pick for `desc` --        */
-/* 0 fp32, 1 ping-pong, 4 split-KV, 5 tiled split, 6 tile stream, 7 tile stream + causal split; -3 bad descriptor. */
+/* 0 fp32, 1 ping-pong, 4 split-KV, 5 tiled split, 7 one wave per SIMD over key-range pieces, 8 one wave per SIMD; -3 bad. */
 /* Host logic only, no aule_init().                                                                                  */
 int32_t aule_hip_debug_forward_route(const aule_attn_desc* desc);
 /* Debug: the causal-split plan of route 7 (small causal grids) as integers -- out = {pieces n, pairs, then per pair of   */
 /* Q blocks: tiles of the far block, of the near block, cut positions b[0..8]}; returns the ints written (negative: the */
 /* capacity needed), 0 when the shape does not take that route.  Host logic only.                                       */
 int32_t aule_hip_debug_forward_split_plan(const aule_attn_desc* desc, int32_t* out, int32_t cap);
+/* Debug: the work item of workgroup `bid` of a grid of batch * heads_q * nblk workgroups -- out4 = {batch, kv head, q head,  */
+/* block}.  ranked = 0: unit by unit (flag: last block first), the 16-bit kernels; ranked = 1: block rank by block rank over  */
+/* all units (flag: descending), the fp32 kernels.  Host logic only; -3 on a bad argument.                                    */
+int32_t aule_hip_debug_work_order(int32_t ranked, int32_t bid, int32_t batch, int32_t heads_q, int32_t heads_kv, int32_t nblk, int32_t flag, int32_t* out4);
 
 /* ---- Direct peer exchange between the per-GPU processes of one node (additive; no counterpart in the reference, which  */
 /* is single-device: SURVEY.md 8e).  A rank allocates its receive buffer here, publishes the 64-byte handle by any means    */

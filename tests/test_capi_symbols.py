@@ -290,3 +290,38 @@ def test_causal_split_plan_invariants(monkeypatch):
         seen += 1
         ns.add(n)
     assert seen > 100 and {2, 4, 8} <= ns, (seen, ns)
+
+
+@pytest.mark.parametrize("ranked", [0, 1])
+def test_work_order_covers_every_work_item_once(ranked):
+    """blockIdx -> (batch, kv head, q head, block) of the tiled kernels (fa_device.h: decode_work, unit by unit; decode_work_ranked,
+    block rank by block rank over all units -- the fp32 kernels since round 4), through aule_hip_debug_work_order (host logic):
+    every (batch, q head, block) exactly once, the kv head is the q head's group, a unit stays on one XCD (blockIdx % 8) when the
+    unit count is a multiple of 8, and in rank order the blocks come heaviest first over ALL units."""
+    from aule import _capi
+    lib = _capi.load()
+    f = lib.aule_hip_debug_work_order
+    f.restype = ctypes.c_int32
+    f.argtypes = [ctypes.c_int32] * 7 + [ctypes.POINTER(ctypes.c_int32)]
+    out = (ctypes.c_int32 * 4)()
+    assert f(ranked, 0, 1, 3, 2, 4, 0, out) == -3 and f(ranked, 8, 1, 2, 2, 4, 0, out) == -3 and f(ranked, 0, 1, 2, 2, 4, 0, None) == -3
+    for (B, Hq, Hkv, nblk) in ((1, 8, 8, 16), (4, 32, 8, 7), (3, 6, 2, 5), (2, 4, 4, 1), (1, 5, 1, 9), (16, 16, 16, 3), (1, 1, 1, 1)):
+        for flag in (0, 1):
+            n = B * Hq * nblk
+            seen, xcd_of_unit, blks = set(), {}, []
+            for bid in range(n):
+                assert f(ranked, bid, B, Hq, Hkv, nblk, flag, out) == 0
+                b, hk, h, blk = out[0], out[1], out[2], out[3]
+                assert 0 <= b < B and 0 <= h < Hq and 0 <= blk < nblk and hk == h // (Hq // Hkv)
+                seen.add((b, h, blk))
+                blks.append(blk)
+                if (B * Hkv) % 8 == 0:
+                    assert xcd_of_unit.setdefault((b, hk), bid % 8) == bid % 8
+            assert len(seen) == n
+            if ranked and (B * Hkv) % 8 != 0:
+                want = sorted(blks, reverse=bool(flag))
+                assert blks == want                       # one global sequence of ranks
+            elif ranked:
+                for x in range(8):                        # per XCD: its sequence of ranks
+                    mine = blks[x::8]
+                    assert mine == sorted(mine, reverse=bool(flag))
