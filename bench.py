@@ -553,6 +553,53 @@ def main():
                                 "rope_attn_c2_workload": "RoPE + attention, B=4 H=32 S=2048 D=128 bf16 causal, inference: rope(K) pass + the "
                                                          "one-wave-per-SIMD forward with Q rotated inside it (attention FLOPs only)"})
         del q7, k7, v7
+        # D = 64 training (the one-wave-per-SIMD backward pair's D = 64 instances, round 4) and the fp32 kernels (what the legacy
+        # C-ABI and NumPy / fp32 torch input run; priced against the 157.3 TF f32-MFMA roof, not the bf16 peak)
+        q8 = torch.randn(8, 32, 2048, 64, device=dev, dtype=torch.bfloat16, generator=g3).requires_grad_(True)
+        k8 = torch.randn(8, 32, 2048, 64, device=dev, dtype=torch.bfloat16, generator=g3).requires_grad_(True)
+        v8 = torch.randn(8, 32, 2048, 64, device=dev, dtype=torch.bfloat16, generator=g3).requires_grad_(True)
+        d8 = torch.randn(8, 32, 2048, 64, device=dev, dtype=torch.bfloat16, generator=g3)
+
+        def step8():
+            q8.grad = k8.grad = v8.grad = None
+            aule.flash_attention(q8, k8, v8, causal=True).backward(d8)
+
+        def step8f():
+            aule.flash_attention(q8, k8, v8, causal=True)
+
+        condition(step8, args.condition_ms)
+        _, ms8 = timed(step8, 20)
+        _, ms8f = timed(step8f, 20)
+        f8 = fwd_flops(8, 32, 2048, 2048, 64, True)
+        b8 = (ms8 - ms8f) / 20
+        result["extra"].update({"d64_fwd_bwd_tflops": 3.5 * f8 / (ms8 / 20 * 1e-3) / 1e12, "d64_bwd_ms": b8,
+                                "d64_bwd_tflops": 2.5 * f8 / (b8 * 1e-3) / 1e12, "d64_bwd_frac": 2.5 * f8 / (b8 * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
+                                "d64_workload": "MHA B=8 H=32 S=2048 D=64 bf16 causal fwd+bwd (autograd); bwd = step - fwd-only step"})
+        del q8, k8, v8, d8
+        F32_ROOF = 157.3
+        q9 = torch.randn(4, 32, 2048, 64, device=dev, dtype=torch.float32, generator=g3).requires_grad_(True)
+        k9 = torch.randn(4, 32, 2048, 64, device=dev, dtype=torch.float32, generator=g3).requires_grad_(True)
+        v9 = torch.randn(4, 32, 2048, 64, device=dev, dtype=torch.float32, generator=g3).requires_grad_(True)
+        d9 = torch.randn(4, 32, 2048, 64, device=dev, dtype=torch.float32, generator=g3)
+
+        def step9():
+            q9.grad = k9.grad = v9.grad = None
+            aule.flash_attention(q9, k9, v9, causal=True).backward(d9)
+
+        def step9f():
+            aule.flash_attention(q9, k9, v9, causal=True)
+
+        condition(step9, args.condition_ms)
+        _, ms9 = timed(step9, 10)
+        _, ms9f = timed(step9f, 10)
+        f9 = fwd_flops(4, 32, 2048, 2048, 64, True)
+        b9 = (ms9 - ms9f) / 10
+        result["extra"].update({"f32_fwd_tflops": f9 / (ms9f / 10 * 1e-3) / 1e12, "f32_fwd_frac_of_f32_roof": f9 / (ms9f / 10 * 1e-3) / 1e12 / F32_ROOF,
+                                "f32_bwd_tflops": 2.5 * f9 / (b9 * 1e-3) / 1e12, "f32_bwd_frac_of_f32_roof": 2.5 * f9 / (b9 * 1e-3) / 1e12 / F32_ROOF,
+                                "f32_roof_tflops": F32_ROOF,
+                                "f32_workload": "MHA B=4 H=32 S=2048 D=64 fp32 causal (v_mfma_f32_32x32x2_f32 kernels: the legacy C-ABI's dtype), "
+                                                "fwd-only step and fwd+bwd step (autograd); bwd = difference"})
+        del q9, k9, v9, d9
         # Power: the same C2 forward on ALL-ZERO inputs (the same launch, the same instruction stream, the same MFMA count; no
         # data-dependent switching in the matrix pipes, the register files and LDS).  The distance between this figure and
         # `steady_state` is what the chip's power cap costs on N(0,1) data: the clock it sustains, not the kernel's schedule

@@ -30,6 +30,11 @@ def run(B, Hq, Hkv, S, D, causal, bwd=False):
 
 
 print("lib:", os.environ.get("AULE_LIBRARY_PATH", "(in-tree)"))
+if len(sys.argv) > 1 and sys.argv[1] == "bwd":      # the backward shapes only (A/B of the backward kernels)
+    for a in ((4, 32, 32, 2048, 64, True), (4, 32, 32, 2048, 128, True), (4, 32, 32, 2048, 128, False), (2, 32, 8, 4096, 128, True),
+              (4, 32, 32, 2048, 64, False), (8, 16, 16, 1024, 64, True)):
+        run(*a, True)
+    sys.exit(0)
 run(1, 8, 8, 2048, 64, True); run(4, 32, 32, 2048, 64, True); run(4, 32, 32, 2048, 128, True); run(4, 32, 32, 2048, 128, False)
 run(2, 32, 8, 4096, 128, True); run(1, 8, 8, 256, 64, True)
 run(4, 32, 32, 2048, 64, True, True); run(4, 32, 32, 2048, 128, True, True)
