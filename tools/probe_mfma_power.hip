@@ -6,6 +6,8 @@
 // body) -- the switching activity of a real kernel's matrix pipes and register files, nothing else.  Whatever TFLOP/s this sustains
 // under the power cap is an upper bound for ANY attention kernel on N(0,1) data on this chip.
 //   mode 0: MFMAs only      mode 1: + 4 v_fma_f32 on random data per MFMA      mode 2: + one ds_read_b128 per MFMA
+//   mode 3: v_mfma_f32_16x16x32_bf16 only (same FLOPs per cycle, a quarter of the accumulator registers per instruction: is its
+//           energy per FLOP -- and so the ceiling at the power limit -- another one?)
 //   hipcc -O2 --offload-arch=gfx950 -Itools tools/probe_mfma_power.hip -o build/probe_mfma_power -lpthread
 //   build/probe_mfma_power <seconds> <amp> <mode> [label]
 #include <hip/hip_runtime.h>
@@ -38,6 +40,24 @@ __global__ void __launch_bounds__(256, 1) kmfma(const bf16x8* __restrict__ ops, 
     const float g = (float)b[0][0] * 0.25f;
     f32x4 ld = {0.f, 0.f, 0.f, 0.f};
     const f32x4* lp = reinterpret_cast<const f32x4*>(lds) + (t & 63);
+    if constexpr (MODE == 3) {
+        f32x4 c4[16];
+        for (int d = 0; d < 16; ++d) c4[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {      // 128 x 16384 FLOP per lane-group = the 64 x 32768 of the other modes
+                    const int ai = (j + (j >> 3)) & 7, bi = j & 7, ci = j & 15;
+                    c4[ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s == 0 ? a[ai] : n[ai], b[bi], c4[ci], 0, 0, 0);
+                }
+            }
+        }
+        float sum4 = 0.f;
+        for (int d = 0; d < 16; ++d) sum4 += c4[d][0] + c4[d][1] + c4[d][2] + c4[d][3];
+        out[blockIdx.x * 256 + t] = sum4;
+        return;
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -84,7 +104,8 @@ int main(int argc, char** argv) {
     auto launch = [&](int nit) {
         if (mode == 0) kmfma<0><<<256, 256>>>((const bf16x8*)ops, out, nit);
         else if (mode == 1) kmfma<1><<<256, 256>>>((const bf16x8*)ops, out, nit);
-        else kmfma<2><<<256, 256>>>((const bf16x8*)ops, out, nit);
+        else if (mode == 2) kmfma<2><<<256, 256>>>((const bf16x8*)ops, out, nit);
+        else kmfma<3><<<256, 256>>>((const bf16x8*)ops, out, nit);
     };
     launch(10); CK(hipDeviceSynchronize());
     PowerSampler ps;
