@@ -6,6 +6,8 @@
 // body) -- the switching activity of a real kernel's matrix pipes and register files, nothing else.  Whatever TFLOP/s this sustains
 // under the power cap is an upper bound for ANY attention kernel on N(0,1) data on this chip.
 //   mode 0: MFMAs only      mode 1: + 4 v_fma_f32 on random data per MFMA      mode 2: + one ds_read_b128 per MFMA
+//   mode 4 / 5: mode 0 with the A operand shared by 2 / 4 consecutive MFMAs (what a kernel whose fragment reads feed two or four row
+//           blocks issues: does holding one operand still save switching energy?)
 //   mode 3: v_mfma_f32_16x16x32_bf16 only (same FLOPs per cycle, a quarter of the accumulator registers per instruction: is its
 //           energy per FLOP -- and so the ceiling at the power limit -- another one?)
 //   hipcc -O2 --offload-arch=gfx950 -Itools tools/probe_mfma_power.hip -o build/probe_mfma_power -lpthread
@@ -63,7 +65,8 @@ __global__ void __launch_bounds__(256, 1) kmfma(const bf16x8* __restrict__ ops, 
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
-                const int ai = (j + (j >> 3)) & 7, bi = j & 7, ci = j & 7;
+                const int jj = MODE == 4 ? (j >> 1) : (MODE == 5 ? (j >> 2) : j);
+                const int ai = (jj + (jj >> 3)) & 7, bi = j & 7, ci = j & 7;
                 acc[ci] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s == 0 ? a[ai] : n[ai], b[bi], acc[ci], 0, 0, 0);
                 if constexpr (MODE == 1) {
                     f0 = __builtin_fmaf(f0, g, f1); f1 = __builtin_fmaf(f1, g, f2); f2 = __builtin_fmaf(f2, g, f3); f3 = __builtin_fmaf(f3, g, f0);
@@ -105,6 +108,8 @@ int main(int argc, char** argv) {
         if (mode == 0) kmfma<0><<<256, 256>>>((const bf16x8*)ops, out, nit);
         else if (mode == 1) kmfma<1><<<256, 256>>>((const bf16x8*)ops, out, nit);
         else if (mode == 2) kmfma<2><<<256, 256>>>((const bf16x8*)ops, out, nit);
+        else if (mode == 4) kmfma<4><<<256, 256>>>((const bf16x8*)ops, out, nit);
+        else if (mode == 5) kmfma<5><<<256, 256>>>((const bf16x8*)ops, out, nit);
         else kmfma<3><<<256, 256>>>((const bf16x8*)ops, out, nit);
     };
     launch(10); CK(hipDeviceSynchronize());
