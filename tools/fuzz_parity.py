@@ -184,6 +184,13 @@ def run_split(rng, i):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "one":
+        # one configuration again: python tools/fuzz_parity.py one bf16 1 4 2 31 500 128 br -1 0.3 1001   (scale: a number or "none")
+        a = sys.argv[2:]
+        cfg = (a[0], int(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[5]), int(a[6]), a[7], int(a[8]), None if a[9] == "none" else float(a[9]))
+        r, errs = run(cfg, int(a[10]))
+        print(f"route={r} cfg={cfg}: {'; '.join(errs) if errs else 'clean'}")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "split":
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 40; seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
         rng = np.random.RandomState(seed); bad = 0; routes = {}
