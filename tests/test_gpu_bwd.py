@@ -188,3 +188,36 @@ def test_backward_on_the_one_wave_per_simd_kernels(which):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_bwd.py"), os.path.join(ROOT, "tests", "test_gpu_bottom_right.py"),
                         "-q", "-x", "-m", "gpu", "-k", "not one_wave_per_simd"], env=e, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and "passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_dq_of_the_one_wave_per_simd_kernel_is_bit_identical_to_its_predecessor():
+    """fa_bwd_dq4_gfx950.hip keeps its predecessor's accumulation order over the keys, so dQ must come out bit for bit the same -- at
+    D = 128 and, since round 4, at D = 64 (another LDS image, another register map).  The switch is read once per process: two
+    subprocesses print the SHA-256 of dQ for the same seeded problems (block pairs, ragged rows and keys, GQA, bottom-right, fp16)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    prog = r'''
+import hashlib, math, sys, torch
+sys.path.insert(0, sys.argv[1])
+from aule import _torch as at
+g = torch.Generator(device="cuda").manual_seed(5)
+for (dt, B, Hq, Hkv, Sq, Sk, D, causal) in ((torch.bfloat16, 2, 8, 2, 640, 640, 128, True), (torch.bfloat16, 2, 8, 2, 640, 640, 64, True),
+                                            (torch.float16, 1, 4, 4, 333, 900, 64, "bottom-right"), (torch.bfloat16, 1, 6, 3, 515, 771, 64, False),
+                                            (torch.bfloat16, 4, 16, 16, 1024, 1024, 64, True)):
+    q = torch.randn(B, Hq, Sq, D, device="cuda", dtype=dt, generator=g); k = torch.randn(B, Hkv, Sk, D, device="cuda", dtype=dt, generator=g)
+    v = torch.randn(B, Hkv, Sk, D, device="cuda", dtype=dt, generator=g); do = torch.randn(B, Hq, Sq, D, device="cuda", dtype=dt, generator=g)
+    sc = 1 / math.sqrt(D)
+    out, lse = at.fwd_raw(q, k, v, causal, sc)
+    dq, dk, dv = at.bwd_raw(q, k, v, out, do, lse, causal, sc)
+    torch.cuda.synchronize()
+    print("DQ", hashlib.sha256(dq.view(torch.int16).cpu().numpy().tobytes()).hexdigest())
+'''
+    outs = {}
+    for which in ("old", "new"):
+        e = dict(os.environ)
+        e["AULE_HIP_BWD_DQ"] = which
+        r = subprocess.run([sys.executable, "-c", prog, os.path.join(ROOT, "aule-attention_amd")], env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[which] = [ln for ln in r.stdout.splitlines() if ln.startswith("DQ ")]
+    assert len(outs["old"]) == 5 and outs["old"] == outs["new"], outs
