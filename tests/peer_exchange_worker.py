@@ -15,7 +15,9 @@ def main(rank, world):
     import aule
     from aule import dist as adist
     ok = True
-    for (B, Hq, Hkv, S) in ((4, 8, 2, 512), (3, 8, 8, 320), (1, 8, 2, 256)):     # 2 + 2, ragged 2 + 1, (batch, kv-head) units
+    # 2 + 2, ragged 2 + 1, (batch, kv-head) units; then two more sizes and the first one again: six distinct buffer sizes walk the
+    # exchange cache past its four keys (aule/dist.py: the least recently used pair is closed, on every rank at the same call)
+    for (B, Hq, Hkv, S) in ((4, 8, 2, 512), (3, 8, 8, 320), (1, 8, 2, 256), (2, 8, 2, 128), (2, 4, 4, 192), (4, 8, 2, 512)):
         g = torch.Generator(device="cuda").manual_seed(5)
         q = torch.randn(B, Hq, S, 128, device="cuda", dtype=torch.bfloat16, generator=g)
         k = torch.randn(B, Hkv, S, 128, device="cuda", dtype=torch.bfloat16, generator=g)
@@ -36,6 +38,7 @@ def main(rank, world):
     sums = [None] * world
     dist.all_gather_object(sums, float(full.float().sum().item()))
     ok = ok and len(set(sums)) == 1          # every rank holds the same gathered tensor
+    ok = ok and len(adist._peer_cache) <= adist._PEER_CACHE_KEYS
     torch.cuda.synchronize()
     adist.release_peer_buffers()
     dist.barrier()
