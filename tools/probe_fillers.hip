@@ -57,6 +57,10 @@ __global__ void __launch_bounds__(256) shadow(unsigned long long* cyc, float* ou
     if constexpr (KIND == 12) { if constexpr (NF > 0) asm volatile("v_pk_add_f32 v[48:49], v[50:51], v[52:53]" ::: "v48", "v49"); if constexpr (NF > 1) asm volatile("v_pk_add_f32 v[56:57], v[58:59], v[60:61]" ::: "v56", "v57"); if constexpr (NF > 2) asm volatile("v_pk_add_f32 v[64:65], v[66:67], v[68:69]" ::: "v64", "v65"); if constexpr (NF > 3) asm volatile("v_pk_add_f32 v[72:73], v[74:75], v[76:77]" ::: "v72", "v73"); if constexpr (NF > 4) asm volatile("v_pk_add_f32 v[80:81], v[82:83], v[84:85]" ::: "v80", "v81"); if constexpr (NF > 5) asm volatile("v_pk_add_f32 v[88:89], v[90:91], v[92:93]" ::: "v88", "v89"); if constexpr (NF > 6) asm volatile("v_pk_add_f32 v[96:97], v[98:99], v[100:101]" ::: "v96", "v97"); if constexpr (NF > 7) asm volatile("v_pk_add_f32 v[104:105], v[106:107], v[108:109]" ::: "v104", "v105"); } \
     if constexpr (KIND == 13) { if constexpr (NF > 0) asm volatile("v_pk_mul_f32 v[48:49], v[50:51], v[52:53]" ::: "v48", "v49"); if constexpr (NF > 1) asm volatile("v_pk_mul_f32 v[56:57], v[58:59], v[60:61]" ::: "v56", "v57"); if constexpr (NF > 2) asm volatile("v_pk_mul_f32 v[64:65], v[66:67], v[68:69]" ::: "v64", "v65"); if constexpr (NF > 3) asm volatile("v_pk_mul_f32 v[72:73], v[74:75], v[76:77]" ::: "v72", "v73"); if constexpr (NF > 4) asm volatile("v_pk_mul_f32 v[80:81], v[82:83], v[84:85]" ::: "v80", "v81"); if constexpr (NF > 5) asm volatile("v_pk_mul_f32 v[88:89], v[90:91], v[92:93]" ::: "v88", "v89"); if constexpr (NF > 6) asm volatile("v_pk_mul_f32 v[96:97], v[98:99], v[100:101]" ::: "v96", "v97"); if constexpr (NF > 7) asm volatile("v_pk_mul_f32 v[104:105], v[106:107], v[108:109]" ::: "v104", "v105"); } \
     if constexpr (KIND == 14) { if constexpr (NF > 0) asm volatile("v_pk_fma_f32 v[48:49], v[50:51], s[4:5], v[52:53] op_sel_hi:[1,1,0]" ::: "v48", "v49"); if constexpr (NF > 1) asm volatile("v_exp_f32 v56, v57" ::: "v56"); if constexpr (NF > 2) asm volatile("v_exp_f32 v58, v59" ::: "v58"); if constexpr (NF > 3) asm volatile("v_pk_add_f32 v[60:61], v[60:61], v[62:63]" ::: "v60", "v61"); if constexpr (NF > 4) asm volatile("v_cvt_pk_bf16_f32 v64, v65, v66" ::: "v64"); if constexpr (NF > 5) asm volatile("v_pk_fma_f32 v[68:69], v[70:71], s[4:5], v[72:73] op_sel_hi:[1,1,0]" ::: "v68", "v69"); if constexpr (NF > 6) asm volatile("v_exp_f32 v74, v75" ::: "v74"); if constexpr (NF > 7) asm volatile("v_exp_f32 v76, v77" ::: "v76"); } \
+    if constexpr (KIND == 15) { if constexpr (NF > 0) asm volatile("v_dot2c_f32_f16 v48, 0x3c003c00, v49" ::: "v48"); if constexpr (NF > 1) asm volatile("v_dot2c_f32_f16 v56, 0x3c003c00, v57" ::: "v56"); if constexpr (NF > 2) asm volatile("v_dot2c_f32_f16 v64, 0x3c003c00, v65" ::: "v64"); if constexpr (NF > 3) asm volatile("v_dot2c_f32_f16 v72, 0x3c003c00, v73" ::: "v72"); if constexpr (NF > 4) asm volatile("v_dot2c_f32_f16 v80, 0x3c003c00, v81" ::: "v80"); if constexpr (NF > 5) asm volatile("v_dot2c_f32_f16 v88, 0x3c003c00, v89" ::: "v88"); if constexpr (NF > 6) asm volatile("v_dot2c_f32_f16 v96, 0x3c003c00, v97" ::: "v96"); if constexpr (NF > 7) asm volatile("v_dot2c_f32_f16 v104, 0x3c003c00, v105" ::: "v104"); } \
+    if constexpr (KIND == 16) { if constexpr (NF > 0) asm volatile("v_dot2c_f32_f16 v48, v50, v49" ::: "v48"); if constexpr (NF > 1) asm volatile("v_dot2c_f32_f16 v56, v58, v57" ::: "v56"); if constexpr (NF > 2) asm volatile("v_dot2c_f32_f16 v64, v66, v65" ::: "v64"); if constexpr (NF > 3) asm volatile("v_dot2c_f32_f16 v72, v74, v73" ::: "v72"); if constexpr (NF > 4) asm volatile("v_dot2c_f32_f16 v80, v82, v81" ::: "v80"); if constexpr (NF > 5) asm volatile("v_dot2c_f32_f16 v88, v90, v89" ::: "v88"); if constexpr (NF > 6) asm volatile("v_dot2c_f32_f16 v96, v98, v97" ::: "v96"); if constexpr (NF > 7) asm volatile("v_dot2c_f32_f16 v104, v106, v105" ::: "v104"); } \
+    if constexpr (KIND == 17) { if constexpr (NF > 0) asm volatile("v_dot2_f32_f16 v48, v49, v50, v48" ::: "v48"); if constexpr (NF > 1) asm volatile("v_dot2_f32_f16 v56, v57, v58, v56" ::: "v56"); if constexpr (NF > 2) asm volatile("v_dot2_f32_f16 v64, v65, v66, v64" ::: "v64"); if constexpr (NF > 3) asm volatile("v_dot2_f32_f16 v72, v73, v74, v72" ::: "v72"); if constexpr (NF > 4) asm volatile("v_dot2_f32_f16 v80, v81, v82, v80" ::: "v80"); if constexpr (NF > 5) asm volatile("v_dot2_f32_f16 v88, v89, v90, v88" ::: "v88"); if constexpr (NF > 6) asm volatile("v_dot2_f32_f16 v96, v97, v98, v96" ::: "v96"); if constexpr (NF > 7) asm volatile("v_dot2_f32_f16 v104, v105, v106, v104" ::: "v104"); } \
+    if constexpr (KIND == 18) { if constexpr (NF > 0) asm volatile("v_dot2c_f32_bf16 v48, v50, v49" ::: "v48"); if constexpr (NF > 1) asm volatile("v_dot2c_f32_bf16 v56, v58, v57" ::: "v56"); if constexpr (NF > 2) asm volatile("v_dot2c_f32_bf16 v64, v66, v65" ::: "v64"); if constexpr (NF > 3) asm volatile("v_dot2c_f32_bf16 v72, v74, v73" ::: "v72"); if constexpr (NF > 4) asm volatile("v_dot2c_f32_bf16 v80, v82, v81" ::: "v80"); if constexpr (NF > 5) asm volatile("v_dot2c_f32_bf16 v88, v90, v89" ::: "v88"); if constexpr (NF > 6) asm volatile("v_dot2c_f32_bf16 v96, v98, v97" ::: "v96"); if constexpr (NF > 7) asm volatile("v_dot2c_f32_bf16 v104, v106, v105" ::: "v104"); } \
     if constexpr (KIND == 5) { LDS1(0) LDS1(1) LDS1(2) LDS1(3) LDS1(4) LDS1(5) LDS1(6) LDS1(7) } \
     if constexpr (KIND == 6) { LDS2(0) LDS2(1) LDS2(2) LDS2(3) LDS2(4) LDS2(5) LDS2(6) LDS2(7) } \
     if constexpr (KIND == 9) { LDS3(0) LDS3(1) LDS3(2) LDS3(3) LDS3(4) LDS3(5) LDS3(6) LDS3(7) } \
@@ -92,5 +96,6 @@ int main() {
     sweep<0>("v_fma_f32"); sweep<1>("v_exp_f32"); sweep<2>("v_add_f32"); sweep<3>("v_cvt_pk_bf16"); sweep<4>("softmax mix");
     sweep<5>("ds_read_tr_b64"); sweep<6>("ds_read_b128>a"); sweep<7>("exp+fma+add +n"); sweep<8>("dma,exp,fma"); sweep<9>("ds_read_b128>v"); sweep<10>("ds_read_tr>a");
     sweep<11>("v_pk_fma_f32"); sweep<12>("v_pk_add_f32"); sweep<13>("v_pk_mul_f32"); sweep<14>("pk softmax mix");
+    sweep<15>("dot2c_f16 lit"); sweep<16>("dot2c_f16 vgpr"); sweep<17>("dot2_f16 vop3p"); sweep<18>("dot2c_bf16");
     return 0;
 }
