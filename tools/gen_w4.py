@@ -59,6 +59,15 @@ PRE_ON = os.environ.get("W4_PRE", "0") != "0"
 #         dealt by ISSUE COST against what an MFMA hides: profiles/r3_probe_fillers.txt -- ~26 cycles per gap, plain VALU 4,
 #         v_exp_f32 8, ds_read_b64_tr_b16 8, ds_read_b128 16, an LDS-DMA piece ~31; four v_exp_f32 in one gap (what quad
 #         produces) overrun it by 10+ cycles
+# W4_MSUM=1 (experiment, OFF): fp16 D = 64 -- the row sums l from the MATRIX pipe: one more MFMA per (row block, 16-key slice) next to the
+# PV MFMAs, ones (32 x 16) times P^T, instead of one v_add_f32 per score (64 v_add_f32 per step go, 8 MFMAs come; l is then the sum of the
+# weights AS ROUNDED to the V dtype: fine for fp16, <= 2^-11 relative on the LSE; bf16 moved it by 1.1-1.5e-3 in round 2, past its bar).  The
+# idea: at D = 64 the step is bound by VALU issue (7 VALU per MFMA against the ~5 an MFMA hides) while the matrix pipe idles half the time.
+# Measured (round 4, session 24, same box, A B A B; parity green, 137 forward tests): C5 (fp16 MQA S16384) 2162 / 2153 -> 2254 / 2251 us (-4.3 %),
+# B8 H32 S2048 causal 179 / 176 -> 184 / 183 (-3.5 %), B4 32q/8kv S4096 305 -> 316 (-3.6 %); only launches of a few workgroup rounds gain
+# (B2 H8 S1111 31.0 -> 30.1 us).  25 % more MFMAs cost more at the chip's power limit than 29 % fewer VALU instructions save: the large
+# D = 64 shapes are energy-bound too (1304 W at 1.88 GHz, profiles/r4_power_trace.txt).  OFF.
+MSUM_ON = os.environ.get("W4_MSUM", "0") != "0"
 ORDER = os.environ.get("W4_ORDER", "pipe")
 PLACE = os.environ.get("W4_PLACE", "count")    # (cost: by the probe's issue costs -- measured WORSE than the even count: profiles/r3_w4_placement_ab.txt)
 CREG = "v" if "cvgpr" in XFLAGS else "s"    # register class of the scale operand (experiment)
@@ -109,6 +118,19 @@ class Cfg:
         self.NMT = self.X - 32 if self.pre else self.X  # - m_ref of block A (16 registers), block B (16)
         self.NV = self.NMT                             # hipcc's budget
         assert self.NV % 2 == 0 and self.XA % 4 == 0, (self.NV, self.XA)
+        # row sums from the matrix pipe (MSUM_ON): l of block qb = any register of a[LA + 16 qb ..] (every row of ones P^T is the same),
+        # the ones fragment at a[ONES ..] -- above the K fragments, free at D = 64
+        self.msum = MSUM_ON and D == 64 and dt == "f16"
+        self.LA = self.KB0 + 8 * self.KS
+        self.ONES = self.LA + 32
+        assert not self.msum or self.ONES + 4 <= 256
+
+    def Lacc(self, qb):
+        return f"a[{self.LA + 16 * qb}:{self.LA + 16 * qb + 15}]"
+
+    def sum_mfma(self, qb, pf, first):
+        """l[qb] += ones P^T of one 16-key slice (pf = the slice's packed weights: the PV MFMAs' B operand)"""
+        return f"{self.mfma} {self.Lacc(qb)}, a[{self.ONES}:{self.ONES + 3}], {pf}, {'0' if first else self.Lacc(qb)}"
 
     def O(self, qb, d):
         b = (qb * self.DB + d) * 16
@@ -192,7 +214,7 @@ def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked, sub=False):
             return [f"v_exp_f32 {x[i]}, {x[i] if need_x else sc[i]}"]
 
         def A(i):
-            return [f"v_add_f32 {l[i & 1]}, {l[i & 1]}, {x[i]}"]
+            return [] if c.msum else [f"v_add_f32 {l[i & 1]}, {l[i & 1]}, {x[i]}"]
 
         def C(p):
             return [f"{c.cvt} v{pbase + p}, {x[2 * p]}, {x[2 * p + 1]}"]
@@ -236,8 +258,9 @@ def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked, sub=False):
                 ops.append(f"v_exp_f32 {x[p][0]}, {src[p][0]}")
                 ops.append(f"v_exp_f32 {x[p][1]}, {src[p][1]}")
             for p in (p0, p0 + 1):
-                ops.append(f"v_add_f32 {l[0]}, {l[0]}, {x[p][0]}")
-                ops.append(f"v_add_f32 {l[1]}, {l[1]}, {x[p][1]}")
+                if not c.msum:
+                    ops.append(f"v_add_f32 {l[0]}, {l[0]}, {x[p][0]}")
+                    ops.append(f"v_add_f32 {l[1]}, {l[1]}, {x[p][1]}")
                 ops.append(f"{c.cvt} v{pbase + p}, {x[p][0]}, {x[p][1]}")
     if "noexp" in XFLAGS:
         ops = [o.replace("v_exp_f32", "v_mov_b32") for o in ops]
@@ -539,8 +562,12 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
             for d in range(DB):
                 o = c.O(qb, d)
                 mf.append(f"{c.mfma} {o}, {c.V(sk, d)}, {pf}, {'0' if (pv == 2 and sk == 0) else o}")
+            if c.msum:
+                mf.append(c.sum_mfma(qb, pf, pv == 2 and sk == 0))
         for d in range(DB):
             clob += aregs((qb * DB + d) * 16, 16)
+        if c.msum:
+            clob += aregs(c.LA + 16 * qb, 16)
     lds = []
     qloads = []
     if kr == 2:
@@ -676,6 +703,8 @@ def gen_diag(c, I, par, sl, ql):
         for d in range(DB):
             o = c.O(qb, d)
             out.append(f"{c.mfma} {o}, {c.V(sk, d)}, {pf}, {o}")
+        if c.msum:
+            out.append(c.sum_mfma(qb, pf, False))
         return out
     if I < 4:
         Q = I
@@ -686,6 +715,8 @@ def gen_diag(c, I, par, sl, ql):
             mf = pv(0, I - 1)
             for d in range(DB):
                 clob += aregs(d * 16, 16)
+            if c.msum:
+                clob += aregs(c.LA, 16)
         sk = Q
         for d in range(DB):
             for i in range(2):
@@ -717,6 +748,8 @@ def gen_diag(c, I, par, sl, ql):
             mf = pv(1, 2) + pv(1, 3)
         for d in range(2 * DB):
             clob += aregs(d * 16, 16)
+        if c.msum:
+            clob += aregs(c.LA, 32)
         npc = c.NP // 2
         for pi in range(J * npc, (J + 1) * npc):
             pieces.append(lit_piece(c, "v", (sl + 2) % 3, pi))
@@ -1004,8 +1037,14 @@ def gen_struct(c):
             first = False
     s += "#endif\n        return mx;\n    }\n"
     # ---- scalars that live in literal registers
-    s += ("    static __device__ __forceinline__ void set_consts() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
-          f"        asm volatile(\"v_mov_b32 v{c.NINF}, 0xff800000\" ::: \"v{c.NINF}\");\n#endif\n    }}\n")
+    if c.msum:    # + the ones fragment of the row-sum MFMAs: (1.0h, 1.0h) in every dword
+        ones = "\\n\\t".join([f"v_mov_b32 v{c.X}, 0x3c003c00", "s_nop 0"] + [f"v_accvgpr_write_b32 a{c.ONES + i}, v{c.X}" for i in range(4)] + ["s_nop 7"])
+        s += ("    static __device__ __forceinline__ void set_consts() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+              f"        asm volatile(\"v_mov_b32 v{c.NINF}, 0xff800000\\n\\t{ones}\" ::: \"v{c.NINF}\", \"v{c.X}\", "
+              + ", ".join(f'\"a{c.ONES + i}\"' for i in range(4)) + ");\n#endif\n    }\n")
+    else:
+        s += ("    static __device__ __forceinline__ void set_consts() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+              f"        asm volatile(\"v_mov_b32 v{c.NINF}, 0xff800000\" ::: \"v{c.NINF}\");\n#endif\n    }}\n")
     s += ("    // start of a part: row sums 0\n"
           "    static __device__ __forceinline__ void zero_sums() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
           f"        asm volatile(\"v_mov_b32 v{c.L}, 0\\n\\tv_mov_b32 v{c.L + 1}, 0\\n\\tv_mov_b32 v{c.L + 2}, 0\\n\\tv_mov_b32 v{c.L + 3}, 0\" ::: "
@@ -1053,10 +1092,20 @@ def gen_struct(c):
         s += emit_asm(lines, [], ['[srd] "s"(srd)', '[vo] "v"(vo)'], ["memory"])
         s += "        }\n"
     s += "#endif\n    }\n"
-    s += ("    // end of a part: row sum (both chains) and - reference of block QB\n"
-          "    template <int QB>\n    static __device__ __forceinline__ void get_sums(float& l, float& nm) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
-          f"        if constexpr (QB == 0) asm volatile(\"v_add_f32 %0, v{c.l(0, 0)}, v{c.l(0, 1)}\\n\\tv_mov_b32 %1, v{c.nm(0)}\" : \"=&v\"(l), \"=v\"(nm));\n"
-          f"        else asm volatile(\"v_add_f32 %0, v{c.l(1, 0)}, v{c.l(1, 1)}\\n\\tv_mov_b32 %1, v{c.nm(1)}\" : \"=&v\"(l), \"=v\"(nm));\n#endif\n    }}\n")
+    if c.msum:
+        # the MFMA's row of ones P^T holds the WHOLE sum of the lane's query row in both lane halves; the callers add the partner
+        # half's value (the VALU form keeps one partial sum per half), so hand back one half of it: exact.  (MFMA result -> read: 19 wait states.)
+        def gs(qb):
+            return (f'asm volatile("s_nop 7\\n\\ts_nop 7\\n\\ts_nop 2\\n\\tv_accvgpr_read_b32 %0, a{c.LA + 16 * qb}\\n\\tv_mov_b32 %1, v{c.nm(qb)}\\n\\t'
+                    f'v_mul_f32 %0, 0.5, %0" : "=&v"(l), "=v"(nm));')
+        s += ("    // end of a part: row sum (from the matrix pipe, halved: see the generator) and - reference of block QB\n"
+              "    template <int QB>\n    static __device__ __forceinline__ void get_sums(float& l, float& nm) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+              f"        if constexpr (QB == 0) {gs(0)}\n        else {gs(1)}\n#endif\n    }}\n")
+    else:
+        s += ("    // end of a part: row sum (both chains) and - reference of block QB\n"
+              "    template <int QB>\n    static __device__ __forceinline__ void get_sums(float& l, float& nm) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+              f"        if constexpr (QB == 0) asm volatile(\"v_add_f32 %0, v{c.l(0, 0)}, v{c.l(0, 1)}\\n\\tv_mov_b32 %1, v{c.nm(0)}\" : \"=&v\"(l), \"=v\"(nm));\n"
+              f"        else asm volatile(\"v_add_f32 %0, v{c.l(1, 0)}, v{c.l(1, 1)}\\n\\tv_mov_b32 %1, v{c.nm(1)}\" : \"=&v\"(l), \"=v\"(nm));\n#endif\n    }}\n")
     s += "};\n\n"
     return s
 
