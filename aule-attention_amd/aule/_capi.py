@@ -10,6 +10,7 @@ There is no fallback: if the library is missing or no HIP device is visible,
 """
 import ctypes
 import os
+import sys
 import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -222,12 +223,36 @@ def find_library():
         "or `python -c 'import __graft_entry__ as g; g.build()'`. Searched: " + ", ".join(cands))
 
 
+def _preload_torch_hip_runtime():
+    """ONE HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 (torch/lib); libaule.so
+    links the system's (/opt/rocm).  If libaule.so is loaded BEFORE torch, the process ends up with both, torch's takes the device
+    and aule_init() then reports "no ROCm-capable device" (found in round 4: build() followed by smoke() in one process).  Loaded
+    after torch, libaule.so binds to the copy that is already there.  So when torch is installed but not imported yet, its runtime is
+    loaded first (by path, without importing torch); a later `import torch` reuses it.  AULE_HIP_RUNTIME=system keeps the system's."""
+    if os.environ.get("AULE_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except Exception:  # noqa: BLE001
+        return
+    if spec is None or not spec.origin:
+        return
+    p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen libaule.so and declare every signature. Does NOT need a GPU."""
     global _lib, _lib_path
     with _lock:
         if _lib is None:
             path = find_library()
+            _preload_torch_hip_runtime()
             lib = ctypes.CDLL(path)
             for name, restype, argtypes in SIGNATURES:
                 fn = getattr(lib, name)  # AttributeError if the export is missing

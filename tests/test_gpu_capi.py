@@ -163,3 +163,33 @@ def test_ex_rejects_bad_arguments(A):
     d.window_size = 4                                                          # accepted (sliding window)
     assert lib.aule_attention_forward_ex(ctypes.byref(d)) == -3                # null pointers
     assert b"null" in lib.aule_get_error()
+
+
+def test_library_loaded_before_torch_still_finds_the_device():
+    """ONE HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64, libaule.so links the system's.  Loading
+    libaule.so first used to leave both in the process -- torch's took the device and aule_init() failed with "no ROCm-capable
+    device" (build() followed by smoke() in one interpreter).  _capi.load() now loads torch's runtime first when torch is installed
+    but not imported yet; this runs that order in a fresh interpreter and counts the runtimes mapped."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    prog = r'''
+import os, sys
+sys.path.insert(0, os.path.join(sys.argv[1], "aule-attention_amd"))
+from aule import _capi
+assert "torch" not in sys.modules
+lib = _capi.load()
+import torch
+assert torch.cuda.is_available()
+_capi.get_lib()          # aule_init()
+hip = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+assert len(hip) == 1, hip
+import aule
+q = torch.randn(1, 2, 128, 64, device="cuda", dtype=torch.bfloat16)
+o = aule.flash_attention(q, q, q, causal=True)
+torch.cuda.synchronize()
+assert torch.isfinite(o.float()).all()
+print("ORDER_OK", hip[0])
+'''
+    r = subprocess.run([sys.executable, "-c", prog, ROOT], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "ORDER_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
