@@ -56,6 +56,8 @@ struct Dkv4Params {
     int nblk;      // work items per (batch, kv head): KV blocks, or pairs of them (causal)
     int coff;      // causal position offset (query i sits at position i + coff)
     unsigned long long* dbg;   // timeline build: {iterations, cycles of [phase 1 + boundary], cycles of [phase 2]} of workgroup 0's waves
+    char* ds;      // SPILL instances (the 5-matmul backward, fa_bwd_dqs_gfx950.hip): the dS workspace, layout in fa_kernels.h (DsLayout)
+    int nq32, nkb32p;
 };
 
 constexpr int kKvBlock4 = 128;   // 4 waves x 32 key rows
@@ -88,7 +90,7 @@ __device__ __forceinline__ void dkv4_store_rows(char* row, int hi, float sc) {
 
 __device__ __forceinline__ int dkv4_rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-template <class T, int D, bool CAUSAL, bool TL>
+template <class T, int D, bool CAUSAL, bool TL, bool SPILL>
 __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
     using A = Bw4Asm<T, D>;
     using std::integral_constant;
@@ -141,6 +143,7 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
         wave_pb = (unsigned)(1040 * wave);
     }
     const unsigned lvo = (unsigned)(hi * 16);   // L' / delta: rows 8 g + 4 hi .. + 3 of the block per dwordx4
+    const unsigned svo = (unsigned)(lane * 16);   // SPILL: the lane's 16 bytes of a dS unit's k-step (unit = [kk][lane][16 B])
 
     unsigned long long tl_a = 0, tl_b = 0, tl_n = 0;
     const int nparts = (CAUSAL && (nkb - 1 - w.blk) != w.blk) ? 2 : 1;
@@ -200,6 +203,18 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             wd = (kr < Sk && hi_r > lo_r) ? hi_r - lo_r : 0;
         };
 
+        // SPILL: block i of the stream (head hh of the group, query block first_qt + t) of this wave's 32 keys (32-key block
+        // kb32 = 4 kb + wave) is unit x = i + first_qt = hh ntq + (first_qt + t) of column (group, kb32): the stream index IS the
+        // address, no cursor (fa_kernels.h, DsLayout; the dQ kernel undoes the first_qt compression per head)
+        const __amdgpu_buffer_rsrc_t srs = [&]() __attribute__((always_inline)) {
+            if constexpr (SPILL) {
+                const long long xs = (long long)g * p.nq32;
+                const long long col = (long long)(w.b * p.Hkv + w.hk) * p.nkb32p + (kb * 4 + wave);
+                return make_srd(p.ds + ((col * xs + first_qt) << 11), (unsigned)dkv4_rfl((int)((xs - first_qt) << 11)));
+            } else {
+                return make_srd(nullptr, 0);
+            }
+        }();
         if (nit > 0) {
             // ---- stream start: blocks 0 .. 3 requested, L' / delta of blocks 0 and 1, the fragments of block 0, S_0 / dP_0.
             // ONE cursor walks the stream, four blocks ahead of the iteration (the block being requested); what an iteration needs
@@ -262,6 +277,7 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
                 unsigned long long t1 = 0;
                 if constexpr (TL) { t1 = __builtin_amdgcn_s_memtime(); tl_a += t1 - t0; }
                 const unsigned b = slot_lds(i + 2) + a_sub, b1 = slot_lds(i + 2) + a_sub1;
+                if constexpr (SPILL) A::store_ds(srs, svo, (unsigned)i << 11);
                 {
                     const unsigned lso = (unsigned)row_nxt[PAR] * 4u, lso3 = (unsigned)row_nxt[PAR ^ 1] * 4u, dso = (unsigned)c4.row * (unsigned)RB;
                     const unsigned dl = slot_lds(i + 4) + wave_pb;
@@ -309,17 +325,17 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
     }
 }
 
-template <class T, bool CAUSAL, bool TL = false>
+template <class T, bool CAUSAL, bool TL = false, bool SPILL = false>
 __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(40))) fa_bwd_dkv4_kernel(const Dkv4Params p) {
     static_assert(Bw4Asm<T, 128>::NV == 40, "amdgpu_num_vgpr must be the generator's NV");
-    dkv4_body<T, 128, CAUSAL, TL>(p);
+    dkv4_body<T, 128, CAUSAL, TL, SPILL>(p);
 }
 
 // D = 64: 72 arch VGPRs for hipcc (the attribute takes a literal, hence a kernel of its own)
-template <class T, bool CAUSAL>
+template <class T, bool CAUSAL, bool SPILL = false>
 __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(72))) fa_bwd_dkv4_kernel_d64(const Dkv4Params p) {
     static_assert(Bw4Asm<T, 64>::NV == 72, "amdgpu_num_vgpr must be the generator's NV");
-    dkv4_body<T, 64, CAUSAL, false>(p);
+    dkv4_body<T, 64, CAUSAL, false, SPILL>(p);
 }
 
 #pragma clang diagnostic pop
@@ -330,7 +346,7 @@ constexpr int kDkv4Lds = kRing4 * Bw4Asm<Bf16Traits, D>::SLOT;
 template <class T, int D>
 int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
     Dkv4Params p;
-    p.q = a.q; p.k = a.k; p.v = a.v; p.dout = a.dout; p.lse = a.lse2; p.delta = a.ndelta;   // (L' = LSE log2(e) and - delta, written by the dQ kernel behind delta)
+    p.q = a.q; p.k = a.k; p.v = a.v; p.dout = a.dout; p.lse = a.lse2; p.delta = a.ndelta;   // (L' = LSE log2(e) and - delta, written by the dQ kernel / the delta pass behind delta)
     p.dk = a.dk; p.dv = a.dv;
     p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
     p.c = a.scale * kLog2e;
@@ -340,9 +356,17 @@ int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
     p.nblk = a.causal ? (nkb + 1) / 2 : nkb;
     const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv)), block(256);
     p.dbg = a.dbg;
+    const DsLayout dl = DsLayout::of(a.Hq, a.Hkv, a.Sq, a.Sk);
+    p.ds = reinterpret_cast<char*>(a.ds); p.nq32 = dl.nq32; p.nkb32p = dl.nkb32p;
+    const bool spill = a.ds != nullptr;   // the 5-matmul backward: dS goes to the workspace for fa_bwd_dqs_gfx950.hip
     constexpr int LDS = kDkv4Lds<D>;
     if constexpr (D == 64) {
-        if (a.causal)
+        if (spill) {
+            if (a.causal)
+                hipLaunchKernelGGL((fa_bwd_dkv4_kernel_d64<T, true, true>), grid, block, LDS, stream, p);
+            else
+                hipLaunchKernelGGL((fa_bwd_dkv4_kernel_d64<T, false, true>), grid, block, LDS, stream, p);
+        } else if (a.causal)
             hipLaunchKernelGGL((fa_bwd_dkv4_kernel_d64<T, true>), grid, block, LDS, stream, p);
         else
             hipLaunchKernelGGL((fa_bwd_dkv4_kernel_d64<T, false>), grid, block, LDS, stream, p);
@@ -362,7 +386,12 @@ int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
             }
         }
 #endif
-        if (a.causal)
+        if (spill) {
+            if (a.causal)
+                hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, true, false, true>), grid, block, LDS, stream, p);
+            else
+                hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, false, false, true>), grid, block, LDS, stream, p);
+        } else if (a.causal)
             hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, true>), grid, block, LDS, stream, p);
         else
             hipLaunchKernelGGL((fa_bwd_dkv4_kernel<T, false>), grid, block, LDS, stream, p);
@@ -427,6 +456,15 @@ int configure_bwd_dkv4() {
     set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<Bf16Traits, false>), kDkv4Lds<64>);
     set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<F16Traits, true>), kDkv4Lds<64>);
     set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<F16Traits, false>), kDkv4Lds<64>);
+    // the SPILL instances (5-matmul backward)
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<Bf16Traits, true, false, true>), kDkv4Lds<128>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<Bf16Traits, false, false, true>), kDkv4Lds<128>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<F16Traits, true, false, true>), kDkv4Lds<128>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<F16Traits, false, false, true>), kDkv4Lds<128>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<Bf16Traits, true, true>), kDkv4Lds<64>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<Bf16Traits, false, true>), kDkv4Lds<64>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<F16Traits, true, true>), kDkv4Lds<64>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<F16Traits, false, true>), kDkv4Lds<64>);
     return rc;
 }
 

@@ -38,6 +38,10 @@ int launch_bwd_dq4(const BwdArgs& a, float* lse2_out, float* ndelta_out, hipStre
 int configure_bwd_dq4();
 int launch_bwd_dkv4(const BwdArgs& a, hipStream_t stream);
 int configure_bwd_dkv4();
+bool bwd_dqs_applicable(const BwdArgs& a);           // fa_bwd_dqs_gfx950.hip: the 5-matmul backward's delta pass and dQ = dS K kernel
+int launch_bwd_delta16(const BwdArgs& a, float* lse2, float* ndelta, hipStream_t stream);
+int launch_bwd_dqs(const BwdArgs& a, hipStream_t stream);
+int configure_bwd_dqs();
 namespace {
 
 // ------------------------------------------------------------------ delta ----
@@ -1065,6 +1069,55 @@ inline uint64_t delta_bytes(int B, int Hq, int Sq) {
     return (((uint64_t)B * Hq * Sq * sizeof(float)) + 255) / 256 * 256;
 }
 
+// ---- the 5-matmul backward (round 5): delta pass -> dK/dV kernel that also spills its packed dS -> dQ = dS K (fa_bwd_dqs_gfx950.hip).
+// AULE_HIP_BWD_MODE=recompute pins the two-kernel pair of rounds 1-4 (7 matmuls, no dS workspace); default: spill wherever the
+// one-wave-per-SIMD dK/dV kernel would run anyway and one batch element's dS fits the cap (AULE_HIP_BWD_DS_CAP_MB, default 8192;
+// the batch runs in chunks of as many elements as the caller's workspace holds).
+inline int bwd_mode() {
+    static const int m = [] {
+        const char* e = std::getenv("AULE_HIP_BWD_MODE");
+        return (e != nullptr && e[0] == 'r') ? 1 : 0;
+    }();
+    return m;
+}
+inline uint64_t bwd_ds_cap_bytes() {
+    static const uint64_t c = [] {
+        const char* e = std::getenv("AULE_HIP_BWD_DS_CAP_MB");
+        const long long mb = e != nullptr ? std::atoll(e) : 8192;
+        return (uint64_t)(mb > 0 ? mb : 0) << 20;
+    }();
+    return c;
+}
+// does the dispatcher take the one-wave-per-SIMD dK/dV kernel for these sizes?  (the grid rule of launch_bwd_16 below)
+inline bool dkv4_by_grid(int B, int Hq, int Hkv, int Sk, int causal) {
+    if (bwd_dkv4_forced()) return true;
+    const int nkb = (Sk + kKvBlock - 1) / kKvBlock;
+    const long long here = (long long)B * Hkv * (causal ? (nkb + 1) / 2 : nkb) * dkdv_gsplit(B, Hq, Hkv, Sk, causal);
+    const int nkb4 = (Sk + 127) / 128;
+    const long long there = (long long)B * Hkv * (causal ? (nkb4 + 1) / 2 : nkb4);
+    return there >= 192 || there >= here;
+}
+// bytes of dS workspace per batch element if the sizes alone allow the 5-matmul backward, else 0
+inline uint64_t spill_bytes_per_batch(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype) {
+    if (bwd_mode() == 1 || (dtype != kBF16 && dtype != kF16) || (D != 128 && D != 64)) return 0;
+    if (Hkv <= 0 || Hq % Hkv != 0 || Sq <= 0 || Sk <= 0) return 0;
+    BwdArgs t{};
+    t.B = B; t.Hq = Hq; t.Hkv = Hkv; t.Sq = Sq; t.Sk = Sk; t.D = D; t.causal = causal; t.dtype = dtype; t.window = -1; t.coff = 0;
+    if (!bwd_dkv4_applicable(t) || !bwd_dqs_applicable(t) || !dkv4_by_grid(B, Hq, Hkv, Sk, causal)) return 0;
+    const uint64_t pb = (uint64_t)Hkv * (uint64_t)DsLayout::of(Hq, Hkv, Sq, Sk).group_bytes;
+    return pb <= bwd_ds_cap_bytes() ? pb : 0;
+}
+inline uint64_t bwd_base_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype) {
+    uint64_t bytes = delta_bytes(B, Hq, Sq);
+    if (dtype != kF32) {
+        bytes += 2 * delta_bytes(B, Hq, Sq);   // L' = LSE log2(e) and - delta, published with delta
+        const int sp = dkdv_gsplit(B, Hq, Hkv, Sk, causal);
+        if (sp > 1) bytes += 2ull * sp * B * Hkv * Sk * D * sizeof(float);
+        bytes = (bytes + 255) / 256 * 256;
+    }
+    return bytes;
+}
+
 template <class T, int D>
 int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     // (delta = rowsum(O * dO) is computed inside the dQ kernel)
@@ -1090,6 +1143,34 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
 #else
     constexpr int only = 0;
 #endif
+    // ---- the 5-matmul backward: no recomputation (see spill_bytes_per_batch above; fa_bwd_dqs_gfx950.hip)
+    if constexpr (D == 128 || D == 64) {
+        const uint64_t pb = (only == 0 && a.dbg == nullptr && a.dbg_dq == nullptr && !dkv4_timeline_wanted() && a.window <= 0 && bwd_dkv4_applicable(a) &&
+                             bwd_dqs_applicable(a))
+                                ? spill_bytes_per_batch(a.B, a.Hq, a.Hkv, a.Sq, a.Sk, D, a.causal, a.dtype) : 0;
+        const uint64_t base = bwd_base_bytes(a.B, a.Hq, a.Hkv, a.Sq, a.Sk, D, a.causal, a.dtype);
+        const uint64_t nb = (pb > 0 && a.ws_bytes > base) ? (a.ws_bytes - base) / pb : 0;
+        if (nb >= 1) {
+            int rc = launch_bwd_delta16(a, p.lse2_out, p.ndelta_out, stream);
+            if (rc) return rc;
+            const size_t rq = (size_t)a.Hq * a.Sq, rk = (size_t)a.Hkv * a.Sk;   // rows per batch element
+            for (int b0 = 0; b0 < a.B; b0 += (int)nb) {
+                BwdArgs c = a;
+                c.B = a.B - b0 < (int)nb ? a.B - b0 : (int)nb;
+                c.q = reinterpret_cast<const char*>(a.q) + b0 * rq * D * 2; c.dout = reinterpret_cast<const char*>(a.dout) + b0 * rq * D * 2;
+                c.k = reinterpret_cast<const char*>(a.k) + b0 * rk * D * 2; c.v = reinterpret_cast<const char*>(a.v) + b0 * rk * D * 2;
+                c.dq = reinterpret_cast<char*>(a.dq) + b0 * rq * D * 2;
+                c.dk = reinterpret_cast<char*>(a.dk) + b0 * rk * D * 2; c.dv = reinterpret_cast<char*>(a.dv) + b0 * rk * D * 2;
+                c.lse2 = p.lse2_out + b0 * rq; c.ndelta = p.ndelta_out + b0 * rq;
+                c.ds = reinterpret_cast<char*>(a.delta) + base;
+                rc = launch_bwd_dkv4(c, stream);
+                if (rc) return rc;
+                rc = launch_bwd_dqs(c, stream);
+                if (rc) return rc;
+            }
+            return 0;
+        }
+    }
     // The one-wave-per-SIMD dQ kernel (fa_bwd_dq4_gfx950.hip: 64 query rows per wave, every K / V fragment read feeds two row
     // blocks; dQ bit-identical to this file's kernel) wherever it can run and the grid has at least 128 work items: ahead or level
     // on all ten shapes of tools/cb_rule_dq.sh (whole backward -0.2 .. -2.5 %, the 128-item grids level), behind on grids of a few
@@ -1223,12 +1304,19 @@ int launch_delta_f32(const BwdArgs& a, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// What launch_bwd NEEDS (delta, L', - delta, the head-split partials) ...
+uint64_t bwd_workspace_min_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype) {
+    return bwd_base_bytes(B, Hq, Hkv, Sq, Sk, D, causal, dtype);
+}
+// ... and what it WANTS: plus the dS workspace of the 5-matmul backward for as many batch elements as fit the cap (at least one).
+// A caller that passes only the minimum gets the recompute pair.
 uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype) {
-    uint64_t bytes = delta_bytes(B, Hq, Sq);
-    if (dtype != kF32) {
-        bytes += 2 * delta_bytes(B, Hq, Sq);   // L' = LSE log2(e) and - delta, published by the dQ kernel with delta
-        const int sp = dkdv_gsplit(B, Hq, Hkv, Sk, causal);
-        if (sp > 1) bytes += 2ull * sp * B * Hkv * Sk * D * sizeof(float);
+    uint64_t bytes = bwd_base_bytes(B, Hq, Hkv, Sq, Sk, D, causal, dtype);
+    const uint64_t pb = spill_bytes_per_batch(B, Hq, Hkv, Sq, Sk, D, causal, dtype);
+    if (pb > 0) {
+        uint64_t nb = bwd_ds_cap_bytes() / pb;
+        if (nb > (uint64_t)B) nb = (uint64_t)B;
+        bytes += nb * pb;
     }
     return bytes;
 }
@@ -1258,6 +1346,7 @@ int configure_bwd() {
     rc |= configure_bwd_f32();
     rc |= configure_bwd_dkv4();
     rc |= configure_bwd_dq4();
+    rc |= configure_bwd_dqs();
     return rc;
 }
 

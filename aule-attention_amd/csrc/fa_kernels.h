@@ -103,6 +103,29 @@ struct BwdArgs {
     int coff = 0;     // as FwdArgs::coff
     unsigned long long* dbg = nullptr;   // debug: s_memtime stamps of the dK/dV kernel's workgroup 0 (bf16 D128 causal)
     unsigned long long* dbg_dq = nullptr;   // ... of the dQ kernel's workgroup 0
+    void* ds = nullptr;            // internal (16-bit path, 5-matmul backward): the dS workspace of this call's batch chunk (DsLayout)
+    uint64_t ws_bytes = 0;         // bytes behind `delta` (0 = just bwd_workspace_min_bytes(): the recompute pair runs)
+};
+
+// The dS workspace of the 5-matmul backward (round 5; fa_bwd_dkv4_gfx950.hip SPILL instances write it, fa_bwd_dqs_gfx950.hip reads it).
+// A UNIT is the packed 16-bit dS of one (32-key block, 32-row query block) tile exactly as the dK/dV kernel holds it for its own
+// dK MFMAs: 2 KB = [kk = 16-row query step][lane = key n + 32 hi][16 bytes = query rows 16 kk + 4 hi + {0..3}, 16 kk + 8 + 4 hi + {0..3}].
+// Units of one (batch, KV head) GROUP and one 32-key block kb32 form a COLUMN of xs = g * nq32 units, indexed by the dK/dV kernel's
+// stream position: head hh of the group, query block qb32 -> x = hh * (nq32 - fq) + qb32, fq = the first query block that sees the
+// 128-key block kb32 / 4 (0 when not causal) -- so that the writer's address is its loop counter.  Columns are padded to whole
+// 128-key blocks (nkb32p = 4 * ceil(Sk / 128)): every wave of the dK/dV kernel owns a column.
+struct DsLayout {
+    int nq32, nkb32p;
+    long long xs;              // units per column
+    long long group_bytes;     // nkb32p * xs * 2048
+    static DsLayout of(int Hq, int Hkv, int Sq, int Sk) {
+        DsLayout l;
+        l.nq32 = (Sq + 31) / 32;
+        l.nkb32p = 4 * ((Sk + 127) / 128);
+        l.xs = (long long)(Hq / (Hkv > 0 ? Hkv : 1)) * l.nq32;
+        l.group_bytes = (long long)l.nkb32p * l.xs * 2048;
+        return l;
+    }
 };
 
 // Paged-KV decode (python/aule/triton_flash_amd.py:543-737): one query token per sequence.
@@ -161,6 +184,8 @@ int launch_bwd(const BwdArgs& a, hipStream_t stream);
 // Bytes of device workspace launch_bwd needs: delta [B,Hq,Sq] fp32, plus (16-bit GQA/MQA problems that
 // do not fill the chip) fp32 dK/dV partials of the head-split dK/dV kernel.
 uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype);
+// ... of which launch_bwd cannot do without (the rest is the dS workspace of the 5-matmul backward: fa_bwd_gfx950.hip)
+uint64_t bwd_workspace_min_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype);
 
 // Set the max-dynamic-LDS attribute on every kernel (call once per device).
 int configure_kernels();

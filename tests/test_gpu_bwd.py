@@ -172,22 +172,73 @@ def test_backward_deterministic(torch_cuda):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("which", ["new", "old"])
+@pytest.mark.parametrize("which", ["spill", "new", "old"])
 def test_backward_on_the_one_wave_per_simd_kernels(which):
-    """fa_bwd_dkv4_gfx950.hip (dK/dV) and fa_bwd_dq4_gfx950.hip (dQ) are the backward kernels of the D = 128 / D = 64 16-bit problems without a
-    window whose grids they cover (the dispatcher's rules in fa_bwd_gfx950.hip); their predecessors keep the rest.
-    AULE_HIP_BWD_DKV=new + AULE_HIP_BWD_DQ=new force both onto every problem they CAN run, =old pins both predecessors everywhere:
-    the sweep, the reference's golden gradients, the bottom-right cases and the determinism test then exercise the masks, the stream
-    start / tail, the idle waves and the GQA loop of either pair on all of them."""
+    """Three backward modes over the same suites (the switches are read once per process, hence subprocesses):
+      spill  the 5-matmul backward (round 5: delta pass, fa_bwd_dkv4_gfx950.hip's SPILL instances, fa_bwd_dqs_gfx950.hip) forced onto every
+             problem it CAN run (AULE_HIP_BWD_DKV=new lifts the grid rule);
+      new    AULE_HIP_BWD_MODE=recompute + the one-wave-per-SIMD pair (fa_bwd_dkv4 / fa_bwd_dq4) forced wherever it can run;
+      old    AULE_HIP_BWD_MODE=recompute + both predecessors (fa_bwd_gfx950.hip) everywhere.
+    The sweep, the reference's golden gradients, the bottom-right cases and the determinism test then exercise the masks, the stream
+    start / tail, the idle waves, the GQA loop and the dS workspace addressing of each mode on all of them."""
     import subprocess
     import sys
     from conftest import ROOT
     e = dict(os.environ)
-    e["AULE_HIP_BWD_DKV"] = which
-    e["AULE_HIP_BWD_DQ"] = which
+    if which == "spill":
+        e["AULE_HIP_BWD_DKV"] = "new"
+        e.pop("AULE_HIP_BWD_MODE", None)
+    else:
+        e["AULE_HIP_BWD_MODE"] = "recompute"
+        e["AULE_HIP_BWD_DKV"] = which
+        e["AULE_HIP_BWD_DQ"] = which
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_bwd.py"), os.path.join(ROOT, "tests", "test_gpu_bottom_right.py"),
                         "-q", "-x", "-m", "gpu", "-k", "not one_wave_per_simd"], env=e, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and "passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_spill_backward_in_batch_chunks_is_bit_identical(torch_cuda):
+    """The dS workspace is used in chunks of as many batch elements as the caller's buffer holds: a buffer for one element (three
+    chunks) and the full one give the same bits; a buffer without any dS room runs the recompute pair (close, not identical)."""
+    import ctypes
+    import aule
+    from aule import _capi, _torch as at
+    torch = torch_cuda
+    lib = _capi.get_lib()
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    B, Hq, Hkv, S, D = 3, 8, 2, 640, 128
+    q, k, v, do = (torch.randn(B, h, S, D, device="cuda", dtype=torch.bfloat16, generator=gen) for h in (Hq, Hkv, Hkv, Hq))
+    sc = 1 / math.sqrt(D)
+    out, lse = at.fwd_raw(q, k, v, True, sc)
+
+    def run(ws_bytes):
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        d = _capi.AttnBwdDesc()
+        d.struct_size = ctypes.sizeof(_capi.AttnBwdDesc)
+        d.dtype = 2
+        d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, S, S, D
+        d.scale, d.causal, d.window_size, d.device = sc, 1, -1, torch.cuda.current_device()
+        d.stream = torch.cuda.current_stream().cuda_stream
+        d.q, d.k, d.v, d.out, d.dout, d.lse = (t.data_ptr() for t in (q, k, v, out, do, lse))
+        d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+        full = int(lib.aule_attention_backward_workspace_size(ctypes.byref(d)))
+        n = full if ws_bytes is None else ws_bytes(full)
+        ws = torch.empty((n,), device="cuda", dtype=torch.uint8)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), n
+        _capi.check(lib.aule_attention_backward_ex(ctypes.byref(d)), "aule_attention_backward_ex")
+        torch.cuda.synchronize()
+        return full, dq, dk, dv
+
+    full, dq, dk, dv = run(None)
+    per_batch = Hkv * 4 * ((S + 127) // 128) * (Hq // Hkv) * ((S + 31) // 32) * 2048
+    base = full - B * per_batch
+    if base <= 0:      # no dS part: the grid rule keeps this small problem on the recompute pair unless AULE_HIP_BWD_DKV=new (the mode test's
+        pytest.skip("no dS workspace for this shape in this mode")   # "spill" leg runs this test with it), or the mode is recompute
+    _, dq1, dk1, dv1 = run(lambda f: base + per_batch)     # one element per chunk
+    assert torch.equal(dq, dq1) and torch.equal(dk, dk1) and torch.equal(dv, dv1)
+    _, dq0, dk0, dv0 = run(lambda f: base)                 # no dS room: the recompute pair
+    for a, b in ((dq, dq0), (dk, dk0), (dv, dv0)):
+        assert (a.float() - b.float()).abs().max().item() <= 2e-2 * max(1.0, b.float().abs().max().item())
 
 
 def test_dq_of_the_one_wave_per_simd_kernel_is_bit_identical_to_its_predecessor():
@@ -217,6 +268,7 @@ for (dt, B, Hq, Hkv, Sq, Sk, D, causal) in ((torch.bfloat16, 2, 8, 2, 640, 640, 
     for which in ("old", "new"):
         e = dict(os.environ)
         e["AULE_HIP_BWD_DQ"] = which
+        e["AULE_HIP_BWD_MODE"] = "recompute"      # (the default 5-matmul backward has no recomputing dQ kernel at all)
         r = subprocess.run([sys.executable, "-c", prog, os.path.join(ROOT, "aule-attention_amd")], env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs[which] = [ln for ln in r.stdout.splitlines() if ln.startswith("DQ ")]

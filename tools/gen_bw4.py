@@ -370,7 +370,17 @@ def gen_struct(c):
     s += emit_asm(lines, [], ['[dlds] "s"(dlds)', '[qsrd] "s"(qsrd)', '[gsrd] "s"(gsrd)', '[dso] "s"(dso)',
                               '[vost0] "v"(vost0)', '[vost1] "v"(vost1)'], ["memory", "m0", "scc"], indent="        ")
     s += "#endif\n    }\n"
-    # ---- one accumulator register
+    # ---- the 5-matmul backward (round 5): the packed dS of the current block -- the B operands of dK's MFMAs, 8 registers: lane
+    # (key n, hi) holds query rows 16 kk + 4 hi + {0..3} and 16 kk + 8 + 4 hi + {0..3} of k-step kk in DS[4 kk .. 4 kk + 3] -- goes
+    # to the workspace as a 2 KB unit [kk][lane][16 bytes]; fa_bwd_dqs_gfx950.hip reads it back (transposed through LDS) as the
+    # B operand of dQ^T += K^T dS^T, so nobody recomputes S / dP.  Issued at the top of phase 2, in front of the iteration's other
+    # VMEM requests: the phase boundary's vmcnt(NP) then covers the stores too (the counter is shared on gfx9).
+    lines = [f"buffer_store_dwordx4 v[{c.DS}:{c.DS + 3}], %[svo], %[ssrd], %[sso] offen",
+             f"buffer_store_dwordx4 v[{c.DS + 4}:{c.DS + 7}], %[svo], %[ssrd], %[sso] offen offset:1024"]
+    s += ("    static __device__ __forceinline__ void store_ds(__amdgpu_buffer_rsrc_t ssrd, unsigned svo, unsigned sso) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n        sso = (unsigned)__builtin_amdgcn_readfirstlane((int)sso);\n")
+    s += emit_asm(lines, [], ['[ssrd] "s"(ssrd)', '[svo] "v"(svo)', '[sso] "s"(sso)'], ["memory"], indent="        ")
+    s += "#endif\n    }\n"
     s += "};\n\n"
     return s
 
