@@ -246,6 +246,20 @@ def _preload_torch_hip_runtime():
             pass
 
 
+def _mapped_hip_runtimes():
+    """paths of every libamdhip64 mapped into this process (two = the double-runtime condition _preload_torch_hip_runtime avoids)"""
+    out = []
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                p = line.split()[-1] if line.strip() else ""
+                if "libamdhip64" in p and p not in out:
+                    out.append(p)
+    except OSError:
+        pass
+    return out
+
+
 def load():
     """dlopen libaule.so and declare every signature. Does NOT need a GPU."""
     global _lib, _lib_path
@@ -276,7 +290,9 @@ def get_lib():
             if not _initialized:
                 rc = lib.aule_init()
                 if rc != 0:
-                    raise AuleError("aule_init failed (%d): %s" % (rc, last_error(lib)))
+                    raise AuleError("aule_init failed (%d): %s [HIP runtime(s) mapped in this process: %s; if torch's bundled copy and the "
+                                    "system's are both listed, or the wrong one is bound, set AULE_HIP_RUNTIME=system or import torch first]"
+                                    % (rc, last_error(lib), ", ".join(_mapped_hip_runtimes()) or "none found in /proc/self/maps"))
                 _initialized = True
     return lib
 

@@ -29,6 +29,7 @@ end-to-end cost of the gather at config 4: ~0.4 ms exposed (the last piece) inst
 Every rank ends with the full [B, Hq, Sq, D] tensor; pass gather=False to keep the shard (what a data-parallel model does:
 it never needs the other ranks' attention outputs).  The backward needs no collective at all: dQ, dK, dV are per unit.
 """
+import os
 from typing import Callable, List, Optional, Tuple
 
 
@@ -102,7 +103,8 @@ def flash_attention_sharded(q, k, v, causal: bool = True, scale: Optional[float]
     """Every rank holds the same full q, k, v (or at least its own shard's rows); each computes its share with `attn_fn`
     (default aule.flash_attention) in `chunks` pieces and, if `gather`, every rank receives the full output: the exchange of
     piece i overlaps the computation of piece i+1 (module docstring).  transport: "allgather", "p2p", "peer" (direct copies into the peers' mapped buffers; the
-    result then lives in a cached exchange buffer and stays valid until the second-next "peer" exchange of the same size) or
+    result then lives in a cached exchange buffer and stays valid until the second-next "peer" exchange of the same size, or until more
+    than AULE_PEER_CACHE_KEYS = 4 other exchange sizes evict its buffer: see _peer_exchange; .clone() a result that must outlive that) or
     "auto" (p2p when the shards differ in size, all-gather otherwise).  Returns the full [B,Hq,Sq,D] output (gather=True) or this rank's
     shard.  Inference path (no autograd through the collective).  chunks=1, transport="allgather" is the single blocking
     collective of round 1."""
@@ -207,7 +209,8 @@ class PeerExchange:
     """The gathered tensor of transport="peer": a device buffer of this rank that every peer has mapped, plus this rank's
     mappings of the peers' buffers and one stream per peer.  Built collectively (every rank of `group` must construct it with
     the same nbytes); cached by _compute_and_exchange per (group, bytes, device), two buffers alternating, so a result stays
-    valid until the second-next exchange of the same size on the same group."""
+    valid until the second-next exchange of the same size on the same group, or until its cache entry is evicted by exchanges of more
+    than AULE_PEER_CACHE_KEYS (default 4) other sizes / groups, whichever comes first (_peer_exchange below): clone what must live longer."""
 
     def __init__(self, nbytes, device, group):
         import ctypes
@@ -300,13 +303,20 @@ class _RawDeviceBytes:
 
 
 _peer_cache = {}          # insertion-ordered: the least recently used key first
-_PEER_CACHE_KEYS = 4      # distinct (group, bytes, device) triples kept; the oldest pair of buffers is closed beyond that
+# distinct (group, bytes, device) triples kept; the oldest pair of buffers is closed (and FREED) beyond that.  A workload whose
+# exchanges come in more sizes than this pays a collective IPC set-up per call: raise AULE_PEER_CACHE_KEYS for it.
+_PEER_CACHE_KEYS = max(1, int(os.environ.get("AULE_PEER_CACHE_KEYS", "4")))
 
 
 def _peer_exchange(nbytes, device, group):
     """Two alternating buffers per (group, bytes, device).  The entry holds the group object itself, so its id() cannot be
     reused by another group while the entry lives; at most _PEER_CACHE_KEYS entries are kept (every rank runs the same
-    sequence of exchanges, so every rank evicts the same entry at the same call -- closing stays collective)."""
+    sequence of exchanges, so every rank evicts the same entry at the same call -- closing stays collective).
+
+    LIFETIME of a result: a tensor returned by a transport="peer" gather aliases one of these buffers (zero-copy).  It stays
+    valid until (a) the second-next peer exchange of the SAME (group, bytes, device) overwrites it, or (b) its entry is evicted -- the
+    exchange that brings the number of distinct keys above _PEER_CACHE_KEYS (default 4, AULE_PEER_CACHE_KEYS) closes and frees the least
+    recently used pair -- or (c) release_peer_buffers().  Callers that keep a gathered tensor across later exchanges must .clone() it."""
     key = (id(group) if group is not None else 0, int(nbytes), str(device))
     ent = _peer_cache.pop(key, None)
     if ent is None:

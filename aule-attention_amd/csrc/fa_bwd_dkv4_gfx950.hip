@@ -39,7 +39,11 @@ namespace {
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
+#ifdef BW4_ASM_INC          // timing variants (tools/sessions/r5_s2.sh)
+#include BW4_ASM_INC
+#else
 #include "fa_bwd_dkv4_asm.inc"
+#endif
 
 struct Dkv4Params {
     const void* q;
@@ -273,11 +277,12 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
 #undef DKV4_P1
                 // block i + 2 has landed for everybody (all but this wave's newest NP requests -- block i + 3 -- are complete:
                 // the scalars of block i + 1 among them)
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(A::NP) : "memory");
+                // (SPILL with the dS stores behind the DMA pieces: the two stores of the previous iteration may stay out as well)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(A::NP + (SPILL ? A::ST_LATE : 0)) : "memory");
                 unsigned long long t1 = 0;
                 if constexpr (TL) { t1 = __builtin_amdgcn_s_memtime(); tl_a += t1 - t0; }
                 const unsigned b = slot_lds(i + 2) + a_sub, b1 = slot_lds(i + 2) + a_sub1;
-                if constexpr (SPILL) A::store_ds(srs, svo, (unsigned)i << 11);
+                if constexpr (SPILL && A::ST_LATE == 0) A::store_ds(srs, svo, (unsigned)i << 11);
                 {
                     const unsigned lso = (unsigned)row_nxt[PAR] * 4u, lso3 = (unsigned)row_nxt[PAR ^ 1] * 4u, dso = (unsigned)c4.row * (unsigned)RB;
                     const unsigned dl = slot_lds(i + 4) + wave_pb;
@@ -286,6 +291,7 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
                     A::template p2<2, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
                     A::template p2<3, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
                 }
+                if constexpr (SPILL && A::ST_LATE != 0) A::store_ds(srs, svo, (unsigned)i << 11);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments of block i + 2 (phase 1 of the next iteration reads them)
                 t_cur[PAR] = t_nxt[PAR]; t_nxt[PAR] = c4.t; row_nxt[PAR] = c4.row;
                 adv(c4);

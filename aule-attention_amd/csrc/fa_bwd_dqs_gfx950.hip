@@ -83,8 +83,20 @@ struct DqsParams {
 
 constexpr int kDqsQBlock = 256;   // 4 waves x 64 query rows
 constexpr int kDqsKB = 32;        // keys per block of the stream
-constexpr int kDqsSlots = 6;      // LDS ring
-constexpr int kDqsAhead = 5;      // blocks requested ahead (< kDqsSlots: the slot of block j + AHEAD is block j - 1's)
+#ifndef DQS_SLOTS
+#define DQS_SLOTS 3
+#endif
+#ifndef DQS_AHEAD
+#define DQS_AHEAD 2
+#endif
+#ifndef DQS_OCC
+#define DQS_OCC 2          // workgroups per CU: two 3-slot rings (150 KB of LDS), two waves per SIMD -- one workgroup's DMA issue and
+#endif                     // transpose reads run under the other's MFMAs (a single workgroup serialises them behind its barrier)
+constexpr int kDqsSlots = DQS_SLOTS;      // LDS ring
+constexpr int kDqsAhead = DQS_AHEAD;      // blocks requested ahead (< kDqsSlots: the slot of block j + AHEAD is block j - 1's)
+static_assert(kDqsAhead < kDqsSlots, "the slot of block j + AHEAD must be block j - 1's or older");
+// timing experiments only (results are garbage): DQS_X_NOMFMA no tr-reads / MFMAs (the stream alone), DQS_X_SEQ a layout in which a
+// wave's units are consecutive in memory, DQS_X_NODS no dS requests (the K side alone)
 
 template <int D>
 struct DqsCfg {
@@ -107,7 +119,7 @@ __device__ __forceinline__ void dqs_dma(unsigned lds, unsigned voff, __amdgpu_bu
 }
 
 template <class T, int D, bool CAUSAL>
-__global__ void __launch_bounds__(256, 1) fa_bwd_dqs_kernel(const DqsParams p) {
+__global__ void __launch_bounds__(256, DQS_OCC) fa_bwd_dqs_kernel(const DqsParams p) {
     using C = DqsCfg<D>;
     using v8 = typename T::v8;
     constexpr int RB = C::RB, DB = C::DB;
@@ -152,10 +164,27 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dqs_kernel(const DqsParams p) {
     // dS: a unit arrives as two 1 KB pieces; LDS chunk 64 p + l of the unit's image holds (key n = 16 p + (l >> 2), query step
     // kk = (l >> 1) & 1, hi = l & 1), i.e. the image is [key][kk][hi][16 bytes] -- a 32-lane pass of the transpose reads below then
     // covers 256 contiguous bytes.  Source (DsLayout): kk * 1024 + (n + 32 hi) * 16.
+#ifndef DQS_DMA_QUAD
+#define DQS_DMA_QUAD 1
+#endif
+#if DQS_DMA_QUAD
+    // (round 5, session 2) the image of a unit is made of 256-byte windows of four keys, window w = keys 4 w .. 4 w + 3 as [c = 2 kk + hi][key & 3]
+    // 16-byte chunks: four consecutive lanes of a piece then fetch 64 CONTIGUOUS source bytes (the first build's [key][kk][hi] order
+    // sent every lane of a quad to another 128-byte line: 3.3 TB/s), and a 32-lane pass of the transpose reads still covers one
+    // whole window.  LDS chunk 64 p + l: window 4 p + (l >> 4), c = (l >> 2) & 3, key & 3 = l & 3.
+    const unsigned svo = (unsigned)(((lane >> 3) & 1) * 1024 + ((lane >> 2) & 1) * 512 + (4 * (lane >> 4) + (lane & 3)) * 16);   // piece 0; piece 1: + 256
+    // transpose read (kk2 = 16-key step, e): lane (hi, qhalf = bit 4, i = lane & 15) addresses key 16 kk2 + 8 e + 4 hi + (i >> 2)
+    // (window 4 kk2 + 2 e + hi, key & 3 = i >> 2), query rows 16 qhalf + 4 (i & 3) .. + 3 = (kk = qhalf, hi' = i & 1, half = (i >> 1) & 1),
+    // and receives query 16 qhalf + i, 4 keys
+    const unsigned str = (unsigned)(256 * hi + 64 * (2 * ((lane >> 4) & 1) + (lane & 1)) + 16 * ((lane & 15) >> 2) + 8 * ((lane >> 1) & 1));
+    constexpr int kStrKK = 1024, kStrE = 512;
+#else
     const unsigned svo = (unsigned)(((lane >> 1) & 1) * 1024 + (lane & 1) * 512 + (lane >> 2) * 16);   // piece 0; piece 1: + 256
     // transpose read (kk2 = 16-key step, e): lane (hi, qhalf = bit 4, i = lane & 15) addresses key 16 kk2 + 8 e + 4 hi + (i >> 2),
     // query rows 16 qhalf + 4 (i & 3) .. + 3 = (kk = qhalf, hi' = i & 1, half = (i >> 1) & 1) and receives query 16 qhalf + i, 4 keys
     const unsigned str = (unsigned)(256 * hi + 64 * ((lane & 15) >> 2) + 32 * ((lane >> 4) & 1) + 16 * (lane & 1) + 8 * ((lane >> 1) & 1));
+    constexpr int kStrKK = 1024, kStrE = 512;
+#endif
     const unsigned sun = (unsigned)(C::IMGK + wave * 4096);   // this wave's two units inside a slot
 
     const int nparts = (CAUSAL && (nqb - 1 - w.blk) != w.blk) ? 2 : 1;
@@ -175,7 +204,11 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dqs_kernel(const DqsParams p) {
         const int u0 = hh * p.nq32 + q0w / 32;
         auto ds_off = [&](int j, int rb) __attribute__((always_inline)) {
             const int fq = CAUSAL ? max(0, (j >> 2) * 128 - coff) >> 5 : 0;
+#ifdef DQS_X_SEQ
+            return (unsigned)((((long long)(u0 + rb) * p.nkb32p + j) << 11) + 0 * fq);
+#else
             return (unsigned)(((long long)j * xs + u0 + rb - hh * fq) << 11);
+#endif
         };
         auto issue = [&](int j, int slot) __attribute__((always_inline)) {
             const unsigned sl = lds0 + (unsigned)slot * C::SLOT;
@@ -185,8 +218,13 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dqs_kernel(const DqsParams p) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const unsigned so = ds_off(j, rb);
+#ifdef DQS_X_NODS
+                dqs_dma(dqs_rfl((int)(sl + sun + rb * 2048)), svo, krs, ko);
+                dqs_dma(dqs_rfl((int)(sl + sun + rb * 2048 + 1024)), svo, krs, ko + 0 * so);
+#else
                 dqs_dma(dqs_rfl((int)(sl + sun + rb * 2048)), svo, srs, so);
                 dqs_dma(dqs_rfl((int)(sl + sun + rb * 2048 + 1024)), svo, srs, so + 256u);
+#endif
             }
         };
 
@@ -207,6 +245,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dqs_kernel(const DqsParams p) {
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((kDqsAhead - 1) * C::NP) : "memory");
             issue(j + kDqsAhead, dslot);
             const char* sl = smem + slot * C::SLOT;
+#ifndef DQS_X_NOMFMA
             v8 kt[2][DB];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -231,14 +270,17 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dqs_kernel(const DqsParams p) {
                 const char* un = sl + sun + rb * 2048 + str;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    u32x2_t a = __builtin_bit_cast(u32x2_t, lds_tr16(un + 1024 * kk));
-                    u32x2_t b = __builtin_bit_cast(u32x2_t, lds_tr16(un + 1024 * kk + 512));
+                    u32x2_t a = __builtin_bit_cast(u32x2_t, lds_tr16(un + kStrKK * kk));
+                    u32x2_t b = __builtin_bit_cast(u32x2_t, lds_tr16(un + kStrKK * kk + kStrE));
                     const u32x4_t m = {a[0] & live, a[1] & live, b[0] & live, b[1] & live};
                     const v8 dsv = as_v8<T>(m);
 #pragma unroll
                     for (int d = 0; d < DB; ++d) acc[rb][d] = T::mfma(kt[kk][d], dsv, acc[rb][d]);
                 }
             }
+#else
+            (void)sl; (void)ktr; (void)str;
+#endif
             slot = slot + 1 == kDqsSlots ? 0 : slot + 1;
             dslot = dslot + 1 == kDqsSlots ? 0 : dslot + 1;
         }

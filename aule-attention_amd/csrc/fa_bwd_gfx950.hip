@@ -253,7 +253,7 @@ constexpr int kDqQBlock = 256;
 constexpr int kDqKV = 64;
 
 // AULE_DQ_DMA=1 (D >= 64): the dQ kernel's K / V images arrive by LDS-DMA (buffer_load ... lds) instead of through staging
-// registers and six ds_write_b128 per thread and tile -- as in the forward (fa_fwd_ps_gfx950.hip): un-padded row-major
+// registers and six ds_write_b128 per thread and tile -- as in the round-2 forward (the tile-stream kernel, retired in round 4): un-padded row-major
 // images with the 16-byte chunks XOR-swizzled, the sub-tiled image as it was (it is lane-linear).
 #ifndef AULE_DQ_DMA
 #define AULE_DQ_DMA 1
@@ -1070,15 +1070,29 @@ inline uint64_t delta_bytes(int B, int Hq, int Sq) {
 }
 
 // ---- the 5-matmul backward (round 5): delta pass -> dK/dV kernel that also spills its packed dS -> dQ = dS K (fa_bwd_dqs_gfx950.hip).
-// AULE_HIP_BWD_MODE=recompute pins the two-kernel pair of rounds 1-4 (7 matmuls, no dS workspace); default: spill wherever the
-// one-wave-per-SIMD dK/dV kernel would run anyway and one batch element's dS fits the cap (AULE_HIP_BWD_DS_CAP_MB, default 8192;
-// the batch runs in chunks of as many elements as the caller's workspace holds).
-inline int bwd_mode() {
+// MEASURED (profiles/r5_bwd_spill.txt): it removes the recomputation (7 -> 5 tile matmuls) but moves 2 x 2 KB per (32 x 32) tile through
+// the memory fabric -- 128 FLOP saved per byte moved, below the chip's ridge of ~315 -- and the dK/dV kernel, whose Q / dO re-reads
+// already miss the 4 MB L2 half of the time, stalls on the added write stream (+18 .. +34 % cycles even on zero inputs); the dQ kernel
+// then runs at the fabric's ~4.2 TB/s.  C2 1794 vs 1751 us, C3 472 .. 486 vs 474 us, D = 64 832 vs 668 us against the recompute pair.
+// So it is an OPT-IN mode, not the default: AULE_HIP_BWD_MODE=spill takes it wherever it can run (and the one-wave-per-SIMD dK/dV kernel
+// would run anyway); AULE_HIP_BWD_DS_AUTO_MB=<n> takes it by itself for problems whose dS fits n MB (the Infinity Cache keeps what a
+// kernel wrote for the next one up to ~256 MB: tools/probe_mall.hip); default: the recompute pair of rounds 1-4.
+// AULE_HIP_BWD_DS_CAP_MB (default 8192) bounds the workspace: the batch runs in chunks of as many elements as the caller's buffer holds.
+inline int bwd_mode() {   // 0: auto (by AULE_HIP_BWD_DS_AUTO_MB), 1: recompute, 2: spill wherever applicable
     static const int m = [] {
         const char* e = std::getenv("AULE_HIP_BWD_MODE");
-        return (e != nullptr && e[0] == 'r') ? 1 : 0;
+        if (e == nullptr) return 0;
+        return e[0] == 'r' ? 1 : (e[0] == 's' ? 2 : 0);
     }();
     return m;
+}
+inline uint64_t bwd_ds_auto_bytes() {
+    static const uint64_t c = [] {
+        const char* e = std::getenv("AULE_HIP_BWD_DS_AUTO_MB");
+        const long long mb = e != nullptr ? std::atoll(e) : 0;
+        return (uint64_t)(mb > 0 ? mb : 0) << 20;
+    }();
+    return c;
 }
 inline uint64_t bwd_ds_cap_bytes() {
     static const uint64_t c = [] {
@@ -1105,7 +1119,12 @@ inline uint64_t spill_bytes_per_batch(int B, int Hq, int Hkv, int Sq, int Sk, in
     t.B = B; t.Hq = Hq; t.Hkv = Hkv; t.Sq = Sq; t.Sk = Sk; t.D = D; t.causal = causal; t.dtype = dtype; t.window = -1; t.coff = 0;
     if (!bwd_dkv4_applicable(t) || !bwd_dqs_applicable(t) || !dkv4_by_grid(B, Hq, Hkv, Sk, causal)) return 0;
     const uint64_t pb = (uint64_t)Hkv * (uint64_t)DsLayout::of(Hq, Hkv, Sq, Sk).group_bytes;
-    return pb <= bwd_ds_cap_bytes() ? pb : 0;
+    if (pb > bwd_ds_cap_bytes()) return 0;
+    if (bwd_mode() == 0) {   // auto: only problems whose TOUCHED dS (the causal half) fits the budget
+        const uint64_t touched = (uint64_t)B * pb / (causal ? 2 : 1);
+        if (touched > bwd_ds_auto_bytes()) return 0;
+    }
+    return pb;
 }
 inline uint64_t bwd_base_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype) {
     uint64_t bytes = delta_bytes(B, Hq, Sq);
@@ -1217,8 +1236,8 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     // spread (MHA / GQA, causal or not, ragged, fp16: -0.5 .. -24 %); what stays here is the tiny grid with a big group (fp16 MQA
     // 32/1 S8192: 32 work items there against 512 here).
     const auto use_dkv4 = [&] {
-        if ((D != 128 && D != 64) || !(a.dbg == nullptr || dkv4_timeline_wanted()) || !bwd_dkv4_applicable(a)) return false;
-        if (bwd_dkv4_forced() || dkv4_timeline_wanted()) return true;
+        if ((D != 128 && D != 64) || !(a.dbg == nullptr || (D == 128 && dkv4_timeline_wanted())) || !bwd_dkv4_applicable(a)) return false;   // (the timeline instance exists at D = 128 only)
+        if (bwd_dkv4_forced() || (D == 128 && dkv4_timeline_wanted())) return true;
         const int nkb = (a.Sk + kKvBlock - 1) / kKvBlock;
         const long long here = (long long)a.B * a.Hkv * (a.causal ? (nkb + 1) / 2 : nkb) * dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal);
         const long long there = bwd_dkv4_items(a);

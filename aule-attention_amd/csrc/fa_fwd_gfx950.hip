@@ -19,6 +19,7 @@
 // (Retired, in the history: the lock-step kernel of round 1 and the in-wave pipelined variants -- fa_fwd_iw_gfx950.hip -- in
 // round 2; the two-waves-per-SIMD persistent tile stream -- fa_fwd_ps_gfx950.hip, routes 6 and 7 of rounds 2-3 -- in round 4,
 // when the one-wave-per-SIMD kernel took its small-grid split and the ping-pong kernel its remaining shapes.)
+#include <cstdio>
 #include <cstdlib>
 
 #include "fa_device.h"
@@ -41,7 +42,12 @@ int configure_fwd_w4();
 static int fwd_kernel_choice() {
     static const int v = [] {
         const char* e = getenv("AULE_HIP_FWD_KERNEL");
-        if (e != nullptr && e[0] == 'p' && e[1] == 'p') return 4;
+        if (e == nullptr || e[0] == 0) return 0;
+        if (e[0] == 'p' && e[1] == 'p' && e[2] == 0) return 4;
+        if (e[0] == 'w' && e[1] == '4' && e[2] == 0) return 0;
+        // ("ps" named the persistent tile stream retired in round 4 and used to be ignored silently: an A/B run then
+        // measured the default kernel twice)
+        fprintf(stderr, "libaule: WARNING: AULE_HIP_FWD_KERNEL=%s is not a kernel of this build (known: pp, w4) -- the default dispatch runs\n", e);
         return 0;
     }();
     return v;

@@ -1,5 +1,5 @@
 // fa_fwd_tile.h -- pieces shared by the 16-bit tiled forward kernels (fa_fwd_pp_gfx950.hip: ping-pong schedule,
-// one workgroup per Q-block pair; fa_fwd_ps_gfx950.hip: the same schedule as a persistent tile stream): LDS tile
+// one workgroup per Q-block pair) and the one-wave-per-SIMD kernels: LDS tile
 // geometry, the single-issue softmax statements and the raw buffer descriptor.  Device code only.
 #pragma once
 #include "fa_device.h"

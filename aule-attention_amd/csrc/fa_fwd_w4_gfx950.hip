@@ -1,7 +1,7 @@
 // fa_fwd_w4_gfx950.hip -- FlashAttention-2 forward (16-bit I/O), ONE WAVE PER SIMD: workgroup = 4 waves x 64 query rows.
 //
 // Replaces python/aule/triton_flash_amd.py:97-240 (_flash_attn_fwd_amd; the tile shapes it autotunes over: :58-95) at the
-// headline shapes.  The predecessors (fa_fwd_ps_gfx950.hip, fa_fwd_pp_gfx950.hip) put two 32-row waves on every SIMD: one
+// headline shapes.  The predecessors (fa_fwd_pp_gfx950.hip and the tile-stream kernel retired in round 4) put two 32-row waves on every SIMD: one
 // ds_read_b128 per QK^T MFMA, two transpose reads per PV MFMA, two barriers per tile, 57 cycles per MFMA measured.  Here
 //
 //   * a wave owns the whole 512-register file of its SIMD: O^T (128 registers), the Q fragments (64) and ONE K tile (64)
@@ -1095,7 +1095,7 @@ int set_attr_w4() {
 
 }  // namespace
 
-// Shapes the one-wave-per-SIMD forward takes (everything else: fa_fwd_ps_gfx950.hip / fa_fwd_pp_gfx950.hip).
+// Shapes the one-wave-per-SIMD forward takes (everything else: fa_fwd_pp_gfx950.hip).
 bool fwd_w4_applicable(const FwdArgs& a) {
     if (a.dtype != kBF16 && a.dtype != kF16) return false;
     if (a.D != 128 && a.D != 64) return false;

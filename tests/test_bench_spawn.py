@@ -29,6 +29,8 @@ def test_plain_launch_with_two_ranks_spawns_itself():
     assert len(lines) == 1, r.stdout
     assert lines[0]["n_gpus"] == 2 and lines[0]["world_size"] == 2 and lines[0]["dry_run"] is True
     assert lines[0]["steps"] == 4 and lines[0]["warmup"] == 1 and lines[0]["value"] is None
+    # N > 1 times BASELINE.json configs[3] (B=64 over 8 GPUs: 8 per GPU, S=8192), not the single-GPU headline's batch
+    assert lines[0]["config"]["workload"].startswith("c4: B=8/GPU Hq=32 Hkv=32 Sq=8192 Sk=8192 D=128 bf16 causal fwd"), lines[0]["config"]
 
 
 def test_dry_run_one_rank_needs_no_launcher():
@@ -36,6 +38,7 @@ def test_dry_run_one_rank_needs_no_launcher():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1 and lines[0]["world_size"] == 1
+    assert lines[0]["config"]["workload"].startswith("c2: B=4/GPU Hq=32 Hkv=32 Sq=4096 Sk=4096 D=128 bf16 causal fwd"), lines[0]["config"]
 
 
 def test_launcher_with_wrong_rank_count_is_refused():

@@ -175,8 +175,9 @@ def test_backward_deterministic(torch_cuda):
 @pytest.mark.parametrize("which", ["spill", "new", "old"])
 def test_backward_on_the_one_wave_per_simd_kernels(which):
     """Three backward modes over the same suites (the switches are read once per process, hence subprocesses):
-      spill  the 5-matmul backward (round 5: delta pass, fa_bwd_dkv4_gfx950.hip's SPILL instances, fa_bwd_dqs_gfx950.hip) forced onto every
-             problem it CAN run (AULE_HIP_BWD_DKV=new lifts the grid rule);
+      spill  AULE_HIP_BWD_MODE=spill: the 5-matmul backward (round 5: delta pass, fa_bwd_dkv4_gfx950.hip's SPILL instances,
+             fa_bwd_dqs_gfx950.hip; an opt-in mode, profiles/r5_bwd_spill.txt) forced onto every problem it CAN run
+             (AULE_HIP_BWD_DKV=new lifts the grid rule);
       new    AULE_HIP_BWD_MODE=recompute + the one-wave-per-SIMD pair (fa_bwd_dkv4 / fa_bwd_dq4) forced wherever it can run;
       old    AULE_HIP_BWD_MODE=recompute + both predecessors (fa_bwd_gfx950.hip) everywhere.
     The sweep, the reference's golden gradients, the bottom-right cases and the determinism test then exercise the masks, the stream
@@ -187,7 +188,7 @@ def test_backward_on_the_one_wave_per_simd_kernels(which):
     e = dict(os.environ)
     if which == "spill":
         e["AULE_HIP_BWD_DKV"] = "new"
-        e.pop("AULE_HIP_BWD_MODE", None)
+        e["AULE_HIP_BWD_MODE"] = "spill"
     else:
         e["AULE_HIP_BWD_MODE"] = "recompute"
         e["AULE_HIP_BWD_DKV"] = which

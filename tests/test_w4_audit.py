@@ -48,6 +48,25 @@ def test_hazard_lint_catches_what_it_is_for():
     assert ok == []
 
 
+def test_audit_flags_compiler_code_in_the_literal_scalar_registers(tmp_path):
+    """the embedded-request forward keeps descriptors, cursors and the LDS base in literal s[NS:NS+13] across statements; only
+    amdgpu_num_sgpr keeps hipcc below NS.  The audit must flag a compiler-made instruction that touches s >= NS -- and must not flag the
+    statements themselves."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_w4 as a
+    ns = a.generator_ns()
+    name = "_ZN8aule_hip12_GLOBAL__N_121fa_fwd_w4_kernel_d128INS_10Bf16TraitsELb1ELb0EEEvNS0_11FwdW4ParamsE"
+    body = ["s_mov_b32 s%d, 0" % (ns + 2), ";;#ASMSTART", "s_add_u32 m0, s%d, 1024" % (ns + 12), "v_mfma_f32_32x32x16_bf16 a[0:15], a[128:131], a[192:195], a[0:15]",
+            ";;#ASMEND", "s_add_i32 s%d, s%d, 1" % (ns - 1, ns - 2), "s_load_dwordx4 s[%d:%d], s[0:1], 0x0" % (ns - 2, ns + 1), "s_endpgm"]
+    text = name + ":\n" + "\n".join("\t" + l for l in body) + "\n  - .name:           " + name + "\n    .private_segment_fixed_size: 0\n    .vgpr_spill_count: 0\n"
+    f = tmp_path / "fake.s"
+    f.write_text(text)
+    probs = a.audit(str(f), verbose=False)
+    hits = [p for p in probs if ">= NS" in p]
+    assert len(hits) == 2 and ("s%d" % (ns + 2)) in hits[0] and ("s%d" % (ns + 1)) in hits[1], probs
+    assert not any("m0, s%d" % (ns + 12) in p for p in probs)
+
+
 @pytest.mark.parametrize("gen,env,inc,hip", [("gen_bw4.py", "BW4_OUT", "fa_bwd_dkv4_asm.inc", "fa_bwd_dkv4_gfx950.hip"),
                                               ("gen_dq4.py", "DQ4_OUT", "fa_bwd_dq4_asm.inc", "fa_bwd_dq4_gfx950.hip")])
 def test_backward_streams_current_and_kernels_clean(tmp_path, gen, env, inc, hip):

@@ -4,7 +4,8 @@ their registers literally, so hipcc must keep out of them.  Compiles the file to
   * no scratch (private_segment_fixed_size 0, vgpr_spill_count 0): a spill reload's vmcnt(0) would drain the LDS-DMA queue, and
     a spill INTO an accumulator register would corrupt O / Q / K silently;
   * no v_accvgpr_* and no scratch_* instruction outside the ;;#ASMSTART / ;;#ASMEND brackets;
-  * hipcc's own VGPRs stay below the generator's budget NV (amdgpu_num_vgpr);
+  * hipcc's own VGPRs stay below the generator's budget NV (amdgpu_num_vgpr), and its own SGPRs below NS: the streams keep the K / V
+    descriptors, cursors and the LDS base in literal s[NS:NS+13] across statements (amdgpu_num_sgpr);
   * the plain tile step (the statements that carry an LDS-DMA piece) is free of v_readlane / v_writelane (SGPR spills) and of
     compiler-made s_waitcnt vmcnt;
   * the hazards the inline-asm statements must keep by themselves (lint_blocks: v_exp_f32 -> next reader, MFMA result -> reader
@@ -129,7 +130,15 @@ def lint_lds_waits(block, entry_pending=0):
     return out[:10]
 
 
+def generator_ns():
+    """NS of the committed streams (fa_fwd_w4_asm.inc: `static constexpr int ... NS = 88`): the first literal scalar register"""
+    inc = open(os.path.join(ROOT, "aule-attention_amd", "csrc", "fa_fwd_w4_asm.inc")).read()
+    m = re.search(r"\bNS = (\d+)", inc)
+    return int(m.group(1)) if m else 88
+
+
 def audit(path, verbose=True):
+    NS = generator_ns()
     text = open(path).read()
     problems = []
     meta = {}
@@ -171,7 +180,18 @@ def audit(path, verbose=True):
                 for r in re.findall(r"\bv(\d+)\b", t) + [x for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", t) for x in (a, b)]:
                     if int(r) >= nv:
                         problems.append(f"{name}: compiler instruction touches v{r} >= NV {nv}: `{t}`")
+                # the streams keep K / V descriptors, cursors and the LDS base in literal s[NS:NS+13] ACROSS statements: hipcc's
+                # own code must stay below NS (amdgpu_num_sgpr keeps it there today; a toolchain bump that does not would corrupt the
+                # descriptors silently).  Only the asm statements may name s >= NS.
+                for r in re.findall(r"\bs(\d+)\b", t) + [x for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", t) for x in (a, b)]:
+                    if int(r) >= NS:
+                        problems.append(f"{name}: compiler instruction touches s{r} >= NS {NS}: `{t}`")
         problems += [f"{name}: {p}" for p in lint_blocks(blocks)]
+        for blk in blocks:
+            for t in blk:
+                for r in re.findall(r"\bs(\d+)\b", t) + [x for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", t) for x in (a, b)]:
+                    if int(r) >= NS + 14 and int(r) < 102:
+                        problems.append(f"{name}: a statement names s{r}, outside the streams' s[{NS}:{NS + 13}]: `{t}`")
         # plain tile steps: eight consecutive statements with MFMAs and embedded LDS-DMA pieces, the tile barrier inside the first
         has_mf = [any("v_mfma" in b for b in blk) for blk in blocks]
         has_dma = [any("offen lds" in b for b in blk) for blk in blocks]

@@ -39,6 +39,11 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from gen_w4 import emit_asm, vregs, aregs, tup   # noqa: E402
 
 OUT = os.environ.get("BW4_OUT", os.path.join(ROOT, "aule-attention_amd", "csrc", "fa_bwd_dkv4_asm.inc"))
+# SPILL instances (the 5-matmul backward): where the two dS stores of an iteration sit -- "start": at the top of phase 2, in front of the
+# iteration's other VMEM requests (the phase boundary's vmcnt(NP) then waits for them too); "end": behind the LDS-DMA pieces, the boundary
+# waits with vmcnt(NP + 2) (the stores get two iterations to retire).  BW4_ST_NT=1: non-temporal stores.
+ST_LATE = 2 if os.environ.get("BW4_ST", "start") == "end" else 0
+ST_NT = os.environ.get("BW4_ST_NT", "0") == "1"
 
 
 class Cfg:
@@ -285,7 +290,7 @@ def gen_p2(c, q, par, mm, rm, ld, dma):
 def gen_struct(c):
     name = f"Bw4Asm<{'Bf16Traits' if c.dt == 'bf16' else 'F16Traits'}, {c.D}>"
     s = f"template <> struct {name} {{\n"
-    s += f"    static constexpr int NV = {c.NV}, NP = {c.NP}, SLOT = {c.SLOT}, IMG = {c.IMG}, PB1 = {c.PBASE[1]}, PB2 = {c.PBASE[2]}, PB4 = {c.PBASE[4] if len(c.PBASE) > 4 else 0};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n"
+    s += f"    static constexpr int NV = {c.NV}, NP = {c.NP}, SLOT = {c.SLOT}, IMG = {c.IMG}, PB1 = {c.PBASE[1]}, PB2 = {c.PBASE[2]}, PB4 = {c.PBASE[4] if len(c.PBASE) > 4 else 0}, ST_LATE = {ST_LATE};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n"
     s += ("    template <int Q, int PAR, int QK, int AR, int TR>\n"
           "    static __device__ __forceinline__ void p1(float c, int lo, int wd, unsigned trb) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n        (void)c; (void)lo; (void)wd; (void)trb;\n")
@@ -375,8 +380,9 @@ def gen_struct(c):
     # to the workspace as a 2 KB unit [kk][lane][16 bytes]; fa_bwd_dqs_gfx950.hip reads it back (transposed through LDS) as the
     # B operand of dQ^T += K^T dS^T, so nobody recomputes S / dP.  Issued at the top of phase 2, in front of the iteration's other
     # VMEM requests: the phase boundary's vmcnt(NP) then covers the stores too (the counter is shared on gfx9).
-    lines = [f"buffer_store_dwordx4 v[{c.DS}:{c.DS + 3}], %[svo], %[ssrd], %[sso] offen",
-             f"buffer_store_dwordx4 v[{c.DS + 4}:{c.DS + 7}], %[svo], %[ssrd], %[sso] offen offset:1024"]
+    nt = " nt" if ST_NT else ""
+    lines = [f"buffer_store_dwordx4 v[{c.DS}:{c.DS + 3}], %[svo], %[ssrd], %[sso] offen{nt}",
+             f"buffer_store_dwordx4 v[{c.DS + 4}:{c.DS + 7}], %[svo], %[ssrd], %[sso] offen offset:1024{nt}"]
     s += ("    static __device__ __forceinline__ void store_ds(__amdgpu_buffer_rsrc_t ssrd, unsigned svo, unsigned sso) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n        sso = (unsigned)__builtin_amdgcn_readfirstlane((int)sso);\n")
     s += emit_asm(lines, [], ['[ssrd] "s"(ssrd)', '[svo] "v"(svo)', '[sso] "s"(sso)'], ["memory"], indent="        ")

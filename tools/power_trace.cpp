@@ -3,7 +3,7 @@
 //   build/power_trace <lib.so> <fwd|bwd> B Hq Hkv Sq Sk D <bf16|fp16> <causal> <seconds> <amp> [label]
 // Launches the call back to back through the C-ABI for `seconds` of wall time with N(0, amp) inputs (amp 0: all-zero inputs) while
 // tools/power_sampler.h reads the hwmon / pp_dpm files every 10 ms; prints the mean launch time per 100-launch window next to the
-// telemetry.  One leg per process (the kernel-choice switches are read once per process: AULE_HIP_FWD_KERNEL=ps etc.).
+// telemetry.  One leg per process (the kernel-choice switches are read once per process: AULE_HIP_FWD_KERNEL=pp, AULE_HIP_BWD_MODE=spill etc.).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cstdint>

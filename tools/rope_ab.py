@@ -6,8 +6,8 @@
 and the plain attention and the two passes alone as the floor / the price list.  Every leg is conditioned on its own
 workload (~250 ms of back-to-back launches: MI355X's clock transient), then timed over N launches with
 one event pair; TFLOP/s count the attention FLOPs only (the rotations are overhead).
-Round 3: the default forward of these shapes (one wave per SIMD) does not rotate Q; the fused legs exist on its predecessor
-(AULE_HIP_FWD_KERNEL=ps).  Run the script both ways: the question is two-pass on the default kernel against q-fused on ps."""
+Round 4: the one-wave-per-SIMD forward rotates Q itself (bit-identical to the pass); the round-3 "ps" leg (AULE_HIP_FWD_KERNEL=ps,
+the tile-stream kernel) is gone with that kernel -- the switch only knows pp / w4 now and says so on stderr for anything else."""
 import math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "aule-attention_amd"))
