@@ -10,6 +10,7 @@ streams, autograd graph); the arithmetic is in aule-attention_amd/csrc/*.hip.
 import ctypes
 import math
 import os
+import threading
 
 import torch
 
@@ -86,7 +87,6 @@ def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1, q_rope=None, out=N
     lib = _capi.get_lib()
     _same_device("flash attention forward", q, k, v)
     B, Hq, Sq, D = q.shape
-    Hkv, Sk = k.shape[1], k.shape[2]
     if out is None:
         out = torch.empty_like(q)
     elif out.shape != q.shape or out.dtype != q.dtype or out.device != q.device or not out.is_contiguous():
@@ -94,26 +94,50 @@ def fwd_raw(q, k, v, causal, scale, want_lse=True, window=-1, q_rope=None, out=N
     lse = torch.empty((B, Hq, Sq), device=q.device, dtype=torch.float32) if want_lse else None
     if q.numel() == 0:
         return out, lse
-    d = _capi.AttnDesc()
-    d.struct_size = ctypes.sizeof(_capi.AttnDesc)
-    d.dtype = _DTYPES[q.dtype]
-    d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
-    d.scale = _abi_scale(scale)
-    d.causal = causal_code(causal)
-    d.window_size = int(window) if window is not None and window > 0 else -1
-    d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
-    d.stream = _stream_ptr(q.device)
+    d, ws_bytes = _fwd_desc(lib, q, k, causal, scale, window)
+    d.stream = torch.cuda.current_stream(q.device).cuda_stream
     d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
     d.lse = lse.data_ptr() if lse is not None else None
-    ws = _workspace(lib.aule_attention_forward_workspace_size(ctypes.byref(d)), q.device)
-    if ws is not None:
-        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    if ws_bytes:
+        ws = torch.empty((ws_bytes,), device=q.device, dtype=torch.uint8)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws_bytes
     if q_rope is not None:
         r = _attn_rope(*q_rope)
         _capi.check(lib.aule_attention_forward_rope_ex(ctypes.byref(d), ctypes.byref(r)), "aule_attention_forward_rope_ex")
     else:
-        _capi.check(lib.aule_attention_forward_ex(ctypes.byref(d)), "aule_attention_forward_ex")
+        rc = lib.aule_attention_forward_ex(ctypes.byref(d))
+        if rc != 0:
+            _capi.check(rc, "aule_attention_forward_ex")
     return out, lse
+
+
+# Per-call host cost (tools/host_overhead.py): the descriptor of a (dtype, shape, flags, device) combination is built
+# once -- struct fill, flag decoding, the workspace-size query -- and kept; a call then sets the stream, four or five pointers and the
+# workspace.  Per thread (a descriptor is mutated by the call that uses it).  Decode loops that need less than this layer can give
+# (~15 us of Python + ctypes + two tensor allocations per call) capture the step in a hipGraph: INTEGRATION.md, tests/test_gpu_graph.py.
+_desc_cache = threading.local()
+
+
+def _fwd_desc(lib, q, k, causal, scale, window):
+    cache = getattr(_desc_cache, "fwd", None)
+    if cache is None:
+        cache = _desc_cache.fwd = {}
+    key = (q.dtype, q.shape, k.shape[1], k.shape[2], causal, scale, window, q.device.index)
+    ent = cache.get(key)
+    if ent is None:
+        B, Hq, Sq, D = q.shape
+        d = _capi.AttnDesc()
+        d.struct_size = ctypes.sizeof(_capi.AttnDesc)
+        d.dtype = _DTYPES[q.dtype]
+        d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, k.shape[1], Sq, k.shape[2], D
+        d.scale = _abi_scale(scale)
+        d.causal = causal_code(causal)
+        d.window_size = int(window) if window is not None and window > 0 else -1
+        d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
+        if len(cache) >= 512:
+            cache.clear()
+        ent = cache[key] = (d, int(lib.aule_attention_forward_workspace_size(ctypes.byref(d))))
+    return ent
 
 
 def rope_fusable(q, k, causal, window, cos, sin, q_pos):

@@ -1091,7 +1091,7 @@ uint64_t aule_attention_paged_decode_workspace_size(const aule_paged_desc* d) {
 static int32_t backward_timeline(const aule_attn_bwd_desc* d, unsigned long long* stamps, bool dq) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_init || d == nullptr || d->struct_size != sizeof(aule_attn_bwd_desc) || stamps == nullptr) return -1;
-    if (d->dtype != AULE_DTYPE_BF16 || d->head_dim != 128 || d->heads_kv == 0 || d->heads_q % d->heads_kv != 0) return -3;
+    if (d->dtype != AULE_DTYPE_BF16 || (d->head_dim != 128 && !(d->head_dim == 64 && !dq)) || d->heads_kv == 0 || d->heads_q % d->heads_kv != 0) return -3;   // (D = 64: the dK/dV timeline only)
     BwdArgs a;
     a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->out; a.dout = d->dout; a.lse = d->lse;
     a.dq = d->dq; a.dk = d->dk; a.dv = d->dv; a.delta = (float*)d->workspace;

@@ -149,7 +149,7 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
     const unsigned lvo = (unsigned)(hi * 16);   // L' / delta: rows 8 g + 4 hi .. + 3 of the block per dwordx4
     const unsigned svo = (unsigned)(lane * 16);   // SPILL: the lane's 16 bytes of a dS unit's k-step (unit = [kk][lane][16 B])
 
-    unsigned long long tl_a = 0, tl_b = 0, tl_n = 0;
+    unsigned long long tl_a = 0, tl_b = 0, tl_n = 0, tl_w = 0;
     const int nparts = (CAUSAL && (nkb - 1 - w.blk) != w.blk) ? 2 : 1;
     for (int part = 0; part < nparts; ++part) {
         const int kb = CAUSAL ? (part == 0 ? nkb - 1 - w.blk : w.blk) : w.blk;   // (the block with more query blocks first)
@@ -277,10 +277,12 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
 #undef DKV4_P1
                 // block i + 2 has landed for everybody (all but this wave's newest NP requests -- block i + 3 -- are complete:
                 // the scalars of block i + 1 among them)
+                unsigned long long tw = 0;
+                if constexpr (TL) tw = __builtin_amdgcn_s_memtime();
                 // (SPILL with the dS stores behind the DMA pieces: the two stores of the previous iteration may stay out as well)
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(A::NP + (SPILL ? A::ST_LATE : 0)) : "memory");
                 unsigned long long t1 = 0;
-                if constexpr (TL) { t1 = __builtin_amdgcn_s_memtime(); tl_a += t1 - t0; }
+                if constexpr (TL) { t1 = __builtin_amdgcn_s_memtime(); tl_a += t1 - t0; tl_w += t1 - tw; }
                 const unsigned b = slot_lds(i + 2) + a_sub, b1 = slot_lds(i + 2) + a_sub1;
                 if constexpr (SPILL && A::ST_LATE == 0) A::store_ds(srs, svo, (unsigned)i << 11);
                 {
@@ -326,7 +328,7 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
     }
     if constexpr (TL) {
         if (blockIdx.x == 0 && lane == 0) {
-            p.dbg[wave * 4 + 0] = tl_n; p.dbg[wave * 4 + 1] = tl_a; p.dbg[wave * 4 + 2] = tl_b;
+            p.dbg[wave * 4 + 0] = tl_n; p.dbg[wave * 4 + 1] = tl_a; p.dbg[wave * 4 + 2] = tl_b; p.dbg[wave * 4 + 3] = tl_w;   // (tl_w: the boundary's wait + barrier, part of tl_a)
         }
     }
 }
@@ -338,10 +340,10 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(40))) f
 }
 
 // D = 64: 72 arch VGPRs for hipcc (the attribute takes a literal, hence a kernel of its own)
-template <class T, bool CAUSAL, bool SPILL = false>
+template <class T, bool CAUSAL, bool SPILL = false, bool TL = false>
 __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(72))) fa_bwd_dkv4_kernel_d64(const Dkv4Params p) {
     static_assert(Bw4Asm<T, 64>::NV == 72, "amdgpu_num_vgpr must be the generator's NV");
-    dkv4_body<T, 64, CAUSAL, false, SPILL>(p);
+    dkv4_body<T, 64, CAUSAL, TL, SPILL>(p);
 }
 
 #pragma clang diagnostic pop
@@ -367,6 +369,20 @@ int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
     const bool spill = a.ds != nullptr;   // the 5-matmul backward: dS goes to the workspace for fa_bwd_dqs_gfx950.hip
     constexpr int LDS = kDkv4Lds<D>;
     if constexpr (D == 64) {
+#ifdef AULE_DEBUG_HOOKS
+        if constexpr (std::is_same<T, Bf16Traits>::value) {
+            if (a.dbg != nullptr) {   // timeline build at D = 64 (round 5: tools/timeline_dkv4.py ... 64)
+                if (a.causal) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<T, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                    hipLaunchKernelGGL((fa_bwd_dkv4_kernel_d64<T, true, false, true>), grid, block, LDS, stream, p);
+                } else {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<T, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                    hipLaunchKernelGGL((fa_bwd_dkv4_kernel_d64<T, false, false, true>), grid, block, LDS, stream, p);
+                }
+                return (int)hipGetLastError();
+            }
+        }
+#endif
         if (spill) {
             if (a.causal)
                 hipLaunchKernelGGL((fa_bwd_dkv4_kernel_d64<T, true, true>), grid, block, LDS, stream, p);

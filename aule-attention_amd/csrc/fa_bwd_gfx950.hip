@@ -1236,8 +1236,8 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     // spread (MHA / GQA, causal or not, ragged, fp16: -0.5 .. -24 %); what stays here is the tiny grid with a big group (fp16 MQA
     // 32/1 S8192: 32 work items there against 512 here).
     const auto use_dkv4 = [&] {
-        if ((D != 128 && D != 64) || !(a.dbg == nullptr || (D == 128 && dkv4_timeline_wanted())) || !bwd_dkv4_applicable(a)) return false;   // (the timeline instance exists at D = 128 only)
-        if (bwd_dkv4_forced() || (D == 128 && dkv4_timeline_wanted())) return true;
+        if ((D != 128 && D != 64) || !(a.dbg == nullptr || dkv4_timeline_wanted()) || !bwd_dkv4_applicable(a)) return false;   // (timeline instances: bf16, D = 128 and, round 5, D = 64)
+        if (bwd_dkv4_forced() || dkv4_timeline_wanted()) return true;
         const int nkb = (a.Sk + kKvBlock - 1) / kKvBlock;
         const long long here = (long long)a.B * a.Hkv * (a.causal ? (nkb + 1) / 2 : nkb) * dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal);
         const long long there = bwd_dkv4_items(a);

@@ -39,6 +39,9 @@ def run_fwd_bwd(torch, q, k, v, do, dtype, causal, scale):
 def grad_close(got, ref, dtype, what):
     atol, rtol = BWD_TOL[dtype]
     scale = max(1.0, float(np.abs(ref).max()))
+    err = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64))
+    # the raw figure next to the bound (pytest -s, or the captured output of a failure)
+    print("%s: max|err| %.3e = %.2e of max|grad| %.3g  [bound %.1e * max(1, max|grad|) + %.0e * |ref|]" % (what, err.max(), err.max() / scale, scale, atol, rtol))
     assert_close(got, ref, atol * scale, rtol, what)
 
 
@@ -132,10 +135,10 @@ def test_config3_gqa_torch_autograd_parity(torch_cuda):
         grad_close(a.float().cpu().numpy(), b.cpu().numpy(), "bf16", "C3 " + name)
         achieved[name] = ((a.float() - b).abs().max() / b.abs().max()).item()
     achieved["out"] = (out.detach().float() - ref.detach()).abs().max().item()
-    # the bar is 2e-2 of max|grad| (tests/util.py); what the kernels actually achieve goes on record (pytest -rP / -s)
+    # the bar is 5e-3 of max|grad| + 1e-2 |ref| (tests/util.py, tightened in round 5); what the kernels actually achieve goes on record (pytest -rP / -s)
     print("C3 B=4 achieved: out max|err| %.3e; max|err| / max|grad|: dq %.3e dk %.3e dv %.3e"
           % (achieved["out"], achieved["dq"], achieved["dk"], achieved["dv"]))
-    assert max(achieved["dq"], achieved["dk"], achieved["dv"]) < 1e-2   # half the documented bar: room to tighten it
+    assert max(achieved["dq"], achieved["dk"], achieved["dv"]) < 5e-3   # (round 4 asserted 1e-2; achieved 2.3 .. 3.4e-3)
 
 
 def test_sgd_step_lowers_loss(torch_cuda):

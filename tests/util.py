@@ -65,8 +65,9 @@ def assert_close_rows(got, ref, nkeys, dtype, vmax, what=""):
 
 # LSE is fp32 in every variant
 LSE_TOL = {"fp32": 1e-5, "fp16": 1e-3, "bf16": 1e-3}
-# Gradients: reference bar is 1e-2 (python/tests/test_triton.py:92-94)
-BWD_TOL = {"fp32": (2e-5, 2e-5), "fp16": (4e-3, 4e-3), "bf16": (1e-2, 1e-2)}
+# Gradients: the reference's bar is element-wise rtol = atol = 1e-2 (python/tests/test_triton.py:92-94).  Here (round 5):
+# |err| <= atol * max(1, max|grad|) + rtol * |ref| with bf16 (5e-3, 1e-2) -- achieved 2.3 .. 3.4e-3 of max|grad| on C3 --, fp16 (4e-3, 4e-3).
+BWD_TOL = {"fp32": (2e-5, 2e-5), "fp16": (4e-3, 4e-3), "bf16": (5e-3, 1e-2)}
 
 
 def assert_close(got, ref, atol, rtol, what=""):

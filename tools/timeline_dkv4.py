@@ -2,7 +2,7 @@
 """Cycle accounting of the one-wave-per-SIMD dK/dV kernel (fa_bwd_dkv4_gfx950.hip, timeline build: debug library, AULE_TL=dkv4):
 per wave of workgroup 0 the number of stream iterations and the shader cycles spent in [phase 1 + phase boundary] and in
 [phase 2], measured at points where the wave has just waited for its LDS reads anyway.
-    python tools/timeline_dkv4.py [causal] [B] [Hq] [Hkv] [S]"""
+    python tools/timeline_dkv4.py [causal] [B] [Hq] [Hkv] [S] [D = 128 | 64]"""
 import ctypes, math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "aule-attention_amd"))
@@ -12,7 +12,7 @@ import torch
 from aule import _capi, _torch as at
 causal = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 B, Hq, Hkv, S = (int(x) for x in sys.argv[2:6]) if len(sys.argv) > 5 else (2, 16, 16, 4096)
-D = 128
+D = int(sys.argv[6]) if len(sys.argv) > 6 else 128
 q = torch.randn(B, Hq, S, D, device="cuda", dtype=torch.bfloat16)
 k = torch.randn(B, Hkv, S, D, device="cuda", dtype=torch.bfloat16); v = torch.randn_like(k); do = torch.randn_like(q)
 sc = 1 / math.sqrt(D)
@@ -36,6 +36,6 @@ torch.cuda.synchronize()
 t = stamps.cpu().tolist()
 print(f"rc {rc} causal={causal} B{B} Hq{Hq} Hkv{Hkv} S{S}")
 for w in range(4):
-    n, a, b = t[4 * w], t[4 * w + 1], t[4 * w + 2]
+    n, a, b, wt = t[4 * w], t[4 * w + 1], t[4 * w + 2], t[4 * w + 3]
     if n:
-        print(f"  wave {w}: {n} iterations, phase 1 + boundary {a / n:7.0f}  phase 2 {b / n:7.0f}  = {(a + b) / n:7.0f} cycles per iteration (32 MFMAs = 1024)")
+        print(f"  wave {w}: {n} iterations, phase 1 {(a - wt) / n:7.0f}  boundary wait + barrier {wt / n:7.0f}  phase 2 (+ lgkmcnt wait) {b / n:7.0f}  = {(a + b) / n:7.0f} cycles per iteration ({D // 4} MFMAs = {D * 8})")
