@@ -133,8 +133,8 @@ int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (sq == 4) return launch_fwd_splitkv(a, stream);
     if (sq == 5) return launch_fwd_pp_split(a, stream);
     if (sq == 0 && a.dtype != kF32 && use_w4_split(a)) return launch_fwd_w4_split(a, stream);
+    if (a.dtype == kF32) return launch_fwd_f32(a, stream);   // (small grids: key-range pieces + merge; answers the dry run itself)
     if (a.query_ws != nullptr) return 0;   // single-launch paths need no workspace
-    if (a.dtype == kF32) return launch_fwd_f32(a, stream);
     if (use_w4(a)) return launch_fwd_w4(a, stream);
     return launch_fwd_pp(a, stream);   // window, fewer than four KV tiles per Q block, D = 32, negative scale, AULE_HIP_FWD_KERNEL=pp
 }

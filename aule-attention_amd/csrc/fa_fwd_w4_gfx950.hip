@@ -1023,6 +1023,20 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
     p.rrows = a.rope_rows; p.rpitch = a.rope_pitch; p.rpos = a.rope_pos;
     // one workgroup per CU; more only when a workgroup's list would not fit its part table
     const long long ncu = device_cu_count(a.device);
+    // Half-empty causal grids (round 5; the reference harness's B 1 H 32 S 2048: 128 pairs on 256 CUs): when every Q block can have
+    // a CU of its own, the blocks are NOT paired -- the launch then lasts as long as its largest block (32 tiles + one part's seam
+    // instead of a pair's 36 tiles + two), on a chip that is ~56 % busy on average.  AULE_HIP_W4_UNPAIR=0 keeps the pairs (A/B).
+    {
+        static const int unpair = [] {
+            const char* e = std::getenv("AULE_HIP_W4_UNPAIR");
+            return (e != nullptr && e[0] == '0') ? 0 : 1;
+        }();
+        if (unpair && a.causal && p.nqb >= 2 && (long long)p.nqb * a.B * a.Hq <= ncu) {
+            p.pair = 0;
+            p.nwork = p.nqb;
+            p.nitems = p.nwork * a.B * a.Hq;
+        }
+    }
     const long long rounds = (p.nitems + ncu * kW4MaxItems - 1) / (ncu * kW4MaxItems);
     long long G = ncu * rounds;
     if (G > p.nitems) G = p.nitems;

@@ -36,8 +36,13 @@ def run_fwd_bwd(torch, q, k, v, do, dtype, causal, scale):
             tv.grad.float().cpu().numpy())
 
 
-def grad_close(got, ref, dtype, what):
+def grad_close(got, ref, dtype, what, sharp=False):
+    """sharp: a softmax scale well above 1/sqrt(D) (scores of std >= 2 on N(0,1) inputs): the weights are concentrated, P and dS carry their
+    16-bit rounding on a few large terms instead of averaging it over many, and bf16 gradients sit at 8e-3 of max|grad| (B1 6q/3kv S97/161 D64
+    scale 0.5: measured in round 5) -- such cases keep the reference's own bar, 1e-2 (python/tests/test_triton.py:92-94)."""
     atol, rtol = BWD_TOL[dtype]
+    if sharp and dtype == "bf16":
+        atol = 1e-2
     scale = max(1.0, float(np.abs(ref).max()))
     err = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64))
     # the raw figure next to the bound (pytest -s, or the captured output of a failure)
@@ -96,9 +101,10 @@ def test_backward_vs_oracle(torch_cuda, oracle_mod, case):
     do = quantize(rng.randn(B, Hq, Sq, D), dtype)
     _, dq, dk, dv = run_fwd_bwd(torch_cuda, q, k, v, do, dtype, causal, scale)
     rq, rk, rv = oracle_mod.bwd_f64(q, k, v, do, causal, scale)
-    grad_close(dq, rq, dtype, "dq")
-    grad_close(dk, rk, dtype, "dk")
-    grad_close(dv, rv, dtype, "dv")
+    sharp = scale is not None and scale * math.sqrt(D) > 2.0
+    grad_close(dq, rq, dtype, "dq", sharp)
+    grad_close(dk, rk, dtype, "dk", sharp)
+    grad_close(dv, rv, dtype, "dv", sharp)
 
 
 def _torch_ref(torch, q, k, v, causal, scale):

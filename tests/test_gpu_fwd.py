@@ -87,6 +87,11 @@ SWEEP = [
     ("fp16", 1, 4, 4, 300, 300, 128, True, None),
     ("fp16", 2, 4, 2, 65, 129, 32, True, 0.2),
     ("fp32", 1, 8, 8, 256, 256, 64, True, None),       # config C1 shape
+    # round 5: fp32 grids that leave most of the chip idle run every Q block as key-range pieces + a merge (fa_fwd_f32.hip, f32_pieces):
+    # the reference's own Zig benchmark shape (tests/benchmark_attention.zig:18-21), a ragged GQA one, and most of the fp32 cases below
+    ("fp32", 4, 8, 8, 512, 512, 64, False, None),
+    ("fp32", 2, 8, 2, 333, 700, 64, True, None),
+    ("fp32", 1, 4, 4, 1000, 1000, 128, True, None),
     ("fp32", 1, 4, 2, 150, 150, 128, True, None),
     ("fp32", 2, 4, 1, 77, 201, 64, False, 0.7),
     ("fp32", 1, 2, 2, 129, 129, 32, True, None),

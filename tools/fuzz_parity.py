@@ -76,6 +76,8 @@ def run(cfg, seed):
     if not np.all(np.isneginf(gl[~fin])): errs.append("lse of empty rows not -inf")
     if fin.any() and np.abs(gl[fin] - rl[fin]).max() > LSE_TOL[dtype] + 1e-5 * np.abs(rl[fin]).max(): errs.append(f"lse err {np.abs(gl[fin]-rl[fin]).max():.3e}")
     a, r = BWD_TOL[dtype]
+    if dtype == "bf16" and scale is not None and abs(scale) * math.sqrt(D) > 2.0:
+        a = 1e-2      # sharp softmax (tests/test_gpu_bwd.py, grad_close): the reference's own bar
     for name, got, want in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
         gg = got.float().cpu().numpy()
         if not np.isfinite(gg).all(): errs.append(name + " non-finite"); continue
