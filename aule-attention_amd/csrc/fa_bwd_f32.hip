@@ -10,6 +10,8 @@
 // MFMA 32x32x2 operand map: A[i = lane&31][k = lane>>5], B[k = lane>>5][n = lane&31];
 // step r of a P/dS product contracts the row pair {crow(r,0), crow(r,1)} = {x, x+4},
 // which is exactly what accumulator register r of the two lane halves holds.
+#include <cstdlib>
+
 #include "fa_device.h"
 #include "fa_kernels.h"
 
@@ -35,6 +37,11 @@ struct BwdF32Params {
     int nblk;
     int window;   // sliding window: key j visible to query i only if i - j < window (0: off)
     int coff;     // causal position offset (query i sits at position i + coff)
+    // small grids (round 5): npiece work items per block, each with 1 / npiece of the block's tiles (dQ: key tiles; dK/dV: the query tiles of
+    // every head of the group); a piece writes its (scaled) sums to part[piece][...] and fa_bwd_f32_sum adds the pieces in a fixed order
+    int npiece;
+    float* part;      // dQ kernel: [npiece][B Hq Sq][D]; dK/dV kernel: [npiece][2][B Hkv Sk][D] (dK, dV)
+    long long prows;  // rows per piece plane
 };
 
 constexpr int kRows = 128;  // rows per workgroup (4 waves x 32)
@@ -119,7 +126,9 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dq_f32_kernel(con
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const WorkItem w = decode_work_ranked(blockIdx.x, p.B, p.Hq, p.Hkv, p.nblk, CAUSAL);   // (causal: every unit's last block first)
+    const int piece = p.npiece > 1 ? (int)(blockIdx.x % (unsigned)p.npiece) : 0;
+    const int item = p.npiece > 1 ? (int)(blockIdx.x / (unsigned)p.npiece) : (int)blockIdx.x;
+    const WorkItem w = decode_work_ranked(item, p.B, p.Hq, p.Hkv, p.nblk, CAUSAL);   // (causal: every unit's last block first)
     const int Sq = p.Sq, Sk = p.Sk;
     const int q0w = w.blk * kRows + wave * 32;
     const int qrow = q0w + l31;
@@ -146,20 +155,26 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dq_f32_kernel(con
     const int nt = (kv_hi + kTile - 1) / kTile;
     const int wave_kv_hi = CAUSAL ? min(Sk, q0w + 32 + coff) : Sk;
     const int W = p.window;
-    const int t_lo = W > 0 ? max(0, w.blk * kRows + coff - W + 1) / kTile : 0;  // tiles before the block's window: skipped
+    int t_lo = W > 0 ? max(0, w.blk * kRows + coff - W + 1) / kTile : 0;  // tiles before the block's window: skipped
     const int wave_kv_lo = W > 0 ? q0w + coff - W + 1 : 0;
+    int nt_end = nt;
+    if (p.npiece > 1) {   // this piece's share of the block's key tiles
+        const int chunk = (max(0, nt - t_lo) + p.npiece - 1) / p.npiece;
+        t_lo = t_lo + piece * chunk;
+        nt_end = min(nt, t_lo + chunk);
+    }
 
     TileRegs<D> kreg, vreg;
-    if (t_lo < nt) {
+    if (t_lo < nt_end) {
         tile_load(kreg, kg, t_lo * kTile, Sk, tid);
         tile_load(vreg, vg, t_lo * kTile, Sk, tid);
     }
-    for (int t = t_lo; t < nt; ++t) {
+    for (int t = t_lo; t < nt_end; ++t) {
         const int kv0 = t * kTile;
         tile_store(kreg, Kt, Kcm, tid);
         tile_store(vreg, Vt, static_cast<float*>(nullptr), tid);
         __syncthreads();
-        if (t + 1 < nt) {   // the next tile's rows travel while this one is computed
+        if (t + 1 < nt_end) {   // the next tile's rows travel while this one is computed
             tile_load(kreg, kg, kv0 + kTile, Sk, tid);
             tile_load(vreg, vg, kv0 + kTile, Sk, tid);
         }
@@ -203,7 +218,7 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dq_f32_kernel(con
     }
 
     if (qrow < Sq) {
-        float* orow = p.dq + (qbase + qrow) * D;
+        float* orow = (p.npiece > 1 ? p.part + (size_t)piece * p.prows * D : p.dq) + (qbase + qrow) * D;
         const float sc = p.scale;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
@@ -236,7 +251,9 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dkdv_f32_kernel(c
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = p.Hq / p.Hkv;
-    const WorkItem w = decode_work_ranked(blockIdx.x, p.B, p.Hkv, p.Hkv, p.nblk, false);   // (key block 0 sees the most queries: first)
+    const int piece = p.npiece > 1 ? (int)(blockIdx.x % (unsigned)p.npiece) : 0;
+    const int item = p.npiece > 1 ? (int)(blockIdx.x / (unsigned)p.npiece) : (int)blockIdx.x;
+    const WorkItem w = decode_work_ranked(item, p.B, p.Hkv, p.Hkv, p.nblk, false);   // (key block 0 sees the most queries: first)
     const int Sq = p.Sq, Sk = p.Sk;
     const int n0w = w.blk * kRows + wave * 32;
     const int kvrow = n0w + l31;
@@ -258,7 +275,12 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dkdv_f32_kernel(c
     const int coff = p.coff;   // query q sits at position q + coff
     int ntq_all = (Sq + kTile - 1) / kTile;
     if (W > 0) ntq_all = min(ntq_all, max(0, w.blk * kRows + kRows - 1 + W - coff + kTile - 1) / kTile);  // q + coff - kv < W
-    const int first_qt = CAUSAL ? max(0, w.blk * kRows - coff) / kTile : 0;
+    int first_qt = CAUSAL ? max(0, w.blk * kRows - coff) / kTile : 0;
+    if (p.npiece > 1) {   // this piece's share of the query tiles (of every head of the group)
+        const int chunk = (max(0, ntq_all - first_qt) + p.npiece - 1) / p.npiece;
+        first_qt = first_qt + piece * chunk;
+        ntq_all = min(ntq_all, first_qt + chunk);
+    }
 
     for (int hh = 0; hh < g; ++hh) {
         const size_t qb = (size_t)(w.b * p.Hq + w.hk * g + hh) * Sq;
@@ -329,8 +351,8 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dkdv_f32_kernel(c
     }
 
     if (kvrow < Sk) {
-        float* krow = p.dk + (kvbase + kvrow) * D;
-        float* vrow = p.dv + (kvbase + kvrow) * D;
+        float* krow = (p.npiece > 1 ? p.part + (size_t)(2 * piece) * p.prows * D : p.dk) + (kvbase + kvrow) * D;
+        float* vrow = (p.npiece > 1 ? p.part + (size_t)(2 * piece + 1) * p.prows * D : p.dv) + (kvbase + kvrow) * D;
         const float sc = p.scale;
 #pragma unroll
         for (int d = 0; d < DB; ++d)
@@ -346,6 +368,51 @@ __global__ void __launch_bounds__(256, D <= 64 ? 2 : 1) fa_bwd_dkdv_f32_kernel(c
     }
 }
 
+// out[i] = sum over the pieces, in piece order (deterministic): n4 float4 per plane, `nout` planes per piece (dQ: 1; dK, dV: 2)
+struct SumF32Params {
+    const float* part;
+    float* out0;
+    float* out1;
+    long long n4;
+    int npiece, nout;
+};
+__global__ void __launch_bounds__(256) fa_bwd_f32_sum(const SumF32Params p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.nout * p.n4) return;
+    const int which = (int)(i / p.n4);
+    const long long e = i % p.n4;
+    const f32x4_t* src = reinterpret_cast<const f32x4_t*>(p.part) + (long long)which * p.n4 + e;
+    f32x4_t acc = src[0];
+    for (int j = 1; j < p.npiece; ++j) {
+        const f32x4_t x = src[(long long)j * p.nout * p.n4];
+        acc[0] += x[0]; acc[1] += x[1]; acc[2] += x[2]; acc[3] += x[3];
+    }
+    reinterpret_cast<f32x4_t*>(which ? p.out1 : p.out0)[e] = acc;
+}
+
+// Pieces per block for grids that leave most of the chip idle (the reference's Zig benchmark shape, tests/benchmark_attention.zig:18-21:
+// B4 H8 S512 D64 = 128 workgroups for 512 slots): as many as fill the slots, at least two tiles each, at most 8.  AULE_HIP_F32_SPLIT=0: off.
+inline int f32_bwd_pieces(long long items, int tiles, int D, int device) {
+    static const int on = [] {
+        const char* e = std::getenv("AULE_HIP_F32_SPLIT");
+        return (e != nullptr && e[0] == '0') ? 0 : 1;
+    }();
+    if (!on) return 1;
+    const long long slots = (D <= 64 ? 2LL : 1LL) * device_cu_count(device);
+    if (items <= 0 || items * 2 > slots) return 1;
+    long long n = slots / items;
+    if (n > tiles / 2) n = tiles / 2;
+    if (n > 8) n = 8;
+    return n < 2 ? 1 : (int)n;
+}
+inline void f32_bwd_plan(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int coff, int device, int& nq, int& nk) {
+    const int nblq = (Sq + kRows - 1) / kRows, nblk = (Sk + kRows - 1) / kRows;
+    const int kv_hi = causal ? (Sk < Sq + coff ? Sk : Sq + coff) : Sk;
+    nq = f32_bwd_pieces((long long)nblq * B * Hq, (kv_hi + kTile - 1) / kTile, D, device);
+    nk = f32_bwd_pieces((long long)nblk * B * Hkv, (Sq + kTile - 1) / kTile, D, device);
+}
+inline uint64_t f32_delta_bytes(int B, int Hq, int Sq) { return (((uint64_t)B * Hq * Sq * sizeof(float)) + 255) / 256 * 256; }
+
 template <int D>
 int launch_bwd_f32_d(const BwdArgs& a, hipStream_t stream) {
     int rc = launch_delta_f32(a, stream);
@@ -359,25 +426,43 @@ int launch_bwd_f32_d(const BwdArgs& a, hipStream_t stream) {
     p.scale = a.scale;
     p.window = a.window > 0 ? a.window : 0;
     p.coff = a.causal ? a.coff : 0;
+    int nq = 1, nk = 1;
+    // (a window changes the tile ranges per block: the plan keeps to the window-less count, pieces beyond a block's tiles are empty)
+    f32_bwd_plan(a.B, a.Hq, a.Hkv, a.Sq, a.Sk, D, a.causal, p.coff, -1, nq, nk);
+    float* const parts = reinterpret_cast<float*>(reinterpret_cast<char*>(a.delta) + f32_delta_bytes(a.B, a.Hq, a.Sq));   // (bwd_f32_partial_bytes() behind delta)
     const dim3 block(256);
     {
         p.nblk = (a.Sq + kRows - 1) / kRows;
-        const dim3 grid((unsigned)(p.nblk * a.B * a.Hq));
+        p.npiece = nq; p.part = parts; p.prows = (long long)a.B * a.Hq * a.Sq;
+        const dim3 grid((unsigned)(p.nblk * a.B * a.Hq * nq));
         if (a.causal)
             hipLaunchKernelGGL((fa_bwd_dq_f32_kernel<D, true>), grid, block, 0, stream, p);
         else
             hipLaunchKernelGGL((fa_bwd_dq_f32_kernel<D, false>), grid, block, 0, stream, p);
         rc = (int)hipGetLastError();
         if (rc) return rc;
+        if (nq > 1) {
+            SumF32Params sp;
+            sp.part = parts; sp.out0 = p.dq; sp.out1 = nullptr; sp.n4 = p.prows * D / 4; sp.npiece = nq; sp.nout = 1;
+            hipLaunchKernelGGL(fa_bwd_f32_sum, dim3((unsigned)((sp.n4 + 255) / 256)), dim3(256), 0, stream, sp);
+            rc = (int)hipGetLastError();
+            if (rc) return rc;
+        }
     }
     {
         p.nblk = (a.Sk + kRows - 1) / kRows;
-        const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv));
+        p.npiece = nk; p.part = parts; p.prows = (long long)a.B * a.Hkv * a.Sk;   // (the dQ pieces were summed: stream order)
+        const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv * nk));
         const size_t lds = DkvF32Cfg<D>::LDS;
         if (a.causal)
             hipLaunchKernelGGL((fa_bwd_dkdv_f32_kernel<D, true>), grid, block, lds, stream, p);
         else
             hipLaunchKernelGGL((fa_bwd_dkdv_f32_kernel<D, false>), grid, block, lds, stream, p);
+        rc = (int)hipGetLastError();
+        if (rc || nk == 1) return rc;
+        SumF32Params sp;
+        sp.part = parts; sp.out0 = p.dk; sp.out1 = p.dv; sp.n4 = p.prows * D / 4; sp.npiece = nk; sp.nout = 2;
+        hipLaunchKernelGGL(fa_bwd_f32_sum, dim3((unsigned)((2 * sp.n4 + 255) / 256)), dim3(256), 0, stream, sp);
         return (int)hipGetLastError();
     }
 }
@@ -392,6 +477,18 @@ int set_attr_f32() {
 }
 
 }  // namespace
+
+// bytes of fp32 partial planes the small-grid split needs behind delta (0: no split for these sizes)
+uint64_t bwd_f32_partial_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal) {
+    int nq = 1, nk = 1;
+    f32_bwd_plan(B, Hq, Hkv, Sq, Sk, D, causal, 0, -1, nq, nk);
+    // (coff only shrinks the causal tile count the plan looks at: coff = Sk - Sq >= 0 gives at least as many tiles; size for both)
+    int nq2 = 1, nk2 = 1;
+    f32_bwd_plan(B, Hq, Hkv, Sq, Sk, D, causal, Sk > Sq ? Sk - Sq : 0, -1, nq2, nk2);
+    const uint64_t nqm = nq > nq2 ? nq : nq2, nkm = nk > nk2 ? nk : nk2;
+    const uint64_t a = nqm > 1 ? nqm * (uint64_t)B * Hq * Sq * D * 4 : 0, b = nkm > 1 ? 2 * nkm * (uint64_t)B * Hkv * Sk * D * 4 : 0;
+    return a > b ? a : b;
+}
 
 int launch_bwd_f32(const BwdArgs& a, hipStream_t stream) {
     if (a.D == 128) return launch_bwd_f32_d<128>(a, stream);

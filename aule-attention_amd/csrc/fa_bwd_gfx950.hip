@@ -42,6 +42,7 @@ bool bwd_dqs_applicable(const BwdArgs& a);           // fa_bwd_dqs_gfx950.hip: t
 int launch_bwd_delta16(const BwdArgs& a, float* lse2, float* ndelta, hipStream_t stream);
 int launch_bwd_dqs(const BwdArgs& a, hipStream_t stream);
 int configure_bwd_dqs();
+uint64_t bwd_f32_partial_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal);   // fa_bwd_f32.hip: planes of its small-grid pieces
 namespace {
 
 // ------------------------------------------------------------------ delta ----
@@ -1128,6 +1129,7 @@ inline uint64_t spill_bytes_per_batch(int B, int Hq, int Hkv, int Sq, int Sk, in
 }
 inline uint64_t bwd_base_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype) {
     uint64_t bytes = delta_bytes(B, Hq, Sq);
+    if (dtype == kF32) bytes += aule_hip::bwd_f32_partial_bytes(B, Hq, Hkv, Sq, Sk, D, causal);   // small grids: the key / query range pieces' planes
     if (dtype != kF32) {
         bytes += 2 * delta_bytes(B, Hq, Sq);   // L' = LSE log2(e) and - delta, published with delta
         const int sp = dkdv_gsplit(B, Hq, Hkv, Sk, causal);

@@ -85,6 +85,10 @@ SWEEP = [
     ("fp16", 1, 4, 1, 384, 384, 64, False, None),
     ("fp16", 1, 4, 4, 300, 300, 128, True, None),
     ("fp32", 1, 8, 8, 256, 256, 64, True, None),
+    # round 5: fp32 grids that leave most of the chip idle run every block as key / query range pieces + a sum (fa_bwd_f32.hip): the
+    # reference's Zig benchmark shape (tests/benchmark_attention.zig:18-21), causal, and a ragged GQA one
+    ("fp32", 4, 8, 8, 512, 512, 64, False, None),
+    ("fp32", 2, 8, 2, 333, 700, 64, True, None),
     ("fp32", 1, 4, 2, 150, 150, 128, True, None),
     ("fp32", 2, 4, 1, 77, 201, 64, False, 0.7),
     ("fp32", 1, 2, 2, 129, 129, 32, True, -0.3),
