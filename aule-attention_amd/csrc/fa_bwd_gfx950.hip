@@ -1075,9 +1075,11 @@ inline uint64_t delta_bytes(int B, int Hq, int Sq) {
 // the memory fabric -- 128 FLOP saved per byte moved, below the chip's ridge of ~315 -- and the dK/dV kernel, whose Q / dO re-reads
 // already miss the 4 MB L2 half of the time, stalls on the added write stream (+18 .. +34 % cycles even on zero inputs); the dQ kernel
 // then runs at the fabric's ~4.2 TB/s.  C2 1794 vs 1751 us, C3 472 .. 486 vs 474 us, D = 64 832 vs 668 us against the recompute pair.
-// So it is an OPT-IN mode, not the default: AULE_HIP_BWD_MODE=spill takes it wherever it can run (and the one-wave-per-SIMD dK/dV kernel
-// would run anyway); AULE_HIP_BWD_DS_AUTO_MB=<n> takes it by itself for problems whose dS fits n MB (the Infinity Cache keeps what a
-// kernel wrote for the next one up to ~256 MB: tools/probe_mall.hip); default: the recompute pair of rounds 1-4.
+// So it is NOT the mode of the large shapes.  Where the touched dS stays inside the 256 MB Infinity Cache (which keeps what a kernel wrote
+// for the next one: tools/probe_mall.hip) it wins: B1 H32 S2048 (141 MB) 158.6 -> 136.6 us, B2 H32 S1024 106.5 -> 88.3, D = 64 B1 H16 S2048
+// 101.0 -> 84.1; B1 H32 S4096 (537 MB) 432 -> 452.  Default ("auto"): the 5-matmul backward for problems whose touched dS is at most
+// AULE_HIP_BWD_DS_AUTO_MB (160) and whose dK/dV grid takes the one-wave-per-SIMD kernel anyway, the recompute pair for everything else;
+// AULE_HIP_BWD_MODE=spill | recompute pin either one.
 // AULE_HIP_BWD_DS_CAP_MB (default 8192) bounds the workspace: the batch runs in chunks of as many elements as the caller's buffer holds.
 inline int bwd_mode() {   // 0: auto (by AULE_HIP_BWD_DS_AUTO_MB), 1: recompute, 2: spill wherever applicable
     static const int m = [] {
@@ -1090,7 +1092,7 @@ inline int bwd_mode() {   // 0: auto (by AULE_HIP_BWD_DS_AUTO_MB), 1: recompute,
 inline uint64_t bwd_ds_auto_bytes() {
     static const uint64_t c = [] {
         const char* e = std::getenv("AULE_HIP_BWD_DS_AUTO_MB");
-        const long long mb = e != nullptr ? std::atoll(e) : 0;
+        const long long mb = e != nullptr ? std::atoll(e) : 160;
         return (uint64_t)(mb > 0 ? mb : 0) << 20;
     }();
     return c;

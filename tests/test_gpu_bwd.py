@@ -151,6 +151,34 @@ def test_config3_gqa_torch_autograd_parity(torch_cuda):
     assert max(achieved["dq"], achieved["dk"], achieved["dv"]) < 5e-3   # (round 4 asserted 1e-2; achieved 2.3 .. 3.4e-3)
 
 
+def test_auto_mode_takes_the_5_matmul_backward_for_cache_sized_problems(torch_cuda):
+    """Default dispatch (round 5): a problem whose dS fits the Infinity Cache budget (AULE_HIP_BWD_DS_AUTO_MB, 160) and whose dK/dV grid runs the
+    one-wave-per-SIMD kernel takes the 5-matmul backward by itself -- B1 H8 S2048 D128: 33 MB of dS; the workspace size shows the mode -- and
+    matches torch autograd like every other mode."""
+    import ctypes
+    import aule
+    from aule import _capi
+    if os.environ.get("AULE_HIP_BWD_MODE", "")[:1] == "r" or os.environ.get("AULE_HIP_BWD_DKV", "")[:1] == "o":
+        pytest.skip("a mode that never spills is pinned in this environment")
+    torch = torch_cuda
+    B, H, S, D = 1, 8, 2048, 128
+    lib = _capi.get_lib()
+    d = _capi.AttnBwdDesc()
+    d.struct_size = ctypes.sizeof(_capi.AttnBwdDesc)
+    d.dtype, d.causal, d.window_size = 2, 1, -1
+    d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, H, H, S, S, D
+    ds_bytes = H * (S // 32) * (S // 32) * 2048
+    assert int(lib.aule_attention_backward_workspace_size(ctypes.byref(d))) >= ds_bytes
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    q, k, v, do = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16, generator=gen) for _ in range(4))
+    q1, k1, v1 = (x.clone().requires_grad_(True) for x in (q, k, v))
+    aule.flash_attention(q1, k1, v1, causal=True).backward(do)
+    q2, k2, v2 = (x.float().requires_grad_(True) for x in (q, k, v))
+    _torch_ref(torch, q2, k2, v2, True, 1.0 / math.sqrt(D)).backward(do.float())
+    for name, a, b in (("dq", q1.grad, q2.grad), ("dk", k1.grad, k2.grad), ("dv", v1.grad, v2.grad)):
+        grad_close(a.float().cpu().numpy(), b.cpu().numpy(), "bf16", "auto-mode " + name)
+
+
 def test_sgd_step_lowers_loss(torch_cuda):
     """Intent of the reference's (dead) tests/test_torch_autograd.py:63: one SGD step lowers an MSE."""
     import aule
