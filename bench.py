@@ -2,12 +2,13 @@
 """bench.py -- throughput of the FlashAttention hot path on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--mode fwd|fwdbwd] [--condition-ms MS]
+    (--config defaults to c2, the single-GPU headline, on one GPU and to c4 -- BASELINE configs[3]: B=64 over 8 GPUs, 8 per GPU, S=8192 -- with --gpus N > 1)
 
 One "step" = one pass of the hot path (aule.flash_attention -> libaule.so -> gfx950
 kernels) over one batch of synthetic [B,H,S,D] tensors already resident in HBM.
 Default workload = BASELINE.json configs[1]:  B=4 H=32 S=4096 D=128 bf16 causal MHA, fwd.
 With N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL) every rank runs
-the same per-GPU batch on its own shard (weak scaling, no data-path collective); the
+configs[3]'s per-GPU batch (B=8 H=32 S=8192) on its own shard (weak scaling, no data-path collective); the
 optional output all-gather over xGMI is timed separately and reported under "gather".
 
 Rank 0 prints ONE JSON line.  FLOP convention: fwd = 4*B*Hq*D*P with
@@ -390,9 +391,10 @@ def main():
                       "traffic_source": "stored: rocprofv3 PMC passes of the last profiled run of this workload (profiles/hbm_traffic.json, "
                                         "FETCH_SIZE x2 + WRITE_SIZE per launch), not measured in this run",
                       "effective_clock_ghz_profiled": stored_profile(args.config, mode).get("effective_clock_ghz"),
-                      # stored telemetry of the last power-trace run of this workload (profiles/r4_power_trace.txt): socket power and
-                      # power limit (hwmon), shader clock while the kernel runs back to back; and what a loop of nothing but MFMAs on
-                      # N(0,1) operands sustains on this chip -- the ceiling of ANY kernel on random data, as a fraction of `peak`
+                      # stored telemetry of the last power-trace run of this workload (profiles/r5_ceiling_control.txt): socket power and
+                      # power limit (hwmon), shader clock while the kernel runs back to back; and what this chip sustains on N(0,1)
+                      # operands as a fraction of `peak` -- a RANGE with its sources (round 5): bare-MFMA loops of two shapes, and the
+                      # vendor GEMM (hipBLASLt bf16 8192^3) as the control that does not depend on this build's own probe
                       **{k: stored_profile(args.config, mode).get(k) for k in ("power_w", "power_cap_w", "sclk_mhz",
                                                                                 "mfma_only_random_frac_of_peak", "power_profile")},
                       "kernel_ms": kern_ms, **launch_stats(),

@@ -42,6 +42,29 @@ OUT = os.environ.get("BW4_OUT", os.path.join(ROOT, "aule-attention_amd", "csrc",
 # SPILL instances (the 5-matmul backward): where the two dS stores of an iteration sit -- "start": at the top of phase 2, in front of the
 # iteration's other VMEM requests (the phase boundary's vmcnt(NP) then waits for them too); "end": behind the LDS-DMA pieces, the boundary
 # waits with vmcnt(NP + 2) (the stores get two iterations to retire).  BW4_ST_NT=1: non-temporal stores.
+# Timing / energy experiments only (tools/bw4_energy_variants.sh; results are garbage): BW4_X = comma list of
+#   novalu  no P / dS arithmetic      nolds  no LDS reads (stale fragments)      nodma  no LDS-DMA requests      noscal  no L' / delta loads
+XFLAGS = set(x for x in os.environ.get("BW4_X", "").split(",") if x)
+
+
+def xfilter(lines):
+    if not XFLAGS:
+        return lines
+    out = []
+    for ln in lines:
+        op = ln.split()[0]
+        if "novalu" in XFLAGS and op.startswith("v_") and not op.startswith("v_mfma"):
+            continue
+        if "nolds" in XFLAGS and op.startswith("ds_read"):
+            continue
+        if "nodma" in XFLAGS and (ln.startswith("s_add_u32 m0") or (op.startswith("buffer_load") and ln.rstrip().endswith("lds"))):
+            continue
+        if "noscal" in XFLAGS and op.startswith("buffer_load") and not ln.rstrip().endswith("lds"):
+            continue
+        out.append(ln)
+    return out or ["s_nop 0"]
+
+
 ST_LATE = 2 if os.environ.get("BW4_ST", "start") == "end" else 0
 ST_NT = os.environ.get("BW4_ST_NT", "0") == "1"
 
@@ -207,7 +230,7 @@ def gen_p1(c, q, par, qk, ar, tr):
             ins += ['[lo] "v"(lo)', '[wd] "v"(wd)']
     if tr:
         ins.append('[trb] "v"(trb)')
-    return emit_asm(lines, [], ins, clob)
+    return emit_asm(xfilter(lines), [], ins, clob)
 
 
 def gen_p2(c, q, par, mm, rm, ld, dma):
@@ -284,7 +307,7 @@ def gen_p2(c, q, par, mm, rm, ld, dma):
             else:
                 out.append(ln)
         lines = out
-    return emit_asm(lines, [], ins, clob)
+    return emit_asm(xfilter(lines), [], ins, clob)
 
 
 def gen_struct(c):
