@@ -79,6 +79,7 @@ struct DqsParams {
     int coff;
     int nq32, nkb32p;
     int rev;       // walk the grid backwards (what the dK/dV kernel wrote last is read first: Infinity Cache)
+    int pair;      // causal: 1 = a work item is the pair of Q blocks (i, n-1-i) (equal work per item), 0 = one block per item (half-empty grids)
 };
 
 constexpr int kDqsQBlock = 256;   // 4 waves x 64 query rows
@@ -187,9 +188,10 @@ __global__ void __launch_bounds__(256, DQS_OCC) fa_bwd_dqs_kernel(const DqsParam
 #endif
     const unsigned sun = (unsigned)(C::IMGK + wave * 4096);   // this wave's two units inside a slot
 
-    const int nparts = (CAUSAL && (nqb - 1 - w.blk) != w.blk) ? 2 : 1;
+    const bool paired = CAUSAL && p.pair != 0;
+    const int nparts = (paired && (nqb - 1 - w.blk) != w.blk) ? 2 : 1;
     for (int part = 0; part < nparts; ++part) {
-        const int qb = CAUSAL ? (part == 0 ? nqb - 1 - w.blk : w.blk) : w.blk;
+        const int qb = paired ? (part == 0 ? nqb - 1 - w.blk : w.blk) : w.blk;
         const int q0w = qb * kDqsQBlock + wave * 64;
         // blocks of the workgroup's stream / of each of this wave's two row blocks (every unit they name was written: a unit exists
         // wherever its 128-key block is seen by ANY row of the 32-row query block)
@@ -316,7 +318,10 @@ int launch_dqs(const BwdArgs& a, hipStream_t stream) {
     const DsLayout dl = DsLayout::of(a.Hq, a.Hkv, a.Sq, a.Sk);
     p.nq32 = dl.nq32; p.nkb32p = dl.nkb32p;
     const int nqb = (a.Sq + kDqsQBlock - 1) / kDqsQBlock;
-    p.nblk = a.causal ? (nqb + 1) / 2 : nqb;
+    // (half-empty grids -- the cache-sized problems the default dispatch sends here are small ones: when every Q block can have a workgroup slot
+    // of its own, the blocks are not paired)
+    p.pair = (a.causal && (long long)nqb * a.B * a.Hq > (long long)DQS_OCC * device_cu_count(-1)) ? 1 : 0;
+    p.nblk = (a.causal && p.pair) ? (nqb + 1) / 2 : nqb;
     static const int rev = [] {
         const char* e = std::getenv("AULE_HIP_DQS_REV");
         return e != nullptr ? std::atoi(e) : 1;

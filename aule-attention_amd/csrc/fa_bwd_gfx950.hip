@@ -1076,8 +1076,8 @@ inline uint64_t delta_bytes(int B, int Hq, int Sq) {
 // already miss the 4 MB L2 half of the time, stalls on the added write stream (+18 .. +34 % cycles even on zero inputs); the dQ kernel
 // then runs at the fabric's ~4.2 TB/s.  C2 1794 vs 1751 us, C3 472 .. 486 vs 474 us, D = 64 832 vs 668 us against the recompute pair.
 // So it is NOT the mode of the large shapes.  Where the touched dS stays inside the 256 MB Infinity Cache (which keeps what a kernel wrote
-// for the next one: tools/probe_mall.hip) it wins: B1 H32 S2048 (141 MB) 158.6 -> 136.6 us, B2 H32 S1024 106.5 -> 88.3, D = 64 B1 H16 S2048
-// 101.0 -> 84.1; B1 H32 S4096 (537 MB) 432 -> 452.  Default ("auto"): the 5-matmul backward for problems whose touched dS is at most
+// for the next one: tools/probe_mall.hip) it wins: B1 H32 S2048 (141 MB) 157.8 -> 129.7 us, B2 H32 S1024 106.6 -> 83.8, D = 64 B1 H16 S2048
+// 99.5 -> 78.8; B1 H32 S4096 (537 MB) 432 -> 452.  Default ("auto"): the 5-matmul backward for problems whose touched dS is at most
 // AULE_HIP_BWD_DS_AUTO_MB (160) and whose dK/dV grid takes the one-wave-per-SIMD kernel anyway, the recompute pair for everything else;
 // AULE_HIP_BWD_MODE=spill | recompute pin either one.
 // AULE_HIP_BWD_DS_CAP_MB (default 8192) bounds the workspace: the batch runs in chunks of as many elements as the caller's buffer holds.
