@@ -325,3 +325,68 @@ def test_work_order_covers_every_work_item_once(ranked):
                 for x in range(8):                        # per XCD: its sequence of ranks
                     mine = blks[x::8]
                     assert mine == sorted(mine, reverse=bool(flag))
+
+
+_WS_CHILD = r'''
+import ctypes, os, sys
+sys.path.insert(0, sys.argv[1])
+from aule import _capi
+lib = _capi.load()
+def bwd_ws(dtype, B, Hq, Hkv, Sq, Sk, D, causal):
+    d = _capi.AttnBwdDesc()
+    d.struct_size = ctypes.sizeof(_capi.AttnBwdDesc)
+    d.dtype, d.causal, d.window_size = dtype, causal, -1
+    d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
+    return int(lib.aule_attention_backward_workspace_size(ctypes.byref(d)))
+def fwd_ws(dtype, B, Hq, Hkv, Sq, Sk, D, causal):
+    d = _capi.AttnDesc()
+    d.struct_size = ctypes.sizeof(_capi.AttnDesc)
+    d.dtype, d.causal, d.window_size = dtype, causal, -1
+    d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
+    return int(lib.aule_attention_forward_workspace_size(ctypes.byref(d)))
+print("B1", bwd_ws(2, 1, 32, 32, 2048, 2048, 128, 1))
+print("C3", bwd_ws(2, 4, 32, 8, 2048, 2048, 128, 1))
+print("C2", bwd_ws(2, 4, 32, 32, 4096, 4096, 128, 1))
+print("F32B", bwd_ws(0, 4, 8, 8, 512, 512, 64, 0))
+print("F32F", fwd_ws(0, 4, 8, 8, 512, 512, 64, 0))
+print("F32BIG", fwd_ws(0, 4, 32, 32, 2048, 2048, 64, 1))
+'''
+
+
+def _ws_sizes(env):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ("AULE_HIP_BWD_MODE", "AULE_HIP_BWD_DS_AUTO_MB", "AULE_HIP_BWD_DS_CAP_MB", "AULE_HIP_BWD_DKV", "AULE_HIP_F32_SPLIT"):
+        e.pop(k, None)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _WS_CHILD, os.path.join(ROOT, "aule-attention_amd")], env=e, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return {l.split()[0]: int(l.split()[1]) for l in r.stdout.splitlines() if l.strip()}
+
+
+def test_backward_workspace_plans_without_a_device():
+    """Host logic of the round-5 dispatch, no device (the mode switches are read once per process: subprocesses).  Default ("auto"): the dS
+    workspace of the 5-matmul backward is asked for when the touched dS fits AULE_HIP_BWD_DS_AUTO_MB (B1 H32 S2048: 134 MB) and not for the
+    large shapes (C3, C2); AULE_HIP_BWD_MODE=spill asks for it wherever the mode can run, within AULE_HIP_BWD_DS_CAP_MB (whole batch elements:
+    the call then runs in chunks); =recompute never.  fp32 small grids: the pieces' planes, forward and backward; AULE_HIP_F32_SPLIT=0: none."""
+    rows = lambda B, H, S: ((B * H * S * 4 + 255) // 256) * 256
+    ds = lambda B, Hq, Hkv, Sq, Sk: B * Hkv * (4 * ((Sk + 127) // 128)) * (Hq // Hkv) * ((Sq + 31) // 32) * 2048
+    c3_partials = 2 * 2 * 4 * 8 * 2048 * 128 * 4     # C3 on the predecessor dK/dV kernel would split its group's heads over 2 workgroups: fp32 dK / dV planes
+    auto = _ws_sizes({})
+    assert auto["B1"] == 3 * rows(1, 32, 2048) + ds(1, 32, 32, 2048, 2048)
+    assert auto["C3"] == 3 * rows(4, 32, 2048) + c3_partials and auto["C2"] == 3 * rows(4, 32, 4096)
+    rec = _ws_sizes({"AULE_HIP_BWD_MODE": "recompute"})
+    assert rec["B1"] == 3 * rows(1, 32, 2048) and rec["C3"] == auto["C3"]
+    sp = _ws_sizes({"AULE_HIP_BWD_MODE": "spill"})
+    assert sp["C3"] == auto["C3"] + ds(4, 32, 8, 2048, 2048)                      # 1.07 GB: the whole batch fits the default 8 GB cap
+    assert sp["C2"] == auto["C2"] + ds(4, 32, 32, 4096, 4096)                    # 4 x 1.07 GB
+    cap = _ws_sizes({"AULE_HIP_BWD_MODE": "spill", "AULE_HIP_BWD_DS_CAP_MB": "2500"})
+    assert cap["C2"] == auto["C2"] + 2 * ds(1, 32, 32, 4096, 4096)               # two batch elements per chunk
+    none = _ws_sizes({"AULE_HIP_BWD_MODE": "spill", "AULE_HIP_BWD_DS_CAP_MB": "500"})
+    assert none["C2"] == auto["C2"]                                              # not even one element fits: the recompute pair
+    # fp32 small grids (the reference's Zig benchmark shape: 128 work items for 512 slots -> 4 pieces)
+    assert auto["F32F"] == 4 * (4 * 8 * 512) * (64 + 4) * 4 and auto["F32BIG"] == 0
+    assert auto["F32B"] == rows(4, 8, 512) + 2 * 4 * (4 * 8 * 512) * 64 * 4        # delta + max(dQ planes, dK + dV planes) of 4 pieces
+    off = _ws_sizes({"AULE_HIP_F32_SPLIT": "0"})
+    assert off["F32F"] == 0 and off["F32B"] == rows(4, 8, 512)
