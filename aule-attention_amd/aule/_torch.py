@@ -140,9 +140,11 @@ def _fwd_desc(lib, q, k, causal, scale, window):
     return ent
 
 
-def rope_fusable(q, k, causal, window, cos, sin, q_pos):
+def rope_fusable(q, k, causal, window, cos, sin, q_pos, scale=None):
     """Would the forward kernel rotate Q itself for this problem (aule_attention_forward_rope_fusable)?  Host logic only:
-    no device, no aule_init()."""
+    no device, no aule_init().  scale: the softmax scale of the call (None = default); it is part of the answer -- the kernel that
+    rotates Q does not take negative scales (round 5: without it, flash_attention_rope(scale < 0) chose the fused form in inference
+    and the launch then refused it; found by tools/fuzz_parity.py split)."""
     lib = _capi.load()
     if q.dtype not in _DTYPES or q.numel() == 0 or cos.stride(-1) != 1:
         return False
@@ -152,6 +154,7 @@ def rope_fusable(q, k, causal, window, cos, sin, q_pos):
     d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3]
     d.causal = causal_code(causal)
     d.window_size = int(window) if window is not None and window > 0 else -1
+    d.scale = 0.0 if scale is None else _abi_scale(scale)
     r = _attn_rope(cos, sin, q_pos)
     return lib.aule_attention_forward_rope_fusable(ctypes.byref(d), ctypes.byref(r)) == 1
 
@@ -345,7 +348,7 @@ def flash_attention_rope_hip(q, k, v, cos, sin, causal=True, scale=None, window=
     Dp = next(x for x in SUPPORTED_HEAD_DIMS if x >= D)
     needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
     if (not needs_grad and layout == "half" and Dp == D and os.environ.get("AULE_HIP_ROPE_FUSE", "1") != "0"
-            and rope_fusable(q, k, code, window, cos, sin, q_pos)):
+            and rope_fusable(q, k, code, window, cos, sin, q_pos, float(scale))):
         # inference: K is rotated once per key, Q on its way into the attention kernel's registers (one read and one
         # write of Q less; bit-identical to the two-pass form -- DESIGN.md 3.6).  The backward needs the rotated Q in
         # memory, so training keeps the separate pass.

@@ -299,3 +299,22 @@ def test_fused_rotation_through_the_exact_maximum_stream(dtype, B, Hq, Hkv, S, D
     fused, lse1 = at.fwd_raw(q, kr, v, code, sc, want_lse=True, q_rope=(cos, sin, 0))
     assert torch.isfinite(fused.float()).all() and torch.isfinite(lse1).all()
     assert torch.equal(fused, two) and torch.equal(lse1, lse2)
+
+
+def test_negative_scale_keeps_the_separate_rotation_pass():
+    """Round 5 (found by tools/fuzz_parity.py split): the kernel that rotates Q itself does not take negative scales, so an inference call of
+    flash_attention_rope with scale < 0 must take the two-pass form -- it used to pick the fused one (the helper did not look at the scale) and
+    the launch then refused it.  Same result as rotating by hand and calling the plain forward."""
+    import torch
+    import aule
+    from aule import _torch as at
+    g = torch.Generator(device="cuda").manual_seed(8)
+    B, Hq, Hkv, S, D = 1, 8, 2, 1500, 128
+    q, k, v = (torch.randn(B, h, S, D, device="cuda", dtype=torch.bfloat16, generator=g) for h in (Hq, Hkv, Hkv))
+    cos, sin = aule.precompute_rope_frequencies(S, D, device="cuda")
+    cos, sin = cos.contiguous(), sin.contiguous()
+    assert at.rope_fusable(q, k, 1, -1, cos, sin, 0) and not at.rope_fusable(q, k, 1, -1, cos, sin, 0, -0.2)
+    with torch.no_grad():
+        out = aule.flash_attention_rope(q, k, v, cos, sin, causal=True, scale=-0.2)
+        ref = aule.flash_attention(at.rope_raw(q, cos, sin), at.rope_raw(k, cos, sin), v, causal=True, scale=-0.2)
+    assert torch.isfinite(out.float()).all() and torch.equal(out, ref)

