@@ -12,12 +12,16 @@
 //
 // 5 tile matmuls, no atomics, bit-deterministic; the price is one 16-bit round trip of dS through HBM / the Infinity Cache
 // (C3: 2 x 0.57 GB per backward, C2: 2 x 2.2 GB) and O(Sq Sk) workspace, which the dispatcher (fa_bwd_gfx950.hip) bounds by
-// running the batch in chunks.  This kernel is bound by that stream (2 KB of dS per 8 MFMAs: 16 TB/s to feed the matrix pipes),
-// not by MFMA issue, so it is plain HIP: compiler-scheduled MFMAs and LDS reads around hand-issued LDS-DMA requests with a counted
-// vmcnt (a ring of 6 block slots, blocks requested 5 iterations ahead: ~100 KB in flight per CU).
+// running the batch in chunks.  This kernel is bound by that stream (2 KB of dS per 8 MFMAs: 16 TB/s to feed the matrix pipes; measured:
+// 4.2 TB/s from HBM, the same with the MFMAs removed -- profiles/r5_bwd_spill.txt), not by MFMA issue, so it is plain HIP: compiler-scheduled
+// MFMAs and LDS reads around hand-issued LDS-DMA requests with a counted vmcnt; a ring of 3 block slots, blocks requested 2 iterations
+// ahead, two workgroups per CU (deeper rings and one workgroup per CU measured the same).
+// MEASURED VERDICT: a loss against the recompute pair wherever the dS leaves the 256 MB Infinity Cache (C2, C3, D = 64
+// training), +14 .. 27 % where it stays inside -- the default dispatch takes this mode for those problems only.
 //
 // Workspace layout: fa_kernels.h, DsLayout.  Work decomposition = the recompute kernel's (fa_bwd_dq4_gfx950.hip): a workgroup of
-// 4 waves x 64 query rows owns a 256-row Q block (causal: the pair (i, n-1-i)) and walks the 32-key blocks its rows see.
+// 4 waves x 64 query rows owns a 256-row Q block (causal: the pair (i, n-1-i); single blocks when every block can have a workgroup
+// slot of its own) and walks the 32-key blocks its rows see.
 #include <cstdlib>
 
 #include "fa_device.h"
