@@ -26,7 +26,7 @@
 // LDS-DMA piece holds two row groups there, so the image is a per-piece chunk permutation instead of per-row-group pads
 // (tools/gen_bw4.py, Cfg / chunk64), 128 accumulator registers, 72 arch VGPRs left to hipcc, a 68 KB ring.
 //
-// Covers bf16 / fp16, D = 128 / 64, causal (coff >= 0) and non-causal, no window; deterministic (no atomics).
+// Covers bf16 / fp16, D = 128 / 64, causal (coff >= 0; round 5: with a sliding window too) and non-causal; deterministic (no atomics).
 #include <cstdlib>
 #include <type_traits>
 
@@ -60,6 +60,7 @@ struct Dkv4Params {
     int nblk;      // work items per (batch, kv head): KV blocks, or pairs of them (causal)
     int coff;      // causal position offset (query i sits at position i + coff)
     unsigned long long* dbg;   // timeline build: {iterations, cycles of [phase 1 + boundary], cycles of [phase 2]} of workgroup 0's waves
+    int window;    // sliding window (round 5): key j visible to query i only if (i + coff) - j < window (0: off); never with SPILL
     char* ds;      // SPILL instances (the 5-matmul backward, fa_bwd_dqs_gfx950.hip): the dS workspace, layout in fa_kernels.h (DsLayout)
     int nq32, nkb32p;
 };
@@ -162,7 +163,10 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
         }
         A::zero_acc();
 
-        const int nq32 = (Sq + kQB - 1) / kQB;
+        const int W = p.window;
+        int nq32 = (Sq + kQB - 1) / kQB;
+        // (window: the last query that sees the block's last key kb 128 + 127 sits at position key + W - 1: the stream of a KV block ends there)
+        if (W > 0) nq32 = min(nq32, max(0, kb * kKvBlock4 + kKvBlock4 - 1 + W - 1 - coff) / kQB + 1);
         const int first_qt = CAUSAL ? max(0, kb * kKvBlock4 - coff) / kQB : 0;
         const int ntq = nq32 > first_qt ? nq32 - first_qt : 0;
         const int nit = ntq * g;   // flattened (query head of the group, query block) stream
@@ -192,7 +196,9 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
         // block if the wave's 32 keys run past Sk), a ragged Sq its last one.
         const int diag_x = CAUSAL ? n0w + 31 - coff - first_qt * kQB : 0;   // block t crosses the diagonal iff t kQB < diag_x
         const int t_diag = (n0w + 32 > Sk) ? 0x7fffffff : (diag_x > 0 ? (diag_x + kQB - 1) / kQB : 0);
-        const int t_plain_end = (Sq % kQB) != 0 ? ntq - 1 : 0x7fffffff;   // blocks t_diag <= t < t_plain_end need no mask:
+        int t_plain_end = (Sq % kQB) != 0 && nq32 * kQB > Sq ? ntq - 1 : 0x7fffffff;   // blocks t_diag <= t < t_plain_end need no mask:
+        // (window: the first query row that does NOT see the wave's first key n0w is n0w + W - coff; blocks that reach it need the mask)
+        if (W > 0) t_plain_end = min(t_plain_end, max(0, max(0, n0w + W - coff) / kQB - first_qt));
         const unsigned t_lo = (unsigned)dkv4_rfl(t_diag);                  // ONE unsigned compare per iteration, t - t_lo < t_span
         const unsigned t_span = (unsigned)dkv4_rfl(t_plain_end > t_diag ? t_plain_end - t_diag : 0);
         // mask of block t for this lane: rows [lo, lo + wd) of the block are valid (as crow(r) + 4 hi)
@@ -202,7 +208,8 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             asm volatile("" : "+v"(lane_o));
             const int kr = n0w + (lane_o & 31);
             const int lo_r = CAUSAL ? max(0, kr - coff - q0) : 0;
-            const int hi_r = min(kQB, Sq - q0);
+            int hi_r = min(kQB, Sq - q0);
+            if (W > 0) hi_r = min(hi_r, kr + W - coff - q0);   // q + coff - kr < W
             lo = lo_r - 4 * (lane_o >> 5);
             wd = (kr < Sk && hi_r > lo_r) ? hi_r - lo_r : 0;
         };
@@ -360,6 +367,7 @@ int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
     p.c = a.scale * kLog2e;
     p.scale = a.scale;
     p.coff = a.causal ? a.coff : 0;
+    p.window = a.window > 0 ? a.window : 0;
     const int nkb = (a.Sk + kKvBlock4 - 1) / kKvBlock4;
     p.nblk = a.causal ? (nkb + 1) / 2 : nkb;
     const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv)), block(256);
@@ -433,7 +441,8 @@ bool bwd_dkv4_applicable(const BwdArgs& a) {
     }();
     if (mode == 1) return false;
     if (a.dtype != kBF16 && a.dtype != kF16) return false;
-    if ((a.D != 128 && a.D != 64) || a.window > 0) return false;
+    if (a.D != 128 && a.D != 64) return false;
+    if (a.window > 0 && !a.causal) return false;      // (round 5: causal sliding windows run here too; a window without the causal rule stays on the predecessor)
     if (a.causal && a.coff < 0) return false;
     if (a.Hkv <= 0 || a.Hq % a.Hkv != 0) return false;
     // one descriptor covers the rows of a whole GQA group; byte offsets inside it are 32-bit

@@ -20,7 +20,8 @@
 // the dK/dV kernel's D = 64 one (a chunk permutation per 1 KB piece: tools/gen_bw4.py, chunk64), 128 accumulator registers, 50 arch
 // VGPRs left to hipcc, a 68 KB ring.
 //
-// Covers bf16 / fp16, D = 128 / 64, causal (coff >= 0) and non-causal, no window; deterministic (no atomics); the accumulation order
+// Covers bf16 / fp16, D = 128 / 64, causal (coff >= 0; round 5: with a sliding window: the stream starts at the first block the Q block's
+// first row sees and every block runs a two-sided mask) and non-causal; deterministic (no atomics); the accumulation order
 // over the keys is the predecessor's, so dQ comes out bit-identical to it.
 #include <cstdlib>
 #include <type_traits>
@@ -56,6 +57,7 @@ struct Dq4Params {
     float scale;   // applied to dQ at the end
     int nblk;      // work items per (batch, q head): Q blocks, or pairs of them (causal)
     int coff;      // causal position offset (query i sits at position i + coff)
+    int window;    // sliding window (round 5; causal only): key j visible to query i only if (i + coff) - j < window (0: off)
 };
 
 constexpr int kQBlock4 = 256;    // 4 waves x 64 query rows
@@ -123,8 +125,7 @@ __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
     const int nqb = (Sq + kQBlock4 - 1) / kQBlock4;
     const size_t qbase = (size_t)(w.b * p.Hq + w.h) * Sq;
     const size_t kvhead = (size_t)(w.b * p.Hkv + w.hk) * Sk * RB;
-    const __amdgpu_buffer_rsrc_t krs = make_srd(reinterpret_cast<const char*>(p.k) + kvhead, (unsigned)Sk * RB);
-    const __amdgpu_buffer_rsrc_t vrs = make_srd(reinterpret_cast<const char*>(p.v) + kvhead, (unsigned)Sk * RB);
+    const int W = p.window;
     const __amdgpu_buffer_rsrc_t qrs = make_srd(reinterpret_cast<const char*>(p.q) + qbase * RB, (unsigned)Sq * RB);
     const __amdgpu_buffer_rsrc_t grs = make_srd(reinterpret_cast<const char*>(p.dout) + qbase * RB, (unsigned)Sq * RB);
     const __amdgpu_buffer_rsrc_t ors = make_srd(reinterpret_cast<const char*>(p.o) + qbase * RB, (unsigned)Sq * RB);
@@ -161,14 +162,20 @@ __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
     for (int part = 0; part < nparts; ++part) {
         const int qb = CAUSAL ? (part == 0 ? nqb - 1 - w.blk : w.blk) : w.blk;
         const int q0w = qb * kQBlock4 + wave * 64;
-        const int kv_hi = CAUSAL ? min(Sk, qb * kQBlock4 + kQBlock4 + coff) : Sk;     // keys the workgroup's rows can see
-        const int n = (kv_hi + kKB4 - 1) / kKB4;                                         // blocks of the workgroup's stream
-        const int kv_hi_w = CAUSAL ? min(Sk, q0w + 64 + coff) : Sk;                    // ... this wave's rows
+        // Sliding window: the workgroup's stream starts at the first 32-key block its FIRST row sees (block t0); everything below is
+        // relative to that block -- the descriptors start there, block indices, key limits and mask thresholds count from it.
+        const int t0 = (CAUSAL && W > 0) ? min(max(0, qb * kQBlock4 + coff - W + 1), Sk) / kKB4 : 0;   // (rows past Sk + W - 1 see no key: an empty range at the end of K)
+        const int k00 = t0 * kKB4;
+        const __amdgpu_buffer_rsrc_t krs = make_srd(reinterpret_cast<const char*>(p.k) + kvhead + (size_t)k00 * RB, (unsigned)dq4_rfl((Sk - k00) * RB));
+        const __amdgpu_buffer_rsrc_t vrs = make_srd(reinterpret_cast<const char*>(p.v) + kvhead + (size_t)k00 * RB, (unsigned)dq4_rfl((Sk - k00) * RB));
+        const int kv_hi = (CAUSAL ? min(Sk, qb * kQBlock4 + kQBlock4 + coff) : Sk) - k00;     // keys the workgroup's rows can see (from k00)
+        const int n = max(0, (kv_hi + kKB4 - 1) / kKB4);                                         // blocks of the workgroup's stream
+        const int kv_hi_w = (CAUSAL ? min(Sk, q0w + 64 + coff) : Sk) - k00;                    // ... this wave's rows
         const int n_w = dq4_rfl(min(n, max(0, (kv_hi_w + kKB4 - 1) / kKB4)));
 
         // ---- Q^T, dO^T fragments into the accumulator file; delta, L' of the lane's two rows (published for the dK/dV kernel)
         A::load_frags(qrs, grs, ors, (unsigned)((q0w + l31) * RB + hi * 16), (unsigned)((q0w + 32 + l31) * RB + hi * 16));
-        int lim4[2];
+        int lim4[2], wd4[2] = {0, 0};
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const int qrow = q0w + 32 * rb + l31;
@@ -182,13 +189,23 @@ __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
                 p.ndelta_out[qbase + qrow] = -delta;
             }
             if (rb == 0) A::set_scal0(-nlse2, delta); else A::set_scal1(-nlse2, delta);
-            // last key visible to the lane's row (minus 4 hi: a score register r holds key crow(r) + 4 hi of its block)
-            lim4[rb] = (CAUSAL ? min(Sk - 1, qrow + coff) : Sk - 1) - 4 * hi;
+            // last key visible to the lane's row (minus 4 hi: a score register r holds key crow(r) + 4 hi of its block), from k00
+            const int last = (CAUSAL ? min(Sk - 1, qrow + coff) : Sk - 1) - k00;
+            lim4[rb] = last - 4 * hi;
+            if (CAUSAL && W > 0) {   // window: lim4 = the FIRST visible key (minus 4 hi), wd4 = the number of visible keys (AR = 3 statements)
+                const int first = max(0, qrow + coff - W + 1) - k00;
+                lim4[rb] = first - 4 * hi;
+                wd4[rb] = max(0, last - first + 1);
+            }
         }
         A::zero_acc();
         // blocks b >= mask_lo need the mask for some row of the wave (causal diagonal); so does a ragged last block of K
-        const int mask_lo = dq4_rfl(CAUSAL ? max(0, q0w + coff + 1) / kKB4 : 0x7fffffff);
-        const int ragged_blk = dq4_rfl((Sk % kKB4) != 0 ? Sk / kKB4 : -1);
+        const int mask_lo = dq4_rfl(CAUSAL ? max(0, q0w + coff + 1 - k00) / kKB4 : 0x7fffffff);
+        const int ragged_blk = dq4_rfl((Sk % kKB4) != 0 ? Sk / kKB4 - t0 : -1);
+        const bool win = CAUSAL && W > 0;
+        // window: blocks whose first key lies at or above the window start of the wave's LAST row are free of the lower bound -- between them
+        // and the diagonal the plain arithmetic runs (W = 256: 6 of a wave's 11 blocks; W = 1024: 30 of 35)
+        const int win_lo = dq4_rfl(win ? max(0, (q0w + 63 + coff - W + 1 - k00 + kKB4 - 1) / kKB4) : 0);
 
         // ---- stream start: blocks 0 .. 3 requested (a block behind the stream reads zeros: the scalar offset is range-checked)
 #pragma unroll
@@ -202,17 +219,17 @@ __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
             const unsigned rab = slot_lds(j) + a_sub1, ra2b = slot_lds(j + 1) + a_sub1;   // (D = 64: the bases of the odd k-slices)
             const unsigned dlds = slot_lds(j + 4) + wave_pb, dso = (unsigned)((j + 4) * kKB4 * RB);
             const int k0 = (j - 1) * kKB4;
-#define DQ4_IT(QK, NXT, AR, DQ, PRE) A::template iter<PAR, QK, NXT, AR, DQ, PRE>(c, ra, rab, ra2, ra2b, trb, lim4[0], lim4[1], k0, dlds, krs, vrs, dso, vost[0], vost[1])
-            const bool plain = (j - 1) < mask_lo && (j - 1) != ragged_blk;
+#define DQ4_IT(QK, NXT, AR, DQ, PRE) A::template iter<PAR, QK, NXT, AR, DQ, PRE>(c, ra, rab, ra2, ra2b, trb, lim4[0], lim4[1], k0, dlds, krs, vrs, dso, vost[0], vost[1], wd4[0], wd4[1])
+            const bool plain = (j - 1) >= win_lo && (j - 1) < mask_lo && (j - 1) != ragged_blk;
             if (j + 1 < n_w) {            // S / dP of block j, and of block j + 1 next time
-                if (j >= 2) { if (plain) DQ4_IT(1, 1, 1, 1, 1); else DQ4_IT(1, 1, 2, 1, 1); }
-                else { if (plain) DQ4_IT(1, 1, 1, 0, 1); else DQ4_IT(1, 1, 2, 0, 1); }
+                if (j >= 2) { if (plain) DQ4_IT(1, 1, 1, 1, 1); else if (win) DQ4_IT(1, 1, 3, 1, 1); else DQ4_IT(1, 1, 2, 1, 1); }
+                else { if (plain) DQ4_IT(1, 1, 1, 0, 1); else if (win) DQ4_IT(1, 1, 3, 0, 1); else DQ4_IT(1, 1, 2, 0, 1); }
             } else if (j < n_w) {         // the wave's last S / dP
-                if (j >= 2) { if (plain) DQ4_IT(1, 0, 1, 1, 1); else DQ4_IT(1, 0, 2, 1, 1); }
-                else { if (plain) DQ4_IT(1, 0, 1, 0, 1); else DQ4_IT(1, 0, 2, 0, 1); }
+                if (j >= 2) { if (plain) DQ4_IT(1, 0, 1, 1, 1); else if (win) DQ4_IT(1, 0, 3, 1, 1); else DQ4_IT(1, 0, 2, 1, 1); }
+                else { if (plain) DQ4_IT(1, 0, 1, 0, 1); else if (win) DQ4_IT(1, 0, 3, 0, 1); else DQ4_IT(1, 0, 2, 0, 1); }
             } else if (j - 1 < n_w) {     // tail: arithmetic of the last block (+ dQ of the one before)
-                if (j >= 2) { if (plain) DQ4_IT(0, 0, 1, 1, 0); else DQ4_IT(0, 0, 2, 1, 0); }
-                else { if (plain) DQ4_IT(0, 0, 1, 0, 0); else DQ4_IT(0, 0, 2, 0, 0); }
+                if (j >= 2) { if (plain) DQ4_IT(0, 0, 1, 1, 0); else if (win) DQ4_IT(0, 0, 3, 1, 0); else DQ4_IT(0, 0, 2, 1, 0); }
+                else { if (plain) DQ4_IT(0, 0, 1, 0, 0); else if (win) DQ4_IT(0, 0, 3, 0, 0); else DQ4_IT(0, 0, 2, 0, 0); }
             } else if (j - 2 < n_w && j >= 2) {
                 DQ4_IT(0, 0, 0, 1, 0);   // dQ of the last block
             } else {
@@ -238,6 +255,7 @@ __device__ __forceinline__ void dq4_body(const Dq4Params& p) {
         };
         int steady_end = min(n_w - 1, mask_lo == 0x7fffffff ? mask_lo : mask_lo + 1);   // j + 1 < n_w and block j - 1 below the diagonal
         if (ragged_blk >= 0) steady_end = min(steady_end, ragged_blk + 1);               // ... and not the ragged last block of K
+        if (win) steady_end = 0;                                                          // (window: no unmasked steady range)
         int j = 1;
         iteration(integral_constant<int, 1>{}, j++);
         for (; j + 1 < steady_end; j += 2) {      // (j is even here)
@@ -291,6 +309,7 @@ int launch_dq4(const BwdArgs& a, float* lse2_out, float* ndelta_out, hipStream_t
     p.c = a.scale * kLog2e;
     p.scale = a.scale;
     p.coff = a.causal ? a.coff : 0;
+    p.window = (a.causal && a.window > 0) ? a.window : 0;
     const int nqb = (a.Sq + kQBlock4 - 1) / kQBlock4;
     p.nblk = a.causal ? (nqb + 1) / 2 : nqb;
     const dim3 grid((unsigned)(p.nblk * a.B * a.Hq)), block(256);
@@ -324,7 +343,8 @@ int bwd_dq4_mode() {
 bool bwd_dq4_applicable(const BwdArgs& a) {
     if (bwd_dq4_mode() == 1) return false;
     if (a.dtype != kBF16 && a.dtype != kF16) return false;
-    if ((a.D != 128 && a.D != 64) || a.window > 0) return false;
+    if (a.D != 128 && a.D != 64) return false;
+    if (a.window > 0 && !a.causal) return false;      // (round 5: causal sliding windows run here; a window without the causal rule stays on the predecessor)
     if (a.causal && a.coff < 0) return false;
     if (a.Hkv <= 0 || a.Hq % a.Hkv != 0) return false;
     if ((long long)a.Sq * a.D * 2 >= (1LL << 31) || ((long long)a.Sk + 6 * kKB4) * a.D * 2 >= (1LL << 31)) return false;

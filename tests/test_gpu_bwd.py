@@ -234,7 +234,9 @@ def test_backward_on_the_one_wave_per_simd_kernels(which):
         e["AULE_HIP_BWD_MODE"] = "recompute"
         e["AULE_HIP_BWD_DKV"] = which
         e["AULE_HIP_BWD_DQ"] = which
+    # (round 5: the one-wave-per-SIMD pair takes causal sliding windows too -- the window suite rides along in every leg)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_bwd.py"), os.path.join(ROOT, "tests", "test_gpu_bottom_right.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_window.py"),
                         "-q", "-x", "-m", "gpu", "-k", "not one_wave_per_simd"], env=e, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and "passed" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
 

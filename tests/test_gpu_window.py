@@ -50,6 +50,12 @@ CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, causal, window
     ("bf16", 1, 2, 2, 600, 200, 128, True, 64),     # rows beyond Sk + W - 1 see no key: O = 0
     ("fp16", 1, 3, 3, 130, 130, 32, True, 7),
     ("bf16", 1, 8, 1, 257, 257, 128, True, 255),
+    # round 5: shapes whose grids put the backward on the one-wave-per-SIMD pair by themselves (the mode test of tests/test_gpu_bwd.py forces it
+    # onto all of the above as well): several Q blocks and KV block pairs, the window shorter and longer than a block, GQA, D = 64, bottom-right
+    ("bf16", 2, 32, 32, 1024, 1024, 128, True, 256),
+    ("bf16", 1, 32, 8, 1100, 1100, 128, True, 100),
+    ("fp16", 2, 32, 32, 1024, 1024, 64, True, 300),
+    ("bf16", 1, 32, 32, 700, 1500, 128, "bottom-right", 200),
 ]
 
 

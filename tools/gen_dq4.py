@@ -104,7 +104,16 @@ def arith_ops(c, par, rb, q, masked):
         ops.append(f"v_sub_f32 v{t[4 + i]}, v{DPr + r0 + i}, v{dl}")
     for i in range(4):
         ops.append(f"v_exp_f32 v{t[i]}, v{t[i]}")
-    if masked:
+    if masked == 3:
+        # sliding window (round 5): THR[rb] holds (first visible key - 4 hi) - k0 here, %[wd{rb}] the number of visible keys of the lane's row:
+        # key crow + 4 hi of the block is visible iff (unsigned)(crow - THR) < wd.  The temporary is a register of this block's dS tuple
+        # (written only by the pack at the end of the group)
+        tm = c.ds(par, rb) + r0 // 2
+        for i in range(4):
+            ops.append(f"v_sub_u32 v{tm}, {crow(r0 + i)}, v{c.THR + rb}")
+            ops.append(f"v_cmp_gt_u32 vcc, %[wd{rb}], v{tm}")
+            ops.append(f"v_cndmask_b32 v{t[i]}, 0, v{t[i]}, vcc")
+    elif masked:
         for i in range(4):
             ops.append(f"v_cmp_le_i32 vcc, {crow(r0 + i)}, v{c.THR + rb}")
             ops.append(f"v_cndmask_b32 v{t[i]}, 0, v{t[i]}, vcc")
@@ -228,10 +237,10 @@ def gen_iter(c, par, qk, nxt, ar, dq, pre):
     if ar:
         for rb in (0, 1):
             for q in range(4):
-                fl += arith_ops(c, par ^ 1, rb, q, ar == 2)
+                fl += arith_ops(c, par ^ 1, rb, q, ar if ar >= 2 else 0)
     head = [f"s_waitcnt vmcnt({2 * c.NP})", "s_barrier"]      # all but the two newest blocks' pieces of this wave: blocks <= j + 1 have landed
-    if ar == 2:
-        head += [f"v_subrev_u32 v{c.THR}, %[k0], %[lim0]", f"v_subrev_u32 v{c.THR + 1}, %[k0], %[lim1]"]   # thr = lim - k0
+    if ar >= 2:
+        head += [f"v_subrev_u32 v{c.THR}, %[k0], %[lim0]", f"v_subrev_u32 v{c.THR + 1}, %[k0], %[lim1]"]   # thr = lim - k0 (window: lim = the first visible key)
     if qk and not pre:
         head += rm_reads(c, 0, "%[ra]") + rm_reads(c, 1, "%[ra]")
     if dq and not qk:
@@ -302,7 +311,7 @@ def gen_iter(c, par, qk, nxt, ar, dq, pre):
         clob += vregs(c.VR, 16)
     if ar:
         clob += vregs(c.T, 8) + vregs(c.DS + 16 * (par ^ 1), 16)
-        if ar == 2:
+        if ar >= 2:
             clob += ["vcc"] + vregs(c.THR, 2)
     if dq:
         clob += vregs(c.KT, 8 * c.DB) + aregs(c.DQ, 32 * c.DB)
@@ -317,8 +326,10 @@ def gen_iter(c, par, qk, nxt, ar, dq, pre):
             ins.append('[ra2b] "v"(ra2b)')
     if ar:
         ins.append('[c] "s"(c)')
-        if ar == 2:
+        if ar >= 2:
             ins += ['[lim0] "v"(lim0)', '[lim1] "v"(lim1)', '[k0] "s"(k0)']
+        if ar == 3:
+            ins += ['[wd0] "v"(wd0)', '[wd1] "v"(wd1)']
     if dq:
         ins.append('[trb] "v"(trb)')
     return emit_asm(lines, [], ins, clob)
@@ -330,19 +341,19 @@ def gen_struct(c):
     s += (f"    static constexpr int NV = {c.NV}, NP = {c.NP}, SLOT = {c.SLOT}, IMG = {c.IMG}, PB1 = {c.PBASE[1]}, PB2 = {c.PBASE[2]}, PB4 = {c.PBASE[4] if len(c.PBASE) > 4 else 0};\n"
           f"    static constexpr int SC = {c.SC}, QF = {c.QF}, DF = {c.DF};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr)\n")
     s += ("    // iteration j (PAR = j & 1): S / dP of block j (QK; PRE: its first fragments were requested by the previous statement),\n"
-          "    // arithmetic of block j - 1 (AR: 1 plain, 2 masked), dQ of block j - 2 (DQ), first fragments of block j + 1 (NXT)\n"
+          "    // arithmetic of block j - 1 (AR: 1 plain, 2 masked, 3 window-masked: lim = first visible key, wd = visible keys), dQ of block j - 2 (DQ), first fragments of block j + 1 (NXT)\n"
           "    template <int PAR, int QK, int NXT, int AR, int DQ, int PRE>\n"
           "    static __device__ __forceinline__ void iter(float c, unsigned ra, unsigned rab, unsigned ra2, unsigned ra2b, unsigned trb, int lim0, int lim1, int k0, unsigned dlds,\n"
-          "                                                __amdgpu_buffer_rsrc_t ksrd, __amdgpu_buffer_rsrc_t vsrd, unsigned dso, unsigned vost0, unsigned vost1) {\n"
+          "                                                __amdgpu_buffer_rsrc_t ksrd, __amdgpu_buffer_rsrc_t vsrd, unsigned dso, unsigned vost0, unsigned vost1, int wd0 = 0, int wd1 = 0) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
-          "        (void)c; (void)ra; (void)rab; (void)ra2; (void)ra2b; (void)trb; (void)lim0; (void)lim1; (void)k0;\n"
+          "        (void)c; (void)ra; (void)rab; (void)ra2; (void)ra2b; (void)trb; (void)lim0; (void)lim1; (void)k0; (void)wd0; (void)wd1;\n"
           "        dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n        dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n"
           "        k0 = __builtin_amdgcn_readfirstlane(k0);\n")
     first = True
     # j = 0: S / dP only; j = 1: + arithmetic; j >= 2: + dQ; j = n_w: no S / dP any more; n_w + 1: dQ only; then idle
     variants = [(0, 1, nxt, 0, 0, 0) for nxt in (0, 1)]
-    variants += [(par, 1, nxt, ar, dq, 1) for par in (0, 1) for nxt in (0, 1) for ar in (1, 2) for dq in (0, 1)]
-    variants += [(par, 0, 0, ar, dq, 0) for par in (0, 1) for ar in (0, 1, 2) for dq in (0, 1)]
+    variants += [(par, 1, nxt, ar, dq, 1) for par in (0, 1) for nxt in (0, 1) for ar in (1, 2, 3) for dq in (0, 1)]
+    variants += [(par, 0, 0, ar, dq, 0) for par in (0, 1) for ar in (0, 1, 2, 3) for dq in (0, 1)]
     for (par, qk, nxt, ar, dq, pre) in variants:
         s += (f"        {'if' if first else 'else if'} constexpr (PAR == {par} && QK == {qk} && NXT == {nxt} && AR == {ar} && DQ == {dq} && PRE == {pre}) {{\n")
         s += gen_iter(c, par, qk, nxt, ar, dq, pre) + "        }\n"
