@@ -76,7 +76,9 @@ def run(cfg, seed):
     if not np.all(np.isneginf(gl[~fin])): errs.append("lse of empty rows not -inf")
     if fin.any() and np.abs(gl[fin] - rl[fin]).max() > LSE_TOL[dtype] + 1e-5 * np.abs(rl[fin]).max(): errs.append(f"lse err {np.abs(gl[fin]-rl[fin]).max():.3e}")
     a, r = BWD_TOL[dtype]
-    if dtype == "bf16" and ((scale is not None and abs(scale) * math.sqrt(D) > 2.0) or Sk < 32):
+    keys_eff = min(Sk, Sq) if causal == "top" else Sk      # the most keys any row sees
+    if W > 0: keys_eff = min(keys_eff, W)
+    if dtype == "bf16" and ((scale is not None and abs(scale) * math.sqrt(D) > 2.0) or keys_eff < 32):
         a = 1e-2      # sharp softmax -- a large scale, or so few keys that single weights are O(1) -- (tests/test_gpu_bwd.py, grad_close): the reference's own bar
     for name, got, want in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
         gg = got.float().cpu().numpy()
