@@ -7,7 +7,7 @@
 //     wave w+4).  The matrix pipe and the VALU are separate pipes of a SIMD, but a
 //     barrier-per-tile loop keeps both waves in the same phase (both in MFMAs, then both
 //     in softmax VALU), so the pipes are used one after the other (measured: MFMA busy
-//     30 %, SQ_WAIT_ANY 38 % of wave cycles -- profiles/r1a).
+//     30 %, SQ_WAIT_ANY 38 % of wave cycles -- profiles/r1_fwd_c2_v1kernel_rocprofv3_summary.txt).
 //   * Here the per-tile work is split into two phases,
 //         V-phase(j): softmax of S_j            (VALU only, no LDS, no MFMA)
 //         M-phase(j): O += P_j V_j  and  S_{j+1} = K_{j+1} Q^T   (32 MFMAs + LDS reads)

@@ -45,7 +45,7 @@ OUT = os.environ.get("W4_OUT", os.path.join(ROOT, "aule-attention_amd", "csrc", 
 #   nodma   no LDS-DMA pieces in the plain step     novalu  no softmax arithmetic at all      nocvt  no packing
 #   nobarrier / novmcnt   the plain step without its s_barrier / its counted wait (racy: cycles only)
 XFLAGS = set(filter(None, os.environ.get("W4_X", "").split(",")))
-# how x = c s - m_ref is computed (hardware finding, profiles/r3_w4_filler_costs.txt: 8-byte VOP3 instructions cost the in-order
+# how x = c s - m_ref is computed (hardware finding, profiles/r3_probe_fillers.txt: 8-byte VOP3 instructions cost the in-order
 # wave several times what 4-byte VOP1 / VOP2 ones do next to the MFMAs)
 SCALE_FORM = os.environ.get("W4_SCALE", "fma")
 # W4_PRE=1: the pre-scaled-Q form of the D = 64 streams.  Measured (profiles/r3_w4_d64_prescale.txt): +8.5 % on C5, +4..7 % on the
