@@ -147,6 +147,8 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
         vost[0] = (unsigned)((wave * 8 + 4 * rgl + rr) * RB + (2 * cd + cb) * 32 + ch * 16);
         wave_pb = (unsigned)(1040 * wave);
     }
+    // (the LDS base goes into the per-lane / per-wave constants once: a relocation the compiler cannot fold costs an s_add per use in the loop)
+    tr_off += lds0; a_sub += lds0; a_sub1 += lds0; wave_pb += lds0;
     const unsigned lvo = (unsigned)(hi * 16);   // L' / delta: rows 8 g + 4 hi .. + 3 of the block per dwordx4
     const unsigned svo = (unsigned)(lane * 16);   // SPILL: the lane's 16 bytes of a dS unit's k-step (unit = [kk][lane][16 B])
 
@@ -178,20 +180,25 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
         // of the NEXT head of the group instead of zeros; its weights are masked to exactly 0, and those rows belong to the
         // same dK / dV sum anyway.  Beyond the group's last head the descriptor's bounds return 0.)
         const size_t grows = (size_t)(w.b * p.Hq + w.hk * g) * Sq;   // first row of the group's first head
-        const __amdgpu_buffer_rsrc_t qrs = make_srd(reinterpret_cast<const char*>(p.q) + grows * RB, (unsigned)dkv4_rfl(g * Sq * RB));
-        const __amdgpu_buffer_rsrc_t grs = make_srd(reinterpret_cast<const char*>(p.dout) + grows * RB, (unsigned)dkv4_rfl(g * Sq * RB));
-        const __amdgpu_buffer_rsrc_t lrs = make_srd(p.lse + grows, (unsigned)dkv4_rfl(g * Sq * 4));
-        const __amdgpu_buffer_rsrc_t drs = make_srd(p.delta + grows, (unsigned)dkv4_rfl(g * Sq * 4));
-        struct Cur { int left, row, t; };   // blocks left in this head (this one included), row of the block in the group, block in the head
+        __amdgpu_buffer_rsrc_t qrs = make_srd(reinterpret_cast<const char*>(p.q) + grows * RB, (unsigned)dkv4_rfl(g * Sq * RB));
+        __amdgpu_buffer_rsrc_t grs = make_srd(reinterpret_cast<const char*>(p.dout) + grows * RB, (unsigned)dkv4_rfl(g * Sq * RB));
+        __amdgpu_buffer_rsrc_t lrs = make_srd(p.lse + grows, (unsigned)dkv4_rfl(g * Sq * 4));
+        __amdgpu_buffer_rsrc_t drs = make_srd(p.delta + grows, (unsigned)dkv4_rfl(g * Sq * 4));
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (whole descriptors, not words: the pairs share their size / flag words, and the compiler would re-assemble a four-register
+        // tuple from the shared words in front of every statement that takes one -- four s_mov per iteration)
+        asm volatile("" : "+s"(qrs), "+s"(grs), "+s"(lrs), "+s"(drs));
+#endif
+        struct Cur { int left, row; };   // blocks left in this head (this one included: the block's place in the head is ntq - left), row of the block in the group
         const int row_first = first_qt * kQB;
         const int row_wrap = Sq - (ntq - 1) * kQB;   // from a head's last block to the next head's first one
         auto adv = [&](Cur& cu) __attribute__((always_inline)) {
-            if (--cu.left == 0) { cu.left = ntq; cu.row += row_wrap; cu.t = 0; }
-            else { cu.row += kQB; ++cu.t; }
+            if (--cu.left == 0) { cu.left = ntq; cu.row += row_wrap; }
+            else cu.row += kQB;
         };
         // (a cursor behind the stream's last block needs no special offset: the scalar offset is part of the descriptor's range
         // check on gfx950 -- tools/probe_soffset.hip -- so rows >= g Sq read zeros / the request writes zeros)
-        auto slot_lds = [&](int x) __attribute__((always_inline)) { return lds0 + (unsigned)(x & (kRing4 - 1)) * SLOT; };
+        auto slot_lds = [&](int x) __attribute__((always_inline)) { return (unsigned)(x & (kRing4 - 1)) * SLOT; };   // (+ tr_off / a_sub / wave_pb: those carry the LDS base)
         // Does anybody's lane need a mask in block t of a head?  The causal diagonal covers the head's first t_diag blocks (every
         // block if the wave's 32 keys run past Sk), a ragged Sq its last one.
         const int diag_x = CAUSAL ? n0w + 31 - coff - first_qt * kQB : 0;   // block t crosses the diagonal iff t kQB < diag_x
@@ -199,7 +206,8 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
         int t_plain_end = (Sq % kQB) != 0 && nq32 * kQB > Sq ? ntq - 1 : 0x7fffffff;   // blocks t_diag <= t < t_plain_end need no mask:
         // (window: the first query row that does NOT see the wave's first key n0w is n0w + W - coff; blocks that reach it need the mask)
         if (W > 0) t_plain_end = min(t_plain_end, max(0, max(0, n0w + W - coff) / kQB - first_qt));
-        const unsigned t_lo = (unsigned)dkv4_rfl(t_diag);                  // ONE unsigned compare per iteration, t - t_lo < t_span
+        // ONE unsigned compare per iteration, t - t_diag < t_span, on the cursor's `left` = ntq - t: (ntq - t_diag) - left < t_span
+        const unsigned t_lo = (unsigned)dkv4_rfl(ntq - t_diag);
         const unsigned t_span = (unsigned)dkv4_rfl(t_plain_end > t_diag ? t_plain_end - t_diag : 0);
         // mask of block t for this lane: rows [lo, lo + wd) of the block are valid (as crow(r) + 4 hi)
         auto mask_of = [&](int t, int& lo, int& wd) __attribute__((always_inline)) {
@@ -232,13 +240,13 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             // of blocks i (its place in the head, for the mask) and i + 2 (its row, for L' / delta) are values the cursor had four /
             // two iterations earlier, kept by block parity (the loop is unrolled by two) -- a second and a third cursor cost ten
             // scalar instructions per iteration, and one wave per SIMD pays ~4.6 cycles of issue for every instruction.
-            Cur c4{ntq, row_first, 0};
-            int t_cur[2], t_nxt[2], row_nxt[2], row_01[2];
+            Cur c4{ntq, row_first};
+            int t_cur[2], t_nxt[2], row_nxt[2], row_01[2];   // (t_*: the cursor's `left` at that block)
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 A::dma_block(slot_lds(x) + wave_pb, qrs, grs, (unsigned)c4.row * (unsigned)RB, vost[0], vost[1]);
-                if (x < 2) { t_cur[x] = c4.t; row_01[x] = c4.row; }
-                else { t_nxt[x - 2] = c4.t; row_nxt[x - 2] = c4.row; }
+                if (x < 2) { t_cur[x] = c4.left; row_01[x] = c4.row; }
+                else { t_nxt[x - 2] = c4.left; row_nxt[x - 2] = c4.row; }
                 adv(c4);
             }
             A::template load_scal<0, 0>(lrs, drs, lvo, (unsigned)row_01[0] * 4u);
@@ -267,18 +275,18 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
                 constexpr int PAR = decltype(par_tag)::value, QK = decltype(qk_tag)::value;
                 unsigned long long t0 = 0;
                 if constexpr (TL) t0 = __builtin_amdgcn_s_memtime();
-                const int t = t_cur[PAR];
+                const int left = t_cur[PAR];   // block t = ntq - left of its head
                 const unsigned trb = slot_lds(i) + tr_off;
 #define DKV4_P1(AR, LO, WD)                               \
     A::template p1<0, PAR, QK, AR, 1>(c, LO, WD, trb);     \
     A::template p1<1, PAR, QK, AR, 1>(c, LO, WD, trb);     \
     A::template p1<2, PAR, QK, AR, 1>(c, LO, WD, trb);     \
     A::template p1<3, PAR, QK, AR, 1>(c, LO, WD, trb);
-                if ((unsigned)t - t_lo < t_span) {
+                if (__builtin_expect(t_lo - (unsigned)left < t_span, 1)) {   // (expected: the masked statements then sit outside the loop body)
                     DKV4_P1(1, 0, 0)
                 } else {
                     int lo, wd;
-                    mask_of(t, lo, wd);
+                    mask_of(ntq - left, lo, wd);
                     DKV4_P1(2, lo, wd)
                 }
 #undef DKV4_P1
@@ -302,7 +310,7 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
                 }
                 if constexpr (SPILL && A::ST_LATE != 0) A::store_ds(srs, svo, (unsigned)i << 11);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments of block i + 2 (phase 1 of the next iteration reads them)
-                t_cur[PAR] = t_nxt[PAR]; t_nxt[PAR] = c4.t; row_nxt[PAR] = c4.row;
+                t_cur[PAR] = t_nxt[PAR]; t_nxt[PAR] = c4.left; row_nxt[PAR] = c4.row;
                 adv(c4);
                 if constexpr (TL) { tl_b += __builtin_amdgcn_s_memtime() - t1; ++tl_n; }
             };

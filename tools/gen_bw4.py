@@ -65,6 +65,7 @@ def xfilter(lines):
     return out or ["s_nop 0"]
 
 
+TR64_EARLY = os.environ.get("BW4_TR64", "") == "early"
 ST_LATE = 2 if os.environ.get("BW4_ST", "start") == "end" else 0
 ST_NT = os.environ.get("BW4_ST_NT", "0") == "1"
 
@@ -104,7 +105,10 @@ class Cfg:
             self.PBASE = [1040 * p for p in range(4)]
             self.IMG = 4352                             # >= PBASE[3] + 1024, a multiple of 256
             self.NP = 2                                 # DMA pieces per wave and block: piece w of Q and of dO
-            self.RM_SPLIT = (2, 2, 2, 2)                # 8 reads: k-slices 0 .. 3 of Q, dO
+            # 8 reads: k-slices 0 .. 3 of Q, dO.  BW4_RM64 (experiment): another split, e.g. 4,4,0,0 -- the reads early in the phase, so that the
+            # lgkmcnt(0) behind statement 3 finds them done
+            self.RM_SPLIT = tuple(int(x) for x in os.environ.get("BW4_RM64", "2,2,2,2").split(","))
+            assert len(self.RM_SPLIT) == 4 and sum(self.RM_SPLIT) == 8
         self.SLOT = 2 * self.IMG                    # Q, dO
         # accumulator file
         self.DV = 0
@@ -217,8 +221,12 @@ def gen_p1(c, q, par, qk, ar, tr):
             clob += ["vcc"]
     lds = []
     if tr:                                         # phase 1 carries steps 0 .. 3 (one per statement), phase 2 the other four
-        lds += tr_reads(c, q)
-        clob += vregs(c.X + 4 * q, 4) + vregs(c.Y + 4 * q, 4)
+        steps = [q]
+        if c.NST == 4 and TR64_EARLY:               # D = 64 experiment: all four steps in statements 0 and 1 (the boundary's lgkmcnt(0) finds them done)
+            steps = [2 * q, 2 * q + 1] if q < 2 else []
+        for st in steps:
+            lds += tr_reads(c, st)
+            clob += vregs(c.X + 4 * st, 4) + vregs(c.Y + 4 * st, 4)
     fill = lds + valu
     lines = deal(mf, fill)
     if qk and not fill:
