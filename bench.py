@@ -24,6 +24,14 @@ that transient.  The number a long-running job sees is therefore measured too an
 the same step repeated for --condition-ms of device time (default 250 ms), then W warm-up + K timed steps again.  (Round 2
 printed the conditioned figure as `value` and the plain one as "cold_start"; the two have swapped places.)  Every timed step
 has its own HIP event pair: mean, median, min and max per launch are in "roofline".
+
+Round 6: every leg is a complete measurement.  A sampler thread reads the hwmon files of the device under test (socket power,
+shader clock, power cap) every few milliseconds for the whole process; each leg reports the mean power and the mean / minimum
+clock of ITS timed window next to the per-step mean, median, minimum and maximum ("legs").  A fwd+bwd step carries an event
+between the forward call and `backward()`, so every backward figure (`*_bwd_ms`, `*_bwd_frac`) is the MEDIAN of the backward
+segment of the very steps that were timed -- same conditioning, same clock -- and not a difference of two means taken minutes
+apart; the difference against a fwd-only leg run right behind it rides along as `*_bwd_ms_by_difference`.  `roofline.power_w` /
+`sclk_mhz` are measured in the timed window of this run; `traffic` stays the stored figure of the last PMC-profiled run.
 """
 import argparse
 import json
@@ -138,6 +146,179 @@ def cpu_baseline(budget_s=10.0):
     }
 
 
+class Telemetry:
+    """hwmon of the device under test, sampled by a daemon thread for the whole process: socket power (power1_input, else
+    power1_average; microwatts), shader clock (freq1_input; Hz), power cap (power1_cap).  The device is found by its PCI address
+    (torch's device properties -> /sys/bus/pci/devices/<domain:bus:device.0>/hwmon/hwmon*): with several cards on a node every
+    rank reads its own.  A leg asks for the statistics of a [t0, t1] window of time.perf_counter().  No file, no permission
+    or no samples -> every statistic is None and `source` says why; the bench never fails on telemetry."""
+
+    PERIOD_S = 0.004
+
+    def __init__(self, torch, index):
+        self.rows, self.hw, self.source, self.cap_w, self.label, self.bdf = [], None, None, None, None, None
+        import glob
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            bdf = self.bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            cand = sorted(glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf))
+            how = "pci " + bdf
+            if not cand:
+                cand = sorted(h for h in glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*") if "-" not in h.split("/")[4])
+                how = "the only card with hwmon power" if len(cand) == 1 else None
+                if len(cand) != 1:
+                    self.source = "no hwmon directory for %s and %d candidate cards" % (bdf, len(cand))
+                    return
+            self.hw = cand[0]
+            self.pfile = next((self.hw + "/" + f for f in ("power1_input", "power1_average") if os.path.exists(self.hw + "/" + f)), None)
+            self.ffile = self.hw + "/freq1_input" if os.path.exists(self.hw + "/freq1_input") else None
+            if self.pfile is None:
+                self.hw, self.source = None, "%s has no power1_input / power1_average" % cand[0]
+                return
+            self.cap_w = self._rd(self.hw + "/power1_cap", 1e-6)
+            try:
+                with open(self.hw + "/power1_label") as fh:
+                    self.label = fh.read().strip()
+            except OSError:
+                pass
+            self.source = "hwmon %s (%s), %s + %s every %.0f ms" % (self.hw, how, os.path.basename(self.pfile),
+                                                                    os.path.basename(self.ffile) if self.ffile else "no clock file", self.PERIOD_S * 1e3)
+        except Exception as e:   # noqa: BLE001
+            self.hw, self.source = None, "telemetry unavailable: %s: %s" % (type(e).__name__, str(e)[:120])
+            return
+        import threading
+        self._stop = False
+        self.th = threading.Thread(target=self._loop, daemon=True)
+        self.th.start()
+
+    @staticmethod
+    def _rd(path, k):
+        try:
+            with open(path) as fh:
+                return float(fh.read().split()[0]) * k
+        except (OSError, ValueError, IndexError):
+            return None
+
+    def _loop(self):
+        while not self._stop:
+            t = time.perf_counter()
+            p = self._rd(self.pfile, 1e-6)
+            f = self._rd(self.ffile, 1e-6) if self.ffile else None
+            self.rows.append((0.5 * (t + time.perf_counter()), p, f))
+            time.sleep(self.PERIOD_S)
+
+    def window(self, t0, t1):
+        """{power_w, power_w_max, sclk_mhz, sclk_mhz_min, samples} over the samples taken in [t0, t1]; a window shorter than the
+        sampling period takes the one sample nearest to its middle (samples = 1, flagged)."""
+        out = {"power_w": None, "power_w_max": None, "sclk_mhz": None, "sclk_mhz_min": None, "power_cap_w": self.cap_w, "samples": 0}
+        if self.hw is None or not self.rows:
+            return out
+        rows = [r for r in self.rows if t0 <= r[0] <= t1]
+        if not rows:
+            mid = 0.5 * (t0 + t1)
+            r = min(self.rows, key=lambda x: abs(x[0] - mid))
+            if abs(r[0] - mid) > 0.05:
+                return out
+            rows, out["nearest_sample_only"] = [r], True
+        ps = [r[1] for r in rows if r[1] is not None]
+        fs = [r[2] for r in rows if r[2] is not None]
+        if ps:
+            out["power_w"], out["power_w_max"] = sum(ps) / len(ps), max(ps)
+        if fs:
+            out["sclk_mhz"], out["sclk_mhz_min"] = sum(fs) / len(fs), min(fs)
+        out["samples"] = len(rows)
+        return out
+
+
+class Limiter:
+    """Which limiter holds the clock down, from a DOCUMENTED interface (round 5 read a guessed byte offset of the
+    gpu_metrics blob): the amdsmi library's violation accumulators (amdsmi_get_violation_status -> amdsmi_violation_status_t:
+    acc_counter, acc_ppt_pwr "PVIOL", acc_socket_thrm "TVIOL", acc_prochot_thrm, acc_vr_thrm, acc_hbm_thrm; the same numbers
+    `amd-smi metric --violation` prints).  Residency of a limiter over a window = delta acc_x * 100 / delta acc_counter
+    (rocm_smi.h's formula for PVIOL / TVIOL).  The two snapshots are taken by a helper thread WHILE the main thread keeps the
+    workload running back to back, so the window holds nothing but the workload."""
+
+    KEYS = (("ppt", "acc_ppt_pwr"), ("socket_thermal", "acc_socket_thrm"), ("prochot", "acc_prochot_thrm"),
+            ("vr_thermal", "acc_vr_thrm"), ("hbm_thermal", "acc_hbm_thrm"))
+
+    def __init__(self, bdf):
+        self.h, self.source = None, None
+        try:
+            import amdsmi
+            self.smi = amdsmi
+            amdsmi.amdsmi_init()
+            for h in amdsmi.amdsmi_get_processor_handles():
+                if bdf is None or str(amdsmi.amdsmi_get_gpu_device_bdf(h)).lower() == bdf:
+                    self.h = h
+                    break
+            self.source = ("amdsmi_get_violation_status (amdsmi %s), device %s" % (getattr(amdsmi, "__version__", "?"), bdf)) if self.h is not None \
+                else "no amdsmi processor handle with BDF %s" % bdf
+        except Exception as e:   # noqa: BLE001
+            self.h, self.source = None, "amdsmi unavailable: %s: %s" % (type(e).__name__, str(e)[:120])
+
+    def snap(self):
+        v = self.smi.amdsmi_get_violation_status(self.h)
+        return {k: v.get(k) for k in ("acc_counter",) + tuple(a for _, a in self.KEYS)}
+
+    def during(self, torch, fn, tel, seconds=1.0):
+        """Runs fn back to back while a helper thread takes two snapshots `seconds` apart; returns the residencies (percent of the
+        window), the hwmon statistics of the same window, and the launch count."""
+        if self.h is None:
+            return {"error": self.source}
+        import threading
+        res = {}
+
+        def helper():
+            try:
+                a = self.snap()
+                t0 = time.perf_counter()
+                time.sleep(seconds)
+                b = self.snap()
+                res.update(a=a, b=b, t0=t0, t1=time.perf_counter())
+            except Exception as e:   # noqa: BLE001
+                res["error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
+
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize()
+        th = threading.Thread(target=helper, daemon=True)
+        th.start()
+        n = 0
+        while th.is_alive():
+            for _ in range(8):
+                fn()
+            n += 8
+            torch.cuda.synchronize()
+        th.join()
+        if "error" in res:
+            return res
+        a, b = res["a"], res["b"]
+        out = {"window_s": seconds, "launches": n, "source": self.source}
+        try:
+            dc = int(b["acc_counter"]) - int(a["acc_counter"])
+            out["acc_counter_delta"] = dc
+            for name, key in self.KEYS:
+                out[name + "_residency_pct"] = (100.0 * (int(b[key]) - int(a[key])) / dc) if dc > 0 else None
+        except (TypeError, ValueError) as e:
+            out["error"] = "accumulators not numeric on this box: %s" % str(e)[:120]
+        out.update(tel.window(res["t0"], res["t1"]))
+        return out
+
+
+def step_stats(xs):
+    """mean / median / min / max of a list of per-step milliseconds + which steps were outliers (> 1.15 x median)."""
+    if not xs:
+        return {}
+    o = sorted(xs)
+    n = len(o)
+    med = o[n // 2] if n % 2 else 0.5 * (o[n // 2 - 1] + o[n // 2])
+    out = {"ms_mean": sum(xs) / n, "ms_median": med, "ms_min": o[0], "ms_max": o[-1], "steps": n}
+    slow = [(i, round(x, 4)) for i, x in enumerate(xs) if x > 1.15 * med]
+    if slow:
+        out["steps_over_1p15_median"] = slow[:12]
+    return out
+
+
 def workload_string(config, B, mode=None):
     _, Hq, Hkv, Sq, Sk, D, dtype, causal, dmode = CONFIGS[config]
     return "%s: B=%d/GPU Hq=%d Hkv=%d Sq=%d Sk=%d D=%d %s %s %s" % (config, B, Hq, Hkv, Sq, Sk, D, dtype, "causal" if causal else "non-causal", mode or dmode)
@@ -161,6 +342,29 @@ def self_spawn(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
     os.execv(sys.executable, cmd)
+
+
+def gather_watchdog(result, rank, limit_s, before_print=None):
+    """The output-exchange section is EXTRA to the contract's line and has never met N > 1 GPUs before the driver's run: whatever
+    happens in it, the line with `value` (measured before it) gets printed.  Returns the Event the section sets when it is through;
+    if it is not set within limit_s the watchdog thread records that in result["gather"]["error"], rank 0 prints the line, and the
+    process ends with status 0 (a hung collective cannot be cancelled from Python; os._exit skips the process group's destructor,
+    which would hang too).  tests/test_bench_spawn.py drives this path on gloo (AULE_BENCH_TEST_HANG)."""
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(timeout=limit_s):
+            result.setdefault("gather", {})["error"] = "the output-exchange section did not finish in %.0f s; line printed by the watchdog" % limit_s
+            if before_print is not None:
+                before_print()
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            sys.stdout.flush()
+            os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    return done
 
 
 def dry_run(args):
@@ -191,11 +395,32 @@ def dry_run(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t[0])
         dist.barrier()
+    result = {"metric": "attention TFLOPS/GPU (fwd, fwd+bwd) + % MFMA roofline at S=4096,D=128", "value": None,
+              "unit": "TFLOP/s", "n_gpus": world, "world_size": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": wall * 1e3 / max(1, args.steps), "dry_run": True,
+              "config": {"workload": workload_string(args.config, args.batch or CONFIGS[args.config][0], args.mode)}}
+    if world > 1:
+        # the sharding arithmetic of the real run, sizes only: who holds what of the gathered output (aule/dist.py)
+        from aule import dist as adist
+        _, Hq, Hkv, Sq, _, D, dtype, _, _ = CONFIGS[args.config]
+        Bl = args.batch or CONFIGS[args.config][0]
+        sizes, total = adist.gather_bytes(Bl * world, Hq, Hkv, Sq, D, 2 if dtype != "fp32" else 4, world)
+        result["gather_plan"] = {"bytes_per_rank": sizes, "total_bytes": total, "shard": adist.shard_plan(Bl * world, Hkv, world)[0]}
+    if os.environ.get("AULE_BENCH_TEST_HANG"):
+        # test hook: an exchange section that never comes back (a collective one rank never joins) -> the watchdog prints the line
+        result["gather"] = {"steps": 0}
+        gather_watchdog(result, rank, float(os.environ.get("AULE_BENCH_GATHER_TIMEOUT", "240")))
+        if dist is not None and rank != 0:
+            time.sleep(3600)            # this rank never joins ...
+        try:
+            if dist is not None:
+                dist.barrier()          # ... so this never returns on rank 0
+            else:
+                time.sleep(3600)
+        except Exception as e:          # noqa: BLE001 -- (the peer's watchdog ended it first: recorded like any failure of the section)
+            result["gather"]["error"] = (type(e).__name__ + ": " + str(e))[:200]
     if rank == 0:
-        print(json.dumps({"metric": "attention TFLOPS/GPU (fwd, fwd+bwd) + % MFMA roofline at S=4096,D=128", "value": None,
-                          "unit": "TFLOP/s", "n_gpus": world, "world_size": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": wall * 1e3 / max(1, args.steps), "dry_run": True,
-                          "config": {"workload": workload_string(args.config, args.batch or CONFIGS[args.config][0], args.mode)}}), flush=True)
+        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -266,11 +491,16 @@ def main():
     # autograd on in both modes: the forward then stores LSE (what a training forward, and the reference's, does)
     q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
 
-    def step():
+    tel = Telemetry(torch, local_rank)
+    dump_steps = bool(os.environ.get("AULE_BENCH_DUMP_STEPS"))
+
+    def step(mid=None):
         if mode == "fwd":
             return aule.flash_attention(q, k, v, causal=causal)
         q.grad = k.grad = v.grad = None
         out = aule.flash_attention(q, k, v, causal=causal)
+        if mid is not None:
+            mid()
         out.backward(do)
         return out
 
@@ -279,29 +509,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    last_launches = []
-
-    def timed(fn, steps):
+    def timed(fn, steps, split=False):
         """Barrier + synchronize, K steps, synchronize; wall clock and HIP-event time on the launch stream (torch's
         current stream = the stream the kernels are launched on), MAX over ranks.  Per-step event pairs give the
-        per-launch spread (rank-local)."""
+        per-launch spread (rank-local).  split: `fn(mid)` calls `mid()` between its forward call and its backward(), which
+        records one more event per step -- the forward and the backward segment of every timed step."""
         sync_all()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        mids = [torch.cuda.Event(enable_timing=True) for _ in range(steps)] if split else None
         t0 = time.perf_counter()
         ev[0].record()
         for i in range(steps):
-            fn()
+            if split:
+                fn(mids[i].record)
+            else:
+                fn()
             ev[i + 1].record()
         torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        wall = t1 - t0
         dev_ms = ev[0].elapsed_time(ev[steps])
-        last_launches[:] = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+        rec = {"per_step": [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)], "t0": t0, "t1": t1}
+        if split:
+            rec["fwd_seg"] = [ev[i].elapsed_time(mids[i]) for i in range(steps)]
+            rec["bwd_seg"] = [mids[i].elapsed_time(ev[i + 1]) for i in range(steps)]
         if dist is not None:
             t = torch.tensor([wall, dev_ms], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall, dev_ms = float(t[0]), float(t[1])
             dist.barrier()
-        return wall, dev_ms
+        rec["wall_s"], rec["dev_ms"] = wall, dev_ms
+        return rec
 
     def condition(fn, ms):
         """Repeat the step for ~ms of device time (power / clock controller into steady state); returns (steps, ms).
@@ -328,23 +566,58 @@ def main():
         torch.cuda.synchronize()
         return n + 3, e0.elapsed_time(e1) + first      # (the two untimed calls are neither counted nor timed)
 
-    # 1. the contract's protocol, first thing, on the chip as the process finds it: W untimed steps, EXACTLY K timed steps -> `value`
-    for _ in range(args.warmup):
-        step()
-    wall, dev_ms = timed(step, args.steps)
-    launches = sorted(last_launches)
-    # 2. the same protocol again behind a conditioning phase -> "steady_state" (reported beside `value`, never as it)
-    cond_steps, cond_ms = condition(step, args.condition_ms)
-    for _ in range(args.warmup):
-        step()
-    steady_wall, steady_dev_ms = timed(step, args.steps)
+    legs = {}
+
+    def leg(name, fn, steps, cond_ms=0.0, warm=0, split=False, flops=None, peak=None):
+        """One complete measurement: optional conditioning on the leg's own step, `warm` untimed steps, `steps` timed ones with
+        an event pair each; statistics of the steps + the telemetry of the timed window -> legs[name].  Returns the record
+        (with the raw `timed` result under "_raw")."""
+        cs, cms = condition(fn, cond_ms)
+        for _ in range(warm):
+            fn()
+        raw = timed(fn, steps, split)
+        rec = step_stats(raw["per_step"])
+        rec["ms_mean_events"] = raw["dev_ms"] / steps          # first event to last: includes the gaps between steps
+        if split:
+            rec["fwd_segment"] = step_stats(raw["fwd_seg"])
+            rec["bwd_segment"] = step_stats(raw["bwd_seg"])
+        if flops is not None:
+            rec["tflops_mean"] = flops / (rec["ms_mean_events"] * 1e-3) / 1e12
+            rec["tflops_median"] = flops / (rec["ms_median"] * 1e-3) / 1e12
+            if peak:
+                rec["frac_mean"], rec["frac_median"] = rec["tflops_mean"] / peak, rec["tflops_median"] / peak
+        rec.update(tel.window(raw["t0"], raw["t1"]))
+        if cond_ms > 0:
+            rec["conditioning_ms"], rec["conditioning_steps"] = cms, cs
+        if dump_steps:
+            rec["per_step_ms"] = [round(x, 4) for x in raw["per_step"]]
+            if split:
+                rec["per_step_bwd_ms"] = [round(x, 4) for x in raw["bwd_seg"]]
+        legs[name] = rec
+        out = dict(rec)
+        out["_raw"] = raw
+        return out
 
     f_fwd = fwd_flops(B, Hq, Sq, Sk, D, causal)
     f_step = f_fwd * (3.5 if mode == "fwdbwd" else 1.0)
+    split_main = mode == "fwdbwd"
+
+    # 1. the contract's protocol, first thing, on the chip as the process finds it: W untimed steps, EXACTLY K timed steps -> `value`
+    main_leg = leg("value", step, args.steps, 0.0, args.warmup, split_main, f_step, PEAK_TFLOPS[dtype])
+    wall, dev_ms = main_leg["_raw"]["wall_s"], main_leg["_raw"]["dev_ms"]
+    launches = sorted(main_leg["_raw"]["per_step"])
+    # 2. the same protocol again behind a conditioning phase -> "steady_state" (reported beside `value`, never as it)
+    steady_leg = leg("steady_state", step, args.steps, args.condition_ms, args.warmup, split_main, f_step, PEAK_TFLOPS[dtype])
+    steady_wall, steady_dev_ms = steady_leg["_raw"]["wall_s"], steady_leg["_raw"]["dev_ms"]
+    cond_steps, cond_ms = steady_leg.get("conditioning_steps", 0), steady_leg.get("conditioning_ms", 0.0)
 
     def launch_stats():
         n = len(launches)
         return {"kernel_ms_median": launches[n // 2], "kernel_ms_min": launches[0], "kernel_ms_max": launches[-1]}
+
+    def measured_telemetry(rec):
+        """what the hwmon sampler saw in the leg's timed window (None where the box has no readable hwmon)"""
+        return {k: rec.get(k) for k in ("power_w", "power_w_max", "power_cap_w", "sclk_mhz", "sclk_mhz_min", "samples")}
 
     ms_per_step = wall * 1e3 / args.steps
     value = f_step * n_gpus * args.steps / wall / 1e12
@@ -353,6 +626,7 @@ def main():
     elt = 2 if dtype != "fp32" else 4
     alg_bytes = elt * (2 * B * Hq * Sq * D + 2 * B * Hkv * Sk * D) + 4 * B * Hq * Sq
     hbm_bound = mode == "fwd" and f_step / alg_bytes < RIDGE
+    tel_value, tel_steady = measured_telemetry(main_leg), measured_telemetry(steady_leg)
 
     result = {
         "metric": "attention TFLOPS/GPU (fwd, fwd+bwd) + % MFMA roofline at S=4096,D=128",
@@ -373,15 +647,19 @@ def main():
             "lse": "stored (autograd is on: the forward writes the log-sum-exp like the reference's, triton_flash_amd.py:410-432)"},
         "steady_state": {"value": f_step * n_gpus * args.steps / steady_wall / 1e12, "ms_per_step": steady_wall * 1e3 / args.steps,
                          "frac": f_step / (steady_dev_ms / args.steps * 1e-3) / 1e12 / PEAK_TFLOPS[dtype],
-                         "conditioning_ms": cond_ms, "conditioning_steps": cond_steps,
+                         "ms_per_step_median": steady_leg["ms_median"], "ms_per_step_min": steady_leg["ms_min"], "ms_per_step_max": steady_leg["ms_max"],
+                         "frac_median": steady_leg.get("frac_median"),
+                         "conditioning_ms": cond_ms, "conditioning_steps": cond_steps, **tel_steady,
                          "note": "the same W + K protocol AFTER repeating the step for --condition-ms of device time: past the MI355X DVFS "
                                  "transient that follows load onset (~60 launches / 40 ms, profiles/r2_dvfs_trace.txt).  What a long-"
-                                 "running job sees; `value` above is the plain protocol (round 2 called that one cold_start)"},
+                                 "running job sees; `value` above is the plain protocol (round 2 called that one cold_start); power_w / "
+                                 "sclk_mhz: hwmon of this device in the timed window of THIS run"},
         "world_size": world,
         "per_gpu_tflops": value / n_gpus,
+        "telemetry_source": tel.source,
         "roofline": ({"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": hbm_traffic(args.config, mode),
-                      "kernel_ms": kern_ms, **launch_stats(),
+                      "kernel_ms": kern_ms, **launch_stats(), **tel_value,
                       "note": "arithmetic intensity %.0f FLOP/B < ridge %.0f: achieved = algorithmic bytes (%d) / HIP-event "
                               "time per step" % (f_step / alg_bytes, RIDGE, int(alg_bytes))}
                      if hbm_bound else
@@ -391,17 +669,25 @@ def main():
                       "traffic_source": "stored: rocprofv3 PMC passes of the last profiled run of this workload (profiles/hbm_traffic.json, "
                                         "FETCH_SIZE x2 + WRITE_SIZE per launch), not measured in this run",
                       "effective_clock_ghz_profiled": stored_profile(args.config, mode).get("effective_clock_ghz"),
-                      # stored telemetry of the last power-trace run of this workload (profiles/r5_ceiling_control.txt): socket power and
-                      # power limit (hwmon), shader clock while the kernel runs back to back; and what this chip sustains on N(0,1)
-                      # operands as a fraction of `peak` -- a RANGE with its sources (round 5): bare-MFMA loops of two shapes, and the
-                      # vendor GEMM (hipBLASLt bf16 8192^3) as the control that does not depend on this build's own probe
-                      **{k: stored_profile(args.config, mode).get(k) for k in ("power_w", "power_cap_w", "sclk_mhz",
-                                                                                "mfma_only_random_frac_of_peak", "power_profile")},
+                      # MEASURED in this run (round 6): hwmon socket power / shader clock of this device in the timed window of the
+                      # `value` leg and of the conditioned leg; the power cap as hwmon reports it
+                      **tel_value,
+                      "steady": tel_steady,
+                      "telemetry": "measured: hwmon sampler thread, the timed window of the `value` leg (top level) and of the conditioned leg (`steady`)",
+                      # stored: what this chip sustains on N(0,1) operands as a fraction of `peak` -- a RANGE with its sources (round 5):
+                      # bare-MFMA loops of two shapes, and the vendor GEMM (hipBLASLt bf16 8192^3) as the control (profiles/r5_ceiling_control.txt)
+                      **{k: stored_profile(args.config, mode).get(k) for k in ("mfma_only_random_frac_of_peak", "power_profile")},
                       "kernel_ms": kern_ms, **launch_stats(),
                       "note": "achieved = algorithmic FLOPs per step / HIP-event time per step on the launch stream (the `value` leg: "
                               "plain W + K protocol); frac_steady = the same for the conditioned leg; algorithmic bytes %d; the nominal "
-                              "peak assumes 2.4 GHz, the chip sustains ~1.9 GHz under this kernel (effective_clock_ghz_profiled)" % int(alg_bytes)}),
+                              "peak assumes 2.4 GHz, sclk_mhz is what hwmon read while the leg ran" % int(alg_bytes)}),
     }
+    if split_main:
+        for nm, lg in (("value", main_leg), ("steady_state", steady_leg)):
+            b = lg["bwd_segment"]["ms_median"]
+            result.setdefault("backward", {})[nm] = {"bwd_ms_median": b, "fwd_ms_median": lg["fwd_segment"]["ms_median"],
+                                                     "bwd_tflops": 2.5 * f_fwd / (b * 1e-3) / 1e12,
+                                                     "bwd_frac": 2.5 * f_fwd / (b * 1e-3) / 1e12 / PEAK_TFLOPS[dtype]}
 
     if dist is not None and (n_gpus > 1 or os.environ.get("AULE_BENCH_FORCE_GATHER")):
         # the one exchange of the sharded path: every rank receives every rank's O over xGMI (RCCL), timed separately
@@ -436,18 +722,12 @@ def main():
         # whatever happens in here, the line with `value` (measured above) gets printed.  A watchdog prints it and ends the
         # process if the section does not come back (a hung collective would otherwise take the whole scaling record with it);
         # an exception is recorded in the line.
-        import threading
-        section_done = threading.Event()
-        limit_s = float(os.environ.get("AULE_BENCH_GATHER_TIMEOUT", "240"))
+        def add_legs():
+            result["legs"] = legs
 
-        def watchdog():
-            if not section_done.wait(timeout=limit_s):
-                result["gather"]["error"] = "the output-exchange section did not finish in %.0f s; line printed by the watchdog" % limit_s
-                if rank == 0:
-                    print(json.dumps(result), flush=True)
-                os._exit(0)
-
-        threading.Thread(target=watchdog, daemon=True).start()
+        section_done = gather_watchdog(result, rank, float(os.environ.get("AULE_BENCH_GATHER_TIMEOUT", "240")), add_legs)
+        if os.environ.get("AULE_BENCH_TEST_HANG"):       # test hook (tests/test_gpu_dist.py): the section never comes back
+            time.sleep(3600)
         try:
             for name, fn in variants.items():
                 try:
@@ -456,9 +736,11 @@ def main():
                 except aule.AuleError as e:     # (raised on every rank alike: aule.dist.PeerExchange)
                     result["gather"][name] = {"error": str(e)[:300]}
                     continue
-                gwall, _ = timed(fn, gsteps)
+                graw = timed(fn, gsteps)
+                gwall = graw["wall_s"]
                 result["gather"][name] = {"ms_per_step": gwall * 1e3 / gsteps, "value": f_step * n_gpus * gsteps / gwall / 1e12,
-                                          "exposed_ms": gwall * 1e3 / gsteps - ms_per_step}
+                                          "exposed_ms": gwall * 1e3 / gsteps - ms_per_step,
+                                          "ms_per_step_median_rank0": step_stats(graw["per_step"])["ms_median"]}
             adist.release_peer_buffers()
         except Exception as e:   # noqa: BLE001 -- keep the contract's line
             result["gather"]["error"] = (type(e).__name__ + ": " + str(e))[:400]
@@ -466,8 +748,41 @@ def main():
         del gathered
 
     if rank == 0 and n_gpus == 1 and not args.no_extra and args.config == "c2":
+        PK = PEAK_TFLOPS["bf16"]
+        extra = result["extra"] = {}
+        # which limiter holds the clock while the headline kernel runs back to back (documented amdsmi accumulators; one second of launches)
+        lim = Limiter(tel.bdf)
+        result["limiter"] = {"c2_fwd": lim.during(torch, step, tel),
+                             "note": "residency = share of the window in which the firmware reports the limiter active (PPT = package power tracking: the "
+                                     "socket power cap); window = the workload back to back for window_s, nothing else; power_w / sclk_mhz = hwmon over the same window"}
+
+        def fwd_bwd_block(prefix, f1, step_fb, step_f, steps, workload, peak=PK):
+            """A fwd+bwd leg with the event between forward and backward, conditioned on itself, and a fwd-only leg RIGHT behind
+            it (no new conditioning: the chip is in the state the fwd+bwd steps left it in).  Every backward figure is a median
+            over the timed steps' backward segments; `_by_difference` = median fwd+bwd step - median fwd-only step."""
+            fb = leg(prefix + "_fwd_bwd", step_fb, steps, args.condition_ms, 0, True, 3.5 * f1, peak)
+            fo = leg(prefix + "_fwd_only", step_f, steps, 0.0, 0, False, f1, peak)
+            b = fb["bwd_segment"]["ms_median"]
+            bd = fb["ms_median"] - fo["ms_median"]
+            extra.update({
+                prefix + "_fwd_bwd_tflops": fb["tflops_mean"], prefix + "_fwd_bwd_frac_of_peak": fb["frac_mean"],
+                prefix + "_fwd_bwd_tflops_median": fb["tflops_median"],
+                prefix + "_ms_per_step": fb["ms_mean_events"], prefix + "_ms_per_step_median": fb["ms_median"],
+                prefix + "_ms_per_step_min": fb["ms_min"], prefix + "_ms_per_step_max": fb["ms_max"],
+                prefix + "_fwd_ms": fo["ms_median"], prefix + "_fwd_tflops": f1 / (fo["ms_median"] * 1e-3) / 1e12,
+                prefix + "_fwd_ms_in_step": fb["fwd_segment"]["ms_median"],
+                prefix + "_bwd_ms": b, prefix + "_bwd_tflops": 2.5 * f1 / (b * 1e-3) / 1e12,
+                prefix + "_bwd_frac": 2.5 * f1 / (b * 1e-3) / 1e12 / peak,
+                prefix + "_bwd_ms_min": fb["bwd_segment"]["ms_min"], prefix + "_bwd_ms_max": fb["bwd_segment"]["ms_max"],
+                prefix + "_bwd_ms_by_difference": bd,
+                prefix + "_bwd_frac_by_difference": (2.5 * f1 / (bd * 1e-3) / 1e12 / peak) if bd > 0 else None,
+                prefix + "_power_w": fb.get("power_w"), prefix + "_sclk_mhz": fb.get("sclk_mhz"), prefix + "_sclk_mhz_min": fb.get("sclk_mhz_min"),
+                prefix + "_workload": workload + "; *_bwd_ms / *_bwd_frac = MEDIAN over the timed steps of the segment between the event behind the "
+                                                 "forward call and the event behind backward(); *_by_difference = median step - median step of the fwd-only leg run right behind it"})
+            return fb, fo
+
         # the other half of the metric: fwd+bwd on config #3 (GQA 32q/8kv S=2048, B=4 as SURVEY 8d assumes), and config #5
-        # (MQA 32q/1kv S=16384 D=64 fp16 non-causal forward), outside the timed region, the chip already conditioned
+        # (MQA 32q/1kv S=16384 D=64 fp16 non-causal forward), outside the timed region of `value`
         B3, H3, K3, S3, _, D3, _, _, _ = CONFIGS["c3"]
         g3 = torch.Generator(device=dev).manual_seed(99)
         q3 = torch.randn(B3, H3, S3, D3, device=dev, dtype=torch.bfloat16, generator=g3).requires_grad_(True)
@@ -475,50 +790,34 @@ def main():
         v3 = torch.randn(B3, K3, S3, D3, device=dev, dtype=torch.bfloat16, generator=g3).requires_grad_(True)
         d3 = torch.randn(B3, H3, S3, D3, device=dev, dtype=torch.bfloat16, generator=g3)
 
-        def step3():
+        def step3(mid=None):
             q3.grad = k3.grad = v3.grad = None
-            aule.flash_attention(q3, k3, v3, causal=True).backward(d3)
+            o = aule.flash_attention(q3, k3, v3, causal=True)
+            if mid is not None:
+                mid()
+            o.backward(d3)
 
         def step3f():
             aule.flash_attention(q3, k3, v3, causal=True)
 
-        condition(step3, args.condition_ms)   # its own steady state: right behind the C2 legs the chip is still power-limited by them
-        _, ms3 = timed(step3, 30)
-        l3 = sorted(last_launches)
-        _, ms3f = timed(step3f, 30)
-        f3f = fwd_flops(B3, H3, S3, S3, D3, True)
-        t3 = 3.5 * f3f / (ms3 / 30 * 1e-3) / 1e12
-        bwd_ms = (ms3 - ms3f) / 30
-        result["extra"] = {"c3_fwd_bwd_tflops": t3, "c3_fwd_bwd_frac_of_peak": t3 / PEAK_TFLOPS["bf16"],
-                           "c3_ms_per_step": ms3 / 30, "c3_ms_per_step_median": l3[len(l3) // 2],
-                           "c3_fwd_ms": ms3f / 30, "c3_fwd_tflops": f3f / (ms3f / 30 * 1e-3) / 1e12,
-                           "c3_bwd_ms": bwd_ms, "c3_bwd_tflops": 2.5 * f3f / (bwd_ms * 1e-3) / 1e12,
-                           "c3_bwd_frac": 2.5 * f3f / (bwd_ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
-                           "c3_workload": "GQA 32q/8kv B=4 S=2048 D=128 bf16 causal fwd+bwd (autograd); bwd = step - fwd-only step "
-                                          "(dQ / dK,dV kernel split: profiles/r3_fwdbwd_c3_*)"}
+        fwd_bwd_block("c3", fwd_flops(B3, H3, S3, S3, D3, True), step3, step3f, 30,
+                      "GQA 32q/8kv B=4 S=2048 D=128 bf16 causal fwd+bwd (autograd)")
         del q3, k3, v3, d3
         # the metric's own fwd+bwd shape: C2 (B4 H32 S4096 D128 bf16 causal) through autograd, on this run's q, k, v
         # (the reference harness sweeps these shapes fwd+bwd: tests/benchmark_mi300x.py:207-233)
         d2 = torch.randn(B, Hq, Sq, D, device=dev, dtype=tdt, generator=g3)
 
-        def step2():
+        def step2(mid=None):
             q.grad = k.grad = v.grad = None
-            aule.flash_attention(q, k, v, causal=causal).backward(d2)
+            o = aule.flash_attention(q, k, v, causal=causal)
+            if mid is not None:
+                mid()
+            o.backward(d2)
 
-        condition(step2, args.condition_ms)
-        _, ms2 = timed(step2, 20)
-        l2 = sorted(last_launches)
-        condition(step, args.condition_ms / 2)
-        _, ms2f = timed(step, 20)
-        t2 = 3.5 * f_fwd / (ms2 / 20 * 1e-3) / 1e12
-        bwd2_ms = (ms2 - ms2f) / 20
-        result["extra"].update({"c2_fwd_bwd_tflops": t2, "c2_fwd_bwd_frac_of_peak": t2 / PEAK_TFLOPS[dtype],
-                                "c2_fwd_bwd_ms_per_step": ms2 / 20, "c2_fwd_bwd_ms_per_step_median": l2[len(l2) // 2],
-                                "c2_fwd_ms": ms2f / 20, "c2_bwd_ms": bwd2_ms,
-                                "c2_bwd_tflops": 2.5 * f_fwd / (bwd2_ms * 1e-3) / 1e12,
-                                "c2_bwd_frac": 2.5 * f_fwd / (bwd2_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype],
-                                "c2_fwd_bwd_workload": "MHA B=4 H=32 S=4096 D=128 bf16 causal fwd+bwd (autograd): the metric's own shape; bwd = "
-                                                       "step - fwd-only step (per-kernel split: profiles/r4_fwdbwd_c2_*)"})
+        fwd_bwd_block("c2", f_fwd, step2, step, 20, "MHA B=4 H=32 S=4096 D=128 bf16 causal fwd+bwd (autograd): the metric's own shape", PEAK_TFLOPS[dtype])
+        # (key names of rounds 4-5)
+        extra["c2_fwd_bwd_ms_per_step"], extra["c2_fwd_bwd_ms_per_step_median"] = extra["c2_ms_per_step"], extra["c2_ms_per_step_median"]
+        result["limiter"]["c2_fwd_bwd"] = lim.during(torch, step2, tel)
         q.grad = k.grad = v.grad = None
         del d2
         B5, H5, K5, S5, _, D5, _, _, _ = CONFIGS["c5"]
@@ -529,11 +828,10 @@ def main():
         def step5():
             aule.flash_attention(q5, k5, v5, causal=False)
 
-        condition(step5, args.condition_ms)
-        _, ms5 = timed(step5, 20)
-        t5 = fwd_flops(B5, H5, S5, S5, D5, False) / (ms5 / 20 * 1e-3) / 1e12
-        result["extra"].update({"c5_fwd_tflops": t5, "c5_fwd_frac_of_peak": t5 / PEAK_TFLOPS["fp16"], "c5_ms_per_step": ms5 / 20,
-                                "c5_workload": "MQA 32q/1kv B=1 S=16384 D=64 fp16 non-causal fwd (LSE stored)"})
+        l5 = leg("c5_fwd", step5, 20, args.condition_ms, 0, False, fwd_flops(B5, H5, S5, S5, D5, False), PEAK_TFLOPS["fp16"])
+        extra.update({"c5_fwd_tflops": l5["tflops_mean"], "c5_fwd_frac_of_peak": l5["frac_mean"], "c5_ms_per_step": l5["ms_mean_events"],
+                      "c5_ms_per_step_median": l5["ms_median"], "c5_power_w": l5.get("power_w"), "c5_sclk_mhz": l5.get("sclk_mhz"),
+                      "c5_workload": "MQA 32q/1kv B=1 S=16384 D=64 fp16 non-causal fwd (LSE stored)"})
 
         del q5, k5, v5
         # single-sequence prefill, the small-grid corner (128 paired items on 256 CUs: route 7, pairs of Q blocks cut into
@@ -544,11 +842,10 @@ def main():
             with torch.no_grad():
                 aule.flash_attention(q6, k6, v6, causal=True)
 
-        condition(step6, args.condition_ms)
-        _, ms6 = timed(step6, 20)
-        result["extra"].update({"b1h8_s8192_fwd_tflops": fwd_flops(1, 8, 8192, 8192, 128, True) / (ms6 / 20 * 1e-3) / 1e12,
-                                "b1h8_s8192_ms_per_step": ms6 / 20,
-                                "b1h8_s8192_workload": "MHA 8 heads B=1 S=8192 D=128 bf16 causal fwd (small grid, route 7: the one-wave-per-SIMD kernel over 256 key-range pieces + merge kernel)"})
+        l6 = leg("b1h8_s8192_fwd", step6, 20, args.condition_ms, 0, False, fwd_flops(1, 8, 8192, 8192, 128, True), PK)
+        extra.update({"b1h8_s8192_fwd_tflops": l6["tflops_mean"], "b1h8_s8192_ms_per_step": l6["ms_mean_events"],
+                      "b1h8_s8192_ms_per_step_median": l6["ms_median"], "b1h8_s8192_sclk_mhz": l6.get("sclk_mhz"),
+                      "b1h8_s8192_workload": "MHA 8 heads B=1 S=8192 D=128 bf16 causal fwd (small grid, route 7: the one-wave-per-SIMD kernel over 256 key-range pieces + merge kernel)"})
         del q6, k6, v6
         B7, H7, S7, D7 = 4, 32, 2048, 128
         q7, k7, v7 = (torch.randn(B7, H7, S7, D7, device=dev, dtype=torch.bfloat16, generator=g3) for _ in range(3))
@@ -558,12 +855,11 @@ def main():
             with torch.no_grad():
                 aule.flash_attention_rope(q7, k7, v7, cos7, sin7, causal=True)
 
-        condition(step7, args.condition_ms)
-        _, ms7 = timed(step7, 20)
-        result["extra"].update({"rope_attn_c2_tflops": fwd_flops(B7, H7, S7, S7, D7, True) / (ms7 / 20 * 1e-3) / 1e12,
-                                "rope_attn_c2_ms_per_step": ms7 / 20,
-                                "rope_attn_c2_workload": "RoPE + attention, B=4 H=32 S=2048 D=128 bf16 causal, inference: rope(K) pass + the "
-                                                         "one-wave-per-SIMD forward with Q rotated inside it (attention FLOPs only)"})
+        l7 = leg("rope_attn", step7, 20, args.condition_ms, 0, False, fwd_flops(B7, H7, S7, S7, D7, True), PK)
+        extra.update({"rope_attn_c2_tflops": l7["tflops_mean"], "rope_attn_c2_ms_per_step": l7["ms_mean_events"],
+                      "rope_attn_c2_ms_per_step_median": l7["ms_median"],
+                      "rope_attn_c2_workload": "RoPE + attention, B=4 H=32 S=2048 D=128 bf16 causal, inference: rope(K) pass + the "
+                                               "one-wave-per-SIMD forward with Q rotated inside it (attention FLOPs only)"})
         del q7, k7, v7
         # D = 64 training (the one-wave-per-SIMD backward pair's D = 64 instances, round 4) and the fp32 kernels (what the legacy
         # C-ABI and NumPy / fp32 torch input run; priced against the 157.3 TF f32-MFMA roof, not the bf16 peak)
@@ -572,21 +868,18 @@ def main():
         v8 = torch.randn(8, 32, 2048, 64, device=dev, dtype=torch.bfloat16, generator=g3).requires_grad_(True)
         d8 = torch.randn(8, 32, 2048, 64, device=dev, dtype=torch.bfloat16, generator=g3)
 
-        def step8():
+        def step8(mid=None):
             q8.grad = k8.grad = v8.grad = None
-            aule.flash_attention(q8, k8, v8, causal=True).backward(d8)
+            o = aule.flash_attention(q8, k8, v8, causal=True)
+            if mid is not None:
+                mid()
+            o.backward(d8)
 
         def step8f():
             aule.flash_attention(q8, k8, v8, causal=True)
 
-        condition(step8, args.condition_ms)
-        _, ms8 = timed(step8, 20)
-        _, ms8f = timed(step8f, 20)
-        f8 = fwd_flops(8, 32, 2048, 2048, 64, True)
-        b8 = (ms8 - ms8f) / 20
-        result["extra"].update({"d64_fwd_bwd_tflops": 3.5 * f8 / (ms8 / 20 * 1e-3) / 1e12, "d64_bwd_ms": b8,
-                                "d64_bwd_tflops": 2.5 * f8 / (b8 * 1e-3) / 1e12, "d64_bwd_frac": 2.5 * f8 / (b8 * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"],
-                                "d64_workload": "MHA B=8 H=32 S=2048 D=64 bf16 causal fwd+bwd (autograd); bwd = step - fwd-only step"})
+        fwd_bwd_block("d64", fwd_flops(8, 32, 2048, 2048, 64, True), step8, step8f, 20,
+                      "MHA B=8 H=32 S=2048 D=64 bf16 causal fwd+bwd (autograd)")
         del q8, k8, v8, d8
         F32_ROOF = 157.3
         q9 = torch.randn(4, 32, 2048, 64, device=dev, dtype=torch.float32, generator=g3).requires_grad_(True)
@@ -594,28 +887,26 @@ def main():
         v9 = torch.randn(4, 32, 2048, 64, device=dev, dtype=torch.float32, generator=g3).requires_grad_(True)
         d9 = torch.randn(4, 32, 2048, 64, device=dev, dtype=torch.float32, generator=g3)
 
-        def step9():
+        def step9(mid=None):
             q9.grad = k9.grad = v9.grad = None
-            aule.flash_attention(q9, k9, v9, causal=True).backward(d9)
+            o = aule.flash_attention(q9, k9, v9, causal=True)
+            if mid is not None:
+                mid()
+            o.backward(d9)
 
         def step9f():
             aule.flash_attention(q9, k9, v9, causal=True)
 
-        condition(step9, args.condition_ms)
-        _, ms9 = timed(step9, 10)
-        _, ms9f = timed(step9f, 10)
-        f9 = fwd_flops(4, 32, 2048, 2048, 64, True)
-        b9 = (ms9 - ms9f) / 10
-        result["extra"].update({"f32_fwd_tflops": f9 / (ms9f / 10 * 1e-3) / 1e12, "f32_fwd_frac_of_f32_roof": f9 / (ms9f / 10 * 1e-3) / 1e12 / F32_ROOF,
-                                "f32_bwd_tflops": 2.5 * f9 / (b9 * 1e-3) / 1e12, "f32_bwd_frac_of_f32_roof": 2.5 * f9 / (b9 * 1e-3) / 1e12 / F32_ROOF,
-                                "f32_roof_tflops": F32_ROOF,
-                                "f32_workload": "MHA B=4 H=32 S=2048 D=64 fp32 causal (v_mfma_f32_32x32x2_f32 kernels: the legacy C-ABI's dtype), "
-                                                "fwd-only step and fwd+bwd step (autograd); bwd = difference"})
+        fwd_bwd_block("f32", fwd_flops(4, 32, 2048, 2048, 64, True), step9, step9f, 10,
+                      "MHA B=4 H=32 S=2048 D=64 fp32 causal (v_mfma_f32_32x32x2_f32 kernels: the legacy C-ABI's dtype), priced against the f32 roof", F32_ROOF)
+        extra.update({"f32_fwd_frac_of_f32_roof": extra["f32_fwd_tflops"] / F32_ROOF, "f32_bwd_frac_of_f32_roof": extra["f32_bwd_frac"],
+                      "f32_roof_tflops": F32_ROOF})
         del q9, k9, v9, d9
         # The reference's OWN harness (python/aule/triton_flash_amd.py:775-813: fp16 causal forward, B 1 / 8, H 32, S 2048 / 8192, D 128, warm-up 10,
         # timed 50; tests/benchmark_mi300x.py:207-233 adds B 1 H 32 S 4096) and its comparator: the only number the reference publishes for
         # this path is relative to torch SDPA (python/README.md:20-23, "+6.1 .. +9.6 %").  Same process, same tensors, same protocol for both;
         # SDPA is a COMPARATOR here and nowhere else (never the product path).  FLOPs: the causal-discounted convention of `value`.
+        # Medians (the reference's harness reports medians: tests/benchmark_mi300x.py).
         import torch.nn.functional as F
         harness = []
         for (Bh, Hh, Sh) in ((1, 32, 2048), (8, 32, 2048), (1, 32, 8192), (1, 32, 4096)):
@@ -631,27 +922,24 @@ def main():
 
             fl = fwd_flops(Bh, Hh, Sh, Sh, 128, True)
             row = {"shape": "B%d H%d S%d D128 fp16 causal fwd" % (Bh, Hh, Sh)}
-            condition(step_a, args.condition_ms / 2)
-            for _ in range(10):
-                step_a()
-            _, msa = timed(step_a, 50)
-            row.update({"aule_ms": msa / 50, "aule_tflops": fl / (msa / 50 * 1e-3) / 1e12, "aule_tokens_per_s": Bh * Sh / (msa / 50 * 1e-3),
-                        "aule_tflops_ref_convention": 4.0 * Bh * Hh * Sh * Sh * 128 / (msa / 50 * 1e-3) / 1e12})
+            la = leg("harness_b%d_s%d_aule" % (Bh, Sh), step_a, 50, args.condition_ms / 2, 10, False, fl, PEAK_TFLOPS["fp16"])
+            msa = la["ms_median"]
+            row.update({"aule_ms": msa, "aule_ms_mean": la["ms_mean_events"], "aule_tflops": fl / (msa * 1e-3) / 1e12, "aule_tokens_per_s": Bh * Sh / (msa * 1e-3),
+                        "aule_tflops_ref_convention": 4.0 * Bh * Hh * Sh * Sh * 128 / (msa * 1e-3) / 1e12,
+                        "aule_power_w": la.get("power_w"), "aule_sclk_mhz": la.get("sclk_mhz")})
             try:
-                condition(step_s, args.condition_ms / 2)
-                for _ in range(10):
-                    step_s()
-                _, mss = timed(step_s, 50)
+                ls = leg("harness_b%d_s%d_sdpa" % (Bh, Sh), step_s, 50, args.condition_ms / 2, 10, False, fl, PEAK_TFLOPS["fp16"])
+                mss = ls["ms_median"]
                 err = (step_a().float() - step_s().float()).abs().max().item()
-                row.update({"sdpa_ms": mss / 50, "sdpa_tflops": fl / (mss / 50 * 1e-3) / 1e12, "speedup_vs_sdpa": mss / msa,
+                row.update({"sdpa_ms": mss, "sdpa_tflops": fl / (mss * 1e-3) / 1e12, "speedup_vs_sdpa": mss / msa,
                             "max_abs_diff_vs_sdpa": err})
             except Exception as e:   # noqa: BLE001 -- the comparator must not take the line with it
                 row["sdpa_error"] = (type(e).__name__ + ": " + str(e))[:200]
             harness.append(row)
             del qh, kh, vh
-        result["extra"]["ref_harness"] = {
+        extra["ref_harness"] = {
             "rows": harness,
-            "protocol": "fp16 causal forward, no LSE (inference call), 10 warm-ups + 50 timed launches between HIP events after conditioning; "
+            "protocol": "fp16 causal forward, no LSE (inference call), 10 warm-ups + 50 timed launches with an event pair each after conditioning, MEDIAN launch; "
                         "torch.nn.functional.scaled_dot_product_attention(is_causal=True) on the same tensors in the same process as the comparator "
                         "(torch %s; backend chosen by torch)" % torch.__version__,
             "reference_claim": "python/README.md:20-23: the reference's Triton kernel vs PyTorch SDPA on MI300X, +6.1 .. +9.6 %"}
@@ -666,17 +954,21 @@ def main():
             with torch.no_grad():
                 aule.flash_attention(qz, kz, vz, causal=causal)
 
-        condition(stepz, args.condition_ms)
-        _, msz = timed(stepz, 20)
-        tz = fwd_flops(B, Hq, Sq, Sk, D, causal) / (msz / 20 * 1e-3) / 1e12
-        result["extra"].update({"c2_zero_inputs_fwd_tflops": tz, "c2_zero_inputs_frac_of_peak": tz / PEAK_TFLOPS[dtype],
-                                "c2_zero_inputs_ms_per_step": msz / 20,
-                                "c2_zero_inputs_note": "the C2 forward on all-zero q, k, v (LSE not stored): the kernel's schedule without the "
-                                                       "data-dependent power of N(0,1) inputs -- NOT a throughput claim"})
+        lz = leg("c2_zero_inputs_fwd", stepz, 20, args.condition_ms, 0, False, fwd_flops(B, Hq, Sq, Sk, D, causal), PEAK_TFLOPS[dtype])
+        tz = lz["tflops_mean"]
+        extra.update({"c2_zero_inputs_fwd_tflops": tz, "c2_zero_inputs_frac_of_peak": tz / PEAK_TFLOPS[dtype],
+                      "c2_zero_inputs_ms_per_step": lz["ms_mean_events"], "c2_zero_inputs_power_w": lz.get("power_w"),
+                      "c2_zero_inputs_sclk_mhz": lz.get("sclk_mhz"),
+                      "c2_zero_inputs_note": "the C2 forward on all-zero q, k, v (LSE not stored): the kernel's schedule without the "
+                                             "data-dependent power of N(0,1) inputs -- NOT a throughput claim"})
+        result["limiter"]["c2_fwd_zero_inputs"] = lim.during(torch, stepz, tel)
         if isinstance(result.get("roofline"), dict):
             # beside frac / frac_steady: what the same kernel reaches of the peak when the power cap is out of the way
             result["roofline"]["frac_zero_inputs"] = tz / PEAK_TFLOPS[dtype]
         del qz, kz, vz
+
+    if rank == 0:
+        result["legs"] = legs
 
     if rank == 0:
         # the reference harness counts 4*B*H*S^2*D with NO causal discount (tests/benchmark_attention.zig:68-75):

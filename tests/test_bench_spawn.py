@@ -59,3 +59,26 @@ def test_without_devices_the_message_names_the_device_count():
     assert r.returncode != 0
     assert "needs 2 devices" in r.stderr + r.stdout
     assert "torch.distributed.run" not in r.stderr + r.stdout
+
+
+def test_plain_launch_with_eight_ranks_names_c4_and_its_shards():
+    """The driver's scaling run at its widest: 8 ranks rendezvous on 127.0.0.1, time, reduce MAX over ranks, and
+    rank 0 prints one line for BASELINE configs[3] -- B = 64 over 8 GPUs, 8 per GPU, 512 MiB of output per rank, 4 GiB gathered."""
+    r = _run("--gpus", "8", "--dry-run", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    rec = lines[0]
+    assert rec["n_gpus"] == 8 and rec["world_size"] == 8 and rec["dry_run"] is True and rec["steps"] == 3
+    assert rec["config"]["workload"].startswith("c4: B=8/GPU Hq=32 Hkv=32 Sq=8192 Sk=8192 D=128 bf16 causal fwd"), rec["config"]
+    assert rec["gather_plan"] == {"bytes_per_rank": [512 << 20] * 8, "total_bytes": 4 << 30, "shard": "batch"}
+
+
+def test_a_hung_exchange_section_still_prints_the_line():
+    """The output-exchange variants have never met N > 1 GPUs: if one of them hangs (here: a barrier rank 1 never joins), the watchdog
+    prints the contract's line with the reason and the process ends with status 0 -- the scaling record survives."""
+    r = _run("--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0", env={"AULE_BENCH_TEST_HANG": "1", "AULE_BENCH_GATHER_TIMEOUT": "3"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    assert lines[0]["world_size"] == 2 and "error" in lines[0]["gather"], lines[0]

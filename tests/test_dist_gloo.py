@@ -140,7 +140,7 @@ def _worker_local(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_local_shards_gathered(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -183,3 +183,34 @@ def test_peer_copy_plans_tile_the_gathered_tensor(B, Hq, Hkv, world, chunks):
         assert a == pos, (covered, pos)
         pos = b
     assert pos == B * Hq * row_bytes
+
+
+def test_config4_sharding_arithmetic_at_world_8():
+    """BASELINE configs[3] as the driver's 8-GPU run shards it -- sizes only, no tensors: B = 64 over 8
+    ranks is 8 batch elements = 512 MiB of output per rank; bench.py exchanges it in 4 pieces of 2 elements = 128 MiB each; every rank's
+    copy plan (transport "peer") writes its 4 pieces at rank * 512 MiB + piece * 128 MiB of every peer's 4 GiB buffer; the 32 pieces
+    tile the gathered tensor exactly; weak-scaling worlds 2 and 4 keep 8 per rank."""
+    sys.path.insert(0, os.path.join(ROOT, "aule-attention_amd"))
+    from aule import dist as adist
+    B, Hq, Hkv, S, D, elt, world = 64, 32, 32, 8192, 128, 2, 8
+    mode, bounds = adist.shard_plan(B, Hkv, world)
+    assert mode == "batch" and bounds == [(8 * r, 8 * r + 8) for r in range(world)]
+    sizes, total = adist.gather_bytes(B, Hq, Hkv, S, D, elt, world)
+    assert sizes == [512 << 20] * world and total == 4 << 30
+    assert adist.chunk_ranges(8, 4) == [(0, 2), (2, 4), (4, 6), (6, 8)]
+    row_bytes = S * D * elt                                  # one (batch, head) row block of the output: 2 MiB
+    lay_mode, n_lead, row0, per_lead, step = adist.shard_layout(B, Hq, Hkv, world)
+    assert lay_mode == "batch" and n_lead == [8] * world and per_lead == Hq and step == 1
+    pieces = []
+    for r in range(world):
+        assert row0[r] * row_bytes == r * (512 << 20)
+        plan = adist.peer_copy_plan(n_lead, row0, per_lead, step, r, 4, row_bytes)
+        assert [(a, b) for a, b, _, _ in plan] == [(0, 2), (2, 4), (4, 6), (6, 8)]
+        for i, (_, _, off, nb) in enumerate(plan):
+            assert nb == 128 << 20 and off == r * (512 << 20) + i * (128 << 20)
+            pieces.append((off, nb))
+    pieces.sort()
+    assert [o for o, _ in pieces] == [i * (128 << 20) for i in range(32)] and sum(n for _, n in pieces) == 4 << 30
+    for w in (2, 4):                                         # the scaling run's other points: 8 per rank again
+        assert adist.shard_plan(8 * w, Hkv, w)[1] == [(8 * r, 8 * r + 8) for r in range(w)]
+        assert adist.gather_bytes(8 * w, Hq, Hkv, S, D, elt, w) == ([512 << 20] * w, w * (512 << 20))

@@ -151,6 +151,44 @@ def test_config3_gqa_torch_autograd_parity(torch_cuda):
     assert max(achieved["dq"], achieved["dk"], achieved["dv"]) < 5e-3   # (round 4 asserted 1e-2; achieved 2.3 .. 3.4e-3)
 
 
+FULL_SIZE = [
+    # name, B, Hq, Hkv, S, D, the (batch, kv-head) units whose gradients are judged
+    ("c2", 4, 32, 32, 4096, 128, ((0, 0), (2, 13), (3, 31))),          # BASELINE configs[1] fwd+bwd: bench.py's extra.c2_fwd_bwd_*, the metric's own shape
+    ("c4shard", 8, 32, 32, 8192, 128, ((0, 7), (7, 31))),              # configs[3]'s per-GPU shard (B = 64 over 8 GPUs): 64 blocks per stream
+    ("c3", 4, 32, 8, 2048, 128, ((1, 0), (3, 7))),                     # configs[2] again, head by head in fp64 (the test above: torch fp32 autograd)
+    ("d64", 8, 32, 32, 2048, 64, ((0, 3), (7, 30))),                   # bench.py's D = 64 training shape
+]
+
+
+@pytest.mark.parametrize("case", FULL_SIZE, ids=lambda c: c[0])
+def test_gradients_at_the_sizes_the_bench_times(torch_cuda, oracle_mod, case):
+    """Gradient parity at full size (replaces python/aule/triton_flash_amd.py:447-500 at the shapes bench.py times):
+    dQ, dK, dV of whole (batch, kv-head) units against the per-head fp64 judge oracle.bwd_head_f64 -- the softmax recomputed in fp64
+    from Q and K, no saved LSE -- with the suite's bf16 bound, raw errors printed.  The mode test below runs this file under
+    AULE_HIP_BWD_MODE=spill and under both kernel generations too."""
+    import aule
+    torch = torch_cuda
+    name, B, Hq, Hkv, S, D, units = case
+    g = Hq // Hkv
+    gen = torch.Generator(device="cuda").manual_seed(zlib.crc32(name.encode()) & 0xFFFF)
+    q, do = (torch.randn(B, Hq, S, D, device="cuda", dtype=torch.bfloat16, generator=gen) for _ in range(2))
+    k, v = (torch.randn(B, Hkv, S, D, device="cuda", dtype=torch.bfloat16, generator=gen) for _ in range(2))
+    q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+    aule.flash_attention(q, k, v, causal=True).backward(do)
+    torch.cuda.synchronize()
+    for (b, hk) in units:
+        hs = slice(hk * g, (hk + 1) * g)
+        f = lambda t: t.detach().float().cpu().numpy()
+        rq, rk, rv = oracle_mod.bwd_head_f64(f(q[b, hs]), f(k[b, hk]), f(v[b, hk]), f(do[b, hs]), None, True)
+        grad_close(f(q.grad[b, hs]), rq, "bf16", "%s dq[%d,%d]" % (name, b, hk))
+        grad_close(f(k.grad[b, hk]), rk, "bf16", "%s dk[%d,%d]" % (name, b, hk))
+        grad_close(f(v.grad[b, hk]), rv, "bf16", "%s dv[%d,%d]" % (name, b, hk))
+    # every unit that was not judged in fp64: finite, and not left at its allocation's content (the kernels write every row)
+    for t in (q.grad, k.grad, v.grad):
+        assert torch.isfinite(t.float()).all()
+        assert (t.float().abs().amax(dim=(-1, -2)) > 0).all()
+
+
 def test_auto_mode_takes_the_5_matmul_backward_for_cache_sized_problems(torch_cuda):
     """Default dispatch (round 5): a problem whose dS fits the Infinity Cache budget (AULE_HIP_BWD_DS_AUTO_MB, 160) and whose dK/dV grid runs the
     one-wave-per-SIMD kernel takes the 5-matmul backward by itself -- B1 H8 S2048 D128: 33 MB of dS; the workspace size shows the mode -- and

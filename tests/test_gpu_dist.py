@@ -65,8 +65,9 @@ print("OK")
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
 
 
-def test_peer_exchange_two_processes_on_one_gpu():
-    """transport="peer" end to end with TWO ranks (the box has one GPU: both use cuda:0; gloo carries the handles and the
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_exchange_two_processes_on_one_gpu(world):
+    """transport="peer" end to end with TWO (round 6: and FOUR -- ranks that hold a single element, or nothing) ranks (the box has one GPU: both use cuda:0; gloo carries the handles and the
     final meeting, the payload goes through aule_peer_alloc / _open / _copy_async): every rank ends with the same gathered
     tensor as the unsharded call, for equal and ragged shards, twice in a row (the cached buffers alternate).  The ranks
     are tests/peer_exchange_worker.py."""
@@ -74,8 +75,22 @@ def test_peer_exchange_two_processes_on_one_gpu():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ)
     env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_exchange_worker.py"), str(r), "2"], cwd=ROOT, env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_exchange_worker.py"), str(r), str(world)], cwd=ROOT, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0 and "RANK_OK" in so, (so[-1500:], se[-2500:])
+
+
+def test_bench_watchdog_prints_the_line_when_the_exchange_hangs():
+    """bench.py's real (device) path: the output-exchange section never comes back (test hook) -> the watchdog prints the contract's
+    line -- `value` measured before the section, the legs, the reason under gather.error -- and the process ends with status 0."""
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+              "--master-addr", "127.0.0.1", "--master-port", "29519", "bench.py", "--gpus", "1", "--steps", "3",
+              "--warmup", "1", "--batch", "1", "--condition-ms", "10", "--no-cpu-baseline", "--no-extra"],
+             {"AULE_BENCH_FORCE_GATHER": "1", "AULE_BENCH_TEST_HANG": "1", "AULE_BENCH_GATHER_TIMEOUT": "4"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["value"] > 0 and "did not finish" in rec["gather"]["error"] and "value" in rec["legs"]

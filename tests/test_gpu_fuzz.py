@@ -54,3 +54,15 @@ def test_random_rope_passes(fuzz):
         if errs:
             failures.append((i, cfg, errs))
     assert not failures, failures
+
+
+def test_random_long_sequence_configurations_forward_and_backward(fuzz):
+    """Round 6: Sq in {2048, 4096} (MHA / GQA, every causal mode, causal windows, D 64 / 128): the longest streams of the backward
+    kernels, gradients judged head by head in fp64 (oracle.bwd_head_f64), forward on sampled rows."""
+    rng = np.random.RandomState(606)
+    failures = []
+    for i in range(10):
+        (route, cfg), errs = fuzz.run_long(rng, i)
+        if errs:
+            failures.append((i, route, cfg, errs))
+    assert not failures, failures

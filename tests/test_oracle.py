@@ -168,6 +168,47 @@ def test_windowed_backward_judges_agree(oracle_mod):
         np.testing.assert_array_equal(x, y)
 
 
+def test_per_head_backward_judge_is_pinned_on_the_c_judge(oracle_mod):
+    """oracle.bwd_head_f64 (round 6: one KV head + its query group at full S, row-blocked BLAS fp64 -- what the C2 / C4-shard gradient
+    tests use) against the scalar C judge of the whole problem: GQA groups, ragged sizes that straddle its row blocks, every causal
+    mode, windows, a custom scale, and a block size that does not divide Sq."""
+    rng = np.random.RandomState(6)
+    for (B, Hq, Hkv, Sq, Sk, D, causal, scale, W, blk) in (
+            (2, 4, 2, 70, 90, 16, True, None, -1, 32), (1, 6, 3, 97, 97, 32, False, 0.37, -1, 40), (1, 4, 1, 50, 130, 16, 2, None, -1, 16),
+            (1, 2, 2, 130, 130, 16, True, None, 33, 64), (1, 4, 2, 64, 200, 8, 2, 0.2, 7, 24), (1, 2, 1, 150, 60, 16, True, None, 5, 512),
+            (1, 2, 2, 90, 90, 16, False, None, 20, 32)):
+        q, do = (rng.randn(B, Hq, Sq, D).astype(np.float32) for _ in range(2))
+        k, v = (rng.randn(B, Hkv, Sk, D).astype(np.float32) for _ in range(2))
+        rq, rk, rv = oracle_mod.bwd_f64(q, k, v, do, causal, scale, W)
+        g = Hq // Hkv
+        for b in range(B):
+            for hk in range(Hkv):
+                dq, dk, dv = oracle_mod.bwd_head_f64(q, k, v, do, (b, hk), causal, scale, W, block=blk)
+                np.testing.assert_allclose(dq, rq[b, hk * g:(hk + 1) * g], rtol=1e-5, atol=1e-6)
+                np.testing.assert_allclose(dk, rk[b, hk], rtol=1e-5, atol=1e-6)
+                np.testing.assert_allclose(dv, rv[b, hk], rtol=1e-5, atol=1e-6)
+    # the sliced calling form is the same function
+    a = oracle_mod.bwd_head_f64(q[0, 0:1], k[0, 0], v[0, 0], do[0, 0:1], None, False, None, 20)
+    for x, y in zip(a, oracle_mod.bwd_head_f64(q, k, v, do, (0, 0), False, None, 20)):
+        np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files("tr_") if "dq" in np.load(p).files][:4], ids=lambda p: p.split("/")[-1][:-4])
+def test_per_head_backward_judge_vs_reference_gradients(oracle_mod, path):
+    """... and on the gradients the reference's own kernels recorded (tests/golden/tr_*: Triton under TRITON_INTERPRET=1), head by head,
+    at the tolerance the whole-problem judge is held to against them."""
+    g = load_golden(path)
+    q, k, v, do = g["q"], g["k"], g["v"], g["dout"]
+    grp = q.shape[1] // k.shape[1]
+    tol = 2e-2 if g["dtype"] != "fp32" else 2e-5
+    for b in range(q.shape[0]):
+        for hk in range(k.shape[1]):
+            dq, dk, dv = oracle_mod.bwd_head_f64(q, k, v, do, (b, hk), g["causal"], g["scale"])
+            np.testing.assert_allclose(dq, g["dq"][b, hk * grp:(hk + 1) * grp], rtol=tol, atol=tol)
+            np.testing.assert_allclose(dk, g["dk"][b, hk], rtol=tol, atol=tol)
+            np.testing.assert_allclose(dv, g["dv"][b, hk], rtol=tol, atol=tol)
+
+
 def test_bottom_right_oracle_pinned_on_torch_lower_right_bias(oracle_mod):
     """The bottom-right alignment is not in the reference; the oracle's causal=2 mode is pinned on
     PyTorch's own definition of it (torch.nn.attention.bias.causal_lower_right) through fp64 SDPA with autograd,

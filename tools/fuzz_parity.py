@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential test of the whole forward/backward dispatch against the fp64 oracle: random dtype, batch,
 GQA ratio, Sq, Sk, head_dim, causal mode, window and scale sign -- the combinations nobody wrote a case for.
-Deterministic per seed; prints every failing configuration.   python tools/fuzz_parity.py [n=200] [seed=0]"""
+Deterministic per seed; prints every failing configuration.   python tools/fuzz_parity.py [n=200] [seed=0]
+Other kinds: `paged`, `rope`, `split` (small grids + fused rotation), `long` (round 6: Sq 2048 / 4096, gradients judged head by head)."""
 import ctypes, math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "aule-attention_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -191,6 +192,58 @@ def run_split(rng, i):
     return (r, cfg), errs
 
 
+def run_long(rng, i):
+    """Round 6: the sizes the backward's longest streams run -- Sq in {2048, 4096}, 16-bit, D 64 / 128, MHA and GQA,
+    every causal mode, causal windows -- forward (sampled rows) AND backward against the fp64 judges.  The whole-problem C judge
+    would take minutes per draw here; gradients are checked head by head (oracle.bwd_head_f64: one KV head + its query group at
+    full S) on two random (batch, kv-head) units, the forward on 48 sampled rows (oracle.fwd_rows_f64)."""
+    dtype = rng.choice(["bf16", "bf16", "fp16"])
+    D = int(rng.choice([64, 128, 128])); Hkv = int(rng.choice([1, 2, 4, 8])); g = int(rng.choice([1, 1, 2, 4])); Hq = Hkv * g
+    B = int(rng.choice([1, 2, 4]))
+    Sq = int(rng.choice([2048, 4096, 4096, 2048 + 77, 4096 - 131]))
+    causal = rng.choice(["none", "top", "top", "br"])
+    Sk = Sq if rng.rand() < 0.6 else int(rng.choice([2048, 4096, 5000, 8192]))
+    if causal == "br" and Sk < Sq: Sk = Sq + int(rng.choice([0, 100, 4000]))
+    W = int(rng.choice([-1, -1, -1, 256, 1024])) if causal != "none" else -1
+    scale = None if rng.rand() < 0.8 else float(rng.choice([0.05, 0.12]))
+    cz = {"none": False, "top": True, "br": "bottom-right"}[causal]
+    code = {"none": 0, "top": 1, "br": 2}[causal]
+    cfg = (dtype, B, Hq, Hkv, Sq, Sk, D, causal, W, scale)
+    sc = (1 / math.sqrt(D)) if scale is None else scale
+    gen = torch.Generator(device="cuda").manual_seed(11000 + i)
+    dt = torch_dtype(dtype)
+    tq, tdo = (torch.randn(B, Hq, Sq, D, device="cuda", dtype=dt, generator=gen) for _ in range(2))
+    tk, tv = (torch.randn(B, Hkv, Sk, D, device="cuda", dtype=dt, generator=gen) for _ in range(2))
+    out, lse = at.fwd_raw(tq, tk, tv, cz, sc, window=W)
+    dq, dk, dv = at.bwd_raw(tq, tk, tv, out, tdo, lse, cz, sc, window=W)
+    torch.cuda.synchronize()
+    errs = []
+    r2 = np.random.RandomState(12000 + i)
+    a, r = BWD_TOL[dtype]
+    keys_eff = min(Sk, Sq) if causal == "top" else Sk
+    if W > 0: keys_eff = min(keys_eff, W)
+    for _ in range(2):
+        b, hk = int(r2.randint(B)), int(r2.randint(Hkv))
+        f = lambda t, hh=slice(hk * g, (hk + 1) * g): t[b, hh].float().cpu().numpy()
+        rq, rk, rv = oracle.bwd_head_f64(f(tq), f(tk, hk), f(tv, hk), f(tdo), None, cz, scale, W)
+        for name, got, want in (("dq", f(dq), rq), ("dk", f(dk, hk), rk), ("dv", f(dv, hk), rv)):
+            if not np.isfinite(got).all(): errs.append(f"{name}[{b},{hk}] non-finite"); continue
+            # (the accumulation-length term of run(): a gradient element sums Sk keys (dQ) or g Sq rows (dK, dV) of 16-bit-rounded terms)
+            acc = max(1.0, math.sqrt(min(keys_eff if name == "dq" else g * Sq, 8192) / 512.0)) if dtype == "bf16" else 1.0
+            tol = a * acc * max(1.0, float(np.abs(want).max()))
+            e = np.abs(got - want)
+            if (e > tol + r * np.abs(want)).any(): errs.append(f"{name}[{b},{hk}] err {e.max():.3e} = {e.max()/max(1.0, float(np.abs(want).max())):.2e} of max|grad| (tol {tol:.1e})")
+    rows = r2.randint(0, B * Hq * Sq, size=48).astype(np.int64)
+    qf, kf, vf = (t.float().cpu().numpy() for t in (tq, tk, tv))
+    ro, rl = oracle.fwd_rows_f64(qf, kf, vf, rows, cz, scale, W)
+    o = out.float().cpu().numpy().reshape(-1, D)[rows]; gl = lse.cpu().numpy().reshape(-1)[rows]
+    atol, rtol = fwd_tol(dtype, float(np.abs(vf).max()))
+    fin = np.isfinite(rl)
+    if (np.abs(o - ro) > atol + rtol * np.abs(ro)).any(): errs.append(f"out err {np.abs(o-ro).max():.3e}")
+    if fin.any() and np.abs(gl[fin] - rl[fin]).max() > LSE_TOL[dtype] + 1e-5 * np.abs(rl[fin]).max(): errs.append(f"lse err {np.abs(gl[fin]-rl[fin]).max():.3e}")
+    return (route(dtype, B, Hq, Hkv, Sq, Sk, D, code, W), cfg), errs
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "one":
         # one configuration again: python tools/fuzz_parity.py one bf16 1 4 2 31 500 128 br -1 0.3 1001   (scale: a number or "none")
@@ -199,18 +252,19 @@ if __name__ == "__main__":
         r, errs = run(cfg, int(a[10]))
         print(f"route={r} cfg={cfg}: {'; '.join(errs) if errs else 'clean'}")
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "split":
+    if len(sys.argv) > 1 and sys.argv[1] in ("split", "long"):
+        kind = sys.argv[1]
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 40; seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
         rng = np.random.RandomState(seed); bad = 0; routes = {}
         for i in range(n):
             try:
-                (r, cfg), errs = run_split(rng, i)
+                (r, cfg), errs = (run_split if kind == "split" else run_long)(rng, i)
             except Exception as e:  # noqa: BLE001
                 (r, cfg), errs = (-9, ("?",)), [f"EXCEPTION {type(e).__name__}: {str(e)[:160]}"]
             routes[r] = routes.get(r, 0) + 1
             if errs:
-                bad += 1; print(f"FAIL split #{i} route={r} cfg={cfg}: {'; '.join(errs)}", flush=True)
-        print(f"split: {n} configurations, {bad} failing; forward routes exercised: {dict(sorted(routes.items()))}")
+                bad += 1; print(f"FAIL {kind} #{i} route={r} cfg={cfg}: {'; '.join(errs)}", flush=True)
+        print(f"{kind}: {n} configurations, {bad} failing; forward routes exercised: {dict(sorted(routes.items()))}")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] in ("paged", "rope"):
         mode = sys.argv[1]; n = int(sys.argv[2]) if len(sys.argv) > 2 else 200; seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
