@@ -201,6 +201,7 @@ SIGNATURES = [
     ("aule_peer_copy_async", _I32, [_I32, ctypes.c_void_p, ctypes.c_void_p, _U64, ctypes.c_void_p]),
     ("aule_hip_build_info", ctypes.c_char_p, []),
     ("aule_hip_debug_forward_route", _I32, [ctypes.POINTER(AttnDesc)]),
+    ("aule_hip_debug_last_backward_route", _I32, []),
     ("aule_hip_debug_forward_split_plan", _I32, [ctypes.POINTER(AttnDesc), ctypes.POINTER(_I32), _I32]),
     ("aule_hip_debug_work_order", _I32, [_I32] * 7 + [ctypes.POINTER(_I32)]),
 ]

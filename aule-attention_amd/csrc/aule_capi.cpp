@@ -1131,6 +1131,9 @@ int32_t aule_hip_debug_forward_route(const aule_attn_desc* d) {
     return aule_hip::fwd_route(a);
 }
 
+/* Debug hook: what the most recent backward launch of this process ran (bit mask, include/aule.h). */
+int32_t aule_hip_debug_last_backward_route(void) { return aule_hip::bwd_last_route(); }
+
 int32_t aule_hip_debug_forward_split_plan(const aule_attn_desc* d, int32_t* out, int32_t cap) {
     if (d == nullptr || d->struct_size != sizeof(aule_attn_desc)) return -3;
     if (d->causal < 0 || d->causal > AULE_CAUSAL_BOTTOM_RIGHT) return -3;

@@ -109,6 +109,27 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
 #else
     const unsigned lds0 = 0;
 #endif
+    // The stream keeps ~90 scalars live in the causal SPILL instances; the tensor pointers and the dS workspace's geometry are needed only where a
+    // part starts and ends, so those places read them through an opaque pointer to the kernel-argument segment (a fresh s_load each time) instead of
+    // holding 20 registers for the whole kernel -- the forward's idiom (fa_fwd_w4_gfx950.hip); with them resident the allocator spilled scalars
+    // into vector lanes inside the loop (tests/test_w4_audit.py forbids that).
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) Dkv4Params* KernargPtr;   // (constant address space: scalar loads)
+#else
+    typedef const Dkv4Params* KernargPtr;
+#endif
+    auto P = [&]() __attribute__((always_inline)) -> KernargPtr {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned long long a = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();   // (the parameter block is the kernel's only argument: offset 0)
+#else
+        const unsigned long long a = 0;
+#endif
+        unsigned lo = (unsigned)a, hi = (unsigned)(a >> 32);
+        asm volatile("" : "+s"(lo), "+s"(hi));   // (not hoistable; its results count as divergent, hence the readfirstlanes)
+        lo = (unsigned)dkv4_rfl((int)lo);
+        hi = (unsigned)dkv4_rfl((int)hi);
+        return (KernargPtr)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    };
     const int g = p.Hq / p.Hkv;
     const int Sq = p.Sq, Sk = p.Sk, coff = p.coff;
     const float c = p.c;
@@ -155,46 +176,68 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
     unsigned long long tl_a = 0, tl_b = 0, tl_n = 0, tl_w = 0;
     const int nparts = (CAUSAL && (nkb - 1 - w.blk) != w.blk) ? 2 : 1;
     for (int part = 0; part < nparts; ++part) {
-        const int kb = CAUSAL ? (part == 0 ? nkb - 1 - w.blk : w.blk) : w.blk;   // (the block with more query blocks first)
+        // Causal pair: the EARLY key block (the long stream: every query block from its diagonal to the end) first, walked DOWNWARDS from the
+        // last query block; then the late one (the short stream) upwards.  Every work item of a (batch, kv head) unit then starts at the
+        // same query block -- the last -- and, the pairs being balanced, enters its second part reading the block the others read too
+        // (block x / g - 4 of the sweep): the unit's items run in lock step through BOTH parts and an XCD's L2 serves all but one of them
+        // (round 6; see the cursor below for the measurements).
+        const int kb = CAUSAL ? (part == 0 ? w.blk : nkb - 1 - w.blk) : w.blk;
+        const int down = dkv4_rfl((CAUSAL && part == 0) ? 1 : 0);
         const int n0w = kb * kKvBlock4 + wave * 32;
         const int kvrow = n0w + l31;
         {
-            const __amdgpu_buffer_rsrc_t krs = make_srd(reinterpret_cast<const char*>(p.k) + kvbase * RB, (unsigned)Sk * RB);
-            const __amdgpu_buffer_rsrc_t vrs = make_srd(reinterpret_cast<const char*>(p.v) + kvbase * RB, (unsigned)Sk * RB);
+            const __amdgpu_buffer_rsrc_t krs = make_srd(reinterpret_cast<const char*>(P()->k) + kvbase * RB, (unsigned)Sk * RB);
+            const __amdgpu_buffer_rsrc_t vrs = make_srd(reinterpret_cast<const char*>(P()->v) + kvbase * RB, (unsigned)Sk * RB);
             A::load_kv(krs, vrs, (unsigned)(kvrow * RB + hi * 16));
         }
         A::zero_acc();
 
-        const int W = p.window;
+        const int W = SPILL ? 0 : P()->window;   // (the 5-matmul mode never carries a window: the dispatcher keeps windowed problems on the recompute pair)
         int nq32 = (Sq + kQB - 1) / kQB;
         // (window: the last query that sees the block's last key kb 128 + 127 sits at position key + W - 1: the stream of a KV block ends there)
         if (W > 0) nq32 = min(nq32, max(0, kb * kKvBlock4 + kKvBlock4 - 1 + W - 1 - coff) / kQB + 1);
         const int first_qt = CAUSAL ? max(0, kb * kKvBlock4 - coff) / kQB : 0;
         const int ntq = nq32 > first_qt ? nq32 - first_qt : 0;
-        const int nit = ntq * g;   // flattened (query head of the group, query block) stream
+        const int nit = ntq * g;   // flattened (query block, query head of the group) stream
 
-        // block x of the stream: head x / ntq of the group, query block first_qt + x % ntq -- kept as cursors that advance with
+        // block x of the stream: query block first_qt + x / g of head x % g of the group (round 6; see the cursor) -- kept as cursors that advance with
         // the stream: (blocks left in the head, global row of the block inside the group's rows).  ONE descriptor per tensor
         // for the whole group, the head and the block go into the request's scalar offset: per-head descriptors cost ~90 scalar
         // instructions per iteration between the MFMA statements.  (A ragged last block of a head then reads the first rows
         // of the NEXT head of the group instead of zeros; its weights are masked to exactly 0, and those rows belong to the
         // same dK / dV sum anyway.  Beyond the group's last head the descriptor's bounds return 0.)
         const size_t grows = (size_t)(w.b * p.Hq + w.hk * g) * Sq;   // first row of the group's first head
-        __amdgpu_buffer_rsrc_t qrs = make_srd(reinterpret_cast<const char*>(p.q) + grows * RB, (unsigned)dkv4_rfl(g * Sq * RB));
-        __amdgpu_buffer_rsrc_t grs = make_srd(reinterpret_cast<const char*>(p.dout) + grows * RB, (unsigned)dkv4_rfl(g * Sq * RB));
-        __amdgpu_buffer_rsrc_t lrs = make_srd(p.lse + grows, (unsigned)dkv4_rfl(g * Sq * 4));
-        __amdgpu_buffer_rsrc_t drs = make_srd(p.delta + grows, (unsigned)dkv4_rfl(g * Sq * 4));
+        __amdgpu_buffer_rsrc_t qrs = make_srd(reinterpret_cast<const char*>(P()->q) + grows * RB, (unsigned)dkv4_rfl(g * Sq * RB));
+        __amdgpu_buffer_rsrc_t grs = make_srd(reinterpret_cast<const char*>(P()->dout) + grows * RB, (unsigned)dkv4_rfl(g * Sq * RB));
+        __amdgpu_buffer_rsrc_t lrs = make_srd(P()->lse + grows, (unsigned)dkv4_rfl(g * Sq * 4));
+        __amdgpu_buffer_rsrc_t drs = make_srd(P()->delta + grows, (unsigned)dkv4_rfl(g * Sq * 4));
 #if defined(__HIP_DEVICE_COMPILE__)
         // (whole descriptors, not words: the pairs share their size / flag words, and the compiler would re-assemble a four-register
         // tuple from the shared words in front of every statement that takes one -- four s_mov per iteration)
         asm volatile("" : "+s"(qrs), "+s"(grs), "+s"(lrs), "+s"(drs));
 #endif
-        struct Cur { int left, row; };   // blocks left in this head (this one included: the block's place in the head is ntq - left), row of the block in the group
-        const int row_first = first_qt * kQB;
-        const int row_wrap = Sq - (ntq - 1) * kQB;   // from a head's last block to the next head's first one
+        // Round 6: the stream is BLOCK-major, head-minor -- query block t of head 0, of head 1, .. of head g - 1, then block t + 1 -- where it
+        // used to be head-major.  Why: the work items of one (batch, kv head) unit run concurrently on one XCD and read the same Q / dO rows.
+        // Key block kb's stream starts at block 4 kb of a head; walking the heads one after the other, an item with a short per-head stream
+        // (a late key block) is in head 1 while its neighbours are still in head 0, and at C3 (4 heads per group) an XCD's 32 items were
+        // spread over 16 MB of Q / dO against a 4 MB L2: 553 MB fetched for 170 MB of inputs (profiles/r5_fwdbwd_c3_*).  Head-minor, item kb
+        // reads block 4 kb + x / g at iteration x: neighbours follow each other 4 g iterations apart (a few hundred KB of reuse distance),
+        // and the second parts of all pairs of a unit run in lock step (they all start at block x / g - 4).  MHA (g = 1) is the same stream
+        // as before.
+        // Measured at C3 (B4 32q/8kv S2048, 170 MB of inputs; FETCH_SIZE of this kernel, profiles/r6_bwd_dkv_order.txt): head-major 578 MB; head-minor
+        // upwards 477 MB (neighbours still 4 g = 16 iterations apart: the XCD's 32 items push 8 MB through the 4 MB L2 in between); lock step (the
+        // directions below) 233 MB.  Time: neutral -- the re-reads came from the Infinity Cache.
+        struct Cur { int hleft, left, row; };   // heads left at this block (this one included); the block's place in its head is ntq - left; row of the block in the group
+        // upwards: head 0 .. g - 1 of block t, then block t + 1; downwards: head g - 1 .. 0 of block t, then block t - 1 (the mirror image,
+        // so that the SPILL unit address stays linear in the stream position)
+        const int row_first = down ? (g - 1) * Sq + (first_qt + ntq - 1) * kQB : first_qt * kQB;
+        const int left_first = down ? 1 : ntq;
+        const int row_hstep = down ? -Sq : Sq;                                   // to the next head of the same block
+        const int row_wrap = down ? (g - 1) * Sq - kQB : kQB - (g - 1) * Sq;     // from the last head of a block to the first head of the next block
+        const int left_step = down ? 1 : -1;
         auto adv = [&](Cur& cu) __attribute__((always_inline)) {
-            if (--cu.left == 0) { cu.left = ntq; cu.row += row_wrap; }
-            else cu.row += kQB;
+            if (--cu.hleft == 0) { cu.hleft = g; cu.left += left_step; cu.row += row_wrap; }
+            else cu.row += row_hstep;
         };
         // (a cursor behind the stream's last block needs no special offset: the scalar offset is part of the descriptor's range
         // check on gfx950 -- tools/probe_soffset.hip -- so rows >= g Sq read zeros / the request writes zeros)
@@ -222,14 +265,15 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             wd = (kr < Sk && hi_r > lo_r) ? hi_r - lo_r : 0;
         };
 
-        // SPILL: block i of the stream (head hh of the group, query block first_qt + t) of this wave's 32 keys (32-key block
-        // kb32 = 4 kb + wave) is unit x = i + first_qt = hh ntq + (first_qt + t) of column (group, kb32): the stream index IS the
-        // address, no cursor (fa_kernels.h, DsLayout; the dQ kernel undoes the first_qt compression per head)
+        // SPILL: the block (query block qb32, head hh of the group) of this wave's 32 keys (32-key block kb32 = 4 kb + wave) is unit
+        // x = g qb32 + hh of column (group, kb32) (fa_kernels.h, DsLayout: block-major, head-minor like the stream -- round 6): stream
+        // position i is unit g first_qt + i walking upwards and g (first_qt + ntq) - 1 - i walking downwards -- a running offset (sp_off)
+        // that moves by one unit per iteration, no cursor
         const __amdgpu_buffer_rsrc_t srs = [&]() __attribute__((always_inline)) {
             if constexpr (SPILL) {
-                const long long xs = (long long)g * p.nq32;
-                const long long col = (long long)(w.b * p.Hkv + w.hk) * p.nkb32p + (kb * 4 + wave);
-                return make_srd(p.ds + ((col * xs + first_qt) << 11), (unsigned)dkv4_rfl((int)((xs - first_qt) << 11)));
+                const long long xs = (long long)g * P()->nq32;
+                const long long col = (long long)(w.b * P()->Hkv + w.hk) * P()->nkb32p + (kb * 4 + wave);
+                return make_srd(P()->ds + ((col * xs + (long long)g * first_qt) << 11), (unsigned)dkv4_rfl((int)((xs - (long long)g * first_qt) << 11)));
             } else {
                 return make_srd(nullptr, 0);
             }
@@ -240,8 +284,10 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             // of blocks i (its place in the head, for the mask) and i + 2 (its row, for L' / delta) are values the cursor had four /
             // two iterations earlier, kept by block parity (the loop is unrolled by two) -- a second and a third cursor cost ten
             // scalar instructions per iteration, and one wave per SIMD pays ~4.6 cycles of issue for every instruction.
-            Cur c4{ntq, row_first};
+            Cur c4{g, left_first, row_first};
             int t_cur[2], t_nxt[2], row_nxt[2], row_01[2];   // (t_*: the cursor's `left` at that block)
+            unsigned sp_off = (SPILL && down) ? (unsigned)(g * ntq - 1) << 11 : 0u;   // SPILL: byte offset of the iteration's unit behind the stream's first
+            const unsigned sp_step = (SPILL && down) ? (unsigned)-2048 : 2048u;
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 A::dma_block(slot_lds(x) + wave_pb, qrs, grs, (unsigned)c4.row * (unsigned)RB, vost[0], vost[1]);
@@ -299,7 +345,7 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
                 unsigned long long t1 = 0;
                 if constexpr (TL) { t1 = __builtin_amdgcn_s_memtime(); tl_a += t1 - t0; tl_w += t1 - tw; }
                 const unsigned b = slot_lds(i + 2) + a_sub, b1 = slot_lds(i + 2) + a_sub1;
-                if constexpr (SPILL && A::ST_LATE == 0) A::store_ds(srs, svo, (unsigned)i << 11);
+                if constexpr (SPILL && A::ST_LATE == 0) A::store_ds(srs, svo, sp_off);
                 {
                     const unsigned lso = (unsigned)row_nxt[PAR] * 4u, lso3 = (unsigned)row_nxt[PAR ^ 1] * 4u, dso = (unsigned)c4.row * (unsigned)RB;
                     const unsigned dl = slot_lds(i + 4) + wave_pb;
@@ -308,7 +354,8 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
                     A::template p2<2, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
                     A::template p2<3, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
                 }
-                if constexpr (SPILL && A::ST_LATE != 0) A::store_ds(srs, svo, (unsigned)i << 11);
+                if constexpr (SPILL && A::ST_LATE != 0) A::store_ds(srs, svo, sp_off);
+                if constexpr (SPILL) sp_off += sp_step;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments of block i + 2 (phase 1 of the next iteration reads them)
                 t_cur[PAR] = t_nxt[PAR]; t_nxt[PAR] = c4.left; row_nxt[PAR] = c4.row;
                 adv(c4);
@@ -336,8 +383,8 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const size_t row = kvbase + (size_t)(n0w + (lane_o & 31));
-            dkv4_store_rows<T, 0, D / 8>(reinterpret_cast<char*>(p.dv) + row * RB, lane_o >> 5, 1.0f);
-            dkv4_store_rows<T, D / 2, D / 8>(reinterpret_cast<char*>(p.dk) + row * RB, lane_o >> 5, p.scale);
+            dkv4_store_rows<T, 0, D / 8>(reinterpret_cast<char*>(P()->dv) + row * RB, lane_o >> 5, 1.0f);
+            dkv4_store_rows<T, D / 2, D / 8>(reinterpret_cast<char*>(P()->dk) + row * RB, lane_o >> 5, P()->scale);
         }
         __syncthreads();
     }

@@ -206,14 +206,14 @@ __global__ void __launch_bounds__(256, DQS_OCC) fa_bwd_dqs_kernel(const DqsParam
             const int qlo = q0w + 32 * rb;
             n_rb[rb] = dqs_rfl(qlo < Sq ? (CAUSAL ? min(nkb32, (qlo + 31 + coff) / kDqsKB + 1) : nkb32) : 0);
         }
-        // unit of (row block rb, key block j): column j, position hh (nq32 - fq(j / 4)) + qb32
-        const int u0 = hh * p.nq32 + q0w / 32;
+        // unit of (row block rb, key block j): column j, position g qb32 + hh (block-major, head-minor: the dK/dV kernel's stream order
+        // since round 6, fa_kernels.h DsLayout)
+        const int u0 = (q0w / 32) * g + hh;
         auto ds_off = [&](int j, int rb) __attribute__((always_inline)) {
-            const int fq = CAUSAL ? max(0, (j >> 2) * 128 - coff) >> 5 : 0;
 #ifdef DQS_X_SEQ
-            return (unsigned)((((long long)(u0 + rb) * p.nkb32p + j) << 11) + 0 * fq);
+            return (unsigned)(((long long)(u0 + rb * g) * p.nkb32p + j) << 11);
 #else
-            return (unsigned)(((long long)j * xs + u0 + rb - hh * fq) << 11);
+            return (unsigned)(((long long)j * xs + u0 + rb * g) << 11);
 #endif
         };
         auto issue = [&](int j, int slot) __attribute__((always_inline)) {

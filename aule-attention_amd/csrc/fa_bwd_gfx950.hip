@@ -20,6 +20,7 @@
 //                       group reduction is the loop, not an atomic.
 // The softmax is recomputed twice (once per kernel): 7 tile matmuls instead of the
 // 5 of the atomic formulation, in exchange for no fp32 atomics on dQ.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -1081,6 +1082,10 @@ inline uint64_t delta_bytes(int B, int Hq, int Sq) {
 // AULE_HIP_BWD_DS_AUTO_MB (160) and whose dK/dV grid takes the one-wave-per-SIMD kernel anyway, the recompute pair for everything else;
 // AULE_HIP_BWD_MODE=spill | recompute pin either one.
 // AULE_HIP_BWD_DS_CAP_MB (default 8192) bounds the workspace: the batch runs in chunks of as many elements as the caller's buffer holds.
+// What the most recent backward launch of this process ran (aule_hip_debug_last_backward_route; tests pin the mode a shape takes with it)
+std::atomic<int> g_last_bwd_route{0};
+enum { kRouteSpill = 1, kRouteDq4 = 2, kRouteDkv4 = 4, kRouteDqOld = 8, kRouteDkvOld = 16, kRouteF32 = 32 };
+
 inline int bwd_mode() {   // 0: auto (by AULE_HIP_BWD_DS_AUTO_MB), 1: recompute, 2: spill wherever applicable
     static const int m = [] {
         const char* e = std::getenv("AULE_HIP_BWD_MODE");
@@ -1123,7 +1128,9 @@ inline uint64_t spill_bytes_per_batch(int B, int Hq, int Hkv, int Sq, int Sk, in
     if (!bwd_dkv4_applicable(t) || !bwd_dqs_applicable(t) || !dkv4_by_grid(B, Hq, Hkv, Sk, causal)) return 0;
     const uint64_t pb = (uint64_t)Hkv * (uint64_t)DsLayout::of(Hq, Hkv, Sq, Sk).group_bytes;
     if (pb > bwd_ds_cap_bytes()) return 0;
-    if (bwd_mode() == 0) {   // auto: only problems whose TOUCHED dS (the causal half) fits the budget
+    if (bwd_mode() == 0) {   // auto: only problems whose TOUCHED dS (the causal half) fits the budget.  (The columns are allocated as full
+        // squares -- the address is the stream position -- so a causal problem asks for up to twice the budget of workspace: INTEGRATION.md,
+        // include/aule.h state it; only the touched half travels through the cache.)
         const uint64_t touched = (uint64_t)B * pb / (causal ? 2 : 1);
         if (touched > bwd_ds_auto_bytes()) return 0;
     }
@@ -1174,6 +1181,7 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
         const uint64_t base = bwd_base_bytes(a.B, a.Hq, a.Hkv, a.Sq, a.Sk, D, a.causal, a.dtype);
         const uint64_t nb = (pb > 0 && a.ws_bytes > base) ? (a.ws_bytes - base) / pb : 0;
         if (nb >= 1) {
+            g_last_bwd_route = kRouteSpill | kRouteDkv4;
             int rc = launch_bwd_delta16(a, p.lse2_out, p.ndelta_out, stream);
             if (rc) return rc;
             const size_t rq = (size_t)a.Hq * a.Sq, rk = (size_t)a.Hkv * a.Sk;   // rows per batch element
@@ -1204,10 +1212,13 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     };
     // D = 64 (round 4): ahead on small grids too (16 .. 64 work items: +1.9 .. +7.5 % on the whole backward, profiles/r4_bwd_d64_dkv4.txt) -- no grid rule there.
     const bool use_dq4 = (D == 128 || D == 64) && a.dbg_dq == nullptr && bwd_dq4_applicable(a) && (bwd_dq4_mode() == 2 || D == 64 || dq4_items() >= 128);
+    g_last_bwd_route = 0;
     if (only != 2 && use_dq4) {
+        g_last_bwd_route |= kRouteDq4;
         int rc = launch_bwd_dq4(a, p.lse2_out, p.ndelta_out, stream);
         if (rc) return rc;
     } else if (only != 2) {
+        g_last_bwd_route |= kRouteDqOld;
         const int nqb = (a.Sq + kDqQBlock - 1) / kDqQBlock;
         p.nblk = a.causal ? (nqb + 1) / 2 : nqb;  // causal: one workgroup per Q-block pair (i, n-1-i)
         p.gsplit = 1;
@@ -1241,20 +1252,19 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     // 32/1 S8192: 32 work items there against 512 here).
     const auto use_dkv4 = [&] {
         if ((D != 128 && D != 64) || !(a.dbg == nullptr || dkv4_timeline_wanted()) || !bwd_dkv4_applicable(a)) return false;   // (timeline instances: bf16, D = 128 and, round 5, D = 64)
-        if (bwd_dkv4_forced() || dkv4_timeline_wanted()) return true;
-        const int nkb = (a.Sk + kKvBlock - 1) / kKvBlock;
-        const long long here = (long long)a.B * a.Hkv * (a.causal ? (nkb + 1) / 2 : nkb) * dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal);
-        const long long there = bwd_dkv4_items(a);
-        return there >= 192 || there >= here;
+        if (dkv4_timeline_wanted()) return true;
+        return dkv4_by_grid(a.B, a.Hq, a.Hkv, a.Sk, a.causal);   // (ONE statement of the grid rule: the auto mode's workspace plan asks the same helper)
     };
     if (use_dkv4())
     {
+        g_last_bwd_route |= kRouteDkv4;
         BwdArgs b = a;
         b.lse2 = p.lse2_out;
         b.ndelta = p.ndelta_out;
         return launch_bwd_dkv4(b, stream);
     }
     {
+        g_last_bwd_route |= kRouteDkvOld;
         const int nkb = (a.Sk + kKvBlock - 1) / kKvBlock;
         p.nblk = a.causal ? (nkb + 1) / 2 : nkb;  // causal: one workgroup per block pair (i, n-1-i)
         p.gsplit = dkdv_gsplit(a.B, a.Hq, a.Hkv, a.Sk, a.causal);
@@ -1344,8 +1354,10 @@ uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int 
     return bytes;
 }
 
+int bwd_last_route() { return g_last_bwd_route.load(); }
+
 int launch_bwd(const BwdArgs& a, hipStream_t stream) {
-    if (a.dtype == kF32) return launch_bwd_f32(a, stream);
+    if (a.dtype == kF32) { g_last_bwd_route = kRouteF32; return launch_bwd_f32(a, stream); }
     if (a.dtype == kBF16) {
         if (a.D == 128) return launch_bwd_16<Bf16Traits, 128>(a, stream);
         if (a.D == 64) return launch_bwd_16<Bf16Traits, 64>(a, stream);

@@ -110,10 +110,10 @@ struct BwdArgs {
 // The dS workspace of the 5-matmul backward (round 5; fa_bwd_dkv4_gfx950.hip SPILL instances write it, fa_bwd_dqs_gfx950.hip reads it).
 // A UNIT is the packed 16-bit dS of one (32-key block, 32-row query block) tile exactly as the dK/dV kernel holds it for its own
 // dK MFMAs: 2 KB = [kk = 16-row query step][lane = key n + 32 hi][16 bytes = query rows 16 kk + 4 hi + {0..3}, 16 kk + 8 + 4 hi + {0..3}].
-// Units of one (batch, KV head) GROUP and one 32-key block kb32 form a COLUMN of xs = g * nq32 units, indexed by the dK/dV kernel's
-// stream position: head hh of the group, query block qb32 -> x = hh * (nq32 - fq) + qb32, fq = the first query block that sees the
-// 128-key block kb32 / 4 (0 when not causal) -- so that the writer's address is its loop counter.  Columns are padded to whole
-// 128-key blocks (nkb32p = 4 * ceil(Sk / 128)): every wave of the dK/dV kernel owns a column.
+// Units of one (batch, KV head) GROUP and one 32-key block kb32 form a COLUMN of xs = g * nq32 units in the dK/dV kernel's stream
+// order -- block-major, head-minor since round 6: query block qb32 of head hh of the group -> x = g * qb32 + hh -- so that the
+// writer's address is its loop counter (its stream starts at the first query block fq that sees the 128-key block: x0 = g * fq).
+// Columns are padded to whole 128-key blocks (nkb32p = 4 * ceil(Sk / 128)): every wave of the dK/dV kernel owns a column.
 struct DsLayout {
     int nq32, nkb32p;
     long long xs;              // units per column
@@ -180,6 +180,9 @@ void work_order_dump(int ranked, int bid, int B, int Hq, int Hkv, int nblk, int 
 uint64_t fwd_workspace_bytes(FwdArgs a);
 uint64_t paged_workspace_bytes(PagedArgs a);   // 0 fp32, 1 ping-pong, 2 in-wave, 3 v1, 4 split-KV, 5 tiled + packed rows + KV splits (host logic only)
 int launch_bwd(const BwdArgs& a, hipStream_t stream);
+// bit mask of what the most recent launch_bwd of this process ran: 1 the 5-matmul mode (delta pass + spilling dK/dV kernel + dQ = dS K),
+// 2 / 4 the one-wave-per-SIMD dQ / dK/dV kernel, 8 / 16 their two-waves-per-SIMD predecessors, 32 the fp32 kernels; 0 before the first
+int bwd_last_route();
 
 // Bytes of device workspace launch_bwd needs: delta [B,Hq,Sq] fp32, plus (16-bit GQA/MQA problems that
 // do not fill the chip) fp32 dK/dV partials of the head-split dK/dV kernel.

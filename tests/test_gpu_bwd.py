@@ -211,10 +211,20 @@ def test_auto_mode_takes_the_5_matmul_backward_for_cache_sized_problems(torch_cu
     q, k, v, do = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16, generator=gen) for _ in range(4))
     q1, k1, v1 = (x.clone().requires_grad_(True) for x in (q, k, v))
     aule.flash_attention(q1, k1, v1, causal=True).backward(do)
+    torch.cuda.synchronize()
+    # the mode actually taken (a silent fall-back to the recompute pair used to pass this test): bit 1 = the 5-matmul mode
+    assert int(lib.aule_hip_debug_last_backward_route()) & 1, lib.aule_hip_debug_last_backward_route()
     q2, k2, v2 = (x.float().requires_grad_(True) for x in (q, k, v))
     _torch_ref(torch, q2, k2, v2, True, 1.0 / math.sqrt(D)).backward(do.float())
     for name, a, b in (("dq", q1.grad, q2.grad), ("dk", k1.grad, k2.grad), ("dv", v1.grad, v2.grad)):
         grad_close(a.float().cpu().numpy(), b.cpu().numpy(), "bf16", "auto-mode " + name)
+    # ... and a shape past the budget (C3: 537 MB of touched dS) takes the recompute pair on the one-wave-per-SIMD kernels by itself
+    if not os.environ.get("AULE_HIP_BWD_MODE") and not os.environ.get("AULE_HIP_BWD_DKV") and not os.environ.get("AULE_HIP_BWD_DQ"):
+        qa, ka, va, da = (torch.randn(4, h, 2048, 128, device="cuda", dtype=torch.bfloat16, generator=gen) for h in (32, 8, 8, 32))
+        qa.requires_grad_(True); ka.requires_grad_(True); va.requires_grad_(True)
+        aule.flash_attention(qa, ka, va, causal=True).backward(da)
+        torch.cuda.synchronize()
+        assert int(lib.aule_hip_debug_last_backward_route()) == 2 | 4, lib.aule_hip_debug_last_backward_route()
 
 
 def test_sgd_step_lowers_loss(torch_cuda):
