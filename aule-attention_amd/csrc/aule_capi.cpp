@@ -928,7 +928,7 @@ int32_t aule_rope_ex(const aule_rope_desc* d) {
 uint64_t aule_attention_backward_workspace_size(const aule_attn_bwd_desc* d) {
     if (d == nullptr) return 0;
     return aule_hip::bwd_workspace_bytes((int)d->batch, (int)d->heads_q, (int)d->heads_kv, (int)d->seq_q, (int)d->seq_k,
-                                         (int)d->head_dim, d->causal != 0, d->dtype);
+                                         (int)d->head_dim, d->causal != 0, d->dtype, d->device);
 }
 
 int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
@@ -958,7 +958,7 @@ int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
     // (aule_attention_backward_workspace_size() also asks for the dS workspace of the 5-matmul backward; a smaller buffer that
     // still holds delta / L' / the partials is accepted and runs the recompute pair)
     const uint64_t need = aule_hip::bwd_workspace_min_bytes((int)d->batch, (int)d->heads_q, (int)d->heads_kv, (int)d->seq_q,
-                                                            (int)d->seq_k, (int)d->head_dim, d->causal != 0, d->dtype);
+                                                            (int)d->seq_k, (int)d->head_dim, d->causal != 0, d->dtype, d->device);
     if (!d->workspace || d->workspace_bytes < need) {
         set_error("Backward failed: workspace too small (%llu < %llu bytes)",
                   (unsigned long long)d->workspace_bytes, (unsigned long long)need);
@@ -971,6 +971,7 @@ int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {
     a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->out; a.dout = d->dout; a.lse = d->lse;
     a.dq = d->dq; a.dk = d->dk; a.dv = d->dv; a.delta = (float*)d->workspace;
     a.ws_bytes = d->workspace_bytes;
+    a.device = d->device;
     a.B = (int)d->batch; a.Hq = (int)d->heads_q; a.Hkv = (int)d->heads_kv;
     a.Sq = (int)d->seq_q; a.Sk = (int)d->seq_k; a.D = (int)d->head_dim;
     a.scale = resolve_scale(d->scale, d->head_dim);

@@ -95,10 +95,21 @@ __device__ __forceinline__ void dkv4_store_rows(char* row, int hi, float sc) {
 
 __device__ __forceinline__ int dkv4_rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-template <class T, int D, bool CAUSAL, bool TL, bool SPILL>
+// NKB (round 6): 32-key blocks per wave.  1: the stream above.  2 (D = 64 only, Bw4Asm2): a wave owns 64 keys, the workgroup a 256-key KV block;
+// every fragment of the query block feeds two MFMAs (tools/gen_bw4.py, Cfg2: twice the MFMAs per iteration for the same LDS reads, scalar
+// loads, requests, barrier and compiler scalars -- the D = 64 stream is issue-bound, profiles/r5_bwd_d64_ablation.txt).
+template <class T, int D, int NKB>
+struct Dkv4Streams { using type = Bw4Asm<T, D>; };
+template <class T>
+struct Dkv4Streams<T, 64, 2> { using type = Bw4Asm2<T>; };
+
+template <class T, int D, bool CAUSAL, bool TL, bool SPILL, int NKB = 1>
 __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
-    using A = Bw4Asm<T, D>;
+    using A = typename Dkv4Streams<T, D, NKB>::type;
     using std::integral_constant;
+    static_assert(NKB == 1 || (NKB == 2 && D == 64 && !SPILL && !TL), "two key blocks per wave: D = 64, recompute mode, no timeline instance");
+    constexpr int KW = 32 * NKB;           // keys per wave
+    constexpr int KB = 4 * KW;             // keys per workgroup (kKvBlock4 with one block per wave)
     constexpr int RB = 2 * D;
     constexpr int SLOT = A::SLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -133,7 +144,7 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
     const int g = p.Hq / p.Hkv;
     const int Sq = p.Sq, Sk = p.Sk, coff = p.coff;
     const float c = p.c;
-    const int nkb = (Sk + kKvBlock4 - 1) / kKvBlock4;
+    const int nkb = (Sk + KB - 1) / KB;
     const WorkItem w = decode_work(blockIdx.x, p.B, p.Hkv, p.Hkv, p.nblk, false);
     const size_t kvbase = (size_t)(w.b * p.Hkv + w.hk) * Sk;
 
@@ -183,20 +194,21 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
         // (round 6; see the cursor below for the measurements).
         const int kb = CAUSAL ? (part == 0 ? w.blk : nkb - 1 - w.blk) : w.blk;
         const int down = dkv4_rfl((CAUSAL && part == 0) ? 1 : 0);
-        const int n0w = kb * kKvBlock4 + wave * 32;
+        const int n0w = kb * KB + wave * KW;
         const int kvrow = n0w + l31;
         {
             const __amdgpu_buffer_rsrc_t krs = make_srd(reinterpret_cast<const char*>(P()->k) + kvbase * RB, (unsigned)Sk * RB);
             const __amdgpu_buffer_rsrc_t vrs = make_srd(reinterpret_cast<const char*>(P()->v) + kvbase * RB, (unsigned)Sk * RB);
-            A::load_kv(krs, vrs, (unsigned)(kvrow * RB + hi * 16));
+            if constexpr (NKB == 2) A::load_kv(krs, vrs, (unsigned)(kvrow * RB + hi * 16), (unsigned)((kvrow + 32) * RB + hi * 16));
+            else A::load_kv(krs, vrs, (unsigned)(kvrow * RB + hi * 16));
         }
         A::zero_acc();
 
         const int W = SPILL ? 0 : P()->window;   // (the 5-matmul mode never carries a window: the dispatcher keeps windowed problems on the recompute pair)
         int nq32 = (Sq + kQB - 1) / kQB;
         // (window: the last query that sees the block's last key kb 128 + 127 sits at position key + W - 1: the stream of a KV block ends there)
-        if (W > 0) nq32 = min(nq32, max(0, kb * kKvBlock4 + kKvBlock4 - 1 + W - 1 - coff) / kQB + 1);
-        const int first_qt = CAUSAL ? max(0, kb * kKvBlock4 - coff) / kQB : 0;
+        if (W > 0) nq32 = min(nq32, max(0, kb * KB + KB - 1 + W - 1 - coff) / kQB + 1);
+        const int first_qt = CAUSAL ? max(0, kb * KB - coff) / kQB : 0;
         const int ntq = nq32 > first_qt ? nq32 - first_qt : 0;
         const int nit = ntq * g;   // flattened (query block, query head of the group) stream
 
@@ -244,8 +256,8 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
         auto slot_lds = [&](int x) __attribute__((always_inline)) { return (unsigned)(x & (kRing4 - 1)) * SLOT; };   // (+ tr_off / a_sub / wave_pb: those carry the LDS base)
         // Does anybody's lane need a mask in block t of a head?  The causal diagonal covers the head's first t_diag blocks (every
         // block if the wave's 32 keys run past Sk), a ragged Sq its last one.
-        const int diag_x = CAUSAL ? n0w + 31 - coff - first_qt * kQB : 0;   // block t crosses the diagonal iff t kQB < diag_x
-        const int t_diag = (n0w + 32 > Sk) ? 0x7fffffff : (diag_x > 0 ? (diag_x + kQB - 1) / kQB : 0);
+        const int diag_x = CAUSAL ? n0w + KW - 1 - coff - first_qt * kQB : 0;   // block t crosses the diagonal (of the wave's last key) iff t kQB < diag_x
+        const int t_diag = (n0w + KW > Sk) ? 0x7fffffff : (diag_x > 0 ? (diag_x + kQB - 1) / kQB : 0);
         int t_plain_end = (Sq % kQB) != 0 && nq32 * kQB > Sq ? ntq - 1 : 0x7fffffff;   // blocks t_diag <= t < t_plain_end need no mask:
         // (window: the first query row that does NOT see the wave's first key n0w is n0w + W - coff; blocks that reach it need the mask)
         if (W > 0) t_plain_end = min(t_plain_end, max(0, max(0, n0w + W - coff) / kQB - first_qt));
@@ -253,11 +265,11 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
         const unsigned t_lo = (unsigned)dkv4_rfl(ntq - t_diag);
         const unsigned t_span = (unsigned)dkv4_rfl(t_plain_end > t_diag ? t_plain_end - t_diag : 0);
         // mask of block t for this lane: rows [lo, lo + wd) of the block are valid (as crow(r) + 4 hi)
-        auto mask_of = [&](int t, int& lo, int& wd) __attribute__((always_inline)) {
+        auto mask_of = [&](int t, int& lo, int& wd, int kofs = 0) __attribute__((always_inline)) {   // kofs: 32 for the wave's second key block (NKB = 2)
             const int q0 = (first_qt + t) * kQB;
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
-            const int kr = n0w + (lane_o & 31);
+            const int kr = n0w + kofs + (lane_o & 31);
             const int lo_r = CAUSAL ? max(0, kr - coff - q0) : 0;
             int hi_r = min(kQB, Sq - q0);
             if (W > 0) hi_r = min(hi_r, kr + W - coff - q0);   // q + coff - kr < W
@@ -290,29 +302,57 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             const unsigned sp_step = (SPILL && down) ? (unsigned)-2048 : 2048u;
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                A::dma_block(slot_lds(x) + wave_pb, qrs, grs, (unsigned)c4.row * (unsigned)RB, vost[0], vost[1]);
+                if constexpr (NKB == 2) A::dma_block(slot_lds(x) + wave_pb, qrs, grs, (unsigned)c4.row * (unsigned)RB, vost[0]);
+                else A::dma_block(slot_lds(x) + wave_pb, qrs, grs, (unsigned)c4.row * (unsigned)RB, vost[0], vost[1]);
                 if (x < 2) { t_cur[x] = c4.left; row_01[x] = c4.row; }
                 else { t_nxt[x - 2] = c4.left; row_nxt[x - 2] = c4.row; }
                 adv(c4);
             }
-            A::template load_scal<0, 0>(lrs, drs, lvo, (unsigned)row_01[0] * 4u);
-            A::template load_scal<1, 0>(lrs, drs, lvo, (unsigned)row_01[1] * 4u);
-            A::load_delta_x(drs, lvo, (unsigned)row_nxt[0] * 4u);   // - delta of block 2: parked until dP_0 has read block 0's
+            if constexpr (NKB == 2) {
+                // (one - delta buffer: block 0's goes straight in, block 1's is parked in X until dP_0's first MFMAs have read block 0's)
+                A::template load_scal<0, 1>(lrs, drs, lvo, (unsigned)row_01[0] * 4u);
+                A::template load_scal<1, 0>(lrs, drs, lvo, (unsigned)row_01[1] * 4u);
+                A::load_delta_x(drs, lvo, (unsigned)row_01[1] * 4u);
+            } else {
+                A::template load_scal<0, 0>(lrs, drs, lvo, (unsigned)row_01[0] * 4u);
+                A::template load_scal<1, 0>(lrs, drs, lvo, (unsigned)row_01[1] * 4u);
+                A::load_delta_x(drs, lvo, (unsigned)row_nxt[0] * 4u);   // - delta of block 2: parked until dP_0 has read block 0's
+            }
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             const __amdgpu_buffer_rsrc_t nosrd = make_srd(nullptr, 0);
             auto rm_reads = [&](int x) __attribute__((always_inline)) {   // row-major fragments of block x -> the accumulator file
                 const unsigned b = slot_lds(x) + a_sub, b1 = slot_lds(x) + a_sub1;
-                A::template p2<0, 0, 0, 1, 0, 0>(b, b1, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
-                A::template p2<1, 0, 0, 1, 0, 0>(b, b1, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
-                A::template p2<2, 0, 0, 1, 0, 0>(b, b1, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
-                A::template p2<3, 0, 0, 1, 0, 0>(b, b1, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                if constexpr (NKB == 2) {
+                    A::template p2<0, 0, 0, 1, 0, 0, 0, 0>(0.f, 0, 0, b, b1, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0);
+                    A::template p2<1, 0, 0, 1, 0, 0, 0, 0>(0.f, 0, 0, b, b1, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0);
+                    A::template p2<2, 0, 0, 1, 0, 0, 0, 0>(0.f, 0, 0, b, b1, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0);
+                    A::template p2<3, 0, 0, 1, 0, 0, 0, 0>(0.f, 0, 0, b, b1, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0);
+                } else {
+                    A::template p2<0, 0, 0, 1, 0, 0>(b, b1, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                    A::template p2<1, 0, 0, 1, 0, 0>(b, b1, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                    A::template p2<2, 0, 0, 1, 0, 0>(b, b1, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                    A::template p2<3, 0, 0, 1, 0, 0>(b, b1, 0, nosrd, nosrd, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0);
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
             rm_reads(0);
-            A::template p1<0, 1, 1, 0, 0>(c, 0, 0, 0);   // S_0, dP_0 (parity 0 buffers)
-            A::template p1<1, 1, 1, 0, 0>(c, 0, 0, 0);
-            A::template p1<2, 1, 1, 0, 0>(c, 0, 0, 0);
-            A::template p1<3, 1, 1, 0, 0>(c, 0, 0, 0);
+            if constexpr (NKB == 2) {   // S_0, then dP_0 of both key blocks (starts from - delta of block 0)
+                A::template p1<0, 1, 1, 0, 0>(c, 0, 0, 0, 0, 0);
+                A::template p1<1, 1, 1, 0, 0>(c, 0, 0, 0, 0, 0);
+                A::template p1<2, 1, 1, 0, 0>(c, 0, 0, 0, 0, 0);
+                A::template p1<3, 1, 1, 0, 0>(c, 0, 0, 0, 0, 0);
+            } else {
+                A::template p1<0, 1, 1, 0, 0>(c, 0, 0, 0);   // S_0, dP_0 (parity 0 buffers)
+                A::template p1<1, 1, 1, 0, 0>(c, 0, 0, 0);
+                A::template p1<2, 1, 1, 0, 0>(c, 0, 0, 0);
+                A::template p1<3, 1, 1, 0, 0>(c, 0, 0, 0);
+            }
+            if constexpr (NKB == 2) {
+                A::template p2<0, 0, 0, 0, 0, 0, 1, 0>(0.f, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0);
+                A::template p2<1, 0, 0, 0, 0, 0, 1, 0>(0.f, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0);
+                A::template p2<2, 0, 0, 0, 0, 0, 1, 0>(0.f, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0);
+                A::template p2<3, 0, 0, 0, 0, 0, 1, 0>(0.f, 0, 0, 0, 0, nosrd, nosrd, 0, 0, 0, nosrd, nosrd, 0, 0);
+            }
             A::mov_delta_x();
             if (nit > 1) rm_reads(1);
 
@@ -328,14 +368,30 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
     A::template p1<1, PAR, QK, AR, 1>(c, LO, WD, trb);     \
     A::template p1<2, PAR, QK, AR, 1>(c, LO, WD, trb);     \
     A::template p1<3, PAR, QK, AR, 1>(c, LO, WD, trb);
+#define DKV4_P1X(AR, LA, WA, LB, WB)                              \
+    A::template p1<0, PAR, QK, AR, 1>(c, LA, WA, LB, WB, trb);     \
+    A::template p1<1, PAR, QK, AR, 1>(c, LA, WA, LB, WB, trb);     \
+    A::template p1<2, PAR, QK, AR, 1>(c, LA, WA, LB, WB, trb);     \
+    A::template p1<3, PAR, QK, AR, 1>(c, LA, WA, LB, WB, trb);
+                // (NKB = 2: the mask of the wave's second key block rides along; a SPLIT build -- tools/gen_bw4.py BW4_K2_SPLIT, an experiment --
+                // applies it in phase 2, where that block's arithmetic then sits)
+                int lob = 0, wdb = 0;
+                bool masked = false;
                 if (__builtin_expect(t_lo - (unsigned)left < t_span, 1)) {   // (expected: the masked statements then sit outside the loop body)
-                    DKV4_P1(1, 0, 0)
+                    if constexpr (NKB == 2) { DKV4_P1X(1, 0, 0, 0, 0) } else { DKV4_P1(1, 0, 0) }
                 } else {
                     int lo, wd;
                     mask_of(ntq - left, lo, wd);
-                    DKV4_P1(2, lo, wd)
+                    if constexpr (NKB == 2) {
+                        mask_of(ntq - left, lob, wdb, 32);
+                        masked = true;
+                        DKV4_P1X(2, lo, wd, lob, wdb)
+                    } else {
+                        DKV4_P1(2, lo, wd)
+                    }
                 }
 #undef DKV4_P1
+#undef DKV4_P1X
                 // block i + 2 has landed for everybody (all but this wave's newest NP requests -- block i + 3 -- are complete:
                 // the scalars of block i + 1 among them)
                 unsigned long long tw = 0;
@@ -349,10 +405,26 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
                 {
                     const unsigned lso = (unsigned)row_nxt[PAR] * 4u, lso3 = (unsigned)row_nxt[PAR ^ 1] * 4u, dso = (unsigned)c4.row * (unsigned)RB;
                     const unsigned dl = slot_lds(i + 4) + wave_pb;
-                    A::template p2<0, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
-                    A::template p2<1, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
-                    A::template p2<2, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
-                    A::template p2<3, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
+                    if constexpr (NKB == 2) {
+                        (void)lso3;   // (one - delta buffer: - delta of block i + 2 rides with its L')
+#define DKV4_P2X(AR)                                                                                            \
+    A::template p2<0, PAR, 1, 1, 1, 1, QK, AR>(c, lob, wdb, b, b1, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0]);   \
+    A::template p2<1, PAR, 1, 1, 1, 1, QK, AR>(c, lob, wdb, b, b1, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0]);   \
+    A::template p2<2, PAR, 1, 1, 1, 1, QK, AR>(c, lob, wdb, b, b1, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0]);   \
+    A::template p2<3, PAR, 1, 1, 1, 1, QK, AR>(c, lob, wdb, b, b1, lrs, drs, lvo, lso, dl, qrs, grs, dso, vost[0]);
+                        if constexpr (A::SPLIT != 0) {
+                            if (__builtin_expect(!masked, 1)) { DKV4_P2X(1) } else { DKV4_P2X(2) }
+                        } else {
+                            (void)masked;
+                            DKV4_P2X(1)
+                        }
+#undef DKV4_P2X
+                    } else {
+                        A::template p2<0, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
+                        A::template p2<1, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
+                        A::template p2<2, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
+                        A::template p2<3, PAR, 1, 1, 1, 1>(b, b1, trb, lrs, drs, lvo, lso, lso3, dl, qrs, grs, dso, vost[0], vost[1]);
+                    }
                 }
                 if constexpr (SPILL && A::ST_LATE != 0) A::store_ds(srs, svo, sp_off);
                 if constexpr (SPILL) sp_off += sp_step;
@@ -383,8 +455,22 @@ __device__ __forceinline__ void dkv4_body(const Dkv4Params& p) {
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
             const size_t row = kvbase + (size_t)(n0w + (lane_o & 31));
-            dkv4_store_rows<T, 0, D / 8>(reinterpret_cast<char*>(P()->dv) + row * RB, lane_o >> 5, 1.0f);
-            dkv4_store_rows<T, D / 2, D / 8>(reinterpret_cast<char*>(P()->dk) + row * RB, lane_o >> 5, P()->scale);
+            if constexpr (NKB == 2) {   // accumulator file: dV_A a[0:31], dV_B a[32:63], dK_A a[64:95], dK_B a[96:127]
+                dkv4_store_rows<T, 0, D / 8>(reinterpret_cast<char*>(P()->dv) + row * RB, lane_o >> 5, 1.0f);
+                dkv4_store_rows<T, 64, D / 8>(reinterpret_cast<char*>(P()->dk) + row * RB, lane_o >> 5, P()->scale);
+            } else {
+                dkv4_store_rows<T, 0, D / 8>(reinterpret_cast<char*>(P()->dv) + row * RB, lane_o >> 5, 1.0f);
+                dkv4_store_rows<T, D / 2, D / 8>(reinterpret_cast<char*>(P()->dk) + row * RB, lane_o >> 5, P()->scale);
+            }
+        }
+        if constexpr (NKB == 2) {
+            if (kvrow + 32 < Sk) {
+                int lane_o = lane;
+                asm volatile("" : "+v"(lane_o));
+                const size_t row = kvbase + (size_t)(n0w + 32 + (lane_o & 31));
+                dkv4_store_rows<T, 32, D / 8>(reinterpret_cast<char*>(P()->dv) + row * RB, lane_o >> 5, 1.0f);
+                dkv4_store_rows<T, 96, D / 8>(reinterpret_cast<char*>(P()->dk) + row * RB, lane_o >> 5, P()->scale);
+            }
         }
         __syncthreads();
     }
@@ -408,10 +494,37 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(72))) f
     dkv4_body<T, 64, CAUSAL, TL, SPILL>(p);
 }
 
+// D = 64, two 32-key blocks per wave (round 6): 40 arch VGPRs for hipcc like D = 128
+template <class T, bool CAUSAL>
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(40))) fa_bwd_dkv4_kernel_d64k2(const Dkv4Params p) {
+    static_assert(Bw4Asm2<T>::NV == 40, "amdgpu_num_vgpr must be the generator's NV");
+    dkv4_body<T, 64, CAUSAL, false, false, 2>(p);
+}
+
 #pragma clang diagnostic pop
 
 template <int D>
 constexpr int kDkv4Lds = kRing4 * Bw4Asm<Bf16Traits, D>::SLOT;
+
+// Does the D = 64 problem take the two-key-blocks-per-wave instance?  Its work items are 256-key blocks (pairs of them): half as many, each
+// ~1.32 x as long as a 128-key item (twice the MFMAs in ~0.66 of twice the time: profiles/r6_bwd_d64_k2.txt).  Whole rounds of the chip decide:
+// ceil(items / CUs) of either kind, priced.  AULE_HIP_BWD_DKV_K2=0 / 1 pins it (A/B, tests).
+inline long long dkv4_items_of(const BwdArgs& a, int kb) {
+    const int nkb = (a.Sk + kb - 1) / kb;
+    return (long long)a.B * a.Hkv * (a.causal ? (nkb + 1) / 2 : nkb);
+}
+inline bool dkv4_use_k2(const BwdArgs& a) {
+    static const int mode = [] {
+        const char* e = std::getenv("AULE_HIP_BWD_DKV_K2");
+        return e == nullptr ? -1 : (e[0] == '0' ? 0 : 1);
+    }();
+    if (a.D != 64 || a.ds != nullptr || a.dbg != nullptr) return false;   // (the 5-matmul mode and the timeline instances stay on the one-block stream)
+    if (mode >= 0) return mode == 1;
+    const long long cus = device_cu_count(a.device);
+    const long long i1 = dkv4_items_of(a, 128), i2 = dkv4_items_of(a, 256);
+    const long long r1 = (i1 + cus - 1) / cus, r2 = (i2 + cus - 1) / cus;
+    return r2 * 132 < r1 * 100;
+}
 
 template <class T, int D>
 int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
@@ -423,7 +536,8 @@ int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
     p.scale = a.scale;
     p.coff = a.causal ? a.coff : 0;
     p.window = a.window > 0 ? a.window : 0;
-    const int nkb = (a.Sk + kKvBlock4 - 1) / kKvBlock4;
+    const bool k2 = D == 64 && dkv4_use_k2(a);
+    const int nkb = k2 ? (a.Sk + 255) / 256 : (a.Sk + kKvBlock4 - 1) / kKvBlock4;
     p.nblk = a.causal ? (nkb + 1) / 2 : nkb;
     const dim3 grid((unsigned)(p.nblk * a.B * a.Hkv)), block(256);
     p.dbg = a.dbg;
@@ -432,6 +546,13 @@ int launch_dkv4(const BwdArgs& a, hipStream_t stream) {
     const bool spill = a.ds != nullptr;   // the 5-matmul backward: dS goes to the workspace for fa_bwd_dqs_gfx950.hip
     constexpr int LDS = kDkv4Lds<D>;
     if constexpr (D == 64) {
+        if (k2) {
+            if (a.causal)
+                hipLaunchKernelGGL((fa_bwd_dkv4_kernel_d64k2<T, true>), grid, block, LDS, stream, p);
+            else
+                hipLaunchKernelGGL((fa_bwd_dkv4_kernel_d64k2<T, false>), grid, block, LDS, stream, p);
+            return (int)hipGetLastError();
+        }
 #ifdef AULE_DEBUG_HOOKS
         if constexpr (std::is_same<T, Bf16Traits>::value) {
             if (a.dbg != nullptr) {   // timeline build at D = 64 (round 5: tools/timeline_dkv4.py ... 64)
@@ -511,6 +632,9 @@ long long bwd_dkv4_items(const BwdArgs& a) {
     return (long long)a.B * a.Hkv * (a.causal ? (nkb + 1) / 2 : nkb);
 }
 
+// D = 64: does launch_bwd_dkv4 run the two-key-blocks-per-wave instance for this problem?  (the dispatcher's route record)
+bool bwd_dkv4_k2(const BwdArgs& a) { return a.D == 64 && dkv4_use_k2(a); }
+
 // AULE_HIP_BWD_DKV=new: take every problem bwd_dkv4_applicable() accepts (tests)
 bool bwd_dkv4_forced() {
     static const int v = [] {
@@ -542,6 +666,10 @@ int configure_bwd_dkv4() {
     set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<Bf16Traits, false>), kDkv4Lds<64>);
     set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<F16Traits, true>), kDkv4Lds<64>);
     set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64<F16Traits, false>), kDkv4Lds<64>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64k2<Bf16Traits, true>), kDkv4Lds<64>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64k2<Bf16Traits, false>), kDkv4Lds<64>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64k2<F16Traits, true>), kDkv4Lds<64>);
+    set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel_d64k2<F16Traits, false>), kDkv4Lds<64>);
     // the SPILL instances (5-matmul backward)
     set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<Bf16Traits, true, false, true>), kDkv4Lds<128>);
     set(reinterpret_cast<const void*>(&fa_bwd_dkv4_kernel<Bf16Traits, false, false, true>), kDkv4Lds<128>);

@@ -428,7 +428,15 @@ int launch_bwd_f32_d(const BwdArgs& a, hipStream_t stream) {
     p.coff = a.causal ? a.coff : 0;
     int nq = 1, nk = 1;
     // (a window changes the tile ranges per block: the plan keeps to the window-less count, pieces beyond a block's tiles are empty)
-    f32_bwd_plan(a.B, a.Hq, a.Hkv, a.Sq, a.Sk, D, a.causal, p.coff, -1, nq, nk);
+    f32_bwd_plan(a.B, a.Hq, a.Hkv, a.Sq, a.Sk, D, a.causal, p.coff, a.device, nq, nk);
+    if (a.ws_bytes != 0) {
+        // (the plan must never outgrow the bytes the caller was told to bring -- the size query and this launch can see
+        // different CU counts if the caller's current device differs from the descriptor's and an entry point forgot to say so)
+        const uint64_t have = a.ws_bytes > f32_delta_bytes(a.B, a.Hq, a.Sq) ? a.ws_bytes - f32_delta_bytes(a.B, a.Hq, a.Sq) : 0;
+        const uint64_t per_q = (uint64_t)a.B * a.Hq * a.Sq * D * 4, per_k = 2ull * a.B * a.Hkv * a.Sk * D * 4;
+        while (nq > 1 && (uint64_t)nq * per_q > have) --nq;
+        while (nk > 1 && (uint64_t)nk * per_k > have) --nk;
+    }
     float* const parts = reinterpret_cast<float*>(reinterpret_cast<char*>(a.delta) + f32_delta_bytes(a.B, a.Hq, a.Sq));   // (bwd_f32_partial_bytes() behind delta)
     const dim3 block(256);
     {
@@ -479,12 +487,12 @@ int set_attr_f32() {
 }  // namespace
 
 // bytes of fp32 partial planes the small-grid split needs behind delta (0: no split for these sizes)
-uint64_t bwd_f32_partial_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal) {
+uint64_t bwd_f32_partial_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int device) {
     int nq = 1, nk = 1;
-    f32_bwd_plan(B, Hq, Hkv, Sq, Sk, D, causal, 0, -1, nq, nk);
+    f32_bwd_plan(B, Hq, Hkv, Sq, Sk, D, causal, 0, device, nq, nk);
     // (coff only shrinks the causal tile count the plan looks at: coff = Sk - Sq >= 0 gives at least as many tiles; size for both)
     int nq2 = 1, nk2 = 1;
-    f32_bwd_plan(B, Hq, Hkv, Sq, Sk, D, causal, Sk > Sq ? Sk - Sq : 0, -1, nq2, nk2);
+    f32_bwd_plan(B, Hq, Hkv, Sq, Sk, D, causal, Sk > Sq ? Sk - Sq : 0, device, nq2, nk2);
     const uint64_t nqm = nq > nq2 ? nq : nq2, nkm = nk > nk2 ? nk : nk2;
     const uint64_t a = nqm > 1 ? nqm * (uint64_t)B * Hq * Sq * D * 4 : 0, b = nkm > 1 ? 2 * nkm * (uint64_t)B * Hkv * Sk * D * 4 : 0;
     return a > b ? a : b;

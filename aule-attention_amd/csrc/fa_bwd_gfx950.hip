@@ -32,6 +32,7 @@ namespace aule_hip {
 static bool dkv4_timeline_wanted() { const char* e = std::getenv("AULE_TL"); return e != nullptr && e[0] == 'd' && e[1] == 'k'; }   // AULE_TL=dkv4 (debug library)
 bool bwd_dkv4_applicable(const BwdArgs& a);          // fa_bwd_dkv4_gfx950.hip: the one-wave-per-SIMD dK/dV kernel
 bool bwd_dkv4_forced();
+bool bwd_dkv4_k2(const BwdArgs& a);                    // D = 64: the two-key-blocks-per-wave instance (round 6)
 long long bwd_dkv4_items(const BwdArgs& a);
 bool bwd_dq4_applicable(const BwdArgs& a);           // fa_bwd_dq4_gfx950.hip: the one-wave-per-SIMD dQ kernel
 int bwd_dq4_mode();
@@ -43,7 +44,7 @@ bool bwd_dqs_applicable(const BwdArgs& a);           // fa_bwd_dqs_gfx950.hip: t
 int launch_bwd_delta16(const BwdArgs& a, float* lse2, float* ndelta, hipStream_t stream);
 int launch_bwd_dqs(const BwdArgs& a, hipStream_t stream);
 int configure_bwd_dqs();
-uint64_t bwd_f32_partial_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal);   // fa_bwd_f32.hip: planes of its small-grid pieces
+uint64_t bwd_f32_partial_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int device);   // fa_bwd_f32.hip: planes of its small-grid pieces
 namespace {
 
 // ------------------------------------------------------------------ delta ----
@@ -1084,7 +1085,7 @@ inline uint64_t delta_bytes(int B, int Hq, int Sq) {
 // AULE_HIP_BWD_DS_CAP_MB (default 8192) bounds the workspace: the batch runs in chunks of as many elements as the caller's buffer holds.
 // What the most recent backward launch of this process ran (aule_hip_debug_last_backward_route; tests pin the mode a shape takes with it)
 std::atomic<int> g_last_bwd_route{0};
-enum { kRouteSpill = 1, kRouteDq4 = 2, kRouteDkv4 = 4, kRouteDqOld = 8, kRouteDkvOld = 16, kRouteF32 = 32 };
+enum { kRouteSpill = 1, kRouteDq4 = 2, kRouteDkv4 = 4, kRouteDqOld = 8, kRouteDkvOld = 16, kRouteF32 = 32, kRouteDkv4K2 = 64 };
 
 inline int bwd_mode() {   // 0: auto (by AULE_HIP_BWD_DS_AUTO_MB), 1: recompute, 2: spill wherever applicable
     static const int m = [] {
@@ -1136,9 +1137,9 @@ inline uint64_t spill_bytes_per_batch(int B, int Hq, int Hkv, int Sq, int Sk, in
     }
     return pb;
 }
-inline uint64_t bwd_base_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype) {
+inline uint64_t bwd_base_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype, int device = -1) {
     uint64_t bytes = delta_bytes(B, Hq, Sq);
-    if (dtype == kF32) bytes += aule_hip::bwd_f32_partial_bytes(B, Hq, Hkv, Sq, Sk, D, causal);   // small grids: the key / query range pieces' planes
+    if (dtype == kF32) bytes += aule_hip::bwd_f32_partial_bytes(B, Hq, Hkv, Sq, Sk, D, causal, device);   // small grids: the key / query range pieces' planes
     if (dtype != kF32) {
         bytes += 2 * delta_bytes(B, Hq, Sq);   // L' = LSE log2(e) and - delta, published with delta
         const int sp = dkdv_gsplit(B, Hq, Hkv, Sk, causal);
@@ -1259,6 +1260,7 @@ int launch_bwd_16(const BwdArgs& a, hipStream_t stream) {
     {
         g_last_bwd_route |= kRouteDkv4;
         BwdArgs b = a;
+        if (bwd_dkv4_k2(b)) g_last_bwd_route |= kRouteDkv4K2;
         b.lse2 = p.lse2_out;
         b.ndelta = p.ndelta_out;
         return launch_bwd_dkv4(b, stream);
@@ -1338,13 +1340,13 @@ int launch_delta_f32(const BwdArgs& a, hipStream_t stream) {
 }
 
 // What launch_bwd NEEDS (delta, L', - delta, the head-split partials) ...
-uint64_t bwd_workspace_min_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype) {
-    return bwd_base_bytes(B, Hq, Hkv, Sq, Sk, D, causal, dtype);
+uint64_t bwd_workspace_min_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype, int device) {
+    return bwd_base_bytes(B, Hq, Hkv, Sq, Sk, D, causal, dtype, device);
 }
 // ... and what it WANTS: plus the dS workspace of the 5-matmul backward for as many batch elements as fit the cap (at least one).
 // A caller that passes only the minimum gets the recompute pair.
-uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype) {
-    uint64_t bytes = bwd_base_bytes(B, Hq, Hkv, Sq, Sk, D, causal, dtype);
+uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype, int device) {
+    uint64_t bytes = bwd_base_bytes(B, Hq, Hkv, Sq, Sk, D, causal, dtype, device);
     const uint64_t pb = spill_bytes_per_batch(B, Hq, Hkv, Sq, Sk, D, causal, dtype);
     if (pb > 0) {
         uint64_t nb = bwd_ds_cap_bytes() / pb;

@@ -105,6 +105,7 @@ struct BwdArgs {
     unsigned long long* dbg_dq = nullptr;   // ... of the dQ kernel's workgroup 0
     void* ds = nullptr;            // internal (16-bit path, 5-matmul backward): the dS workspace of this call's batch chunk (DsLayout)
     uint64_t ws_bytes = 0;         // bytes behind `delta` (0 = just bwd_workspace_min_bytes(): the recompute pair runs)
+    int device = -1;               // the descriptor's device ordinal (-1: the current one): the grid-sizing rules ask THAT device's CU count (as FwdArgs::device)
 };
 
 // The dS workspace of the 5-matmul backward (round 5; fa_bwd_dkv4_gfx950.hip SPILL instances write it, fa_bwd_dqs_gfx950.hip reads it).
@@ -181,14 +182,15 @@ uint64_t fwd_workspace_bytes(FwdArgs a);
 uint64_t paged_workspace_bytes(PagedArgs a);   // 0 fp32, 1 ping-pong, 2 in-wave, 3 v1, 4 split-KV, 5 tiled + packed rows + KV splits (host logic only)
 int launch_bwd(const BwdArgs& a, hipStream_t stream);
 // bit mask of what the most recent launch_bwd of this process ran: 1 the 5-matmul mode (delta pass + spilling dK/dV kernel + dQ = dS K),
-// 2 / 4 the one-wave-per-SIMD dQ / dK/dV kernel, 8 / 16 their two-waves-per-SIMD predecessors, 32 the fp32 kernels; 0 before the first
+// 2 / 4 the one-wave-per-SIMD dQ / dK/dV kernel, 8 / 16 their two-waves-per-SIMD predecessors, 32 the fp32 kernels, 64 (with 4) the D = 64
+// dK/dV instance with two key blocks per wave; 0 before the first
 int bwd_last_route();
 
 // Bytes of device workspace launch_bwd needs: delta [B,Hq,Sq] fp32, plus (16-bit GQA/MQA problems that
 // do not fill the chip) fp32 dK/dV partials of the head-split dK/dV kernel.
-uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype);
+uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype, int device = -1);
 // ... of which launch_bwd cannot do without (the rest is the dS workspace of the 5-matmul backward: fa_bwd_gfx950.hip)
-uint64_t bwd_workspace_min_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype);
+uint64_t bwd_workspace_min_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype, int device = -1);
 
 // Set the max-dynamic-LDS attribute on every kernel (call once per device).
 int configure_kernels();

@@ -263,7 +263,8 @@ const char* aule_hip_build_info(void);
 int32_t aule_hip_debug_forward_route(const aule_attn_desc* desc);
 /* Debug: bit mask of the kernels the most recent backward launch of this process ran -- 1 the 5-matmul mode (delta pass, dK/dV kernel  */
 /* spilling its dS, dQ = dS K), 2 / 4 the one-wave-per-SIMD dQ / dK/dV kernel, 8 / 16 their two-waves-per-SIMD predecessors, 32 the    */
-/* fp32 kernels; 0 before the first backward.  Lets a test assert the mode a shape takes by itself.                        */
+/* fp32 kernels, 64 (with 4) the D = 64 dK/dV instance with two key blocks per wave; 0 before the first backward.  Lets a test assert  */
+/* the mode a shape takes by itself.                                                                                      */
 int32_t aule_hip_debug_last_backward_route(void);
 /* Debug: the causal-split plan of route 7 (small causal grids) as integers -- out = {pieces n, pairs, then per pair of   */
 /* Q blocks: tiles of the far block, of the near block, cut positions b[0..8]}; returns the ints written (negative: the */

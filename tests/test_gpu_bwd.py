@@ -183,6 +183,10 @@ def test_gradients_at_the_sizes_the_bench_times(torch_cuda, oracle_mod, case):
         grad_close(f(q.grad[b, hs]), rq, "bf16", "%s dq[%d,%d]" % (name, b, hk))
         grad_close(f(k.grad[b, hk]), rk, "bf16", "%s dk[%d,%d]" % (name, b, hk))
         grad_close(f(v.grad[b, hk]), rv, "bf16", "%s dv[%d,%d]" % (name, b, hk))
+    if name == "d64" and not any(os.environ.get(k) for k in ("AULE_HIP_BWD_MODE", "AULE_HIP_BWD_DKV", "AULE_HIP_BWD_DQ", "AULE_HIP_BWD_DKV_K2")):
+        # bench.py's D = 64 training shape takes the two-key-blocks-per-wave dK/dV instance by itself (1024 work items of 256 keys)
+        from aule import _capi
+        assert int(_capi.get_lib().aule_hip_debug_last_backward_route()) == 2 | 4 | 64
     # every unit that was not judged in fp64: finite, and not left at its allocation's content (the kernels write every row)
     for t in (q.grad, k.grad, v.grad):
         assert torch.isfinite(t.float()).all()
@@ -261,14 +265,17 @@ def test_backward_deterministic(torch_cuda):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("which", ["spill", "new", "old"])
+@pytest.mark.parametrize("which", ["spill", "new", "old", "k2", "k1"])
 def test_backward_on_the_one_wave_per_simd_kernels(which):
     """Three backward modes over the same suites (the switches are read once per process, hence subprocesses):
       spill  AULE_HIP_BWD_MODE=spill: the 5-matmul backward (round 5: delta pass, fa_bwd_dkv4_gfx950.hip's SPILL instances,
              fa_bwd_dqs_gfx950.hip; an opt-in mode, profiles/r5_bwd_spill.txt) forced onto every problem it CAN run
              (AULE_HIP_BWD_DKV=new lifts the grid rule);
       new    AULE_HIP_BWD_MODE=recompute + the one-wave-per-SIMD pair (fa_bwd_dkv4 / fa_bwd_dq4) forced wherever it can run;
-      old    AULE_HIP_BWD_MODE=recompute + both predecessors (fa_bwd_gfx950.hip) everywhere.
+      old    AULE_HIP_BWD_MODE=recompute + both predecessors (fa_bwd_gfx950.hip) everywhere;
+      k2     (round 6) as `new`, and every D = 64 problem on the dK/dV instance with TWO key blocks per wave (AULE_HIP_BWD_DKV_K2=1: 256-key work
+             items; by itself only grids that fill the chip take it) -- its masks per key block, ragged second blocks, the one-buffer delta pipeline;
+      k1     as `new` with that instance off: the one-block D = 64 stream on the shapes that would leave it.
     The sweep, the reference's golden gradients, the bottom-right cases and the determinism test then exercise the masks, the stream
     start / tail, the idle waves, the GQA loop and the dS workspace addressing of each mode on all of them."""
     import subprocess
@@ -278,6 +285,10 @@ def test_backward_on_the_one_wave_per_simd_kernels(which):
     if which == "spill":
         e["AULE_HIP_BWD_DKV"] = "new"
         e["AULE_HIP_BWD_MODE"] = "spill"
+    elif which in ("k2", "k1"):
+        e["AULE_HIP_BWD_MODE"] = "recompute"
+        e["AULE_HIP_BWD_DKV"] = e["AULE_HIP_BWD_DQ"] = "new"
+        e["AULE_HIP_BWD_DKV_K2"] = "1" if which == "k2" else "0"
     else:
         e["AULE_HIP_BWD_MODE"] = "recompute"
         e["AULE_HIP_BWD_DKV"] = which

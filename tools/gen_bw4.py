@@ -422,15 +422,296 @@ def gen_struct(c):
     return s
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# Round 6: D = 64 with TWO 32-key blocks per wave (Bw4Asm2<T>; workgroup = 4 waves x 64 keys = a 256-key KV block).
+#
+# Why (profiles/r5_bwd_d64_ablation.txt): at D = 64 an iteration is 16 MFMAs (512 cycles of matrix pipe) inside ~1300 cycles of in-order
+# issue -- the same 16 scores per lane of arithmetic, the same 24 LDS reads, 8 scalar loads and 2 LDS-DMA pieces as at D = 128 behind
+# half the MFMAs.  With two key blocks A, B per wave every fragment of the query block feeds TWO MFMAs: 32 MFMAs (1024 cycles) per
+# iteration for twice the arithmetic and the SAME LDS reads, scalar loads, requests, barrier and compiler scalars.
+#
+#     phase 1   S'_A, S'_B of block i + 1 (8 MFMAs)  |  the arithmetic of block i, key block A  |  its 16 transpose reads
+#     ---- s_waitcnt vmcnt(NP) lgkmcnt(0); s_barrier ----
+#     phase 2   dP'_A of block i + 1 (4 MFMAs: they overwrite the dP_A the arithmetic has consumed -- ONE dP buffer), dV_A, dK_A of block i (8)
+#               |  the arithmetic of block i, key block B;  then dP'_B (4), dV_B, dK_B (8)  |  L' of block i + 2 (behind the arithmetic that reads
+#               its buffer), the dO fragments and - delta of block i + 2 (behind the last dP' MFMA: ONE delta buffer, read as their C operand),
+#               the LDS-DMA requests last.  (First build, session r6_s5: all arithmetic in phase 1 -- 8 MFMAs against 900 cycles of VALU issue
+#               there, 24 MFMAs against 650 in phase 2: B8 H32 S2048 694.6 -> 590.6 us; this split: see profiles/r6_bwd_d64_k2.txt.)
+#
+# Register map (NV = 40 like D = 128):
+#     accumulator file                                     arch VGPRs
+#     a[0:31] dV_A^T   a[32:63] dV_B^T                      v[40:47]   T      v[48:63]   DL (- delta, one buffer)
+#     a[64:95] dK_A^T  a[96:127] dK_B^T                     v[64:95]   LD[2]  L' by block parity
+#     a[128:143] K_A   a[144:159] K_B  fragments            v[96:111]  DS_A, DS_B (8 each)      v[112:127] P_A, P_B
+#     a[160:175] V_A   a[176:191] V_B                       v[128:159] DP_A, DP_B (one buffer)
+#     a[192:207] Q_b   a[208:223] dO_b  row-major           v[160:223] S[parity][A, B]
+#                                                           v[224:239] Y   v[240:255] X   transposed fragments of Q_b / dO_b
+# BW4_K2_SPLIT=1 (experiment, measured slower: profiles/r6_bwd_d64_k2.txt): key block B's arithmetic in phase 2, behind the dV_A / dK_A MFMAs, instead of
+# phase 1 -- phase 1 then has 8 MFMAs for half the VALU work, phase 2 24 MFMAs for the other half
+K2_SPLIT = os.environ.get("BW4_K2_SPLIT", "0") == "1"
+
+
+class Cfg2:
+    def __init__(self, dt):
+        b = Cfg(64, dt)
+        self.D, self.dt, self.RB, self.KS, self.DB, self.NST = 64, dt, 128, 4, 2, 4
+        self.mfma, self.cvt = b.mfma, b.cvt
+        self.PBASE, self.IMG, self.NP, self.SLOT = b.PBASE, b.IMG, b.NP, b.SLOT
+        self.DV, self.DK = (0, 32), (64, 96)
+        self.KF, self.VF = (128, 144), (160, 176)
+        self.QA, self.DA = 192, 208
+        self.X, self.Y = 240, 224
+        self.DP, self.P, self.DS = (128, 144), (112, 120), (96, 104)
+        self.LD, self.DL, self.T, self.NV = (64, 80), 48, 40, 40
+
+    def S(self, par, blk):
+        return 160 + 32 * par + 16 * blk
+
+    def frag(self, base, i, file="a"):
+        return f"{file}[{base + 4 * i}:{base + 4 * i + 3}]"
+
+
+def arith2(c, par, blk, q, masked):
+    """P / dS of scores 4 q .. 4 q + 3 of key block blk (the arithmetic of arith_ops on this map; masks per key block)"""
+    S, DPr, LD = c.S(par, blk), c.DP[blk], c.LD[par]
+    t = [c.T + i for i in range(8)]
+    r0 = 4 * q
+    sfx = "ab"[blk]
+    ops = [f"v_fma_f32 v{t[i]}, v{S + r0 + i}, %[c], -v{LD + r0 + i}" for i in range(4)]
+    ops += [f"v_exp_f32 v{t[i]}, v{t[i]}" for i in range(4)]
+    if masked:
+        tm = c.DS[blk] + r0 // 2
+        for i in range(4):
+            ops += [f"v_sub_u32 v{tm}, {crow(r0 + i)}, %[lo{sfx}]", f"v_cmp_gt_u32 vcc, %[wd{sfx}], v{tm}", f"v_cndmask_b32 v{t[i]}, 0, v{t[i]}, vcc"]
+    ops += [f"v_mul_f32 v{t[4 + i]}, v{t[i]}, v{DPr + r0 + i}" for i in range(4)]
+    for j in range(2):
+        ops.append(f"{c.cvt} v{c.P[blk] + r0 // 2 + j}, v{t[2 * j]}, v{t[2 * j + 1]}")
+        ops.append(f"{c.cvt} v{c.DS[blk] + r0 // 2 + j}, v{t[4 + 2 * j]}, v{t[5 + 2 * j]}")
+    return ops
+
+
+def gen2_p1(c, q, par, qk, ar, tr):
+    """phase-1 statement q: S' of block i + 1 for BOTH key blocks (k-slice q), the arithmetic of block i for key block A only (scores 4 q ..; key
+    block B's runs in phase 2, behind the dV_A / dK_A MFMAs: the VALU work is split over the two phases like the MFMAs), transpose reads of step q."""
+    mf, clob = [], ["memory"]
+    npar = par ^ 1
+    if qk:
+        for b in (0, 1):
+            s = tup(c.S(npar, b), 16)
+            mf.append(f"{c.mfma} {s}, {c.frag(c.QA, q)}, {c.frag(c.KF[b], q)}, {'0' if q == 0 else s}")
+            clob += vregs(c.S(npar, b), 16)
+    valu = []
+    blocks = (0,) if K2_SPLIT else (0, 1)
+    if ar:
+        for b in blocks:
+            valu += arith2(c, par, b, q, ar == 2)
+            clob += vregs(c.P[b] + 2 * q, 2) + vregs(c.DS[b] + 2 * q, 2)
+        clob += vregs(c.T, 8) + (["vcc"] if ar == 2 else [])
+    lds = []
+    if tr:
+        lds = tr_reads(c, q)
+        clob += vregs(c.X + 4 * q, 4) + vregs(c.Y + 4 * q, 4)
+    fill = lds + valu
+    lines = deal(mf, fill)
+    if qk and not fill:
+        lines += ["s_nop 7", "s_nop 7"]
+    ins = []
+    if ar:
+        ins.append('[c] "s"(c)')
+        if ar == 2:
+            ins += ['[loa] "v"(loa)', '[wda] "v"(wda)'] + ([] if K2_SPLIT else ['[lob] "v"(lob)', '[wdb] "v"(wdb)'])
+    if tr:
+        ins.append('[trb] "v"(trb)')
+    return emit_asm(xfilter(lines), [], ins, list(dict.fromkeys(clob)))
+
+
+def gen2_p2(c, q, par, mm, rm, ld, dma, qk, ar):
+    """phase-2 statement q.  MFMA order: dP'_A (4), dV_A / dK_A (8) -- statements 0, 1, with the arithmetic of block i for key block B as their
+    filler (ar: 0 none, 1 plain, 2 masked; two groups of four scores per statement) --, then dP'_B (4: behind the arithmetic, which reads the dP_B
+    they overwrite), dV_B / dK_B (8) -- statements 2, 3, with L' of block i + 2 (behind the arithmetic, which reads the buffer it lands in), the dO
+    fragments of block i + 2 and - delta of block i + 2 (both behind the last dP' MFMA) and, last of all requests, the two LDS-DMA pieces."""
+    L, clob = [], ["memory"]
+
+    def dps(b):
+        dp = tup(c.DP[b], 16)
+        return [f"{c.mfma} {dp}, {c.frag(c.DA, ks)}, {c.frag(c.VF[b], ks)}, {tup(c.DL, 16) if ks == 0 else dp}" for ks in range(c.KS)]
+
+    def mms(b):
+        out = []
+        for st in range(c.NST):
+            kk, d = st // c.DB, st % c.DB
+            dv = f"a[{c.DV[b] + 16 * d}:{c.DV[b] + 16 * d + 15}]"
+            dk = f"a[{c.DK[b] + 16 * d}:{c.DK[b] + 16 * d + 15}]"
+            out.append(f"{c.mfma} {dv}, {c.frag(c.X, st, 'v')}, {c.frag(c.P[b], kk, 'v')}, {dv}")
+            out.append(f"{c.mfma} {dk}, {c.frag(c.Y, st, 'v')}, {c.frag(c.DS[b], kk, 'v')}, {dk}")
+        return out
+
+    if K2_SPLIT:
+        for b in (0, 1):
+            L += (dps(b) if qk else []) + (mms(b) if mm else [])
+    else:
+        # all of dP' first (key blocks interleaved: the chains alternate), then the dV / dK steps with both key blocks behind each fragment
+        da, db_, ma, mb = dps(0), dps(1), mms(0), mms(1)
+        if qk:
+            L += [x for pair in zip(da, db_) for x in pair]
+        if mm:
+            for st in range(c.NST):
+                L += [ma[2 * st], mb[2 * st], ma[2 * st + 1], mb[2 * st + 1]]
+    per = (len(L) + 3) // 4
+    mf = L[q * per:(q + 1) * per]
+    for ln in mf:
+        dst = ln.split()[1].rstrip(",")
+        lo, hi = (int(x) for x in dst[2:-1].split(":"))
+        clob += (aregs if dst[0] == "a" else vregs)(lo, hi - lo + 1)
+    fill, ins = [], []
+    if ar and q < 2 and K2_SPLIT:
+        for grp in (2 * q, 2 * q + 1):
+            fill += arith2(c, par, 1, grp, ar == 2)
+            clob += vregs(c.P[1] + 2 * grp, 2) + vregs(c.DS[1] + 2 * grp, 2)
+        clob += vregs(c.T, 8) + (["vcc"] if ar == 2 else [])
+        ins.append('[c] "s"(c)')
+        if ar == 2:
+            ins += ['[lob] "v"(lob)', '[wdb] "v"(wdb)']
+    if rm:
+        if mm and not K2_SPLIT:
+            # Q fragments (k-slices 2 q, 2 q + 1) in statements 0, 1; dO fragments in statements 2, 3: behind the last dP' MFMA (statement 1's
+            # second), which reads the dO fragments of block i + 1 these reads overwrite
+            t = 0 if q < 2 else 1
+            reads = [(2 * (q & 1), t), (2 * (q & 1) + 1, t)]
+        elif mm:
+            # Q fragments (k-slices 2 q, 2 q + 1) in statements 0, 1; the four dO fragments in statement 3: behind the last dP' MFMA (statement
+            # 2's fourth), which reads the dO fragments of block i + 1 these reads overwrite
+            reads = [(2 * q, 0), (2 * q + 1, 0)] if q < 2 else ([(ks, 1) for ks in range(c.KS)] if q == 3 else [])
+        else:
+            order = [(ks, t) for ks in range(c.KS) for t in (0, 1)]
+            reads = order[2 * q:2 * q + 2]
+        for ks, t in reads:
+            fill.append(f"ds_read_b128 {c.frag(c.DA if t else c.QA, ks)}, %[ra{'1' if ks & 1 else ''}] offset:{t * c.IMG + 512 * (ks >> 1)}")
+            clob += aregs((c.DA if t else c.QA) + 4 * ks, 4)
+        ins += ['[ra] "v"(ra)', '[ra1] "v"(ra1)']
+    ldq = 2 if K2_SPLIT else 0      # L' in statement ldq, - delta in statement ldq + 1 (not split: L' may go first -- its buffer was consumed in phase 1;
+    #                                 - delta behind statement 0's first two MFMAs, which read the buffer as their C operand)
+    if ld and ldq <= q < ldq + 2:
+        base = c.LD[par] if q == ldq else c.DL
+        srd = "%[lsrd]" if q == ldq else "%[dsrd]"
+        for g in range(4):
+            fill.append(f"buffer_load_dwordx4 v[{base + 4 * g}:{base + 4 * g + 3}], %[lvo], {srd}, %[lso] offen offset:{32 * g}")
+        clob += vregs(base, 16)
+        ins += ['[lsrd] "s"(lsrd)' if q == ldq else '[dsrd] "s"(dsrd)', '[lso] "s"(lso)', '[lvo] "v"(lvo)']
+    lines = deal(mf, fill)
+    if mf and not fill and not mm:
+        lines += ["s_nop 7", "s_nop 7"]
+    if dma and q == 3:
+        # the two pieces behind everything else (the boundary's vmcnt(NP) must leave exactly them out): the M0 write of a piece in front of one
+        # of the statement's last two MFMAs, its request behind that MFMA (an M0 write and the request that reads it have to be an instruction apart)
+        mi = [j for j, o in enumerate(lines) if o.startswith("v_mfma")]
+        assert len(mi) >= 2
+        tail = lines[mi[-1] + 1:]                       # fillers dealt behind the last MFMA: they go in front of it
+        lines = lines[:mi[-2]] + lines[mi[-2] + 1:mi[-1]] + tail + \
+            [f"s_add_u32 m0, %[dlds], 0", lines[mi[-2]], "buffer_load_dwordx4 %[vost0], %[qsrd], %[dso] offen lds",
+             f"s_add_u32 m0, %[dlds], {c.IMG}", lines[mi[-1]], "buffer_load_dwordx4 %[vost0], %[gsrd], %[dso] offen lds"]
+        clob += ["m0", "scc"]
+        ins += ['[dlds] "s"(dlds)', '[qsrd] "s"(qsrd)', '[gsrd] "s"(gsrd)', '[dso] "s"(dso)', '[vost0] "v"(vost0)']
+    return emit_asm(xfilter(lines), [], ins, list(dict.fromkeys(clob)))
+
+
+def gen2_struct(c):
+    name = f"Bw4Asm2<{'Bf16Traits' if c.dt == 'bf16' else 'F16Traits'}>"
+    s = f"template <> struct {name} {{\n"
+    s += f"    static constexpr int NV = {c.NV}, NP = {c.NP}, SLOT = {c.SLOT}, IMG = {c.IMG}, PB1 = {c.PBASE[1]}, PB2 = {c.PBASE[2]}, PB4 = 0, ST_LATE = 0, SPLIT = {int(K2_SPLIT)};   // NV: hipcc's VGPR budget (amdgpu_num_vgpr); SPLIT: key block B's arithmetic in phase 2\n"
+    s += ("    template <int Q, int PAR, int QK, int AR, int TR>\n"
+          "    static __device__ __forceinline__ void p1(float c, int loa, int wda, int lob, int wdb, unsigned trb) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n        (void)c; (void)loa; (void)wda; (void)lob; (void)wdb; (void)trb;\n")
+    first = True
+    for q in range(4):
+        for par in range(2):
+            for (qk, ar, tr) in ((1, 1, 1), (1, 2, 1), (0, 1, 1), (0, 2, 1), (1, 0, 0)):
+                s += f"        {'if' if first else 'else if'} constexpr (Q == {q} && PAR == {par} && QK == {qk} && AR == {ar} && TR == {tr}) {{\n"
+                s += gen2_p1(c, q, par, qk, ar, tr) + "        }\n"
+                first = False
+    s += "        else static_assert(Q < 0, \"fa_bwd_dkv4_asm.inc: phase-1 variant not generated\");\n#endif\n    }\n"
+    s += ("    template <int Q, int PAR, int MM, int RM, int LD, int DMA, int QK, int AR>\n"
+          "    static __device__ __forceinline__ void p2(float c, int lob, int wdb, unsigned ra, unsigned ra1, __amdgpu_buffer_rsrc_t lsrd, __amdgpu_buffer_rsrc_t dsrd, unsigned lvo,\n"
+          "                                              unsigned lso, unsigned dlds, __amdgpu_buffer_rsrc_t qsrd, __amdgpu_buffer_rsrc_t gsrd, unsigned dso, unsigned vost0) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n"
+          "        (void)c; (void)lob; (void)wdb; (void)ra; (void)ra1; (void)lsrd; (void)dsrd; (void)lvo; (void)lso; (void)dlds; (void)qsrd; (void)gsrd; (void)dso; (void)vost0;\n"
+          "        if constexpr (DMA != 0) {\n            dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n            dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n        }\n"
+          "        if constexpr (LD != 0) lso = (unsigned)__builtin_amdgcn_readfirstlane((int)lso);\n")
+    first = True
+    for q in range(4):
+        for par in range(2):
+            for (mm, rm, ld, dma, qk, ar) in ((1, 1, 1, 1, 1, 1), (1, 1, 1, 1, 1, 2), (1, 1, 1, 1, 0, 1), (1, 1, 1, 1, 0, 2), (0, 1, 0, 0, 0, 0), (0, 0, 0, 0, 1, 0)):
+                s += f"        {'if' if first else 'else if'} constexpr (Q == {q} && PAR == {par} && MM == {mm} && RM == {rm} && LD == {ld} && DMA == {dma} && QK == {qk} && AR == {ar}) {{\n"
+                s += gen2_p2(c, q, par, mm, rm, ld, dma, qk, ar) + "        }\n"
+                first = False
+    s += "        else static_assert(Q < 0, \"fa_bwd_dkv4_asm.inc: phase-2 variant not generated\");\n#endif\n    }\n"
+    # ---- K / V fragments of the wave's two 32-key blocks: lane (key, hi) holds d = 16 ks + 8 hi .. + 7 of key row n0w + key (vo) and n0w + 32 + key (vo1)
+    lines = ["s_nop 4"]
+    for b, vo in ((0, "%[vo]"), (1, "%[vo1]")):
+        for ks in range(c.KS):
+            lines.append(f"buffer_load_dwordx4 {c.frag(c.KF[b], ks)}, {vo}, %[ksrd], 0 offen offset:{32 * ks}")
+            lines.append(f"buffer_load_dwordx4 {c.frag(c.VF[b], ks)}, {vo}, %[vsrd], 0 offen offset:{32 * ks}")
+    lines.append("s_waitcnt vmcnt(0)")
+    s += "    static __device__ __forceinline__ void load_kv(__amdgpu_buffer_rsrc_t ksrd, __amdgpu_buffer_rsrc_t vsrd, unsigned vo, unsigned vo1) {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+    s += emit_asm(lines, [], ['[ksrd] "s"(ksrd)', '[vsrd] "s"(vsrd)', '[vo] "v"(vo)', '[vo1] "v"(vo1)'], ["memory"] + aregs(c.KF[0], 64), indent="        ")
+    s += "#endif\n    }\n"
+    lines = [f"v_accvgpr_write_b32 a{i}, 0" for i in range(128)]
+    s += "    static __device__ __forceinline__ void zero_acc() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+    s += emit_asm(lines, [], [], aregs(0, 128), indent="        ")
+    s += "#endif\n    }\n"
+    # ---- stream start: L' of a block into LD[PAR]; WITH_DL: its - delta into the delta buffer too
+    s += ("    template <int PAR, int WITH_DL>\n    static __device__ __forceinline__ void load_scal(__amdgpu_buffer_rsrc_t lsrd, __amdgpu_buffer_rsrc_t dsrd, unsigned lvo, unsigned lso) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n        lso = (unsigned)__builtin_amdgcn_readfirstlane((int)lso);\n")
+    first = True
+    for par in range(2):
+        for wd in range(2):
+            lines = ["s_nop 4"]
+            for g in range(4):
+                lines.append(f"buffer_load_dwordx4 v[{c.LD[par] + 4 * g}:{c.LD[par] + 4 * g + 3}], %[lvo], %[lsrd], %[lso] offen offset:{32 * g}")
+                if wd:
+                    lines.append(f"buffer_load_dwordx4 v[{c.DL + 4 * g}:{c.DL + 4 * g + 3}], %[lvo], %[dsrd], %[lso] offen offset:{32 * g}")
+            lines.append("s_waitcnt vmcnt(0)")
+            s += f"        {'if' if first else 'else if'} constexpr (PAR == {par} && WITH_DL == {wd}) {{\n"
+            s += emit_asm(lines, [], ['[lsrd] "s"(lsrd)', '[dsrd] "s"(dsrd)', '[lvo] "v"(lvo)', '[lso] "s"(lso)'],
+                          ["memory"] + vregs(c.LD[par], 16) + (vregs(c.DL, 16) if wd else []))
+            s += "        }\n"
+            first = False
+    s += "#endif\n    }\n"
+    # ---- stream start: - delta of block 1 (the C operand of dP_1 in iteration 0's phase 2) parked in X, moved to DL once dP_0 is under way
+    lines = ["s_nop 4"] + [f"buffer_load_dwordx4 v[{c.X + 4 * g}:{c.X + 4 * g + 3}], %[lvo], %[dsrd], %[lso] offen offset:{32 * g}" for g in range(4)]
+    s += ("    static __device__ __forceinline__ void load_delta_x(__amdgpu_buffer_rsrc_t dsrd, unsigned lvo, unsigned lso) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n        lso = (unsigned)__builtin_amdgcn_readfirstlane((int)lso);\n")
+    s += emit_asm(lines, [], ['[dsrd] "s"(dsrd)', '[lvo] "v"(lvo)', '[lso] "s"(lso)'], ["memory"] + vregs(c.X, 16), indent="        ")
+    s += "#endif\n    }\n"
+    lines = ["s_nop 7", "s_nop 7"] + [f"v_mov_b32 v{c.DL + i}, v{c.X + i}" for i in range(16)]
+    s += "    static __device__ __forceinline__ void mov_delta_x() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+    s += emit_asm(lines, [], [], ["memory"] + vregs(c.DL, 16), indent="        ")
+    s += "#endif\n    }\n"
+    lines = ["s_nop 4"]
+    for img in range(2):
+        srd = "%[qsrd]" if img == 0 else "%[gsrd]"
+        lines += [f"s_add_u32 m0, %[dlds], {img * c.IMG}", "s_nop 0", f"buffer_load_dwordx4 %[vost0], {srd}, %[dso] offen lds"]
+    s += ("    static __device__ __forceinline__ void dma_block(unsigned dlds, __amdgpu_buffer_rsrc_t qsrd, __amdgpu_buffer_rsrc_t gsrd, unsigned dso, unsigned vost0) {\n"
+          "#if defined(__HIP_DEVICE_COMPILE__)\n"
+          "        dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n        dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n")
+    s += emit_asm(lines, [], ['[dlds] "s"(dlds)', '[qsrd] "s"(qsrd)', '[gsrd] "s"(gsrd)', '[dso] "s"(dso)', '[vost0] "v"(vost0)'], ["memory", "m0", "scc"], indent="        ")
+    s += "#endif\n    }\n"
+    s += "};\n\n"
+    return s
+
+
 def main():
     hdr = ("// fa_bwd_dkv4_asm.inc -- GENERATED by tools/gen_bw4.py (do not edit; edit the generator and re-run it).\n"
            "// Instruction streams of the one-wave-per-SIMD dK / dV kernel: register map, pipeline and hazards in the generator's docstring.\n"
            "// Included by fa_bwd_dkv4_gfx950.hip inside namespace aule_hip::{anonymous}.\n\n"
-           "template <class T, int D> struct Bw4Asm;\n\n")
+           "template <class T, int D> struct Bw4Asm;\n"
+           "template <class T> struct Bw4Asm2;   // D = 64, two 32-key blocks per wave (round 6)\n\n")
     body = ""
     for D in (128, 64):
         for dt in ("bf16", "fp16"):
             body += gen_struct(Cfg(D, dt))
+    for dt in ("bf16", "fp16"):
+        body += gen2_struct(Cfg2(dt))
     with open(OUT, "w") as fh:
         fh.write(hdr + body)
     for D in (128, 64):
