@@ -70,6 +70,7 @@ struct FwdW4Params {
     unsigned magic;
     float* part;       // [npiece][part_rows][D + kPartPad]
     int part_rows;     // B * Hq * Sq
+    int window;        // sliding window (round 6, WIN instances only): query at position x sees keys x - window < k <= x; 0: none
     int generic;       // AULE_HIP_W4_BODIES=generic: every step through the generic bodies (the embedded-request flow off: A/B, bit-identity test)
     unsigned long long* dbg;   // timeline build only: [4 waves][kW4TLMax] tagged s_memtime stamps of workgroup 0
 };
@@ -109,9 +110,18 @@ template <int D> constexpr int w4_lds_bytes() {   // 3 K + 3 V ring slots, one 3
     return 6 * 64 * 2 * D + 4 * 32 * (2 * D + 16) + kW4MaxSlot * 20 + 16;
 }
 
-template <class T, int D, bool CAUSAL, bool TL>
+// WIN (round 6): causal sliding window.  A part is the range of its block's key tiles any of its rows sees (the part table's tile range, as
+// for the key-range pieces); a WAVE starts at the first tile ITS 64 rows see (rounded down to an even position: the parity copies of the
+// score / weight registers then line up with a part's own start): positions in front of it are idle ones, the position in front of its first
+// tile runs the part prologue's body on that tile ("wave prologue": bare QK^T, references, P[A]); tiles that cross the window's left edge
+// take the two-sided mask variants of the streams (SM 5: lo <= key <= thr).  The fixed reference of a row is the maximum of the wave's first
+// tile under the CAUSAL mask only -- the keys in front of the window are real keys of the same head: a finite reference of the right size
+// even for the rows whose window starts in the next tile -- and the exact-maximum stream takes the maximum under both bounds.
+template <class T, int D, bool CAUSAL, bool TL, bool WIN = false>
 __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     using A = W4Asm<T, D>;
+    static_assert(!WIN || (CAUSAL && !TL && !A::PRE), "window instances: causal, no timeline build, no pre-scaled form");
+    constexpr int MK = WIN ? 5 : 2;   // SM code of a masked softmax statement
     using std::integral_constant;
     constexpr int RB = 2 * D, RBP = RB + 16, CPR = RB / 16, KS = D / 16, DB = D / 32;
     constexpr int KT = 64 * RB, VT = KT, NP = KT / 4096, NQ = 2 * KS;   // NQ: buffer loads of a wave's Q fragments
@@ -156,6 +166,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         return (KernargPtr)(uintptr_t)(((unsigned long long)hi << 32) | lo);
     };
     const int Sk = p.Sk, coff = p.coff;
+    const int win = WIN ? p.window : 0;
     const float c = p.c;
     const bool rope = p.rcos != nullptr;
     const bool embedded = p.generic == 0;
@@ -227,6 +238,13 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 else if (far != w.blk) qb = w.blk;
             } else if ((tid & 1) == 0) {
                 qb = w.blk;
+                if constexpr (WIN) {   // the key tiles the block's rows see: from its first row's first key to its last row's diagonal
+                    // (a part has at least four tiles -- a ragged last block under a short window would have fewer: tiles in front of the window
+                    // are masked like any other key outside it)
+                    const int t1 = (max(1, min(Sk, qb * kQBlock + kQBlock + coff)) + kKVTile - 1) / kKVTile;
+                    const int t0 = min(max(0, qb * kQBlock + coff - win + 1) / kKVTile, max(0, t1 - 4));
+                    if (t0 > 0) range = t0 | (t1 << 16);
+                }
             }
         }
         tab[tid] = int4{(w.b * p.Hq + w.h) * p.Sq, (w.b * p.Hkv + w.hk) * Sk, qb, range};
@@ -304,6 +322,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
 
         // ---- part scalars
         int qoff, kvoff, qb, nt, nt3, na, jm, r0;   // nt3: nt rounded up to a multiple of 3 (idle steps pad the part: every part starts at ring phase 0)
+        int f0 = 0, jl = 0;         // WIN: the wave's first position with arithmetic (even), the first tile no row of the wave sees cut by the window's left edge
         int tb = 0, pid = 0;        // first key tile of the part's range (kvoff already points at it), partial plane + 1 (0: O is final)
         unsigned nrec = oob;        // bytes of the head's K / V behind kvoff: the descriptors' bound (rows >= Sk read as zeros)
         int n_slot;
@@ -376,6 +395,13 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             // logic once per kernel and keeps the ~25 results -- 64-bit lane masks -- alive across the stream: 48 scalar spills
             // and, with the spill lanes' own register, a vector spill to scratch in the non-causal D = 128 instance)
             asm volatile("" : "+s"(nt), "+s"(nt3), "+s"(na), "+s"(jm));
+            if constexpr (WIN) {
+                const int lo_first = max(0, r0 + coff - win + 1);        // first key the wave's FIRST row sees, ... its LAST row sees:
+                const int lo_last = max(0, r0 + 63 + coff - win + 1);
+                f0 = min(max(0, (lo_first >> 6) - tb), na - 1) & ~1;
+                jl = max(0, ((lo_last + kKVTile - 1) >> 6) - tb);
+                asm volatile("" : "+s"(f0), "+s"(jl));
+            }
             n_slot = next_valid(sl);
             pre = !REDO && n_slot < nslot;
             q_asked = false;
@@ -393,6 +419,13 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             const int row = r0 + 32 * qbsel + (lane_o & 31) + coff;
             return (CAUSAL ? min(row, Sk - 1) : Sk - 1) - (lane_o >> 5) * 4 - 64 * (j + tb);
         };
+        // WIN: first visible key (minus 4 hi) of the lane's row in block QB, relative to tile j: key k of the tile is visible iff lo <= k (<= thr)
+        auto lo_of = [&](int qbsel, int j) __attribute__((always_inline)) {
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            return r0 + 32 * qbsel + (lane_o & 31) + coff - win + 1 - (lane_o >> 5) * 4 - 64 * (j + tb);
+        };
+        auto masked_at = [&](int j) __attribute__((always_inline)) { return j >= jm || (WIN && j < jl); };
         // after step j: the ring moves on, the cursors of step j + 1 (K tile j + 5, V tile j + 3)
         auto advance = [&](int j) __attribute__((always_inline)) {
             rp = slot(1);
@@ -620,21 +653,24 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             if constexpr (PV == 2)   // tile 0: K_3 goes where K_0 was (this step's tile barrier freed the slot); it is older than this
                                      // step's own requests, so the NEXT tile barrier covers it.  (The embedded-request step 0 carries
                                      // the same four pieces in its first statement.)
-                A::dma_tile(ring_lds(0, 0), head_srd(kbase, kvoff, Sk - tb * kKVTile), 3u * KT, kvo);
+                if (!WIN || j == 0)  // (WIN: a wave that starts late asked for its pieces of K_3 in its idle position 0)
+                    A::dma_tile(ring_lds(0, 0), head_srd(kbase, kvoff, Sk - tb * kKVTile), 3u * KT, kvo);
             const int n = requests();
             const unsigned vap = va + (unsigned)rp * VT, kb = ka0 + (unsigned)slot(2) * KT;
-            const int tB = SMB == 2 ? thr_of(1, j) : 0;
-            constexpr int SMB1 = PV == 2 ? SMB + 2 : SMB;   // tile 0: S_0 is the prologue's bare QK^T (streams: SM 3 / 4)
-            A::template p1<0, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
-            A::template p1<1, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
-            A::template p1<2, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
-            A::template p1<3, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0);
+            const int tB = SMB >= 2 ? thr_of(1, j) : 0;
+            const int lB = SMB == 5 ? lo_of(1, j) : 0;
+            constexpr int SMB1 = (PV == 2 && SMB != 5) ? SMB + 2 : SMB;   // tile 0: S_0 is the prologue's bare QK^T (streams: SM 3 / 4; the window form has no pre variant)
+            A::template p1<0, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0, lB);
+            A::template p1<1, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0, lB);
+            A::template p1<2, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0, lB);
+            A::template p1<3, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0, lB);
             stamp(0x18);
-            const int tA = SMA == 2 ? thr_of(0, j + 1) : 0;
-            A::template p2<0, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0);
-            A::template p2<1, PAR, PV, SMA, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0);
-            A::template p2<2, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), tA, 0, ksrd, 0, 0);
-            A::template p2<3, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0);
+            const int tA = SMA >= 2 ? thr_of(0, j + 1) : 0;
+            const int lA = SMA == 5 ? lo_of(0, j + 1) : 0;
+            A::template p2<0, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0, lA);
+            A::template p2<1, PAR, PV, SMA, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
+            A::template p2<2, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
+            A::template p2<3, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0, lA);
             stamp(0x19);
             advance(j);
             nprev = n;
@@ -643,13 +679,20 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         auto step_rt = [&](auto par_tag, auto pv_tag, int j) __attribute__((always_inline)) {
             using I0 = integral_constant<int, 0>;
             using I1 = integral_constant<int, 1>;
-            using I2 = integral_constant<int, 2>;
-            if (j + 1 >= na) step(par_tag, I0{}, I2{}, I0{}, pv_tag, j);
-            else if (j >= jm) step(par_tag, I1{}, I2{}, I2{}, pv_tag, j);
-            else if (j + 1 >= jm) step(par_tag, I1{}, I1{}, I2{}, pv_tag, j);
+            using IM = integral_constant<int, MK>;
+            if (j + 1 >= na) step(par_tag, I0{}, IM{}, I0{}, pv_tag, j);
+            else if constexpr (WIN) {   // (a left-edge tile can be followed by a whole one)
+                const bool mb = masked_at(j), ma = masked_at(j + 1);
+                if (mb && ma) step(par_tag, I1{}, IM{}, IM{}, pv_tag, j);
+                else if (mb) step(par_tag, I1{}, IM{}, I1{}, pv_tag, j);
+                else if (ma) step(par_tag, I1{}, I1{}, IM{}, pv_tag, j);
+                else step(par_tag, I1{}, I1{}, I1{}, pv_tag, j);
+            }
+            else if (j >= jm) step(par_tag, I1{}, IM{}, IM{}, pv_tag, j);
+            else if (j + 1 >= jm) step(par_tag, I1{}, I1{}, IM{}, pv_tag, j);
             else step(par_tag, I1{}, I1{}, I1{}, pv_tag, j);
         };
-        auto idle = [&](int j) __attribute__((always_inline)) {   // a tile this wave does not see, or a padding position of the part
+        auto idle = [&](int j, bool kread = false) __attribute__((always_inline)) {   // a tile this wave does not see, or a padding position of the part
             stamp(0x08);
             // (a padding position has no readers: its barrier only keeps requests from overtaking the last tile's LDS reads.  It
             // does NOT wait for tiles -- what is in flight there are the next head's first tiles, first touches with ~2x the usual
@@ -657,7 +700,20 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             if (j >= nt) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else begin_n();
             stamp(0x09);
+            if constexpr (WIN) {   // position 0 of a wave that starts late: its pieces of K_3 (what step 0 of the other waves carries)
+                if (j == 0) A::dma_tile(ring_lds(0, 0), head_srd(kbase, kvoff, Sk - tb * kKVTile), 3u * KT, kvo);
+            }
             int n = requests();
+            if constexpr (WIN) {
+                // two positions in front of a late wave's first tile f0: its K fragments, from the slot every other wave reads them from in
+                // this step's phase 2 (K_{j+2}; the next step's request overwrites it: done before the next tile barrier's lgkmcnt(0))
+                if (kread) {
+                    unsigned kap[KS];
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) kap[ks] = kaddr(ka0 + (unsigned)slot(2) * KT, ks);
+                    A::kread_all(kap);
+                }
+            }
             stamp(0x0a);
             // the wave's Q registers are free (its last QK^T is behind it): the next part's Q rows now, not at the seam, where the
             // four waves' 64 row-strided loads (one 16-byte chunk per lane and row: ~64 cache lines per instruction) queue up
@@ -714,13 +770,25 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
             }
             stamp(0x31);
+            if constexpr (WIN) {
+                if (f0 > 0) {   // a wave that starts late: its own prologue runs on tile f0, in the position in front of it (wave_prologue)
+                    nprev = 0;
+                    return;
+                }
+            }
             const int tA = thr_of(0, 0);
             if constexpr (!REDO) {
                 A::template set_ref<0>(neg_ref(integral_constant<int, 0>{}, jm == 0, tA));
                 A::template set_ref<1>(neg_ref(integral_constant<int, 1>{}, jm == 0, thr_of(1, 0)));
             }
             const unsigned kb = ka0 + (unsigned)slot(1) * KT;   // K_1
-            if (jm == 0) {
+            if (WIN && masked_at(0)) {
+                const int lA = lo_of(0, 0);
+                A::template p2<0, 1, 0, MK, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0, lA);
+                A::template p2<1, 1, 0, MK, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
+                A::template p2<2, 1, 0, MK, 1, 0>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
+                A::template p2<3, 1, 0, MK, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0, lA);
+            } else if (jm == 0) {
                 A::template p2<0, 1, 0, 2, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0);
                 A::template p2<1, 1, 0, 2, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0);
                 A::template p2<2, 1, 0, 2, 1, 0>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), tA, 0, ksrd, 0, 0);
@@ -734,6 +802,33 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             stamp(0x33);
             nprev = 0;   // (the vmcnt(0) above left nothing in flight; step 0's tile barrier follows: every wave holds K_0 and K_1 then,
                          // and step 0 requests K_3 and K_4 into their slots)
+        };
+
+        // WIN: the prologue of a wave whose first tile is f0 = j + 1 > 0 (j odd: the statements of "step -1", parity 1): the position's tile
+        // barrier and requests, then the bare QK^T of tile f0 (its K fragments were read two positions earlier: idle(j - 1, true)), the
+        // references, P_{f0}[A] next to the reads of K_{f0 + 1} (= K_{j+2}: ring slot rp + 2, like any step's phase 2)
+        auto wave_prologue = [&](int j) __attribute__((always_inline)) {
+            const __amdgpu_buffer_rsrc_t ksrd = make_srd(nullptr, 0);   // (unused operand)
+            stamp(0x38);
+            begin_n();
+            const int n = requests();
+            A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+            A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+            A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+            A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
+            const int tA = thr_of(0, j + 1), lA = lo_of(0, j + 1);
+            if constexpr (!REDO) {   // (causal mask only: see the comment at the top of w4_body)
+                A::template set_ref<0>(neg_ref(integral_constant<int, 0>{}, jm <= j + 1, tA));
+                A::template set_ref<1>(neg_ref(integral_constant<int, 1>{}, jm <= j + 1, thr_of(1, j + 1)));
+            }
+            const unsigned kb = ka0 + (unsigned)slot(2) * KT;
+            A::template p2<0, 1, 0, MK, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0, lA);
+            A::template p2<1, 1, 0, MK, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
+            A::template p2<2, 1, 0, MK, 1, 0>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
+            A::template p2<3, 1, 0, MK, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0, lA);
+            stamp(0x39);
+            advance(j);
+            nprev = n;
         };
 
         // ---- epilogue of a part: O = O^T / l, rounded, transposed through the wave's LDS slab (block A, then block B), whole-row
@@ -863,8 +958,16 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                     A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
                     A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
                     A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
-                    mA = fmaxf(mA, -neg_ref(integral_constant<int, 0>{}, true, thr_of(0, j)));
-                    mB = fmaxf(mB, -neg_ref(integral_constant<int, 1>{}, true, thr_of(1, j)));
+                    if constexpr (WIN) {   // the exact maximum of what the row SEES: both bounds (a tile in front of the window: -inf)
+                        float xa = A::template rowmax<0, 2>(thr_of(0, j), lo_of(0, j)), xb = A::template rowmax<1, 2>(thr_of(1, j), lo_of(1, j));
+                        xa = fmaxf(xa, xhalf_fast(xa));
+                        xb = fmaxf(xb, xhalf_fast(xb));
+                        mA = fmaxf(mA, xa * c);
+                        mB = fmaxf(mB, xb * c);
+                    } else {
+                        mA = fmaxf(mA, -neg_ref(integral_constant<int, 0>{}, true, thr_of(0, j)));
+                        mB = fmaxf(mB, -neg_ref(integral_constant<int, 1>{}, true, thr_of(1, j)));
+                    }
                 }
             }
             A::template set_ref<0>(-mA);
@@ -896,7 +999,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             // mask -- every part of a causal or ragged problem but a head's first block -- step 0, the plain steps, the step in
             // front of the last tile and the last tile all run bodies with static ring slots, literal scalar operands and the
             // requests in their MFMA gaps.  Everything else (and the exact-maximum stream) takes the generic bodies.
-            const bool fast = !REDO && embedded && na >= 3 && jm >= na - 1;
+            const bool fast = !WIN && !REDO && embedded && na >= 3 && jm >= na - 1;
             if (!seam_done) prologue(integral_constant<int, 0>{}, 0.f, 0.f, [](auto) {});
             seam_done = false;
             using I0 = integral_constant<int, 0>;
@@ -912,7 +1015,15 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 fast_pads(na);
                 j = nt3;
             } else {
-                step_rt(I0{}, I2{}, 0);   // tile 0 (O starts at 0)
+                if (WIN && f0 > 0) {   // the wave starts at tile f0 (even, >= 2): idle positions, its K fragments, its own prologue, its first tile
+                    for (j = 0; j < f0 - 2; ++j) idle(j);
+                    idle(f0 - 2, true);
+                    wave_prologue(f0 - 1);
+                    step_rt(I0{}, I2{}, f0);
+                    j = f0 + 1;
+                } else {
+                    step_rt(I0{}, I2{}, 0);   // tile 0 (O starts at 0)
+                }
                 while (j < na) {
                     if (j & 1) step_rt(I1{}, I1{}, j);
                     else step_rt(I0{}, I1{}, j);
@@ -988,6 +1099,20 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(W4_NV_D
     static_assert(W4Asm<T, 64>::NV == W4_NV_D64, "amdgpu_num_vgpr of the D = 64 kernel must be the generator's NV");
     w4_body<T, 64, CAUSAL, TL>(p);
 }
+// the sliding-window instances (causal)
+template <class T>
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(52), amdgpu_num_sgpr(W4_NS + 8))) fa_fwd_w4_kernel_d128_win(const FwdW4Params p) {
+    w4_body<T, 128, true, false, true>(p);
+}
+template <class T>
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(W4_NV_D64), amdgpu_num_sgpr(W4_NS + 8))) fa_fwd_w4_kernel_d64_win(const FwdW4Params p) {
+    w4_body<T, 64, true, false, true>(p);
+}
+template <class T, int D>
+constexpr auto w4_kernel_win() {
+    if constexpr (D == 128) return &fa_fwd_w4_kernel_d128_win<T>;
+    else return &fa_fwd_w4_kernel_d64_win<T>;
+}
 template <class T, int D, bool CAUSAL, bool TL>
 constexpr auto w4_kernel() {
     if constexpr (D == 128) return &fa_fwd_w4_kernel_d128<T, CAUSAL, TL>;
@@ -1019,6 +1144,7 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
     p.dbg = dbg;
     p.npiece = 1; p.pcoff = 0; p.magic = 0; p.part = nullptr; p.part_rows = 0;
     p.generic = w4_generic_bodies();
+    p.window = a.window > 0 ? a.window : 0;
     p.rcos = a.rope_cos; p.rsin = a.rope_sin;
     p.rrows = a.rope_rows; p.rpitch = a.rope_pitch; p.rpos = a.rope_pos;
     // one workgroup per CU; more only when a workgroup's list would not fit its part table
@@ -1031,7 +1157,8 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
             const char* e = std::getenv("AULE_HIP_W4_UNPAIR");
             return (e != nullptr && e[0] == '0') ? 0 : 1;
         }();
-        if (unpair && a.causal && p.nqb >= 2 && (long long)p.nqb * a.B * a.Hq <= ncu) {
+        // (a sliding window: every block's part has about W / 64 + 4 tiles -- nothing to balance by pairing)
+        if (a.causal && (p.window > 0 || (unpair && p.nqb >= 2 && (long long)p.nqb * a.B * a.Hq <= ncu))) {
             p.pair = 0;
             p.nwork = p.nqb;
             p.nitems = p.nwork * a.B * a.Hq;
@@ -1045,7 +1172,7 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
     {   // round order (w4_body): needs whole rounds -- W a multiple of the heads' Q blocks -- and an even number of them
         static const char* const e = std::getenv("AULE_HIP_W4_ORDER");   // "pairs": the item order everywhere (A/B)
         const int units = a.B * a.Hkv, W = (int)(G / 8), g = a.Hq / a.Hkv;
-        if (a.causal && !(e != nullptr && e[0] == 'p') && G == ncu && (G & 7) == 0 && (units & 7) == 0 && p.nqb <= W && W % p.nqb == 0) {
+        if (a.causal && p.window == 0 && !(e != nullptr && e[0] == 'p') && G == ncu && (G & 7) == 0 && (units & 7) == 0 && p.nqb <= W && W % p.nqb == 0) {
             const int m = W / p.nqb, hx = units / 8 * g;
             if (hx % (2 * m) == 0 && hx / m <= kW4MaxSlot) {
                 p.rounds = hx / m;
@@ -1055,7 +1182,9 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
     }
     const dim3 grid((unsigned)G), block(256);
     const size_t lds = w4_lds_bytes<D>() + (TL ? 4 * kW4TLLds * 8 : 0);
-    if (a.causal)
+    if (p.window > 0)
+        hipLaunchKernelGGL((w4_kernel_win<T, D>()), grid, block, lds, stream, p);
+    else if (a.causal)
         hipLaunchKernelGGL((w4_kernel<T, D, true, TL>()), grid, block, lds, stream, p);
     else
         hipLaunchKernelGGL((w4_kernel<T, D, false, TL>()), grid, block, lds, stream, p);
@@ -1084,6 +1213,7 @@ int launch_w4_split(const FwdArgs& a, hipStream_t stream) {
     p.part = static_cast<float*>(ws.ptr);
     p.part_rows = a.B * a.Hq * a.Sq;
     p.generic = w4_generic_bodies();
+    p.window = 0;
     const size_t lds = w4_lds_bytes<D>();
     if (a.causal)
         hipLaunchKernelGGL((w4_kernel<T, D, true, false>()), dim3((unsigned)s.nitems), dim3(256), lds, stream, p);
@@ -1104,6 +1234,7 @@ int set_attr_w4() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(w4_kernel<T, D, false, false>()),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(w4_kernel_win<T, D>()), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     return rc;
 }
 
@@ -1113,7 +1244,16 @@ int set_attr_w4() {
 bool fwd_w4_applicable(const FwdArgs& a) {
     if (a.dtype != kBF16 && a.dtype != kF16) return false;
     if (a.D != 128 && a.D != 64) return false;
-    if (a.window > 0) return false;
+    if (a.window > 0) {
+        // sliding window (round 6, WIN instances): causal, every query with its own diagonal key inside Sk (no row without a visible key: the
+        // references are taken from real scores), tile indices that fit the part table's 16 bits; AULE_HIP_W4_WINDOW=0: the ping-pong kernel (A/B)
+        static const int on = [] {
+            const char* e = std::getenv("AULE_HIP_W4_WINDOW");
+            return (e != nullptr && e[0] == '0') ? 0 : 1;
+        }();
+        // (windows shorter than a key tile stay where they were: a wave would see one or two tiles of a five-tile part)
+        if (!on || !a.causal || a.window < kKVTile || a.coff < 0 || (long long)a.Sq + a.coff > a.Sk || (long long)a.Sk >= 65535LL * kKVTile) return false;
+    }
     if (a.rope_cos != nullptr) {   // fused query rotation: table geometry the 32-bit row offsets of the requests can address
         if (a.rope_sin == nullptr || a.rope_pitch < a.D / 2 || (a.rope_pitch & 3) != 0) return false;
         if ((reinterpret_cast<uintptr_t>(a.rope_cos) | reinterpret_cast<uintptr_t>(a.rope_sin)) & 15) return false;
@@ -1136,7 +1276,7 @@ bool fwd_w4_applicable(const FwdArgs& a) {
 
 // Small grids the forward cuts along the keys (route 7).
 bool fwd_w4_split_applicable(const FwdArgs& a) {
-    if (split_max_pieces() < 2 || a.rope_cos != nullptr || !fwd_w4_applicable(a)) return false;
+    if (split_max_pieces() < 2 || a.rope_cos != nullptr || a.window > 0 || !fwd_w4_applicable(a)) return false;
     if ((long long)a.Sk >= 65535LL * kKVTile) return false;                               // tile indices are 16-bit in the part table
     if ((long long)a.Sq * (a.D + kPartPad) * 4 >= (1LL << 32)) return false;              // partial rows of a head: 32-bit offsets
     return split_plan(a, device_cu_count(a.device)).ok;

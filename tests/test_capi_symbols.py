@@ -124,7 +124,7 @@ def test_forward_routing_rule(monkeypatch):
     pairs of Q blocks cut into key ranges + merge) when every Q block has at least four KV tiles, there is no window, D = 128 / 64
     and the scale is positive -- else to the ping-pong kernel (1); fp32 to 0.  (6, the two-waves-per-SIMD stream of rounds 2-3, is
     gone.)"""
-    for var in ("AULE_HIP_FWD_KERNEL", "AULE_HIP_FWD_SPLITKV", "AULE_HIP_FWD_PPSPLIT"):
+    for var in ("AULE_HIP_FWD_KERNEL", "AULE_HIP_FWD_SPLITKV", "AULE_HIP_FWD_PPSPLIT", "AULE_HIP_W4_WINDOW"):
         monkeypatch.delenv(var, raising=False)
     WAVE, TILED_SPLIT, PP, F32, PS_SPLIT, W4 = 4, 5, 1, 0, 7, 8
     assert _route(1, 32, 1, 1, 16384, 64, dtype=1) == TILED_SPLIT    # C5b: 32 -> 17 us
@@ -154,9 +154,19 @@ def test_forward_routing_rule(monkeypatch):
     assert _route(4, 32, 8, 1024, 4096, 128, causal=2) == W4         # Sq > 256
     assert _route(8, 32, 8, 64, 8192, 128, causal=2, window=16) == PP
     assert _route(8, 32, 8, 64, 8192, 128, causal=1) == W4           # top-left: sees the first Sq keys only
-    assert _route(1, 32, 8, 1, 8192, 128, causal=2, window=128) == PP   # a window from the end needs the mask
+    assert _route(1, 32, 8, 1, 8192, 128, causal=2, window=128) == W4   # a window from the end needs the mask (round 6: the window instances; W < 64: PP)
     assert _route(1, 32, 8, 8, 8192, 128, window=4) == PP            # window
     assert _route(1, 32, 8, 8, 8192, 128, window=64) == TILED_SPLIT  # W >= Sq masks nothing: dropped
+    # round 6: causal sliding windows of at least one key tile on the one-wave-per-SIMD kernel's window instances (every query's diagonal key inside
+    # Sk); smaller windows, non-causal windows and rows without a visible key stay on the ping-pong kernel; never the key-range split
+    assert _route(4, 32, 32, 8192, 8192, 128, causal=1, window=256) == W4
+    assert _route(4, 32, 8, 4096, 4096, 64, dtype=1, causal=1, window=1024) == W4
+    assert _route(1, 8, 8, 8192, 8192, 128, causal=1, window=256) == W4     # (without the window: PS_SPLIT)
+    assert _route(1, 32, 32, 700, 1500, 128, causal=2, window=200) == W4
+    assert _route(4, 32, 32, 8192, 8192, 128, causal=1, window=63) == PP
+    assert _route(4, 32, 32, 4096, 4096, 128, causal=0, window=256) == PP
+    assert _route(1, 2, 2, 600, 200, 128, causal=1, window=64) == PP
+    assert _route(4, 32, 32, 4096, 4096, 32, causal=1, window=256) == PP
     assert _route(1, 32, 8, 1, 8192, 128, dtype=0) == F32
     assert _route(4, 32, 32, 4096, 4096, 128, causal=1) == W4        # the headline shape
     assert _route(1, 8, 8, 128, 128, 128, causal=1) == PP            # fewer than four KV tiles per Q block
@@ -208,7 +218,8 @@ assert fusable(pitch=68) == 1                                              # 16-
 assert fusable(B=1, Hq=8, Hkv=8, Sq=8192, Sk=8192, rows=8192) == 1         # small causal grid (split over the keys)
 assert fusable(D=32) == 0                                                  # no fused instance
 assert fusable(dtype=0) == 0                                               # fp32 kernel
-assert fusable(window=64) == 0                                             # ping-pong kernel
+assert fusable(window=64) == 1                                             # (round 6) the window instances of the same kernel
+assert fusable(window=32) == 0                                             # windows shorter than a key tile: ping-pong kernel
 assert fusable(Sq=128, Sk=128) == 0                                        # fewer than four KV tiles: ping-pong kernel
 assert fusable(Hq=8, Hkv=8, B=1, Sq=1, Sk=8192, causal=0, rows=8192) == 0  # short-query split paths
 assert fusable(layout=1) == 0                                              # interleaved pairs: separate pass

@@ -215,6 +215,9 @@ FUSED_CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, causal
     ("fp16", 16, 16, 4, 300, 2048, 128, "bottom-right"),  # queries at positions Sk - Sq + i (enough pairs of Q blocks that the
                                                           # un-fused launch stays on the plain stream too: same kernel, same order)
     ("bf16", 1, 4, 4, 512, 512, 64, False),
+    # round 6: the sliding-window instances rotate Q in their part prologue like the plain ones (waves that start late included)
+    ("bf16", 2, 8, 8, 2048, 2048, 128, True, 256),
+    ("fp16", 1, 8, 2, 1500, 1500, 64, True, 300),
 ]
 
 
@@ -225,7 +228,8 @@ def test_fused_query_rotation_is_the_separate_pass_bit_for_bit(case, oracle_mod,
     EQUAL; and both against the fp64 oracle chain.  The Python inference path takes the fused route by itself."""
     import torch
     from aule import _torch as at
-    dtype, B, Hq, Hkv, Sq, Sk, D, causal = case
+    dtype, B, Hq, Hkv, Sq, Sk, D, causal = case[:8]
+    W = case[8] if len(case) > 8 else -1
     rng = np.random.RandomState(23)
     q, k, v = (quantize(rng.randn(*s).astype(np.float32), dtype) for s in ((B, Hq, Sq, D), (B, Hkv, Sk, D), (B, Hkv, Sk, D)))
     cos, sin = oracle_mod.rope_tables(max(Sq, Sk) + 3, D)
@@ -233,25 +237,25 @@ def test_fused_query_rotation_is_the_separate_pass_bit_for_bit(case, oracle_mod,
     tq, tk, tv, tc, ts = _dev(torch, q, dtype), _dev(torch, k, dtype), _dev(torch, v, dtype), _dev(torch, cos), _dev(torch, sin)
     code = at.causal_code(causal)
     # the one-wave-per-SIMD kernel rotates Q itself (table rows land in its score registers between two parts): fusable == route 8 (fa_fwd_gfx950.hip)
-    fus = at.rope_fusable(tq, tk, code, -1, tc, ts, qoff)
+    fus = at.rope_fusable(tq, tk, code, W, tc, ts, qoff)
     assert fus
     sc = 1.0 / math.sqrt(D)
     kr = at.rope_raw(tk, tc, ts, "half", False, 0)
     qr = at.rope_raw(tq, tc, ts, "half", False, qoff)
-    two_pass, lse = at.fwd_raw(qr, kr, tv, code, sc, want_lse=True)
+    two_pass, lse = at.fwd_raw(qr, kr, tv, code, sc, want_lse=True, window=W)
     if fus:
-        fused, lse = at.fwd_raw(tq, kr, tv, code, sc, want_lse=True, q_rope=(tc, ts, qoff))
+        fused, lse = at.fwd_raw(tq, kr, tv, code, sc, want_lse=True, q_rope=(tc, ts, qoff), window=W)
         assert torch.equal(fused, two_pass)
     with torch.no_grad():
-        auto = at.flash_attention_rope_hip(tq, tk, tv, tc, ts, causal=causal)
+        auto = at.flash_attention_rope_hip(tq, tk, tv, tc, ts, causal=causal, window=W)
     assert torch.equal(auto, two_pass)
     monkeypatch.setenv("AULE_HIP_ROPE_FUSE", "0")
     with torch.no_grad():
-        assert torch.equal(at.flash_attention_rope_hip(tq, tk, tv, tc, ts, causal=causal), two_pass)
+        assert torch.equal(at.flash_attention_rope_hip(tq, tk, tv, tc, ts, causal=causal, window=W), two_pass)
     if B * Hq * Sq * Sk <= 2 * 8 * 1024 * 1024:
         qo = quantize(oracle_mod.rope_f64(q, cos, sin, "half", False, qoff), dtype)
         ko = quantize(oracle_mod.rope_f64(k, cos, sin, "half"), dtype)
-        ref, ref_lse = oracle_mod.fwd_f64(qo, ko, v, causal, None, -1)
+        ref, ref_lse = oracle_mod.fwd_f64(qo, ko, v, causal, None, W)
         atol, rtol = fwd_tol(dtype, np.abs(v).max())
         assert_close(two_pass.float().cpu().numpy(), ref, atol, rtol, "out")
         assert_close(lse.cpu().numpy(), ref_lse, LSE_TOL[dtype], 0, "lse")

@@ -9,6 +9,7 @@ causal rule (the convention of the kernel the reference runs on ROCm, triton_fla
   * the C-ABI handle path (aule_attention_forward_gpu with window_size).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -56,7 +57,19 @@ CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, causal, window
     ("bf16", 1, 32, 8, 1100, 1100, 128, True, 100),
     ("fp16", 2, 32, 32, 1024, 1024, 64, True, 300),
     ("bf16", 1, 32, 32, 700, 1500, 128, "bottom-right", 200),
+    # round 6: the sliding-window instances of the one-wave-per-SIMD forward (causal, W >= 64, every query's diagonal key inside Sk): aligned and
+    # unaligned windows, shorter and longer than a Q block, waves that start late (W = 256: wave 3 of a block at its part's tile 3 -> position 2),
+    # ragged last blocks, GQA, D = 64, a bottom-right offset that is not a multiple of the tile
+    ("bf16", 1, 4, 4, 2048, 2048, 128, True, 256),
+    ("bf16", 1, 2, 2, 1536, 1536, 128, True, 64),
+    ("bf16", 1, 4, 1, 1300, 1300, 64, True, 200),
+    ("bf16", 1, 2, 2, 900, 2000, 128, "bottom-right", 700),
+    ("bf16", 1, 2, 2, 4096, 4096, 128, True, 1024),
+    ("fp16", 1, 2, 2, 1024, 1024, 128, True, 129),
+    ("fp16", 1, 4, 2, 3000, 3000, 64, True, 1000),
 ]
+W4_WINDOW_CASES = {c for c in CASES if c[0] != "fp32" and c[6] in (64, 128) and c[7] and c[8] >= 64 and min(256 + (c[5] - c[4] if c[7] == "bottom-right" else 0), c[5]) > 192
+                   and c[4] + (c[5] - c[4] if c[7] == "bottom-right" else 0) <= c[5]}
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(x) for x in c))
@@ -70,6 +83,8 @@ def test_window_forward_backward_vs_oracle(case, oracle_mod):
     sc = 1 / math.sqrt(D)
     tq, tk, tv, tdo = (_dev(torch, x, dtype) for x in (q, k, v, do))
     out, lse = at.fwd_raw(tq, tk, tv, causal, sc, window=W)
+    if not os.environ.get("AULE_HIP_W4_WINDOW") and not os.environ.get("AULE_HIP_FWD_KERNEL") and not os.environ.get("AULE_HIP_FWD_SOFTMAX"):
+        assert (_fwd_route(dtype, B, Hq, Hkv, Sq, Sk, D, causal, W) == 8) == (case in W4_WINDOW_CASES), "route"
     ref, ref_lse = oracle_mod.fwd_f64(q, k, v, causal, None, W)
     atol, rtol = fwd_tol(dtype, np.abs(v).max())
     assert_close(out.float().cpu().numpy(), ref, atol, rtol, "out")
@@ -82,6 +97,44 @@ def test_window_forward_backward_vs_oracle(case, oracle_mod):
     a, r = BWD_TOL[dtype]
     for name, got, want in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
         assert_close(got.float().cpu().numpy(), want, a * max(1.0, float(np.abs(want).max())), r, name)
+
+
+def _fwd_route(dtype, B, Hq, Hkv, Sq, Sk, D, causal, W):
+    """aule_hip_debug_forward_route for the problem (host logic only): 8 = the one-wave-per-SIMD forward, 1 = the ping-pong kernel"""
+    import ctypes
+    from aule import _capi
+    d = _capi.AttnDesc()
+    d.struct_size = ctypes.sizeof(_capi.AttnDesc)
+    d.batch, d.heads_q, d.heads_kv, d.seq_q, d.seq_k, d.head_dim = B, Hq, Hkv, Sq, Sk, D
+    d.dtype = {"fp32": 0, "fp16": 1, "bf16": 2}[dtype]
+    d.causal = 2 if causal == "bottom-right" else int(bool(causal))
+    d.window_size = W
+    return int(_capi.get_lib().aule_hip_debug_forward_route(ctypes.byref(d)))
+
+
+def test_window_with_large_logits_takes_the_exact_maximum_stream(oracle_mod):
+    """The window instances take a row's fixed reference from the wave's first tile under the CAUSAL mask only -- keys in front of the window
+    included.  A key just OUTSIDE a block's window whose logit is far above everything inside must not poison the rows (the row sums underflow,
+    the range verdict fails, the exact-maximum stream -- which takes the maximum under BOTH bounds -- repairs the part), and neither must a key
+    INSIDE the window far above the first tile's scores (overflow)."""
+    import torch
+    from aule import _torch as at
+    rng = np.random.RandomState(5)
+    B, H, S, D, W = 1, 4, 2048, 128, 256
+    mk = lambda *s: torch.from_numpy(rng.randn(*s).astype(np.float32)).to(torch.bfloat16)
+    q, k, v = mk(B, H, S, D), mk(B, H, S, D), mk(B, H, S, D)
+    # head 0: key 1290 is outside the window of row 1600 (1600 - 1290 = 310 >= 256) but inside the first tile of its wave; aligned with that row's query
+    k[:, 0, 1290, :] = (40.0 * q[:, 0, 1600, :].float()).to(torch.bfloat16)
+    # head 1: key 1500 is inside the window of rows 1500 .. 1755, far above their first tile's scores for row 1600
+    k[:, 1, 1500, :] = (40.0 * q[:, 1, 1600, :].float()).to(torch.bfloat16)
+    out, lse = at.fwd_raw(q.cuda(), k.cuda(), v.cuda(), True, 1 / math.sqrt(D), window=W)
+    torch.cuda.synchronize()
+    ref, rl = oracle_mod.fwd_f64(q.float().numpy(), k.float().numpy(), v.float().numpy(), True, None, W)
+    o = out.float().cpu().numpy()
+    assert not np.isnan(o).any()
+    atol, rtol = fwd_tol("bf16", float(v.float().abs().max()))
+    assert_close(o, ref, atol, rtol, "out")
+    assert_close(lse.cpu().numpy(), rl, LSE_TOL["bf16"], 1e-5, "lse")
 
 
 def test_window_properties():

@@ -208,6 +208,9 @@ def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked, sub=False):
             if masked:
                 o.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + i)}, %[thr]")
                 o.append(f"v_cndmask_b32 {x[i]}, v{c.NINF}, {x[i] if (not c.pre or sub) else sc[i]}, vcc")
+            if masked == 2:     # sliding window: the key must not lie in front of the row's first visible one either
+                o.append(f"v_cmp_ge_i32 vcc, {kk(blk_h, e0 + i)}, %[lo]")
+                o.append(f"v_cndmask_b32 {x[i]}, v{c.NINF}, {x[i]}, vcc")
             return o
 
         def E(i):
@@ -254,6 +257,9 @@ def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked, sub=False):
                     for i in range(2):
                         ops.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + 2 * p + i)}, %[thr]")
                         ops.append(f"v_cndmask_b32 {x[p][i]}, v{c.NINF}, {(x if not (c.pre and not sub) else scp)[p][i]}, vcc")
+                        if masked == 2:
+                            ops.append(f"v_cmp_ge_i32 vcc, {kk(blk_h, e0 + 2 * p + i)}, %[lo]")
+                            ops.append(f"v_cndmask_b32 {x[p][i]}, v{c.NINF}, {x[p][i]}, vcc")
             for p in (p0, p0 + 1):
                 ops.append(f"v_exp_f32 {x[p][0]}, {src[p][0]}")
                 ops.append(f"v_exp_f32 {x[p][1]}, {src[p][1]}")
@@ -450,6 +456,10 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
     reads (ring slot in the address register).  dma: this statement's piece of the K tile the step requests."""
     qb, KS, DB = Q >> 1, c.KS, c.DB
     mf, clob = [], ["memory"]
+    two = sm == 5           # sliding window (round 6): the masked form with a lower bound too (%[lo]); tile 0 of a part takes it as it is (no pre form)
+    if two:
+        assert not c.pre
+        sm = 2
     sub = sm >= 3
     if sub:
         sm -= 2
@@ -475,7 +485,7 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
     valu = []
     if sm:
         h = Q >> 1
-        valu = softmax_ops(c, c.sB(h, par), h, 8 * (Q & 1), c.pB(Q), 1, sm == 2, sub)
+        valu = softmax_ops(c, c.sB(h, par), h, 8 * (Q & 1), c.pB(Q), 1, (2 if two else 1) if sm == 2 else 0, sub)
         clob += [f'v{t}' for t in c.T] + vregs(c.pB(Q), 4) + vregs(c.l(1, 0), 2)
         if sm == 2:
             clob.append("vcc")
@@ -543,6 +553,8 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
             ins.append(f'[c] "{CREG}"(c)')
         if sm == 2:
             ins.append('[thr] "v"(thr)')
+        if two:
+            ins.append('[lo] "v"(lo)')
     if vr:
         ins.append('[va] "v"(va)')
     if pieces:
@@ -555,6 +567,10 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
     -> pA[PAR ^ 1][Q].  kr: reads of K_{j+2} (ring slot in the address registers).  dma: this statement's piece of the V tile."""
     qb, KS, DB = Q >> 1, c.KS, c.DB
     mf, clob = [], ["memory"]
+    two = sm == 5           # (as in gen_p1)
+    if two:
+        assert not c.pre
+        sm = 2
     if pv:
         for t in range(2):
             sk = 2 * (Q & 1) + t
@@ -590,7 +606,7 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
     valu = []
     if sm:
         h = Q >> 1
-        valu = softmax_ops(c, c.sA(h), h, 8 * (Q & 1), c.pA(par ^ 1, Q), 0, sm == 2, pv == 0)
+        valu = softmax_ops(c, c.sA(h), h, 8 * (Q & 1), c.pA(par ^ 1, Q), 0, (2 if two else 1) if sm == 2 else 0, pv == 0)
         clob += [f'v{t}' for t in c.T] + vregs(c.pA(par ^ 1, Q), 4) + vregs(c.l(0, 0), 2)
         if sm == 2:
             clob.append("vcc")
@@ -629,6 +645,8 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
             ins.append(f'[c] "{CREG}"(c)')
         if sm == 2:
             ins.append('[thr] "v"(thr)')
+        if two:
+            ins.append('[lo] "v"(lo)')
     if kr == 1:
         ins += [f'[ka{t}] "v"(ka{t})' for t in range(KS // 4)]
     if kr == 2:
@@ -789,6 +807,8 @@ def p1_variants():
             for qk in (0, 1):
                 for sm in (1, 2) if par else (1, 2, 3, 4):  # (3 / 4: tile 0 -- step 0 of a part, PAR 0)
                     v.append((Q, par, qk, sm, 1, 0, 0))     # generic steps: ring slot in the address register, requests apart
+                if not PRE_ON:
+                    v.append((Q, par, qk, 5, 1, 0, 0))      # ... of a sliding-window part: two-sided mask
         v.append((Q, 1, 1, 0, 0, 0, 0))             # bare QK^T of tile 0 ("step -1": part prologue, exact-maximum pass)
         v.append((Q, 0, 1, 3, 1, 3 if Q == 0 else 2, 0))   # step 0 of a part in the embedded-request form (stream position 0, parity 0)
     return sorted(set(v))
@@ -803,10 +823,12 @@ def p2_variants():
                 v.append((Q, par, 1, 2, 1, 2, sl))  # the step in front of the wave's diagonal tile: S_{j+1}[A] masked
                 v.append((Q, par, 1, 0, 0, 2, sl))  # the diagonal tile itself: O^T += V^T P^T and the V request, nothing else
                 v.append((Q, par, 1, 0, 2, 2, sl))  # ... and the next part's Q rows (KR 2)
-            for sm in (0, 1, 2):
-                v.append((Q, par, 1, sm, 1, 0, 0))  # generic steps
+            for sm in (0, 1, 2) + (() if PRE_ON else (5,)):
+                v.append((Q, par, 1, sm, 1, 0, 0))  # generic steps (5: sliding window, two-sided mask)
         v += [(Q, 0, 2, 0, 1, 0, 0), (Q, 0, 2, 1, 1, 0, 0), (Q, 0, 2, 2, 1, 0, 0)]   # first step of a part (O starts at 0)
         v += [(Q, 1, 0, 1, 1, 0, 0), (Q, 1, 0, 2, 1, 0, 0)]                          # part prologue: P_0[A] next to the reads of K_1
+        if not PRE_ON:
+            v += [(Q, 0, 2, 5, 1, 0, 0), (Q, 1, 0, 5, 1, 0, 0)]                      # sliding window: first step / prologue (of the part, or of a wave that starts late)
         v.append((Q, 0, 2, 1, 1, 2, 2))                                              # step 0 of a part, embedded-request form
     return sorted(set(v))
 
@@ -835,9 +857,9 @@ def gen_struct(c):
     s += ("    // SL: ring slot of the tile the statement reads, as an immediate (plain steps); 0 where the address register carries it\n"
           "    template <int Q, int PAR, int QK, int SM, int VR, int DMA, int SL = 0>\n"
           "    static __device__ __forceinline__ void p1(float c, unsigned va, int thr, unsigned dlds, __amdgpu_buffer_rsrc_t dsrd, unsigned dso,\n"
-          "                                              unsigned dvo) {\n"
+          "                                              unsigned dvo, int lo = 0) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
-          "        (void)c; (void)va; (void)thr; (void)dlds; (void)dsrd; (void)dso; (void)dvo;\n"
+          "        (void)c; (void)va; (void)thr; (void)dlds; (void)dsrd; (void)dso; (void)dvo; (void)lo;\n"
           "        if constexpr (DMA != 0) {   // (readfirstlane: hipcc sometimes moves uniform arithmetic to the vector unit; the request wants scalars)\n"
           "            dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n            dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n        }\n")
     first = True
@@ -851,9 +873,9 @@ def gen_struct(c):
     # ---- phase 2
     s += ("    template <int Q, int PAR, int PV, int SM, int KR, int DMA, int SL = 0>\n"
           "    static __device__ __forceinline__ void p2(float c, unsigned ka0, unsigned ka1, int thr, unsigned dlds, __amdgpu_buffer_rsrc_t dsrd,\n"
-          "                                              unsigned dso, unsigned dvo) {\n"
+          "                                              unsigned dso, unsigned dvo, int lo = 0) {\n"
           "#if defined(__HIP_DEVICE_COMPILE__)\n"
-          "        (void)c; (void)ka0; (void)ka1; (void)thr; (void)dlds; (void)dsrd; (void)dso; (void)dvo;\n"
+          "        (void)c; (void)ka0; (void)ka1; (void)thr; (void)dlds; (void)dsrd; (void)dso; (void)dvo; (void)lo;\n"
           "        if constexpr (DMA != 0) {\n"
           "            dlds = (unsigned)__builtin_amdgcn_readfirstlane((int)dlds);\n            dso = (unsigned)__builtin_amdgcn_readfirstlane((int)dso);\n        }\n")
     first = True
@@ -1006,10 +1028,11 @@ def gen_struct(c):
     s += emit_asm(lines, ['[t] "=&s"(t)'], ['[lds] "s"(dlds)', '[srd] "s"(dsrd)', '[soff] "s"(dsoff)', '[vo] "v"(dvo)'], ["memory", "m0", "scc"], indent="        ")
     s += "#endif\n    }\n"
     # ---- row maximum of tile 0: BLK 0 = S[A] (xa0, xa1), 1 = S[B] written by the bare QK^T (yb0, yb1[0]); lane-local 32 values
-    s += "    template <int BLK, int MASKED>\n    static __device__ __forceinline__ float rowmax(int thr) {\n        float mx = 0.f;\n#if defined(__HIP_DEVICE_COMPILE__)\n        (void)thr;\n"
+    s += ("    // MASKED 2 (sliding window, the exact-maximum pass): lo <= key <= thr\n"
+          "    template <int BLK, int MASKED>\n    static __device__ __forceinline__ float rowmax(int thr, int lo = 0) {\n        float mx = 0.f;\n#if defined(__HIP_DEVICE_COMPILE__)\n        (void)thr; (void)lo;\n")
     first = True
     for blk in range(2):
-        for masked in range(2):
+        for masked in range(3):
             b = [c.sA(0), c.sA(1)] if blk == 0 else [c.sB(0, 0), c.sB(1, 0)]
             lines = []
             regs = []
@@ -1025,6 +1048,11 @@ def gen_struct(c):
                     lines.append(f"v_cndmask_b32 v{c.X}, v{c.NINF}, v{ra}, vcc")
                     lines.append(f"v_cmp_le_i32 vcc, {kb_}, %[thr]")
                     lines.append(f"v_cndmask_b32 v{c.X + 1}, v{c.NINF}, v{rb}, vcc")
+                    if masked == 2:
+                        lines.append(f"v_cmp_ge_i32 vcc, {ka_}, %[lo]")
+                        lines.append(f"v_cndmask_b32 v{c.X}, v{c.NINF}, v{c.X}, vcc")
+                        lines.append(f"v_cmp_ge_i32 vcc, {kb_}, %[lo]")
+                        lines.append(f"v_cndmask_b32 v{c.X + 1}, v{c.NINF}, v{c.X + 1}, vcc")
                     lines.append(f"v_max3_f32 %[mx], %[mx], v{c.X}, v{c.X + 1}")
             else:
                 lines.append(f"v_max3_f32 %[mx], v{regs[0][0]}, v{regs[1][0]}, v{regs[2][0]}")
@@ -1032,7 +1060,7 @@ def gen_struct(c):
                     lines.append(f"v_max3_f32 %[mx], %[mx], v{regs[i][0]}, v{regs[i + 1][0]}")
                 lines.append(f"v_max_f32 %[mx], %[mx], v{regs[31][0]}")
             s += f"        {'if' if first else 'else if'} constexpr (BLK == {blk} && MASKED == {masked}) {{\n"
-            s += emit_asm(lines, ['[mx] "=&v"(mx)'], ['[thr] "v"(thr)'] if masked else [], ["memory"] + (["vcc"] + vregs(c.X, 2) if masked else []))
+            s += emit_asm(lines, ['[mx] "=&v"(mx)'], (['[thr] "v"(thr)'] + (['[lo] "v"(lo)'] if masked == 2 else [])) if masked else [], ["memory"] + (["vcc"] + vregs(c.X, 2) if masked else []))
             s += "        }\n"
             first = False
     s += "#endif\n        return mx;\n    }\n"
