@@ -114,14 +114,13 @@ template <int D> constexpr int w4_lds_bytes() {   // 3 K + 3 V ring slots, one 3
 // for the key-range pieces); a WAVE starts at the first tile ITS 64 rows see (rounded down to an even position: the parity copies of the
 // score / weight registers then line up with a part's own start): positions in front of it are idle ones, the position in front of its first
 // tile runs the part prologue's body on that tile ("wave prologue": bare QK^T, references, P[A]); tiles that cross the window's left edge
-// take the two-sided mask variants of the streams (SM 5: lo <= key <= thr).  The fixed reference of a row is the maximum of the wave's first
+// take the left-edge mask variants of the streams (SM 6: lo <= key; windows are at least two key tiles long, so no tile is cut on both sides).  The fixed reference of a row is the maximum of the wave's first
 // tile under the CAUSAL mask only -- the keys in front of the window are real keys of the same head: a finite reference of the right size
 // even for the rows whose window starts in the next tile -- and the exact-maximum stream takes the maximum under both bounds.
 template <class T, int D, bool CAUSAL, bool TL, bool WIN = false>
 __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     using A = W4Asm<T, D>;
     static_assert(!WIN || (CAUSAL && !TL && !A::PRE), "window instances: causal, no timeline build, no pre-scaled form");
-    constexpr int MK = WIN ? 5 : 2;   // SM code of a masked softmax statement
     using std::integral_constant;
     constexpr int RB = 2 * D, RBP = RB + 16, CPR = RB / 16, KS = D / 16, DB = D / 32;
     constexpr int KT = 64 * RB, VT = KT, NP = KT / 4096, NQ = 2 * KS;   // NQ: buffer loads of a wave's Q fragments
@@ -204,11 +203,11 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     // round start their parts together at tile 0: the K/V re-reads that missed the 4 MB L2 (profiles/r3_fwd_c2_*) mostly go.
     const int G = (int)gridDim.x;
     const int nit = (p.nitems - (int)blockIdx.x + G - 1) / G;
-    const int nslot = p.rounds > 0 ? p.rounds : 2 * nit;
+    const int nslot = (!WIN && p.rounds > 0) ? p.rounds : 2 * nit;
     if (tid < nslot) {
         int qb = -1, range = 0;   // .z = qb | (partial plane + 1) << 24 (0: O is final), .w = first tile | end tile << 16 (0: the whole block)
         WorkItem w;
-        if (p.npiece > 1) {
+        if (!WIN && p.npiece > 1) {   // (the window instances: no key-range pieces, no round order)
             // item = (pair, piece): slot 0 its range of the far block, slot 1 of the near block (non-causal: no pairing, far == near)
             w = decode_work((int)blockIdx.x + (tid >> 1) * G, p.B, p.Hq, p.Hkv, p.npiece * p.nwork, false);
             const int near = w.blk / p.npiece, piece = w.blk % p.npiece, far = p.pair ? p.nqb - 1 - near : near;
@@ -220,7 +219,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 qb = ((tid & 1) ? near : far) | ((t0 == 0 && t1 == whole) ? 0 : (piece + 1) << 24);
                 range = t0 | (t1 << 16);
             }
-        } else if (p.rounds > 0) {
+        } else if (!WIN && p.rounds > 0) {
             const int W = G >> 3, wx = (int)blockIdx.x >> 3, pos = (tid & 1) ? W - 1 - wx : wx;
             const int g = p.Hq / p.Hkv;
             const int c = tid * p.mper + pos % p.mper;          // head of this XCD's list: kv unit c / g, head c % g of its group
@@ -420,12 +419,13 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             return (CAUSAL ? min(row, Sk - 1) : Sk - 1) - (lane_o >> 5) * 4 - 64 * (j + tb);
         };
         // WIN: first visible key (minus 4 hi) of the lane's row in block QB, relative to tile j: key k of the tile is visible iff lo <= k (<= thr)
-        auto lo_of = [&](int qbsel, int j) __attribute__((always_inline)) {
-            int lane_o = lane;
-            asm volatile("" : "+v"(lane_o));
-            return r0 + 32 * qbsel + (lane_o & 31) + coff - win + 1 - (lane_o >> 5) * 4 - 64 * (j + tb);
-        };
-        auto masked_at = [&](int j) __attribute__((always_inline)) { return j >= jm || (WIN && j < jl); };
+        // = thr - (window - 1): the window instances only take problems whose every query has its diagonal key inside Sk, so thr_of's clamp never
+        // binds on a row that is stored (rows >= Sq: a window shifted left over real keys, results dropped) -- one lane value to keep, not two
+        auto lo_from = [&](int thr) __attribute__((always_inline)) { return thr - (win - 1); };
+        // SM code of tile j's softmax: 6 the window's left edge cuts it (key >= lo), 2 the diagonal does (key <= thr), 1 neither.  Never both: the
+        // window instances take windows of at least two key tiles (fwd_w4_applicable), so the last row's first key lies at least a tile in front of
+        // the first row's diagonal key: jl <= jm
+        auto code_at = [&](int j) __attribute__((always_inline)) { return (WIN && j < jl) ? 6 : (j >= jm ? 2 : 1); };
         // after step j: the ring moves on, the cursors of step j + 1 (K tile j + 5, V tile j + 3)
         auto advance = [&](int j) __attribute__((always_inline)) {
             rp = slot(1);
@@ -586,6 +586,20 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 plain(I0{}, I0{}); fix_cursors(j); ++j;
             }
         };
+        // WIN: one plain step at ANY position (a window part's whole tiles start behind the wave's left-edge tiles, wherever those end)
+        auto plain_one = [&](int j) __attribute__((always_inline)) {
+            using I0 = integral_constant<int, 0>;
+            using I1 = integral_constant<int, 1>;
+            using I2 = integral_constant<int, 2>;
+            switch (j % 6) {
+                case 0: plain(I0{}, I0{}); break;
+                case 1: plain(I1{}, I1{}); break;
+                case 2: plain(I2{}, I0{}); break;
+                case 3: plain(I0{}, I1{}); break;
+                case 4: plain(I1{}, I0{}); break;
+                default: plain(I2{}, I1{}); break;
+            }
+        };
         // the wave's last two tiles in the embedded-request form: step j (in front of the last tile) and step j + 1 (the last
         // tile); ring slot and parity follow from the position
         auto fast_tail = [&](int j) __attribute__((always_inline)) {
@@ -658,15 +672,15 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             const int n = requests();
             const unsigned vap = va + (unsigned)rp * VT, kb = ka0 + (unsigned)slot(2) * KT;
             const int tB = SMB >= 2 ? thr_of(1, j) : 0;
-            const int lB = SMB == 5 ? lo_of(1, j) : 0;
-            constexpr int SMB1 = (PV == 2 && SMB != 5) ? SMB + 2 : SMB;   // tile 0: S_0 is the prologue's bare QK^T (streams: SM 3 / 4; the window form has no pre variant)
+            const int lB = SMB == 6 ? lo_from(tB) : 0;
+            constexpr int SMB1 = (PV == 2 && SMB != 6) ? SMB + 2 : SMB;   // tile 0: S_0 is the prologue's bare QK^T (streams: SM 3 / 4; the window form has no pre variant)
             A::template p1<0, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0, lB);
             A::template p1<1, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0, lB);
             A::template p1<2, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0, lB);
             A::template p1<3, PAR, QK, SMB1, 1, 0>(c, vap, tB, 0, ksrd, 0, 0, lB);
             stamp(0x18);
             const int tA = SMA >= 2 ? thr_of(0, j + 1) : 0;
-            const int lA = SMA == 5 ? lo_of(0, j + 1) : 0;
+            const int lA = SMA == 6 ? lo_from(tA) : 0;
             A::template p2<0, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0, lA);
             A::template p2<1, PAR, PV, SMA, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
             A::template p2<2, PAR, PV, SMA, 1, 0>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
@@ -679,17 +693,16 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         auto step_rt = [&](auto par_tag, auto pv_tag, int j) __attribute__((always_inline)) {
             using I0 = integral_constant<int, 0>;
             using I1 = integral_constant<int, 1>;
-            using IM = integral_constant<int, MK>;
-            if (j + 1 >= na) step(par_tag, I0{}, IM{}, I0{}, pv_tag, j);
-            else if constexpr (WIN) {   // (a left-edge tile can be followed by a whole one)
-                const bool mb = masked_at(j), ma = masked_at(j + 1);
-                if (mb && ma) step(par_tag, I1{}, IM{}, IM{}, pv_tag, j);
-                else if (mb) step(par_tag, I1{}, IM{}, I1{}, pv_tag, j);
-                else if (ma) step(par_tag, I1{}, I1{}, IM{}, pv_tag, j);
-                else step(par_tag, I1{}, I1{}, I1{}, pv_tag, j);
+            using I2 = integral_constant<int, 2>;
+            using I6 = integral_constant<int, 6>;
+            if (j + 1 >= na) step(par_tag, I0{}, I2{}, I0{}, pv_tag, j);
+            else if (WIN && j < jl) {   // a left-edge tile: followed by another one, a whole one, or the diagonal tile
+                if (j + 1 < jl) step(par_tag, I1{}, I6{}, I6{}, pv_tag, j);
+                else if (j + 1 >= jm) step(par_tag, I1{}, I6{}, I2{}, pv_tag, j);
+                else step(par_tag, I1{}, I6{}, I1{}, pv_tag, j);
             }
-            else if (j >= jm) step(par_tag, I1{}, IM{}, IM{}, pv_tag, j);
-            else if (j + 1 >= jm) step(par_tag, I1{}, I1{}, IM{}, pv_tag, j);
+            else if (j >= jm) step(par_tag, I1{}, I2{}, I2{}, pv_tag, j);
+            else if (j + 1 >= jm) step(par_tag, I1{}, I1{}, I2{}, pv_tag, j);
             else step(par_tag, I1{}, I1{}, I1{}, pv_tag, j);
         };
         auto idle = [&](int j, bool kread = false) __attribute__((always_inline)) {   // a tile this wave does not see, or a padding position of the part
@@ -782,12 +795,12 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 A::template set_ref<1>(neg_ref(integral_constant<int, 1>{}, jm == 0, thr_of(1, 0)));
             }
             const unsigned kb = ka0 + (unsigned)slot(1) * KT;   // K_1
-            if (WIN && masked_at(0)) {
-                const int lA = lo_of(0, 0);
-                A::template p2<0, 1, 0, MK, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0, lA);
-                A::template p2<1, 1, 0, MK, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
-                A::template p2<2, 1, 0, MK, 1, 0>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
-                A::template p2<3, 1, 0, MK, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0, lA);
+            if (WIN && 0 < jl) {
+                const int lA = lo_from(tA);
+                A::template p2<0, 1, 0, 6, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0, lA);
+                A::template p2<1, 1, 0, 6, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
+                A::template p2<2, 1, 0, 6, 1, 0>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
+                A::template p2<3, 1, 0, 6, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0, lA);
             } else if (jm == 0) {
                 A::template p2<0, 1, 0, 2, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0);
                 A::template p2<1, 1, 0, 2, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0);
@@ -816,16 +829,20 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             A::template p1<1, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
             A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
             A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
-            const int tA = thr_of(0, j + 1), lA = lo_of(0, j + 1);
+            const int tA = thr_of(0, j + 1), lA = lo_from(tA);
             if constexpr (!REDO) {   // (causal mask only: see the comment at the top of w4_body)
                 A::template set_ref<0>(neg_ref(integral_constant<int, 0>{}, jm <= j + 1, tA));
                 A::template set_ref<1>(neg_ref(integral_constant<int, 1>{}, jm <= j + 1, thr_of(1, j + 1)));
             }
             const unsigned kb = ka0 + (unsigned)slot(2) * KT;
-            A::template p2<0, 1, 0, MK, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0, lA);
-            A::template p2<1, 1, 0, MK, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
-            A::template p2<2, 1, 0, MK, 1, 0>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);
-            A::template p2<3, 1, 0, MK, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0, lA);
+#define W4_WP_P2(SMC)                                                                                                     \
+    A::template p2<0, 1, 0, SMC, 1, 0>(c, kaddr(kb, 0), kaddr(kb, KS / 4 - 1), tA, 0, ksrd, 0, 0, lA);                     \
+    A::template p2<1, 1, 0, SMC, 1, 0>(c, kaddr(kb, KS / 4), kaddr(kb, 2 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);          \
+    A::template p2<2, 1, 0, SMC, 1, 0>(c, kaddr(kb, 2 * (KS / 4)), kaddr(kb, 3 * (KS / 4) - 1), tA, 0, ksrd, 0, 0, lA);    \
+    A::template p2<3, 1, 0, SMC, 1, 0>(c, kaddr(kb, 3 * (KS / 4)), kaddr(kb, KS - 1), tA, 0, ksrd, 0, 0, lA);
+            const int cd = code_at(j + 1);
+            if (cd == 6) { W4_WP_P2(6) } else if (cd == 2) { W4_WP_P2(2) } else { W4_WP_P2(1) }
+#undef W4_WP_P2
             stamp(0x39);
             advance(j);
             nprev = n;
@@ -892,7 +909,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                     }
                 }
             };
-            if (pid != 0) {
+            if (!WIN && pid != 0) {
                 partial(integral_constant<int, 0>{});
                 stamp(0x42);
                 partial(integral_constant<int, 1>{});
@@ -959,7 +976,8 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                     A::template p1<2, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
                     A::template p1<3, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
                     if constexpr (WIN) {   // the exact maximum of what the row SEES: both bounds (a tile in front of the window: -inf)
-                        float xa = A::template rowmax<0, 2>(thr_of(0, j), lo_of(0, j)), xb = A::template rowmax<1, 2>(thr_of(1, j), lo_of(1, j));
+                        const int ta = thr_of(0, j), tb1 = thr_of(1, j);
+                        float xa = A::template rowmax<0, 2>(ta, lo_from(ta)), xb = A::template rowmax<1, 2>(tb1, lo_from(tb1));
                         xa = fmaxf(xa, xhalf_fast(xa));
                         xb = fmaxf(xb, xhalf_fast(xb));
                         mA = fmaxf(mA, xa * c);
@@ -999,7 +1017,19 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             // mask -- every part of a causal or ragged problem but a head's first block -- step 0, the plain steps, the step in
             // front of the last tile and the last tile all run bodies with static ring slots, literal scalar operands and the
             // requests in their MFMA gaps.  Everything else (and the exact-maximum stream) takes the generic bodies.
-            const bool fast = !WIN && !REDO && embedded && na >= 3 && jm >= na - 1;
+            // WIN: the wave's head -- idle positions, its own prologue, step 0, the tiles that cross the window's left edge -- takes the generic
+            // bodies and everything behind it (whole tiles, the step in front of the diagonal tile, the diagonal tile, the pads) the
+            // embedded-request ones, when the diagonal is the only masked tile there
+            const bool fast = !WIN && !REDO && embedded && na >= 3 && jm >= na - 1;   // (WIN: step 0 is always a generic one -- one flow less for hipcc's scalar budget)
+            int jgen = na;        // WIN: generic steps run up to here
+            bool wtail = false;   // ... and the embedded-request bodies take over
+            if constexpr (WIN) {
+                const int js = max(max(f0 + 1, jl), 1);
+                // (at least four whole tiles: with the two a W = 256 part has per wave, the change of flow costs more than it saves -- S 8192 W 256
+                // 354 -> 367 us, W 1024 665 -> 627 us, gpurun sessions r6_s9 / r6_s10)
+                wtail = !fast && !REDO && embedded && jm >= na - 1 && js + 4 <= na - 2;
+                if (wtail) jgen = js;
+            }
             if (!seam_done) prologue(integral_constant<int, 0>{}, 0.f, 0.f, [](auto) {});
             seam_done = false;
             using I0 = integral_constant<int, 0>;
@@ -1024,17 +1054,29 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 } else {
                     step_rt(I0{}, I2{}, 0);   // tile 0 (O starts at 0)
                 }
-                while (j < na) {
+                while (j < jgen) {
                     if (j & 1) step_rt(I1{}, I1{}, j);
                     else step_rt(I0{}, I1{}, j);
                     ++j;
+                }
+                if constexpr (WIN) {
+                    if (wtail) {
+                        sync_regs();   // (the generic steps moved the shadows: cursors of step j into the literal registers)
+                        for (; j < na - 2; ++j) {
+                            plain_one(j);
+                            fix_cursors(j);
+                        }
+                        fast_tail(j);
+                        fast_pads(na);
+                        j = nt3;
+                    }
                 }
             }
             for (; j < nt3; ++j) idle(j);   // (tiles the wave does not see, and the padding of the part to a multiple of three positions)
             if (pre && na == nt && !q_asked) issue_q(w4_rfl(tab[n_slot].x), qb_of(n_slot));   // (waves with idle steps asked in their first one;
                                                                                                    // the embedded-request flow: in the last tile)
             if constexpr (!REDO) {
-                if (pre && pid == 0 && embedded) {
+                if (pre && (WIN || pid == 0) && embedded) {
                     // the seam: this part's pack inside the next part's prologue (pre: there IS a next part of this stream; pid 0: the
                     // part's O is final -- a partial part stores its accumulators as they are)
                     float invA, invB;
@@ -1251,8 +1293,9 @@ bool fwd_w4_applicable(const FwdArgs& a) {
             const char* e = std::getenv("AULE_HIP_W4_WINDOW");
             return (e != nullptr && e[0] == '0') ? 0 : 1;
         }();
-        // (windows shorter than a key tile stay where they were: a wave would see one or two tiles of a five-tile part)
-        if (!on || !a.causal || a.window < kKVTile || a.coff < 0 || (long long)a.Sq + a.coff > a.Sk || (long long)a.Sk >= 65535LL * kKVTile) return false;
+        // (windows shorter than two key tiles stay where they were: a wave would see two or three tiles of a five-tile part, and a tile could be
+        // cut by the window's left edge AND the diagonal -- the streams carry no mask variant with both bounds)
+        if (!on || !a.causal || a.window < 2 * kKVTile || a.coff < 0 || (long long)a.Sq + a.coff > a.Sk || (long long)a.Sk >= 65535LL * kKVTile) return false;
     }
     if (a.rope_cos != nullptr) {   // fused query rotation: table geometry the 32-bit row offsets of the requests can address
         if (a.rope_sin == nullptr || a.rope_pitch < a.D / 2 || (a.rope_pitch & 3) != 0) return false;

@@ -154,16 +154,17 @@ def test_forward_routing_rule(monkeypatch):
     assert _route(4, 32, 8, 1024, 4096, 128, causal=2) == W4         # Sq > 256
     assert _route(8, 32, 8, 64, 8192, 128, causal=2, window=16) == PP
     assert _route(8, 32, 8, 64, 8192, 128, causal=1) == W4           # top-left: sees the first Sq keys only
-    assert _route(1, 32, 8, 1, 8192, 128, causal=2, window=128) == W4   # a window from the end needs the mask (round 6: the window instances; W < 64: PP)
+    assert _route(1, 32, 8, 1, 8192, 128, causal=2, window=128) == W4   # a window from the end needs the mask (round 6: the window instances; W < 128: PP)
     assert _route(1, 32, 8, 8, 8192, 128, window=4) == PP            # window
     assert _route(1, 32, 8, 8, 8192, 128, window=64) == TILED_SPLIT  # W >= Sq masks nothing: dropped
-    # round 6: causal sliding windows of at least one key tile on the one-wave-per-SIMD kernel's window instances (every query's diagonal key inside
+    # round 6: causal sliding windows of at least two key tiles on the one-wave-per-SIMD kernel's window instances (every query's diagonal key inside
     # Sk); smaller windows, non-causal windows and rows without a visible key stay on the ping-pong kernel; never the key-range split
     assert _route(4, 32, 32, 8192, 8192, 128, causal=1, window=256) == W4
     assert _route(4, 32, 8, 4096, 4096, 64, dtype=1, causal=1, window=1024) == W4
     assert _route(1, 8, 8, 8192, 8192, 128, causal=1, window=256) == W4     # (without the window: PS_SPLIT)
     assert _route(1, 32, 32, 700, 1500, 128, causal=2, window=200) == W4
-    assert _route(4, 32, 32, 8192, 8192, 128, causal=1, window=63) == PP
+    assert _route(4, 32, 32, 8192, 8192, 128, causal=1, window=127) == PP
+    assert _route(4, 32, 32, 8192, 8192, 128, causal=1, window=128) == W4
     assert _route(4, 32, 32, 4096, 4096, 128, causal=0, window=256) == PP
     assert _route(1, 2, 2, 600, 200, 128, causal=1, window=64) == PP
     assert _route(4, 32, 32, 4096, 4096, 32, causal=1, window=256) == PP
@@ -218,8 +219,8 @@ assert fusable(pitch=68) == 1                                              # 16-
 assert fusable(B=1, Hq=8, Hkv=8, Sq=8192, Sk=8192, rows=8192) == 1         # small causal grid (split over the keys)
 assert fusable(D=32) == 0                                                  # no fused instance
 assert fusable(dtype=0) == 0                                               # fp32 kernel
-assert fusable(window=64) == 1                                             # (round 6) the window instances of the same kernel
-assert fusable(window=32) == 0                                             # windows shorter than a key tile: ping-pong kernel
+assert fusable(window=128) == 1                                            # (round 6) the window instances of the same kernel
+assert fusable(window=64) == 0                                             # windows shorter than two key tiles: ping-pong kernel
 assert fusable(Sq=128, Sk=128) == 0                                        # fewer than four KV tiles: ping-pong kernel
 assert fusable(Hq=8, Hkv=8, B=1, Sq=1, Sk=8192, causal=0, rows=8192) == 0  # short-query split paths
 assert fusable(layout=1) == 0                                              # interleaved pairs: separate pass

@@ -33,7 +33,7 @@ CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, window
     ("fp32", 1, 2, 1, 300, 420, 32, -1),
     ("fp32", 1, 2, 2, 77, 400, 128, -1),
     ("bf16", 1, 4, 2, 512, 1024, 128, 100),        # window measured from the shifted position
-    ("bf16", 1, 4, 2, 512, 1024, 128, 40),          # a window shorter than a key tile: the ping-pong kernel (round 6: longer ones run the window instances of route 8)
+    ("bf16", 1, 4, 2, 512, 1024, 128, 200),         # round 6: windows of at least two key tiles run the window instances of the one-wave-per-SIMD kernel (route 8)
     ("bf16", 1, 2, 2, 300, 900, 64, 301),
     ("fp16", 1, 2, 1, 200, 1000, 128, 64),
     ("fp32", 1, 2, 2, 150, 400, 64, 33),
@@ -51,7 +51,7 @@ CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, window
 ROUTES = {  # forward kernel each of these shapes is meant to exercise (aule_hip_debug_forward_route)
     ("bf16", 2, 8, 2, 64, 8192, 128, -1): 5, ("fp16", 1, 8, 2, 17, 3000, 64, -1): 5, ("fp16", 2, 6, 3, 33, 2049, 32, -1): 5,
     ("bf16", 1, 32, 1, 5, 4100, 128, -1): 5, ("bf16", 8, 32, 8, 1, 4096, 128, -1): 4, ("bf16", 1, 8, 1, 64, 2048, 128, -1): 5,
-    ("bf16", 2, 2, 2, 1000, 1500, 128, -1): 7, ("bf16", 2, 64, 16, 520, 1100, 128, -1): 8, ("bf16", 1, 4, 2, 512, 1024, 128, 100): 8, ("bf16", 1, 4, 2, 512, 1024, 128, 40): 1, ("fp32", 1, 2, 1, 300, 420, 32, -1): 0,
+    ("bf16", 2, 2, 2, 1000, 1500, 128, -1): 7, ("bf16", 2, 64, 16, 520, 1100, 128, -1): 8, ("bf16", 1, 4, 2, 512, 1024, 128, 100): 1, ("bf16", 1, 4, 2, 512, 1024, 128, 200): 8, ("fp32", 1, 2, 1, 300, 420, 32, -1): 0,
 }
 
 

@@ -57,18 +57,19 @@ CASES = [  # dtype, B, Hq, Hkv, Sq, Sk, D, causal, window
     ("bf16", 1, 32, 8, 1100, 1100, 128, True, 100),
     ("fp16", 2, 32, 32, 1024, 1024, 64, True, 300),
     ("bf16", 1, 32, 32, 700, 1500, 128, "bottom-right", 200),
-    # round 6: the sliding-window instances of the one-wave-per-SIMD forward (causal, W >= 64, every query's diagonal key inside Sk): aligned and
+    # round 6: the sliding-window instances of the one-wave-per-SIMD forward (causal, W >= 128, every query's diagonal key inside Sk): aligned and
     # unaligned windows, shorter and longer than a Q block, waves that start late (W = 256: wave 3 of a block at its part's tile 3 -> position 2),
     # ragged last blocks, GQA, D = 64, a bottom-right offset that is not a multiple of the tile
     ("bf16", 1, 4, 4, 2048, 2048, 128, True, 256),
-    ("bf16", 1, 2, 2, 1536, 1536, 128, True, 64),
+    ("bf16", 1, 2, 2, 1536, 1536, 128, True, 128),
+    ("bf16", 1, 2, 2, 1536, 1536, 128, True, 64),       # (shorter than two key tiles: the ping-pong kernel)
     ("bf16", 1, 4, 1, 1300, 1300, 64, True, 200),
     ("bf16", 1, 2, 2, 900, 2000, 128, "bottom-right", 700),
     ("bf16", 1, 2, 2, 4096, 4096, 128, True, 1024),
     ("fp16", 1, 2, 2, 1024, 1024, 128, True, 129),
     ("fp16", 1, 4, 2, 3000, 3000, 64, True, 1000),
 ]
-W4_WINDOW_CASES = {c for c in CASES if c[0] != "fp32" and c[6] in (64, 128) and c[7] and c[8] >= 64 and min(256 + (c[5] - c[4] if c[7] == "bottom-right" else 0), c[5]) > 192
+W4_WINDOW_CASES = {c for c in CASES if c[0] != "fp32" and c[6] in (64, 128) and c[7] and c[8] >= 128 and min(256 + (c[5] - c[4] if c[7] == "bottom-right" else 0), c[5]) > 192
                    and c[4] + (c[5] - c[4] if c[7] == "bottom-right" else 0) <= c[5]}
 
 
@@ -135,6 +136,19 @@ def test_window_with_large_logits_takes_the_exact_maximum_stream(oracle_mod):
     atol, rtol = fwd_tol("bf16", float(v.float().abs().max()))
     assert_close(o, ref, atol, rtol, "out")
     assert_close(lse.cpu().numpy(), rl, LSE_TOL["bf16"], 1e-5, "lse")
+
+
+def test_window_suite_on_the_ping_pong_route():
+    """The same cases with the window instances off (AULE_HIP_W4_WINDOW=0: read once per process, hence a child): the ping-pong kernel's window
+    path still serves non-causal windows, windows shorter than two key tiles and rows without a visible key, and stays the A/B partner of
+    tools/window_bench.py."""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e["AULE_HIP_W4_WINDOW"] = "0"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "forward_backward_vs_oracle or goldens or large_logits"], env=e, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_window_properties():

@@ -205,10 +205,10 @@ def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked, sub=False):
                     o += [f"v_mov_b32 {x[i]}, {nm}", f"v_fmac_f32 {x[i]}, %[c], {sc[i]}"]
                 else:
                     o += [f"v_mul_f32 {x[i]}, %[c], {sc[i]}", f"v_add_f32 {x[i]}, {nm}, {x[i]}"]
-            if masked:
+            if masked in (1, 2):
                 o.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + i)}, %[thr]")
                 o.append(f"v_cndmask_b32 {x[i]}, v{c.NINF}, {x[i] if (not c.pre or sub) else sc[i]}, vcc")
-            if masked == 2:     # sliding window: the key must not lie in front of the row's first visible one either
+            if masked in (2, 3):     # sliding window: the key must not lie in front of the row's first visible one (2: both bounds, 3: this one only)
                 o.append(f"v_cmp_ge_i32 vcc, {kk(blk_h, e0 + i)}, %[lo]")
                 o.append(f"v_cndmask_b32 {x[i]}, v{c.NINF}, {x[i]}, vcc")
             return o
@@ -255,9 +255,10 @@ def softmax_ops(c, sbase, blk_h, e0, pbase, qb, masked, sub=False):
             if masked:
                 for p in (p0, p0 + 1):
                     for i in range(2):
-                        ops.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + 2 * p + i)}, %[thr]")
-                        ops.append(f"v_cndmask_b32 {x[p][i]}, v{c.NINF}, {(x if not (c.pre and not sub) else scp)[p][i]}, vcc")
-                        if masked == 2:
+                        if masked in (1, 2):
+                            ops.append(f"v_cmp_le_i32 vcc, {kk(blk_h, e0 + 2 * p + i)}, %[thr]")
+                            ops.append(f"v_cndmask_b32 {x[p][i]}, v{c.NINF}, {(x if not (c.pre and not sub) else scp)[p][i]}, vcc")
+                        if masked in (2, 3):
                             ops.append(f"v_cmp_ge_i32 vcc, {kk(blk_h, e0 + 2 * p + i)}, %[lo]")
                             ops.append(f"v_cndmask_b32 {x[p][i]}, v{c.NINF}, {x[p][i]}, vcc")
             for p in (p0, p0 + 1):
@@ -456,8 +457,10 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
     reads (ring slot in the address register).  dma: this statement's piece of the K tile the step requests."""
     qb, KS, DB = Q >> 1, c.KS, c.DB
     mf, clob = [], ["memory"]
-    two = sm == 5           # sliding window (round 6): the masked form with a lower bound too (%[lo]); tile 0 of a part takes it as it is (no pre form)
-    if two:
+    # sliding window (round 6): 5 = the masked form with a lower bound too (%[lo]), 6 = the lower bound only (a tile that crosses the window's
+    # left edge and not the diagonal); tile 0 of a part takes them as they are (no pre form)
+    mk = {5: 2, 6: 3}.get(sm, 1)
+    if mk != 1:
         assert not c.pre
         sm = 2
     sub = sm >= 3
@@ -485,7 +488,7 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
     valu = []
     if sm:
         h = Q >> 1
-        valu = softmax_ops(c, c.sB(h, par), h, 8 * (Q & 1), c.pB(Q), 1, (2 if two else 1) if sm == 2 else 0, sub)
+        valu = softmax_ops(c, c.sB(h, par), h, 8 * (Q & 1), c.pB(Q), 1, mk if sm == 2 else 0, sub)
         clob += [f'v{t}' for t in c.T] + vregs(c.pB(Q), 4) + vregs(c.l(1, 0), 2)
         if sm == 2:
             clob.append("vcc")
@@ -551,9 +554,9 @@ def gen_p1(c, Q, par, qk, sm, vr, dma, sl=0):
     if sm:
         if not c.pre:
             ins.append(f'[c] "{CREG}"(c)')
-        if sm == 2:
+        if sm == 2 and mk != 3:
             ins.append('[thr] "v"(thr)')
-        if two:
+        if mk != 1:
             ins.append('[lo] "v"(lo)')
     if vr:
         ins.append('[va] "v"(va)')
@@ -567,8 +570,8 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
     -> pA[PAR ^ 1][Q].  kr: reads of K_{j+2} (ring slot in the address registers).  dma: this statement's piece of the V tile."""
     qb, KS, DB = Q >> 1, c.KS, c.DB
     mf, clob = [], ["memory"]
-    two = sm == 5           # (as in gen_p1)
-    if two:
+    mk = {5: 2, 6: 3}.get(sm, 1)           # (as in gen_p1)
+    if mk != 1:
         assert not c.pre
         sm = 2
     if pv:
@@ -606,7 +609,7 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
     valu = []
     if sm:
         h = Q >> 1
-        valu = softmax_ops(c, c.sA(h), h, 8 * (Q & 1), c.pA(par ^ 1, Q), 0, (2 if two else 1) if sm == 2 else 0, pv == 0)
+        valu = softmax_ops(c, c.sA(h), h, 8 * (Q & 1), c.pA(par ^ 1, Q), 0, mk if sm == 2 else 0, pv == 0)
         clob += [f'v{t}' for t in c.T] + vregs(c.pA(par ^ 1, Q), 4) + vregs(c.l(0, 0), 2)
         if sm == 2:
             clob.append("vcc")
@@ -643,9 +646,9 @@ def gen_p2(c, Q, par, pv, sm, kr, dma, sl=0):
     if sm:
         if not c.pre:
             ins.append(f'[c] "{CREG}"(c)')
-        if sm == 2:
+        if sm == 2 and mk != 3:
             ins.append('[thr] "v"(thr)')
-        if two:
+        if mk != 1:
             ins.append('[lo] "v"(lo)')
     if kr == 1:
         ins += [f'[ka{t}] "v"(ka{t})' for t in range(KS // 4)]
@@ -808,7 +811,8 @@ def p1_variants():
                 for sm in (1, 2) if par else (1, 2, 3, 4):  # (3 / 4: tile 0 -- step 0 of a part, PAR 0)
                     v.append((Q, par, qk, sm, 1, 0, 0))     # generic steps: ring slot in the address register, requests apart
                 if not PRE_ON:
-                    v.append((Q, par, qk, 5, 1, 0, 0))      # ... of a sliding-window part: two-sided mask
+                    v.append((Q, par, qk, 6, 1, 0, 0))      # ... of a sliding-window part: a tile that crosses the window's left edge (windows of at
+                                                            # least two key tiles: never the diagonal as well -- code 5, both bounds, is not generated)
         v.append((Q, 1, 1, 0, 0, 0, 0))             # bare QK^T of tile 0 ("step -1": part prologue, exact-maximum pass)
         v.append((Q, 0, 1, 3, 1, 3 if Q == 0 else 2, 0))   # step 0 of a part in the embedded-request form (stream position 0, parity 0)
     return sorted(set(v))
@@ -823,12 +827,12 @@ def p2_variants():
                 v.append((Q, par, 1, 2, 1, 2, sl))  # the step in front of the wave's diagonal tile: S_{j+1}[A] masked
                 v.append((Q, par, 1, 0, 0, 2, sl))  # the diagonal tile itself: O^T += V^T P^T and the V request, nothing else
                 v.append((Q, par, 1, 0, 2, 2, sl))  # ... and the next part's Q rows (KR 2)
-            for sm in (0, 1, 2) + (() if PRE_ON else (5,)):
-                v.append((Q, par, 1, sm, 1, 0, 0))  # generic steps (5: sliding window, two-sided mask)
+            for sm in (0, 1, 2) + (() if PRE_ON else (6,)):
+                v.append((Q, par, 1, sm, 1, 0, 0))  # generic steps (6: sliding window, the left edge)
         v += [(Q, 0, 2, 0, 1, 0, 0), (Q, 0, 2, 1, 1, 0, 0), (Q, 0, 2, 2, 1, 0, 0)]   # first step of a part (O starts at 0)
         v += [(Q, 1, 0, 1, 1, 0, 0), (Q, 1, 0, 2, 1, 0, 0)]                          # part prologue: P_0[A] next to the reads of K_1
         if not PRE_ON:
-            v += [(Q, 0, 2, 5, 1, 0, 0), (Q, 1, 0, 5, 1, 0, 0)]                      # sliding window: first step / prologue (of the part, or of a wave that starts late)
+            v += [(Q, 0, 2, 6, 1, 0, 0), (Q, 1, 0, 6, 1, 0, 0)]                      # sliding window: first step / prologue (of the part, or of a wave that starts late)
         v.append((Q, 0, 2, 1, 1, 2, 2))                                              # step 0 of a part, embedded-request form
     return sorted(set(v))
 

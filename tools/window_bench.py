@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Sliding-window forward / forward+backward timings on the shapes of the reference's README (python/README.md:36-40: S 2K / 4K / 8K,
-window 256) -- the ping-pong kernel's route (fa_fwd_pp_gfx950.hip; the one-wave-per-SIMD forward does not take windows: DESIGN.md 3.2).
+window 256).  Round 6: the window instances of the one-wave-per-SIMD forward (fa_fwd_w4_gfx950.hip WIN) by default; AULE_HIP_W4_WINDOW=0 = the
+ping-pong kernel's route (fa_fwd_pp_gfx950.hip), the A/B partner.
 TFLOP/s counts the visible scores only (a band of `window` keys per query)."""
 import math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
