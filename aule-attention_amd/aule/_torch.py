@@ -122,7 +122,11 @@ def _fwd_desc(lib, q, k, causal, scale, window):
     cache = getattr(_desc_cache, "fwd", None)
     if cache is None:
         cache = _desc_cache.fwd = {}
-    key = (q.dtype, q.shape, k.shape[1], k.shape[2], causal, scale, window, q.device.index)
+    # (the key holds VALUES -- a 0-dim tensor or numpy scalar as `scale` / `window` hashes by identity, never hits and stays alive in
+    # the cache -- and the RESOLVED device: an index-less "cuda" device means the current one at the time of the call)
+    dev = q.device.index if q.device.index is not None else torch.cuda.current_device()
+    key = (q.dtype, tuple(q.shape), int(k.shape[1]), int(k.shape[2]), causal_code(causal), None if scale is None else float(scale),
+           int(window) if window is not None and window > 0 else -1, dev)
     ent = cache.get(key)
     if ent is None:
         B, Hq, Sq, D = q.shape
@@ -133,7 +137,7 @@ def _fwd_desc(lib, q, k, causal, scale, window):
         d.scale = _abi_scale(scale)
         d.causal = causal_code(causal)
         d.window_size = int(window) if window is not None and window > 0 else -1
-        d.device = q.device.index if q.device.index is not None else torch.cuda.current_device()
+        d.device = dev
         if len(cache) >= 512:
             cache.clear()
         ent = cache[key] = (d, int(lib.aule_attention_forward_workspace_size(ctypes.byref(d))))

@@ -927,8 +927,11 @@ int32_t aule_rope_ex(const aule_rope_desc* d) {
 
 uint64_t aule_attention_backward_workspace_size(const aule_attn_bwd_desc* d) {
     if (d == nullptr) return 0;
+    // (a window that masks something -- the rule of aule_attention_backward_ex -- keeps the call on the recompute pair: no dS workspace then)
+    const int coff = d->causal == AULE_CAUSAL_BOTTOM_RIGHT ? (int)d->seq_k - (int)d->seq_q : 0;
+    const bool windowed = d->window_size > 0 && (long long)d->window_size < (long long)d->seq_q + coff;
     return aule_hip::bwd_workspace_bytes((int)d->batch, (int)d->heads_q, (int)d->heads_kv, (int)d->seq_q, (int)d->seq_k,
-                                         (int)d->head_dim, d->causal != 0, d->dtype, d->device);
+                                         (int)d->head_dim, d->causal != 0, d->dtype, d->device, windowed);
 }
 
 int32_t aule_attention_backward_ex(const aule_attn_bwd_desc* d) {

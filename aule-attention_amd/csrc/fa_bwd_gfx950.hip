@@ -1345,9 +1345,10 @@ uint64_t bwd_workspace_min_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, 
 }
 // ... and what it WANTS: plus the dS workspace of the 5-matmul backward for as many batch elements as fit the cap (at least one).
 // A caller that passes only the minimum gets the recompute pair.
-uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype, int device) {
+// (windowed: the dispatcher keeps windowed problems on the recompute pair -- no dS room is asked for: ADVICE r5)
+uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype, int device, bool windowed) {
     uint64_t bytes = bwd_base_bytes(B, Hq, Hkv, Sq, Sk, D, causal, dtype, device);
-    const uint64_t pb = spill_bytes_per_batch(B, Hq, Hkv, Sq, Sk, D, causal, dtype);
+    const uint64_t pb = windowed ? 0 : spill_bytes_per_batch(B, Hq, Hkv, Sq, Sk, D, causal, dtype);
     if (pb > 0) {
         uint64_t nb = bwd_ds_cap_bytes() / pb;
         if (nb > (uint64_t)B) nb = (uint64_t)B;

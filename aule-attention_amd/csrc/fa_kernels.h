@@ -188,7 +188,7 @@ int bwd_last_route();
 
 // Bytes of device workspace launch_bwd needs: delta [B,Hq,Sq] fp32, plus (16-bit GQA/MQA problems that
 // do not fill the chip) fp32 dK/dV partials of the head-split dK/dV kernel.
-uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype, int device = -1);
+uint64_t bwd_workspace_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype, int device = -1, bool windowed = false);
 // ... of which launch_bwd cannot do without (the rest is the dS workspace of the 5-matmul backward: fa_bwd_gfx950.hip)
 uint64_t bwd_workspace_min_bytes(int B, int Hq, int Hkv, int Sq, int Sk, int D, int causal, int dtype, int device = -1);
 

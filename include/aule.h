@@ -238,7 +238,8 @@ int32_t aule_rope_ex(const aule_rope_desc* desc);
 /* rotated in registers with exactly aule_rope_ex()'s arithmetic and rounding: the result is bit-identical to        */
 /* aule_rope_ex(Q) followed by aule_attention_forward_ex(), minus one read and one write of Q.  Taken only by the    */
 /* persistent forward kernel: fp16 / bf16, head_dim 64 or 128, AULE_ROPE_HALF, 16-byte aligned tables with           */
-/* table_pitch % 4 == 0, no sliding window -- ask aule_attention_forward_rope_fusable() (host logic only; 1 = yes)   */
+/* table_pitch % 4 == 0, no sliding window other than a causal one of >= 128 keys (round 6: the kernel's window     */
+/* instances) -- ask aule_attention_forward_rope_fusable() (host logic only; 1 = yes)                               */
 /* and fall back to the two calls otherwise; aule_attention_forward_rope_ex() returns -3 for other configurations.   */
 typedef struct aule_attn_rope {
     uint32_t struct_size;      /* = sizeof(aule_attn_rope) */
