@@ -71,6 +71,8 @@ struct FwdW4Params {
     float* part;       // [npiece][part_rows][D + kPartPad]
     int part_rows;     // B * Hq * Sq
     int window;        // sliding window (round 6, WIN instances only): query at position x sees keys x - window < k <= x; 0: none
+    float sum_lo;      // lower bound of the range verdict on a row's sum of weights (w4_body: kSumLo)
+    int wtail_min;     // WIN: whole tiles a wave needs between its left-edge tiles and its diagonal before its tail takes the embedded-request bodies
     int generic;       // AULE_HIP_W4_BODIES=generic: every step through the generic bodies (the embedded-request flow off: A/B, bit-identity test)
     unsigned long long* dbg;   // timeline build only: [4 waves][kW4TLMax] tagged s_memtime stamps of workgroup 0
 };
@@ -125,10 +127,10 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     // first tile), so its largest weight is >= 1 and only the upper bound can fail; 2^-100 catches empty sums.  WIN: the reference may come from
     // keys IN FRONT of the row's window and lie above everything the row sees -- every weight below 1.  bf16 weights keep their 8 bits down to
     // 2^-126; fp16 weights lose theirs below 2^-14 (found by tools/fuzz_parity.py window: a key 29 log2 units above the window's maximum,
-    // outside it, left O = 0 for fp16 rows whose verdict passed): the sum must reach 1 -- with up to 32 K visible keys the rounding of the
+    // outside it, left O = 0 for fp16 rows whose verdict passed): the sum must stay above 1/2 -- with up to 16 K visible keys the rounding of the
     // weights that fall below fp16's normal range (2^-25 each) then stays under 2^-10 of the result -- or the part goes to the exact-maximum stream.  On N(0, 1) logits
     // the sum is ~0.15 W: the bound is never near.
-    constexpr float kSumLo = (WIN && T::kDType != 2) ? 1.0f : 0x1p-100f;
+    // (the bound itself: FwdW4Params::sum_lo, read where a verdict is taken -- 1/2 for the fp16 window instances: a row with ONE visible key sums to exactly 1)
     using std::integral_constant;
     constexpr int RB = 2 * D, RBP = RB + 16, CPR = RB / 16, KS = D / 16, DB = D / 32;
     constexpr int KT = 64 * RB, VT = KT, NP = KT / 4096, NQ = 2 * KS;   // NQ: buffer loads of a wave's Q fragments
@@ -172,6 +174,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
         hi = (unsigned)w4_rfl((int)hi);
         return (KernargPtr)(uintptr_t)(((unsigned long long)hi << 32) | lo);
     };
+    auto sum_lo = [&]() __attribute__((always_inline)) { return WIN ? P()->sum_lo : 0x1p-100f; };
     const int Sk = p.Sk, coff = p.coff;
     const int win = WIN ? p.window : 0;
     const float c = p.c;
@@ -886,7 +889,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 const u32x2_t ml = {__builtin_bit_cast(unsigned, -nm), __builtin_bit_cast(unsigned, lt)};
                 __builtin_amdgcn_raw_buffer_store_b64(ml, prs, hio == 0 ? (int)(roff + D * 4) : 0x7ffffff0, 0, 0);
 #ifndef W4_X_NOVERDICT
-                if constexpr (!REDO) bad = bad || !((lt > kSumLo) && (lt < (T::kDType == 2 ? 0x1p110f : 0x1p15f)));
+                if constexpr (!REDO) bad = bad || !((lt > sum_lo()) && (lt < (T::kDType == 2 ? 0x1p110f : 0x1p15f)));
 #endif
             };
             auto half = [&](auto qb_tag) __attribute__((always_inline)) {
@@ -899,7 +902,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 const float lse = (fast_log2(lt) - nm) * kLn2;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lse), lrs, hio == 0 ? (r0 + 32 * QB + l31o) * 4 : 0x7ffffff0, 0, 0);
 #ifndef W4_X_NOVERDICT   // (timing experiments with garbage arithmetic: no second stream)
-                if constexpr (!REDO) bad = bad || !((lt > kSumLo) && (lt < (T::kDType == 2 ? 0x1p110f : 0x1p15f)));
+                if constexpr (!REDO) bad = bad || !((lt > sum_lo()) && (lt < (T::kDType == 2 ? 0x1p110f : 0x1p15f)));
 #endif
                 // (the wave's own LDS accesses are ordered: no barrier between the slab's writes, reads and next writes)
 #pragma unroll
@@ -952,7 +955,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 const float lse = (fast_log2(lt) - nm) * kLn2;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lse), lrs, hio == 0 ? (r0 + 32 * QB + l31o) * 4 : 0x7ffffff0, 0, 0);
 #ifndef W4_X_NOVERDICT
-                bad = bad || !((lt > kSumLo) && (lt < (T::kDType == 2 ? 0x1p110f : 0x1p15f)));
+                bad = bad || !((lt > sum_lo()) && (lt < (T::kDType == 2 ? 0x1p110f : 0x1p15f)));
 #endif
             };
             one(integral_constant<int, 0>{}, invA);
@@ -1035,7 +1038,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 const int js = max(max(f0 + 1, jl), 1);
                 // (at least four whole tiles: with the two a W = 256 part has per wave, the change of flow costs more than it saves -- S 8192 W 256
                 // 354 -> 367 us, W 1024 665 -> 627 us, gpurun sessions r6_s9 / r6_s10)
-                wtail = !fast && !REDO && embedded && jm >= na - 1 && js + 4 <= na - 2;
+                wtail = !fast && !REDO && embedded && jm >= na - 1 && js + w4_rfl(P()->wtail_min) <= na - 2;
                 if (wtail) jgen = js;
             }
             if (!seam_done) prologue(integral_constant<int, 0>{}, 0.f, 0.f, [](auto) {});
@@ -1195,6 +1198,19 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
     p.npiece = 1; p.pcoff = 0; p.magic = 0; p.part = nullptr; p.part_rows = 0;
     p.generic = w4_generic_bodies();
     p.window = a.window > 0 ? a.window : 0;
+    {   // AULE_HIP_W4_WTAIL=<n> (A/B; default 4: profiles/r6_window_shapes.txt)
+        static const int wt = [] {
+            const char* e = std::getenv("AULE_HIP_W4_WTAIL");
+            return (e != nullptr && e[0] >= '0' && e[0] <= '9') ? std::atoi(e) : 4;
+        }();
+        p.wtail_min = wt;
+        // (AULE_HIP_W4_SUMLO=<x>: A/B of the verdict's lower bound)
+        static const float sl = [] {
+            const char* e = std::getenv("AULE_HIP_W4_SUMLO");
+            return e != nullptr ? (float)std::atof(e) : -1.0f;
+        }();
+        p.sum_lo = sl >= 0.f ? sl : ((p.window > 0 && a.dtype != kBF16) ? 0.5f : 0x1p-100f);
+    }
     p.rcos = a.rope_cos; p.rsin = a.rope_sin;
     p.rrows = a.rope_rows; p.rpitch = a.rope_pitch; p.rpos = a.rope_pos;
     // one workgroup per CU; more only when a workgroup's list would not fit its part table
@@ -1263,7 +1279,7 @@ int launch_w4_split(const FwdArgs& a, hipStream_t stream) {
     p.part = static_cast<float*>(ws.ptr);
     p.part_rows = a.B * a.Hq * a.Sq;
     p.generic = w4_generic_bodies();
-    p.window = 0;
+    p.window = 0; p.wtail_min = 0; p.sum_lo = 0x1p-100f;
     const size_t lds = w4_lds_bytes<D>();
     if (a.causal)
         hipLaunchKernelGGL((w4_kernel<T, D, true, false>()), dim3((unsigned)s.nitems), dim3(256), lds, stream, p);
