@@ -248,6 +248,14 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                 else if (far != w.blk) qb = w.blk;
             } else if ((tid & 1) == 0) {
                 qb = w.blk;
+                if constexpr (WIN) {
+                    // Which block of its head an item is, is free to choose per head (a rotation of the block indices of one head is a bijection whatever
+                    // the grid): rotate by the head's position in the XCD's unit list.  Without it workgroup g gets block (g / 8) % nqb in EVERY item of
+                    // its list (the items of a workgroup are a whole number of heads apart), and the workgroups that hold a head's first blocks -- whose
+                    // windows are cut short by the start of the sequence -- idle while the others finish (W 1024 at S 8192: 4 of 32 block indices).
+                    const int unit = w.b * p.Hkv + w.hk;
+                    qb = (w.blk + (unit >> 3) * 13 + w.h * 7) % p.nqb;
+                }
                 if constexpr (WIN) {   // the key tiles the block's rows see: from its first row's first key to its last row's diagonal
                     // (a part has at least four tiles -- a ragged last block under a short window would have fewer: tiles in front of the window
                     // are masked like any other key outside it)
