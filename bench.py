@@ -861,6 +861,21 @@ def main():
                       "rope_attn_c2_workload": "RoPE + attention, B=4 H=32 S=2048 D=128 bf16 causal, inference: rope(K) pass + the "
                                                "one-wave-per-SIMD forward with Q rotated inside it (attention FLOPs only)"})
         del q7, k7, v7
+        # sliding-window forward (round 6: the window instances of the one-wave-per-SIMD kernel; the shapes of the reference's README, python/README.md:36-40
+        # -- S = 8192, window 256 -- and window 1024); FLOPs count the VISIBLE scores only (a band of W keys per query)
+        qw, kw, vw = (torch.randn(4, 32, 8192, 128, device=dev, dtype=torch.bfloat16, generator=g3) for _ in range(3))
+        for W in (256, 1024):
+            vis = W * (W + 1) // 2 + (8192 - W) * W
+
+            def stepw(W=W):
+                with torch.no_grad():
+                    aule.flash_attention(qw, kw, vw, causal=True, window_size=W)
+
+            lw = leg("window_s8192_w%d_fwd" % W, stepw, 20, args.condition_ms, 0, False, 4.0 * 4 * 32 * 128 * vis, PK)
+            extra.update({"window_s8192_w%d_fwd_tflops_visible" % W: lw["tflops_median"], "window_s8192_w%d_ms_per_step_median" % W: lw["ms_median"]})
+        extra["window_workload"] = ("B=4 H=32 S=8192 D=128 bf16 causal, window_size 256 / 1024, fwd: route 8, the window instances of the one-wave-per-SIMD kernel "
+                                    "(TFLOP/s of the visible scores only, median step)")
+        del qw, kw, vw
         # D = 64 training (the one-wave-per-SIMD backward pair's D = 64 instances, round 4) and the fp32 kernels (what the legacy
         # C-ABI and NumPy / fp32 torch input run; priced against the 157.3 TF f32-MFMA roof, not the bf16 peak)
         q8 = torch.randn(8, 32, 2048, 64, device=dev, dtype=torch.bfloat16, generator=g3).requires_grad_(True)
