@@ -25,6 +25,7 @@ SHAPES = [  # name, B, Hq, Hkv, Sq, Sk, D, dtype, causal
     ("route7-noncausal-split", 1, 8, 8, 2048, 2048, 128, "fp16", False),
     ("route8-one-wave-per-simd", 4, 16, 16, 1024, 1024, 128, "bf16", True),   # the D = 128 default: several parts per workgroup
     ("route8-fused-rope", 4, 16, 16, 1024, 1024, 128, "bf16", True),      # the forward that rotates Q itself (tables captured too)
+    ("route8-window-256", 2, 16, 4, 2048, 2048, 128, "bf16", True),       # round 6: the window instances (late waves, several parts per workgroup)
 ]
 
 
@@ -66,9 +67,10 @@ def test_forward_capture_replays_bit_identical(shape):
         cos, sin = aule.precompute_rope_frequencies(Sk, D)
         rope = (cos.contiguous(), sin.contiguous(), 0)
         assert at.rope_fusable(q, k, 1, -1, rope[0], rope[1], 0)
-    eager, eager_lse = at.fwd_raw(q, k, v, causal, sc, q_rope=rope)
+    W = int(shape[0].rsplit("-", 1)[1]) if "-window-" in shape[0] else -1
+    eager, eager_lse = at.fwd_raw(q, k, v, causal, sc, q_rope=rope, window=W)
     torch.cuda.synchronize()
-    g, outs = _capture(torch, lambda: at.fwd_raw(q, k, v, causal, sc, q_rope=rope))
+    g, outs = _capture(torch, lambda: at.fwd_raw(q, k, v, causal, sc, q_rope=rope, window=W))
     for o, l in outs:
         o.zero_(); l.zero_()
     g.replay()
@@ -77,7 +79,7 @@ def test_forward_capture_replays_bit_identical(shape):
         assert torch.equal(o, eager) and torch.equal(l, eager_lse)
     # new inputs in the captured buffers: the replay computes on them (no stale pointers into a freed workspace)
     q.copy_(torch.randn_like(q))
-    want, _ = at.fwd_raw(q, k, v, causal, sc, q_rope=rope)
+    want, _ = at.fwd_raw(q, k, v, causal, sc, q_rope=rope, window=W)
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(outs[-1][0], want)
