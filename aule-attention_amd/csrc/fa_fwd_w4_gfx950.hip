@@ -51,7 +51,8 @@ struct FwdW4Params {
     void* o;
     float* lse;
     int B, Hq, Hkv, Sq, Sk;
-    float c;      // scale * log2(e) > 0
+    float c;      // |scale| * log2(e) > 0
+    int negq;     // scale < 0 (round 6): the Q fragments are negated in registers (W4Asm::negate_q) -- c s = |c| ((-q) k) exactly
     int nqb;      // 256-row Q blocks
     int nwork;    // work items per head: ceil(nqb/2) when pairing, else nqb
     int pair;     // item = Q blocks (nqb-1-i, i)
@@ -179,6 +180,9 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
     const int win = WIN ? p.window : 0;
     const float c = p.c;
     const bool rope = p.rcos != nullptr;
+    // (negq is NOT held in a register: held, it cost the causal D = 128 instance 21 more scalar lane spills at its part boundaries -- the part
+    // prologue re-reads it from the kernel arguments, once per part)
+    auto negq = [&]() __attribute__((always_inline)) { return w4_rfl(P()->negq) != 0; };
     const bool embedded = p.generic == 0;
     // K / V base pointers stay in scalar registers for the whole kernel (round 4): a head's base is then a 64-bit add where the
     // cursors cross into the next part, not a load from the kernel-argument segment and its wait in the middle of a part's last steps
@@ -779,6 +783,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
             A::kread_all(kap);
             if constexpr (!REDO) {
                 if (rope) A::rope_rotate();          // (the second stream rotated in its exact-maximum pass)
+                if (negq()) A::negate_q();           // (a negative scale: see FwdW4Params::negq)
                 A::prescale_q(c);                    // (pre form only)
             }
             if constexpr (SEAM) {
@@ -988,6 +993,7 @@ __device__ __forceinline__ void w4_body(const FwdW4Params& p) {
                     A::kread_all(kap);
                     if (j == 0) {
                         if (rope) A::rope_rotate();
+                        if (negq()) A::negate_q();
                         A::prescale_q(c);
                     }
                     A::template p1<0, 1, 1, 0, 0, 0>(c, va, 0, 0, ksrd, 0, 0);
@@ -1196,7 +1202,8 @@ int launch_w4(const FwdArgs& a, hipStream_t stream, unsigned long long* dbg = nu
     FwdW4Params p;
     p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o; p.lse = a.lse;
     p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
-    p.c = a.scale * kLog2e;
+    p.c = (a.scale < 0.f ? -a.scale : a.scale) * kLog2e;
+    p.negq = a.scale < 0.f ? 1 : 0;
     p.nqb = (a.Sq + kQBlock - 1) / kQBlock;
     p.pair = a.causal ? 1 : 0;
     p.nwork = p.pair ? (p.nqb + 1) / 2 : p.nqb;
@@ -1279,7 +1286,8 @@ int launch_w4_split(const FwdArgs& a, hipStream_t stream) {
     FwdW4Params p{};
     p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o; p.lse = a.lse;
     p.B = a.B; p.Hq = a.Hq; p.Hkv = a.Hkv; p.Sq = a.Sq; p.Sk = a.Sk;
-    p.c = a.scale * kLog2e;
+    p.c = (a.scale < 0.f ? -a.scale : a.scale) * kLog2e;
+    p.negq = a.scale < 0.f ? 1 : 0;
     p.nqb = s.nqb; p.pair = a.causal ? 1 : 0; p.nwork = s.nwork; p.coff = a.causal ? a.coff : 0;
     p.nitems = (int)s.nitems;
     p.rounds = 0; p.mper = 1;
@@ -1337,7 +1345,10 @@ bool fwd_w4_applicable(const FwdArgs& a) {
         const long long last = ((long long)(a.Sq + kQBlock - 1) / kQBlock * kQBlock + a.rope_pos) * a.rope_pitch * 4;
         if ((long long)a.rope_rows * a.rope_pitch * 4 >= (1LL << 32) || last >= (1LL << 32)) return false;
     }
-    if (!(a.scale > 0.f) || !(a.scale < 3.0e38f)) return false;
+    {   // (round 6: negative scales run here too, on negated Q fragments; scale = 0 -- uniform attention -- stays on the ping-pong kernel)
+        const float as = a.scale < 0.f ? -a.scale : a.scale;
+        if (!(as > 0.f) || !(as < 3.0e38f)) return false;
+    }
     if (a.causal && a.coff < 0) return false;
     // every part needs >= 4 KV tiles (its prologue consumes tiles 0 and 1 and requests tile 2 before the first plain step):
     // the shortest part is the first Q block

@@ -140,7 +140,7 @@ def test_fused_rotation_rule_from_python():
     assert at.rope_fusable(q, k, 0, -1, cos, sin, 0)
     assert at.rope_fusable(q, k, 1, 128, cos, sin, 0)                        # (round 6) a causal window of >= two key tiles: the window instances rotate Q too
     assert not at.rope_fusable(q, k, 1, 100, cos, sin, 0) and not at.rope_fusable(q, k, 0, 128, cos, sin, 0)   # shorter / non-causal windows: the ping-pong kernel
-    assert at.rope_fusable(q, k, 1, -1, cos, sin, 0, 0.11) and not at.rope_fusable(q, k, 1, -1, cos, sin, 0, -0.2)   # a negative scale: the ping-pong kernel too
+    assert at.rope_fusable(q, k, 1, -1, cos, sin, 0, 0.11) and at.rope_fusable(q, k, 1, -1, cos, sin, 0, -0.2)   # (round 6) a negative scale runs the same kernel, on negated Q fragments
     assert not at.rope_fusable(q.float(), k.float(), 1, -1, cos, sin, 0)     # fp32 kernel
     assert not at.rope_fusable(q[..., :32].contiguous(), k[..., :32].contiguous(), 1, -1, cos[:, :16].contiguous(), sin[:, :16].contiguous(), 0)
     assert not at.rope_fusable(q, k, 1, -1, cos[:1000], sin[:1000], 0)       # table shorter than the sequence

@@ -184,7 +184,8 @@ def test_forward_routing_rule(monkeypatch):
     assert _route(1, 8, 8, 8192, 8192, 128) == W4                    # non-causal: 256 blocks, one per CU
     assert _route(1, 8, 8, 4096, 4096, 128) == PS_SPLIT              # non-causal: 128 blocks, each cut in two
     assert _route(1, 8, 8, 8192, 8192, 32, causal=1) == PP           # D = 32: the ping-pong kernel
-    assert _route(4, 32, 32, 4096, 4096, 128, causal=1, scale=-0.1) == PP    # negative scale too
+    assert _route(4, 32, 32, 4096, 4096, 128, causal=1, scale=-0.1) == W4    # (round 6) negative scales: the same kernel on negated Q fragments
+    assert _route(1, 8, 8, 8192, 8192, 128, causal=1, scale=-0.1) == PS_SPLIT  # ... and its key-range split
     assert _route(8, 32, 32, 2048, 2048, 64, dtype=1, causal=1) == W4         # D = 64 too
     assert _route(1, 8, 8, 300, 300, 128, causal=1) == W4            # one pair whose far block is too short to cut
     assert _route(1, 3, 2, 1, 8192, 128) == -3                       # heads not divisible

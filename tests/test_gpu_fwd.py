@@ -97,6 +97,12 @@ SWEEP = [
     ("fp32", 1, 2, 2, 129, 129, 32, True, None),
     ("fp32", 1, 2, 2, 40, 40, 128, True, -0.3),        # negative scale
     ("bf16", 1, 2, 2, 96, 96, 128, True, -0.2),
+    # round 6: negative scales on the one-wave-per-SIMD kernel (Q fragments negated in registers): several parts per workgroup, GQA, ragged, D = 64,
+    # a bottom-right offset, a grid small enough for the key-range split
+    ("bf16", 2, 8, 2, 1024, 1024, 128, True, -0.2),
+    ("fp16", 1, 4, 4, 700, 1300, 64, False, -0.1),
+    ("bf16", 1, 4, 1, 900, 2000, 128, "bottom-right", -0.05),
+    ("bf16", 1, 8, 8, 4096, 4096, 128, True, -0.09),
     # scale = 0: uniform attention over the visible keys (the reference's and the oracle's reading; the C-ABI's
     # "0 = default" sentinel is resolved above it, aule/_torch.py:_abi_scale)
     ("bf16", 1, 2, 2, 300, 300, 128, True, 0.0),

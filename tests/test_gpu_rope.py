@@ -305,10 +305,11 @@ def test_fused_rotation_through_the_exact_maximum_stream(dtype, B, Hq, Hkv, S, D
     assert torch.equal(fused, two) and torch.equal(lse1, lse2)
 
 
-def test_negative_scale_keeps_the_separate_rotation_pass():
-    """Round 5 (found by tools/fuzz_parity.py split): the kernel that rotates Q itself does not take negative scales, so an inference call of
-    flash_attention_rope with scale < 0 must take the two-pass form -- it used to pick the fused one (the helper did not look at the scale) and
-    the launch then refused it.  Same result as rotating by hand and calling the plain forward."""
+def test_negative_scale_with_the_fused_rotation():
+    """Round 5 (found by tools/fuzz_parity.py split): flash_attention_rope with scale < 0 used to pick the fused rotation although the kernel that
+    rotates Q did not take negative scales (the helper did not look at the scale), and the launch refused it.  Round 6: the kernel takes negative
+    scales -- the Q fragments are negated in registers after the rotation, c = |scale| log2(e) -- so the inference call is fused again, and still
+    the same bits as rotating by hand and calling the plain forward."""
     import torch
     import aule
     from aule import _torch as at
@@ -317,7 +318,7 @@ def test_negative_scale_keeps_the_separate_rotation_pass():
     q, k, v = (torch.randn(B, h, S, D, device="cuda", dtype=torch.bfloat16, generator=g) for h in (Hq, Hkv, Hkv))
     cos, sin = aule.precompute_rope_frequencies(S, D, device="cuda")
     cos, sin = cos.contiguous(), sin.contiguous()
-    assert at.rope_fusable(q, k, 1, -1, cos, sin, 0) and not at.rope_fusable(q, k, 1, -1, cos, sin, 0, -0.2)
+    assert at.rope_fusable(q, k, 1, -1, cos, sin, 0) and at.rope_fusable(q, k, 1, -1, cos, sin, 0, -0.2)
     with torch.no_grad():
         out = aule.flash_attention_rope(q, k, v, cos, sin, causal=True, scale=-0.2)
         ref = aule.flash_attention(at.rope_raw(q, cos, sin), at.rope_raw(k, cos, sin), v, causal=True, scale=-0.2)

@@ -129,7 +129,7 @@ def test_causal_split_forward_vs_oracle(case, oracle_mod):
     q, k, v = (quantize(x, dtype) for x in (q, k, v))
     sc = (1 / math.sqrt(D)) if scale is None else scale
     dev = lambda a: torch.from_numpy(a).to("cuda", torch_dtype(dtype))
-    want = 7 if sc > 0 else 1   # (a negative scale: the ping-pong kernel)
+    want = 7   # (round 6: a negative scale takes the same route, on negated Q fragments)
     assert _route_causal(dtype, B, Hq, Hkv, Sq, Sk, D, causal, sc) == want, "the dispatch rule moved this shape off the key-range split"
     out, lse = at.fwd_raw(dev(q), dev(k), dev(v), at.causal_code(causal), sc)
     ref, ref_lse = oracle_mod.fwd_f64(q, k, v, causal, scale)

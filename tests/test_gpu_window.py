@@ -143,6 +143,22 @@ def test_window_with_large_logits_takes_the_exact_maximum_stream(oracle_mod, dty
     assert_close(lse.cpu().numpy(), rl, LSE_TOL[dtype] * max(1.0, mag / 8.0), 1e-5, "lse")
 
 
+def test_window_with_a_negative_scale(oracle_mod):
+    """Round 6: negative scales run the one-wave-per-SIMD kernel on negated Q fragments -- its window instances included (late waves negate in the
+    part prologue like everybody else)."""
+    import torch
+    from aule import _torch as at
+    rng = np.random.RandomState(9)
+    B, Hq, Hkv, S, D, W, sc = 1, 4, 2, 1024, 128, 256, -0.15
+    q, k, v = (quantize(rng.randn(*s).astype(np.float32), "bf16") for s in ((B, Hq, S, D), (B, Hkv, S, D), (B, Hkv, S, D)))
+    assert _fwd_route("bf16", B, Hq, Hkv, S, S, D, True, W) == 8
+    out, lse = at.fwd_raw(_dev(torch, q, "bf16"), _dev(torch, k, "bf16"), _dev(torch, v, "bf16"), True, sc, window=W)
+    ref, rl = oracle_mod.fwd_f64(q, k, v, True, sc, W)
+    atol, rtol = fwd_tol("bf16", np.abs(v).max())
+    assert_close(out.float().cpu().numpy(), ref, atol, rtol, "out")
+    assert_close(lse.cpu().numpy(), rl, LSE_TOL["bf16"] * 2, 1e-5, "lse")
+
+
 def test_window_suite_on_the_ping_pong_route():
     """The same cases with the window instances off (AULE_HIP_W4_WINDOW=0: read once per process, hence a child): the ping-pong kernel's window
     path still serves non-causal windows, windows shorter than two key tiles and rows without a visible key, and stays the A/B partner of

@@ -1019,6 +1019,17 @@ def gen_struct(c):
     s += "    static __device__ __forceinline__ void rope_rotate() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
     s += emit_asm(lines, [], [], ["memory"] + vregs(c.VB0, 8 * NWAY) + aregs(c.QB0, 8 * c.KS), indent="        ")
     s += "#endif\n    }\n"
+    # ---- negative scales (round 6): the Q fragments with their sign bits flipped -- (-q) k = -(q k) exactly, so c s with c < 0 is |c| times the scores of
+    #      the negated Q, and the stream's maximum of c s (the reference's rule) is the maximum it computes anyway.  Four registers in flight.
+    lines = []
+    for r0 in range(0, 8 * c.KS, 4):
+        lines += [f"v_accvgpr_read_b32 v{c.X + i}, a{c.QB0 + r0 + i}" for i in range(4)]
+        lines += [f"v_xor_b32 v{c.X + i}, 0x80008000, v{c.X + i}" for i in range(4)]
+        lines += [f"v_accvgpr_write_b32 a{c.QB0 + r0 + i}, v{c.X + i}" for i in range(4)]
+    lines += ["s_nop 7"]                                          # v_accvgpr_write -> MFMA operand
+    s += "    static __device__ __forceinline__ void negate_q() {\n#if defined(__HIP_DEVICE_COMPILE__)\n"
+    s += emit_asm(lines, [], [], ["memory"] + vregs(c.X, 4) + aregs(c.QB0, 8 * c.KS), indent="        ")
+    s += "#endif\n    }\n"
     # ---- LDS-DMA of this wave's pieces of one tile (everywhere but the plain step)
     lines = ["s_nop 4"]
     for i in range(c.NP):
