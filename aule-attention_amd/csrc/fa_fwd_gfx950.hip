@@ -10,8 +10,8 @@
 // The kernels live in their own files; this one only picks among them (host logic):
 //   fa_fwd_w4_gfx950.hip       16-bit, one wave per SIMD (4 x 64 query rows), persistent part lists: the default for tiled problems;
 //                              small grids as key-range pieces + merge (fa_fwd_split.h)
-//   fa_fwd_pp_gfx950.hip       16-bit, two waves per SIMD, one workgroup per Q-block pair: sliding window, fewer than four KV tiles
-//                              per Q block, D = 32, negative scale, and the SPLIT instances (packed rows + KV splits) for short queries
+//   fa_fwd_pp_gfx950.hip       16-bit, two waves per SIMD, one workgroup per Q-block pair: sliding windows below 128 keys or without the causal rule, fewer
+//                              than four KV tiles per Q block, D = 32, scale = 0, and the SPLIT instances (packed rows + KV splits) for short queries
 //   fa_fwd_splitkv_gfx950.hip  16-bit, wave-per-chunk split-KV (decode streaming corner) and paged decode
 //   fa_fwd_f32.hip             fp32 I/O
 // Common to the 16-bit kernels: "swapped" S^T = K.Q^T so that a lane owns one query row; P stays in registers as
@@ -136,7 +136,7 @@ int launch_fwd(const FwdArgs& a, hipStream_t stream) {
     if (a.dtype == kF32) return launch_fwd_f32(a, stream);   // (small grids: key-range pieces + merge; answers the dry run itself)
     if (a.query_ws != nullptr) return 0;   // single-launch paths need no workspace
     if (use_w4(a)) return launch_fwd_w4(a, stream);
-    return launch_fwd_pp(a, stream);   // window, fewer than four KV tiles per Q block, D = 32, negative scale, AULE_HIP_FWD_KERNEL=pp
+    return launch_fwd_pp(a, stream);   // short / non-causal windows, fewer than four KV tiles per Q block, D = 32, scale = 0, AULE_HIP_FWD_KERNEL=pp
 }
 
 int configure_fwd() {

@@ -24,8 +24,9 @@
 // verdict on the row sums at the end of the part.  A part that fails it is run again after the stream with the EXACT
 // row maximum as reference (one extra QK^T-only pass over its tiles), so the fast path is the only softmax code.
 //
-// Covers: bf16 / fp16, D = 128 / 64, causal (top-left or shifted by coff >= 0) and non-causal, scale > 0, any Sq, every part
-// with at least 4 KV tiles, no window; optional fused query rotation (half-split pairs) -- everything else stays on the predecessors.
+// Covers: bf16 / fp16, D = 128 / 64, causal (top-left or shifted by coff >= 0) and non-causal, scale != 0 (round 6: negative scales on negated Q
+// fragments), any Sq, every part with at least 4 KV tiles, no window or (round 6: the WIN instances) a causal one of >= 128 keys; optional fused query
+// rotation (half-split pairs) -- everything else stays on the predecessors.
 #include <cstdlib>
 #include <type_traits>
 
