@@ -66,3 +66,18 @@ def test_random_long_sequence_configurations_forward_and_backward(fuzz):
         if errs:
             failures.append((i, route, cfg, errs))
     assert not failures, failures
+
+
+def test_random_window_configurations_on_the_window_instances(fuzz):
+    """Round 6: causal sliding windows on the one-wave-per-SIMD forward's window instances (windows of 128 .. 2500 keys, aligned and not, bottom-right
+    offsets that are no tile multiples, ragged blocks, GQA, D 64 / 128, fp16 and bf16; one draw in four with a spiked key in front of or inside some
+    rows' windows): every output row and LSE against the fp64 judge.  The kind that found the fp16 verdict bound."""
+    rng = np.random.RandomState(77)
+    failures, routes = [], {}
+    for i in range(40):
+        (route, cfg), errs = fuzz.run_window(rng, i)
+        routes[route] = routes.get(route, 0) + 1
+        if errs:
+            failures.append((i, route, cfg, errs))
+    assert not failures, failures
+    assert routes.get(8, 0) >= 30, routes     # (a window beyond the sequence is dropped at the boundary: those draws run the plain routes)
