@@ -113,6 +113,16 @@ inline int split_max_pieces() {
     return v;
 }
 
+// AULE_HIP_FWD_SPLIT_MIN=<tiles>: the shortest piece (A/B; default kSplitMinTiles)
+inline int split_min_tiles() {
+    static const int v = [] {
+        const char* e = getenv("AULE_HIP_FWD_SPLIT_MIN");
+        const int n = (e != nullptr && e[0] >= '0' && e[0] <= '9') ? atoi(e) : kSplitMinTiles;
+        return n < 4 ? 4 : n;
+    }();
+    return v;
+}
+
 struct SplitPlan {
     bool ok;
     int nqb, nwork, n;
@@ -131,13 +141,13 @@ inline SplitPlan split_plan(const FwdArgs& a, int slots) {
     const int T = split_tiles(s.nqb - 1, a.Sk, pcoff) + (a.causal && s.nqb > 1 ? split_tiles(0, a.Sk, pcoff) : 0);
     long long n = slots / (pairs > 0 ? pairs : 1);
     n = n < split_max_pieces() ? n : split_max_pieces();
-    n = n < T / kSplitMinTiles ? n : T / kSplitMinTiles;
+    n = n < T / split_min_tiles() ? n : T / split_min_tiles();
     // Two pieces that fill the chip need twice the length: going from half the CUs to all of them the busy ones lose ~a quarter of
     // their clock (the socket's power limit, profiles/r4_power_trace.txt), so 2 x 18 tiles on 256 workgroups is SLOWER than 36 on 128
     // once a piece's prologue, its partial rows and the merge launch are paid (round 4, one-wave-per-SIMD kernel, same box: B1 32q/8kv
     // S2048 63.6 us cut against 56.5 whole; non-causal B1 H8 S2048 47.4 against 42.0), while 2 x 34 (B1 H16 S4096: 86.9 against 90.1),
     // 2 x 66 (B1 H8 S8192: 135.8 against 148.4) and 4 x 17 on a quarter-full chip (B1 H8 S4096: 63.4 against 84.0) win.
-    if (n == 2 && 2 * pairs > slots / 2 && T < 4 * kSplitMinTiles) n = 1;
+    if (n == 2 && 2 * pairs > slots / 2 && T < 4 * kSplitMinTiles) n = 1;   // (the measured rule below keeps its constant: 64 tiles)
     s.n = (int)n;
     s.nitems = pairs * s.n;
     s.bytes = (size_t)s.n * a.B * a.Hq * a.Sq * (size_t)(a.D + kPartPad) * sizeof(float);
