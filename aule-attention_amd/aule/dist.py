@@ -99,7 +99,7 @@ def gather_bytes(batch: int, heads_q: int, heads_kv: int, seq_q: int, head_dim: 
 
 def flash_attention_sharded(q, k, v, causal: bool = True, scale: Optional[float] = None, group=None,
                             gather: bool = True, attn_fn: Optional[Callable] = None, chunks: int = 4,
-                            transport: str = "auto"):
+                            transport: str = "auto", window_size: int = -1):
     """Every rank holds the same full q, k, v (or at least its own shard's rows); each computes its share with `attn_fn`
     (default aule.flash_attention) in `chunks` pieces and, if `gather`, every rank receives the full output: the exchange of
     piece i overlaps the computation of piece i+1 (module docstring).  transport: "allgather", "p2p", "peer" (direct copies into the peers' mapped buffers; the
@@ -107,10 +107,12 @@ def flash_attention_sharded(q, k, v, causal: bool = True, scale: Optional[float]
     than AULE_PEER_CACHE_KEYS = 4 other exchange sizes evict its buffer: see _peer_exchange; .clone() a result that must outlive that) or
     "auto" (p2p when the shards differ in size, all-gather otherwise).  Returns the full [B,Hq,Sq,D] output (gather=True) or this rank's
     shard.  Inference path (no autograd through the collective).  chunks=1, transport="allgather" is the single blocking
-    collective of round 1."""
+    collective of round 1.  window_size > 0: the sliding window of aule.flash_attention (round 6; every shard is a set of whole heads: the window needs
+    nothing from another rank); a caller-supplied attn_fn receives it as `window_size=` only when it is set."""
     import torch
     import torch.distributed as dist
     into = _into_ok(q, k, v, causal, attn_fn)
+    wkw = {"window_size": int(window_size)} if window_size is not None and window_size > 0 else {}
     if attn_fn is None:
         from . import flash_attention as attn_fn
     world = dist.get_world_size(group)
@@ -129,8 +131,8 @@ def flash_attention_sharded(q, k, v, causal: bool = True, scale: Optional[float]
         else:   # heads of one flattened batch item: the KV heads of the same units
             kk, vv = ks[:, sl.start // g:(sl.stop + g - 1) // g], vs[:, sl.start // g:(sl.stop + g - 1) // g]
         if out is not None:
-            return _attn_into(qq, kk, vv, causal, scale, out.view(qq.shape))
-        return attn_fn(qq.contiguous(), kk.contiguous(), vv.contiguous(), causal=causal, scale=scale)
+            return _attn_into(qq, kk, vv, causal, scale, out.view(qq.shape), window_size)
+        return attn_fn(qq.contiguous(), kk.contiguous(), vv.contiguous(), causal=causal, scale=scale, **wkw)
 
     if not gather:
         if n_lead[rank] == 0:
@@ -142,12 +144,13 @@ def flash_attention_sharded(q, k, v, causal: bool = True, scale: Optional[float]
 
 
 def attention_and_gather(q, k, v, causal: bool = True, scale: Optional[float] = None, group=None,
-                         attn_fn: Optional[Callable] = None, chunks: int = 4, transport: str = "allgather"):
+                         attn_fn: Optional[Callable] = None, chunks: int = 4, transport: str = "allgather", window_size: int = -1):
     """The same exchange for ranks that hold ONLY their own shard (equal shards along the batch axis: what a data-parallel
     caller and bench.py have): q [Bl,Hq,Sq,D], k / v [Bl,Hkv,Sk,D] local; returns [world*Bl,Hq,Sq,D] on every rank,
     rank r's rows at [r*Bl, (r+1)*Bl)."""
     import torch.distributed as dist
     into = _into_ok(q, k, v, causal, attn_fn)
+    wkw = {"window_size": int(window_size)} if window_size is not None and window_size > 0 else {}
     if attn_fn is None:
         from . import flash_attention as attn_fn
     world = dist.get_world_size(group)
@@ -156,8 +159,8 @@ def attention_and_gather(q, k, v, causal: bool = True, scale: Optional[float] = 
 
     def run(sl, out=None):
         if out is not None:
-            return _attn_into(q[sl], k[sl], v[sl], causal, scale, out.view(q[sl].shape))
-        return attn_fn(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), causal=causal, scale=scale)
+            return _attn_into(q[sl], k[sl], v[sl], causal, scale, out.view(q[sl].shape), window_size)
+        return attn_fn(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), causal=causal, scale=scale, **wkw)
 
     full = _compute_and_exchange(run, [Bl] * world, [r * Bl * Hq for r in range(world)], Hq, 1, rank, world,
                                  (world * Bl * Hq, Sq, D), q.dtype, q.device, chunks, transport, group, into=into)
@@ -184,12 +187,13 @@ def _into_ok(q, k, v, causal, attn_fn):
     return True
 
 
-def _attn_into(q, k, v, causal, scale, out):
+def _attn_into(q, k, v, causal, scale, out, window_size=-1):
     """aule.flash_attention (inference form: no autograd node, no LSE) with the result written to `out`."""
     import math
     from . import _torch as at
     sc = float(scale) if scale is not None else 1.0 / math.sqrt(q.shape[-1])
-    at.fwd_raw(q.contiguous(), k.contiguous(), v.contiguous(), at.causal_code(causal), sc, want_lse=False, out=out)
+    at.fwd_raw(q.contiguous(), k.contiguous(), v.contiguous(), at.causal_code(causal), sc, want_lse=False, out=out,
+               window=int(window_size) if window_size is not None and window_size > 0 else -1)
     return out
 
 

@@ -36,12 +36,18 @@ def _worker(rank, world, port, case, q):
     tk = torch.from_numpy(rng.randn(B, Hkv, Sk, D).astype(np.float32))
     tv = torch.from_numpy(rng.randn(B, Hkv, Sk, D).astype(np.float32))
 
-    def attn(a, b, c, causal=True, scale=None):
-        o, _ = oracle.fwd_f64(a.numpy(), b.numpy(), c.numpy(), causal, scale)
+    def attn(a, b, c, causal=True, scale=None, window_size=-1):
+        o, _ = oracle.fwd_f64(a.numpy(), b.numpy(), c.numpy(), causal, scale, window_size)
         return torch.from_numpy(o)
 
     ref = attn(tq, tk, tv, causal=causal)
     ok = True
+    # (round 6) the sliding window passes through the sharded entry point: every shard is a set of whole heads
+    if causal:
+        W = max(2, Sq // 3)
+        wref = attn(tq, tk, tv, causal=causal, window_size=W)
+        ok = ok and not bool(torch.equal(wref, ref))
+        ok = ok and bool(torch.equal(adist.flash_attention_sharded(tq, tk, tv, causal=causal, attn_fn=attn, chunks=2, window_size=W), wref))
     equal_shards = len({e - s for s, e in adist.shard_plan(B, Hkv, world)[1]}) == 1
     for transport in ("auto", "p2p") + (("allgather",) if equal_shards else ()):
         for chunks in (1, 2, 3, 8):

@@ -58,6 +58,12 @@ for transport in ("auto", "allgather", "p2p", "peer"):
         assert torch.equal(full, ref), (transport, chunks)
 full = adist.attention_and_gather(q, k, v, causal=True, chunks=2)
 assert torch.equal(full, ref)
+qw, kw, vw = (torch.randn(2, h, 1024, 128, device="cuda", dtype=torch.bfloat16) for h in (8, 2, 2))
+wref = aule.flash_attention(qw, kw, vw, causal=True, window_size=256)      # (round 6: the window instances behind the sharded entry points)
+assert not torch.equal(wref, aule.flash_attention(qw, kw, vw, causal=True))
+for transport in ("allgather", "peer"):
+    assert torch.equal(adist.flash_attention_sharded(qw, kw, vw, causal=True, chunks=2, transport=transport, window_size=256), wref), transport
+assert torch.equal(adist.attention_and_gather(qw, kw, vw, causal=True, chunks=2, window_size=256), wref)
 dist.destroy_process_group()
 print("OK")
 """ % ROOT
