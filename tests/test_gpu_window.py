@@ -159,6 +159,26 @@ def test_window_with_a_negative_scale(oracle_mod):
     assert_close(lse.cpu().numpy(), rl, LSE_TOL["bf16"] * 2, 1e-5, "lse")
 
 
+def test_window_launch_with_two_rounds_of_part_tables(oracle_mod):
+    """More work items than the part tables of one workgroup per CU hold (64 each): the grid then has 2 x CUs workgroups.  65 blocks x 256 heads on sampled
+    rows against the fp64 judge (tools/win_big_check.py is the same check at B 16 H 32 S 16384 D 128)."""
+    import torch
+    from aule import _torch as at
+    B, Hq, Hkv, S, D, W = 4, 64, 8, 16640, 64, 300
+    g = torch.Generator(device="cuda").manual_seed(3)
+    q = torch.randn(B, Hq, S, D, device="cuda", dtype=torch.float16, generator=g)
+    k, v = (torch.randn(B, Hkv, S, D, device="cuda", dtype=torch.float16, generator=g) for _ in range(2))
+    assert _fwd_route("fp16", B, Hq, Hkv, S, S, D, True, W) == 8
+    out, lse = at.fwd_raw(q, k, v, True, 1 / math.sqrt(D), window=W)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    rows = np.random.RandomState(1).randint(0, B * Hq * S, size=48).astype(np.int64)
+    ro, rl = oracle_mod.fwd_rows_f64(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(), rows, True, None, W)
+    atol, rtol = fwd_tol("fp16", float(v.float().abs().max()))
+    assert_close(out.float().cpu().numpy().reshape(-1, D)[rows], ro, atol, rtol, "out")
+    assert_close(lse.cpu().numpy().reshape(-1)[rows], rl, LSE_TOL["fp16"], 1e-5, "lse")
+
+
 def test_window_suite_on_the_ping_pong_route():
     """The same cases with the window instances off (AULE_HIP_W4_WINDOW=0: read once per process, hence a child): the ping-pong kernel's window
     path still serves non-causal windows, windows shorter than two key tiles and rows without a visible key, and stays the A/B partner of
